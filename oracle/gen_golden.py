@@ -1,0 +1,167 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box).
+The reference is imported read-only with the two tiny sys.modules stubs described in SURVEY.md
+section 8c; nothing from it is copied: only tensors (inputs, parameters, outputs) are stored.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+Outputs
+  tests/golden/lsigf_cases.npz    LSIGF / BatchLSIGF / GraphFilter / GraphFilterBatch I/O
+  tests/golden/policy_model.npz   DecentralPlannerNet parameters (reference init + randomised BN
+                                  running stats) and forward I/O for several (N, K, B)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    stub = types.ModuleType('torchsummaryX')
+    stub.summary = lambda *a, **k: None
+    sys.modules['torchsummaryX'] = stub
+    for name, path in (('utils', REF + '/utils'), ('utils.graphUtils', REF + '/utils/graphUtils')):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [path]
+        sys.modules[name] = pkg
+    from graphs.models.decentralplanner import DecentralPlannerNet
+    import utils.graphUtils.graphML as gml
+    return DecentralPlannerNet, gml
+
+
+class Cfg:
+    def __init__(self, n, k):
+        self.num_agents = n
+        self.nGraphFilterTaps = k
+        self.device = torch.device('cpu')
+
+
+def gen_lsigf(gml):
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle.policy_oracle import synth_gso_geometric, synth_gso_sparse
+    g = torch.Generator().manual_seed(20260926)
+    store, meta = {}, []
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g)
+
+    def add(kind, h, S, x, b, y, extra=None):
+        i = len(meta)
+        store['c%d_h' % i] = h.numpy()
+        store['c%d_S' % i] = S.numpy()
+        store['c%d_x' % i] = x.numpy()
+        if b is not None:
+            store['c%d_b' % i] = b.numpy()
+        store['c%d_y' % i] = y.numpy()
+        m = {'kind': kind, 'has_bias': b is not None, 'F': h.shape[0], 'E': h.shape[1],
+             'K': h.shape[2], 'G': h.shape[3], 'S_dtype': str(S.dtype).replace('torch.', '')}
+        m.update(extra or {})
+        meta.append(m)
+
+    # functional forms -----------------------------------------------------------------
+    for K in (1, 2, 3, 4):
+        for N in (1, 2, 10, 50, 100):
+            G, F_out = (128, 128) if (K == 3 and N in (10, 50)) else (16, 24)
+            B = 2
+            E = 2 if (K == 2 and N == 10) else 1
+            h = rnd(F_out, E, K, G) / (G * K) ** 0.5
+            b = rnd(F_out, 1) * 0.1 if (K + N) % 2 == 0 else None
+            x = torch.relu(rnd(B, G, N))
+            # shared GSO (LSIGF): asymmetric sparse
+            S1 = synth_gso_sparse(E, N, 3.5, seed=K * 1000 + N)
+            with torch.no_grad():
+                add('LSIGF', h, S1, x, b, gml.LSIGF(h, S1, x, b))
+            # per-sample GSO (BatchLSIGF): geometric fp64 for even K, sparse asymmetric fp32 else
+            if K % 2 == 0:
+                Sb = torch.from_numpy(synth_gso_geometric(B * E, N, max(4, int(N ** 0.5 * 6)),
+                                                          seed=K * 77 + N)).reshape(B, E, N, N)
+            else:
+                Sb = synth_gso_sparse(B * E, N, 3.5, seed=K * 31 + N).reshape(B, E, N, N)
+            with torch.no_grad():
+                add('BatchLSIGF', h, Sb, x, b, gml.BatchLSIGF(h, Sb, x, b))
+
+    # module forms incl. the Nin < N zero-padding path --------------------------------------
+    for (G, F_out, K, N, Nin) in ((8, 12, 3, 10, 7), (128, 128, 3, 10, 10), (5, 3, 2, 6, 6)):
+        B = 3
+        gf = gml.GraphFilter(G, F_out, K, 1, True)
+        gfb = gml.GraphFilterBatch(G, F_out, K, 1, True)
+        x = torch.relu(rnd(B, G, Nin))
+        S1 = synth_gso_sparse(1, N, 3.0, seed=G * 13 + N)
+        Sb = synth_gso_sparse(B, N, 3.0, seed=G * 17 + N).reshape(B, 1, N, N)
+        with torch.no_grad():
+            gf.addGSO(S1)
+            add('GraphFilter', gf.weight.detach(), S1, x, gf.bias.detach(), gf(x), {'Nin': Nin})
+            gfb.addGSO(Sb)
+            add('GraphFilterBatch', gfb.weight.detach(), Sb, x, gfb.bias.detach(), gfb(x),
+                {'Nin': Nin})
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'lsigf_cases.npz'), **store)
+    print('lsigf_cases: %d cases' % len(meta))
+
+
+def gen_policy(DecentralPlannerNet):
+    from oracle.policy_oracle import synth_gso_geometric, synth_gso_sparse, synth_obs
+    torch.manual_seed(1337)
+    base = DecentralPlannerNet(Cfg(10, 3)).eval()
+    # default BN running stats make eval-BN nearly the identity: randomise them
+    g = torch.Generator().manual_seed(4242)
+    with torch.no_grad():
+        for m in base.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+                m.bias.copy_(0.05 * torch.randn(m.num_features, generator=g))
+        base.compressMLP[0].bias.copy_(0.05 * torch.randn(128, generator=g))
+        base.actionsMLP[0].bias.copy_(0.05 * torch.randn(5, generator=g))
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    store = {'sd/' + k: v.numpy() for k, v in sd.items()}
+    meta = []
+    gfl_extra = {}
+    for (N, K, B, gso) in ((10, 3, 4, 'geo64'), (10, 2, 2, 'sparse32'), (10, 4, 2, 'geo64'),
+                           (1, 3, 2, 'geo64'), (3, 3, 2, 'sparse32'), (23, 3, 1, 'geo64')):
+        net = DecentralPlannerNet(Cfg(N, K)).eval()
+        sdk = dict(sd)
+        if K != 3:
+            if K not in gfl_extra:
+                gfl_extra[K] = net.state_dict()['GFL.0.weight'].clone()
+                store['gfl_w_K%d' % K] = gfl_extra[K].numpy()
+            sdk['GFL.0.weight'] = gfl_extra[K]
+        net.load_state_dict(sdk)
+        obs = synth_obs(B, N, seed=N * 100 + K)
+        if gso == 'geo64':
+            S = torch.from_numpy(synth_gso_geometric(B, N, 20, seed=N * 7 + K))
+        else:
+            S = synth_gso_sparse(B, N, 3.0, seed=N * 5 + K)
+        feats = {}
+        hook = net.GFL.register_forward_pre_hook(lambda mod, inp: feats.__setitem__('x', inp[0].clone()))
+        with torch.no_grad():
+            net.addGSO(S)
+            out = net(obs)
+        hook.remove()
+        i = len(meta)
+        store['p%d_obs' % i] = obs.numpy()
+        store['p%d_S' % i] = S.numpy()
+        store['p%d_feat' % i] = feats['x'].numpy()
+        store['p%d_logits' % i] = torch.stack(out, dim=1).numpy()      # [B,N,5]
+        meta.append({'N': N, 'K': K, 'B': B, 'gso': gso})
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'policy_model.npz'), **store)
+    print('policy_model: %d cases' % len(meta))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    Net, gml = import_reference()
+    sys.path.insert(0, os.path.dirname(HERE))
+    gen_lsigf(gml)
+    gen_policy(Net)

@@ -1,0 +1,39 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    meta = json.loads(bytes(z['meta']).decode())
+    return z, meta
+
+
+@pytest.fixture(scope='session')
+def lsigf_golden():
+    return _load('lsigf_cases.npz')
+
+
+@pytest.fixture(scope='session')
+def policy_golden():
+    return _load('policy_model.npz')
+
+
+def golden_state_dict(z, K=3):
+    import torch
+    sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith('sd/')}
+    if K != 3:
+        sd['GFL.0.weight'] = torch.from_numpy(np.array(z['gfl_w_K%d' % K]))
+    return sd

@@ -1,0 +1,87 @@
+"""CPU: pin the oracle (oracle/policy_oracle.py) to the golden vectors produced by the real
+reference (oracle/gen_golden.py).  Tolerance 5e-6 absolute on O(1) values (observed: bit-equal
+up to ~1e-6: same op sequence, BLAS blocking differs with layout)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import policy_oracle as orc
+from conftest import golden_state_dict
+
+TOL = 5e-6
+
+
+def _case(z, i, m):
+    h = torch.from_numpy(z['c%d_h' % i])
+    S = torch.from_numpy(z['c%d_S' % i])
+    x = torch.from_numpy(z['c%d_x' % i])
+    b = torch.from_numpy(z['c%d_b' % i]) if m['has_bias'] else None
+    y = z['c%d_y' % i]
+    return h, S, x, b, y
+
+
+def test_lsigf_family_matches_reference(lsigf_golden):
+    z, meta = lsigf_golden
+    fn = {'LSIGF': orc.lsigf, 'BatchLSIGF': orc.batch_lsigf,
+          'GraphFilter': lambda h, S, x, b: orc.graph_filter(h, b, S, x),
+          'GraphFilterBatch': lambda h, S, x, b: orc.graph_filter_batch(h, b, S, x)}
+    kinds = set()
+    for i, m in enumerate(meta):
+        h, S, x, b, y = _case(z, i, m)
+        got = fn[m['kind']](h, S, x, b).numpy()
+        assert got.shape == y.shape, (i, m)
+        assert np.abs(got - y).max() <= TOL, (i, m, np.abs(got - y).max())
+        kinds.add(m['kind'])
+    assert kinds == set(fn)
+
+
+def test_f64_einsum_statement_agrees(lsigf_golden):
+    z, meta = lsigf_golden
+    for i, m in enumerate(meta):
+        if m['kind'] not in ('LSIGF', 'BatchLSIGF'):
+            continue
+        h, S, x, b, y = _case(z, i, m)
+        ref = orc.lsigf_f64(h.numpy(), S.numpy(), x.numpy(), None if b is None else b.numpy())
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(ref - y).max() <= 2e-5 * scale, (i, m)
+
+
+def test_policy_matches_reference(policy_golden):
+    z, meta = policy_golden
+    for i, m in enumerate(meta):
+        sd = golden_state_dict(z, m['K'])
+        obs = torch.from_numpy(z['p%d_obs' % i])
+        S = torch.from_numpy(z['p%d_S' % i])
+        with torch.no_grad():
+            out = orc.policy_forward(sd, S, obs)
+            feat = orc.policy_features(sd, obs)
+        assert len(out) == m['N'] and out[0].shape == (m['B'], 5)
+        logits = torch.stack(out, dim=1).numpy()
+        assert np.abs(feat.numpy() - z['p%d_feat' % i]).max() <= TOL
+        assert np.abs(logits - z['p%d_logits' % i]).max() <= TOL, (i, m)
+        want = torch.from_numpy(z['p%d_logits' % i]).argmax(-1)
+        assert torch.equal(orc.decode_actions(out), want)
+
+
+def test_state_dict_contract(policy_golden):
+    z, _ = policy_golden
+    sd = golden_state_dict(z)
+    mine = orc.init_state_dict(3)
+    assert set(sd) == set(mine)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(mine[k].shape), k
+        assert sd[k].dtype == mine[k].dtype, k
+    assert sum(v.numel() for k, v in sd.items()
+               if 'running' not in k and 'num_batches' not in k) == 206501
+
+
+def test_synth_gso_properties():
+    S = orc.synth_gso_geometric(8, 10, 20, seed=3)
+    assert S.dtype == np.float64 and S.shape == (8, 10, 10)
+    assert np.allclose(S, S.transpose(0, 2, 1))
+    assert (np.diagonal(S, axis1=1, axis2=2) == 0).all()
+    deg = (S != 0).sum(-1)
+    assert deg.min() >= 1                      # connected => no isolated node
+    assert 2.0 < deg.mean() < 6.0              # ~3.4 under the reference rule at (10, 20x20)
+    A = orc.synth_gso_sparse(4, 50, 6.6, seed=1)
+    assert not torch.allclose(A, A.transpose(1, 2))
