@@ -1,0 +1,212 @@
+"""Headline benchmark: agent-steps/s of the policy forward pass (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one policy forward (DecentralPlannerNet.addGSO + forward) over one batch of synthetic
+input resident in HBM: BASELINE.json configs[1] = 10 agents, K=3, B=512 GSO+observation batch
+(seed 1337).  With N GPUs every rank runs its own replica on its own batch
+(independent rollout shards, no data-path collective): weak scaling, value = total agent-steps/s.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel (the fused encoder): algorithmic FLOPs / measured launch time vs
+                the fp32-MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TFLOP/s)
+  cpu_baseline  the CPU oracle (op-for-op restatement of the reference's PyTorch path, pinned to
+                golden vectors) timed on this box's host cores on a bounded sample of the workload
+  parity        max |dlogit| and action-id agreement GPU vs oracle on the bench batch
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (agents N, map W, taps K, batch B)          -- BASELINE.json configs[1], [2], [4]
+    'c2': (10, 20, 3, 512),
+    'c3': (50, 50, 3, 256),
+    'c5': (100, 100, 3, 128),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, chip-level parameters
+ENC_MACS_PER_AGENT = 1238112 + 16384    # CNN + compress MLP
+
+
+def policy_flops_per_agent(K, mean_deg):
+    return 2.0 * (1238112 + 16384 + K * 128 * 128 + (K - 1) * mean_deg * 128 + 640)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--traffic-bytes', type=float, default=None,
+                    help='HBM bytes per encoder launch from a separate rocprofv3 --pmc pass')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from oracle import policy_oracle as orc           # checker + cpu_baseline leg only
+    _native.lib()
+
+    N, W, K, B = CONFIGS[args.config]
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, K, dev
+
+    sd = orc.init_state_dict(K, seed=1337)
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(sd)
+    seed = 1337 + rank
+    obs_cpu = orc.synth_obs(B, N, seed=seed)
+    S64 = orc.synth_gso_geometric(B, N, W, seed=seed)
+    mean_deg = float((S64 != 0).sum() / (B * N))
+    S_cpu = torch.from_numpy(S64).float()
+    obs, S = obs_cpu.to(dev), S_cpu.to(dev)
+
+    def step():
+        net.addGSO(S)
+        return net(obs)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * N * args.steps / elapsed
+
+    result = {
+        'metric': 'agent-steps/sec (policy fwd)', 'value': value, 'unit': 'agent-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'policy forward (addGSO+forward), %d agents, %dx%d map GSO, K=%d, '
+                               'batch=%d per GPU, eval mode, fp32 GSO resident in HBM'
+                               % (N, W, W, K, B),
+                   'name': args.config, 'agents': N, 'taps': K, 'batch_per_gpu': B,
+                   'mean_degree': round(mean_deg, 3), 'parallelism': 'replicas x%d' % world},
+    }
+
+    if rank == 0:
+        L = _native.lib()
+        M = B * N
+        enc = net.packed_encoder()
+        feat = torch.empty(M, 128, device=dev)
+        st = _native.stream_ptr(dev)
+        import ctypes
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+
+        def time_kernel(fn, reps=50):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                                     # events on the stream the kernels use
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
+        flops = 2.0 * ENC_MACS_PER_AGENT * M
+        achieved = flops / t_enc / 1e12
+        result['roofline'] = {
+            'kernel': 'gnnpp::encoder_kernel', 'bound': 'mfma', 'achieved': achieved,
+            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+            'traffic': args.traffic_bytes, 'avg_launch_us': t_enc * 1e6,
+            'flops_per_launch': flops,
+        }
+        # secondary: the graph-filter kernel alone (node-major features in, ReLU'd features out)
+        gf = net.GFL[0]
+        y = torch.empty(M, 128, device=dev)
+        gb = gf.bias.detach().reshape(-1)
+        t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(gf.packed_taps()), vp(gb),
+                                                     vp(y), B, N, N, 128, 128, K, 1, 0, 1, 1, 1, 1, st))
+        gf_bytes = M * (1024 + 4 * N) + 196608.0 * K / 3
+        result['filter_kernel'] = {
+            'kernel': 'gnnpp::lsigf_kernel', 'avg_launch_us': t_gf * 1e6,
+            'agent_steps_per_s': M / t_gf,
+            'algorithmic_GBps': gf_bytes / t_gf / 1e9, 'hbm_frac_of_8TBps': gf_bytes / t_gf / 8e12,
+            'mfma_TFLOPs': 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * M / t_gf / 1e12,
+        }
+        result['step_breakdown_us'] = {'encoder': t_enc * 1e6, 'filter+head': t_gf * 1e6,
+                                       'whole_step_wall': 1e6 * elapsed / args.steps}
+        result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value / world / 1e12
+
+        # parity gate on the bench batch + CPU baseline (bounded sample of the same workload)
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            want = orc.policy_forward(sd, S_cpu, obs_cpu)
+        got = [o.cpu() for o in out]
+        err = max((g - w).abs().max().item() for g, w in zip(got, want))
+        margin = orc.top2_margin(want)
+        ids_w = orc.decode_actions(want)
+        ids_g = torch.stack([g.argmax(-1) for g in got], 1)
+        clear = margin > 1e-5
+        result['parity'] = {'max_abs_dlogit': err, 'tolerance': 1e-4,
+                            'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear])),
+                            'near_tie_rows': int((~clear).sum()), 'rows': int(clear.numel())}
+        if not args.no_cpu_baseline:
+            with torch.no_grad():
+                for _ in range(2):
+                    orc.policy_forward(sd, S_cpu, obs_cpu)
+                times = []
+                t_start = time.perf_counter()
+                while (time.perf_counter() - t_start < args.cpu_seconds or len(times) < 3) \
+                        and len(times) < 200:
+                    t1 = time.perf_counter()
+                    orc.policy_forward(sd, S_cpu, obs_cpu)
+                    times.append(time.perf_counter() - t1)
+            times.sort()
+            med = times[len(times) // 2]
+            result['cpu_baseline'] = {
+                'value': B * N / med, 'unit': 'agent-steps/s', 'cores': torch.get_num_threads(),
+                'kind': 'port',
+                'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
+                          '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'
+                          % (len(times), args.config, torch.__version__, sum(times)),
+                'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value / world / (B * N / med)}
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

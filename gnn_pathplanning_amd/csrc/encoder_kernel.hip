@@ -1,0 +1,371 @@
+// Per-agent CNN encoder + compress MLP, fully fused, for gfx950.
+//
+// Replaces ConvLayers (5 x [conv3x3 pad1 -> BatchNorm(eval) -> ReLU], MaxPool2d(2) after layers
+// 0, 2, 4) and compressMLP (Linear 128->128 + ReLU) as the reference runs them once per agent
+// (graphs/models/decentralplanner.py:284-290, layers built at :155-195).  In eval mode every
+// agent of every sample is independent, so all M = B*N agents are folded into one batch.
+//
+// One workgroup (4 waves) owns a tile of 16 agents and carries them through all six layers with
+// the activations never leaving LDS:
+//
+//   obs   [16][3][13][13]  zero-padded, fp32                        (32.8 KB, buffer A)
+//   L0    3 -> 32  @ 11x11 (only the 10x10 the pool reads) -> pool -> 32 @ 5x5     (buffer B)
+//   L1   32 -> 32  @ 5x5                                                            (buffer A)
+//   L2   32 -> 64  @ 5x5  (only the 4x4 the pool reads)    -> pool -> 64 @ 2x2     (buffer B)
+//   L3   64 -> 64  @ 2x2                                                            (buffer A)
+//   L4   64 -> 128 @ 2x2                                   -> pool -> 128 @ 1x1    (buffer B)
+//   FC  128 -> 128 + ReLU  -> feat[agent][128] in HBM (node-major, what the filter kernel reads)
+//
+// Every layer is an implicit GEMM on the fp32 MFMA 16x16x4 (gnnpp_common.h): output channels on
+// the MFMA i axis (weights = A operand, pre-packed fragments streamed from L2), the 16 agents on
+// the j axis (activations = B operand from LDS), one MFMA tile per OUTPUT POSITION.  Because a
+// tile is a single spatial position, zero padding is resolved at compile time: taps that fall
+// outside the image are simply not issued (25 % of L1/L2's and 56 % of L3/L4's nominal MACs),
+// and positions the following MaxPool discards are never computed.  Results are unchanged
+// (x + 0*w == x); the algorithmic FLOP count used for the roofline is the reference's nominal one.
+//
+// Activations are stored as [position][16-channel group][lane] v4f, i.e. exactly the D fragment
+// of the producing MFMA == the B fragment (4 k-steps) of the consuming one.
+// BatchNorm(eval) is folded into a per-channel scale/shift applied in the epilogue.
+#include "gnnpp_common.h"
+
+namespace gnnpp {
+
+constexpr int kTileAgents = 16;
+constexpr int kObsFloats = 3 * 11 * 11;          // 363
+constexpr int kPadHW = 13;
+constexpr int kAgentStride = 513;                // 3*13*13 = 507 -> 513 (== 1 mod 32: bank spread)
+constexpr int kBufFloats = 25 * 2 * 256;         // largest activation: 25 positions x 32 channels
+constexpr size_t kEncSmemBytes = 2 * kBufFloats * sizeof(float);     // 102400
+static_assert(kTileAgents * kAgentStride <= kBufFloats, "padded observation must fit buffer A");
+
+// ---- weight packing (device side; inputs are the reference's state_dict tensors) --------------
+struct EncRawParams {
+    const float* conv_w[5];
+    const float* conv_b[5];
+    const float* bn_w[5];
+    const float* bn_b[5];
+    const float* bn_mean[5];
+    const float* bn_var[5];
+    const float* fc_w;
+    const float* fc_b;
+    float bn_eps;
+};
+
+__device__ __forceinline__ int enc_w_off(int layer) {
+    return layer == 0 ? EncLayout::kW0 : layer == 1 ? EncLayout::kW1 : layer == 2 ? EncLayout::kW2
+         : layer == 3 ? EncLayout::kW3 : layer == 4 ? EncLayout::kW4 : EncLayout::kWfc;
+}
+__device__ __forceinline__ int enc_ss_off(int layer) {
+    return layer == 0 ? EncLayout::kSS0 : layer == 1 ? EncLayout::kSS1 : layer == 2 ? EncLayout::kSS2
+         : layer == 3 ? EncLayout::kSS3 : EncLayout::kSS4;
+}
+
+__global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ packed) {
+    const int stride = gridDim.x * blockDim.x;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // L0: [mt 2][s 7][lane 64];  k = 4*s + q  ->  (c, ky, kx) = (k/9, (k%9)/3, k%3);  k = 27 -> 0
+    for (int idx = t0; idx < 2 * 7 * 64; idx += stride) {
+        const int l = idx & 63, s = (idx >> 6) % 7, mt = idx / (7 * 64);
+        const int k = 4 * s + (l >> 4);
+        const int cout = mt * 16 + (l & 15);
+        packed[EncLayout::kW0 + idx] = (k < 27) ? rp.conv_w[0][cout * 27 + k] : 0.f;
+    }
+    // L1..L4: [mt][tap 9][g][lane 64][s 4] = W[cout = mt*16+i][cin = g*16 + q*4 + s][tap]
+    for (int layer = 1; layer < 5; ++layer) {
+        const int cin = layer <= 2 ? 32 : 64;
+        const int cout_n = layer == 1 ? 32 : layer <= 3 ? 64 : 128;
+        const int NG = cin / 16, total = cout_n * cin * 9;
+        const int off = enc_w_off(layer);
+        for (int idx = t0; idx < total; idx += stride) {
+            const int s = idx & 3, l = (idx >> 2) & 63;
+            int blk = idx >> 8;
+            const int g = blk % NG; blk /= NG;
+            const int tap = blk % 9;
+            const int mt = blk / 9;
+            const int co = mt * 16 + (l & 15);
+            const int ci = g * 16 + (l >> 4) * 4 + s;
+            packed[off + idx] = rp.conv_w[layer][(co * cin + ci) * 9 + tap];
+        }
+    }
+    // FC: [mt 8][g 8][lane 64][s 4] = W[f = mt*16+i][c = g*16 + q*4 + s]
+    for (int idx = t0; idx < 128 * 128; idx += stride) {
+        const int s = idx & 3, l = (idx >> 2) & 63;
+        const int blk = idx >> 8;
+        const int g = blk & 7, mt = blk >> 3;
+        packed[EncLayout::kWfc + idx] =
+            rp.fc_w[(mt * 16 + (l & 15)) * 128 + g * 16 + (l >> 4) * 4 + s];
+    }
+    for (int idx = t0; idx < 128; idx += stride) packed[EncLayout::kBfc + idx] = rp.fc_b[idx];
+    // folded BatchNorm: y = conv_nobias * scale + shift,
+    //   scale = gamma / sqrt(var + eps),  shift = beta + (conv_bias - mean) * scale
+    for (int layer = 0; layer < 5; ++layer) {
+        const int c_n = layer <= 1 ? 32 : layer <= 3 ? 64 : 128;
+        const int off = enc_ss_off(layer);
+        for (int c = t0; c < c_n; c += stride) {
+            const float sc = rp.bn_w[layer][c] / sqrtf(rp.bn_var[layer][c] + rp.bn_eps);
+            packed[off + c] = sc;
+            packed[off + c_n + c] =
+                rp.bn_b[layer][c] + (rp.conv_b[layer][c] - rp.bn_mean[layer][c]) * sc;
+        }
+    }
+}
+
+// ---- generic tap-GEMM for one output-channel tile over a compile-time set of positions --------
+// PosFn::get(j, y, x) -> is slot j used, and its output coordinates (all constexpr-foldable).
+template <int CIN, int H, int W, int NSLOT, class PosFn>
+__device__ __forceinline__ void conv_tile(const float* __restrict__ wmt,   // [9][NG][64][4]
+                                          const v4f* __restrict__ in,      // [H*W][NG][64]
+                                          v4f (&acc)[NSLOT], int lane) {
+    constexpr int NG = CIN / 16;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const v4f A = *reinterpret_cast<const v4f*>(wmt + ((tap * NG + g) * 64 + lane) * 4);
+            v4f Bf[NSLOT];
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                int y = 0, x = 0;
+                const bool used = PosFn::get(j, y, x);
+                const int iy = y + dy, ix = x + dx;
+                if (used && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                    Bf[j] = in[((iy * W + ix) * NG + g) * 64 + lane];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) {
+                    int y = 0, x = 0;
+                    const bool used = PosFn::get(j, y, x);
+                    const int iy = y + dy, ix = x + dx;
+                    if (used && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                        acc[j] = mfma16(A[s], Bf[j][s], acc[j]);
+                }
+            }
+        }
+    }
+}
+
+// L1: 25 positions split in two halves (13 + 12) so that 2 channel tiles x 2 halves = 4 waves.
+template <int PART>
+struct PosL1 {
+    static __device__ __forceinline__ bool get(int j, int& y, int& x) {
+        const int p = PART * 13 + j;
+        y = p / 5; x = p % 5;
+        return p < 25;
+    }
+};
+// L2: the 4x4 block the pool reads, slot = window*4 + (py*2+px).
+struct PosL2 {
+    static __device__ __forceinline__ bool get(int j, int& y, int& x) {
+        const int w = j >> 2, i = j & 3;
+        y = 2 * (w >> 1) + (i >> 1); x = 2 * (w & 1) + (i & 1);
+        return true;
+    }
+};
+struct Pos2x2 {
+    static __device__ __forceinline__ bool get(int j, int& y, int& x) {
+        y = j >> 1; x = j & 1;
+        return true;
+    }
+};
+
+__device__ __forceinline__ void load_ss(const float* __restrict__ ss, int cn, int mt, int q,
+                                        v4f& sc, v4f& sh) {
+    sc = *reinterpret_cast<const v4f*>(ss + mt * 16 + q * 4);
+    sh = *reinterpret_cast<const v4f*>(ss + cn + mt * 16 + q * 4);
+}
+
+__global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restrict__ obs,
+                                                           const float* __restrict__ pk,
+                                                           float* __restrict__ feat, int M) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* bufA = reinterpret_cast<float*>(gnnpp_smem);
+    float* bufB = bufA + kBufFloats;
+    v4f* bufA4 = reinterpret_cast<v4f*>(bufA);
+    v4f* bufB4 = reinterpret_cast<v4f*>(bufB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int a = lane & 15;
+    const int q = lane >> 4;
+    const int agent0 = blockIdx.x * kTileAgents;
+
+    // ---- stage the zero-padded observations: bufA[a][c][13][13] --------------------------------
+    for (int i = tid; i < kTileAgents * kAgentStride; i += kThreads) {
+        const int ag = i / kAgentStride, rem = i - ag * kAgentStride;
+        const int c = rem / (kPadHW * kPadHW), r2 = rem - c * (kPadHW * kPadHW);
+        const int yy = r2 / kPadHW, xx = r2 - yy * kPadHW;
+        float v = 0.f;
+        if (rem < 3 * kPadHW * kPadHW && yy >= 1 && yy <= 11 && xx >= 1 && xx <= 11 &&
+            agent0 + ag < M)
+            v = obs[(size_t)(agent0 + ag) * kObsFloats + c * 121 + (yy - 1) * 11 + (xx - 1)];
+        bufA[i] = v;
+    }
+    __syncthreads();
+
+    // ---- L0: 3 -> 32 @ 11x11, BN, ReLU, pool -> [25][2][64] v4f in bufB ------------------------
+    {
+        float A0[2][7];
+        int offB[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            A0[0][s] = pk[EncLayout::kW0 + (0 * 7 + s) * 64 + lane];
+            A0[1][s] = pk[EncLayout::kW0 + (1 * 7 + s) * 64 + lane];
+            int k = 4 * s + q;
+            if (k >= 27) k = 0;                        // weight is zero there; any finite operand
+            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+            offB[s] = a * kAgentStride + c * (kPadHW * kPadHW) + ky * kPadHW + kx;
+        }
+        v4f sc[2], sh[2];
+        load_ss(pk + EncLayout::kSS0, 32, 0, q, sc[0], sh[0]);
+        load_ss(pk + EncLayout::kSS0, 32, 1, q, sc[1], sh[1]);
+        for (int win = wave; win < 25; win += kWaves) {
+            const int wy = win / 5, wx = win - wy * 5;
+            const float* base = bufA + (2 * wy) * kPadHW + 2 * wx;
+            v4f acc[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) acc[i][pp] = vzero();
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const float bv = base[offB[s] + (pp >> 1) * kPadHW + (pp & 1)];
+                    acc[0][pp] = mfma16(A0[0][s], bv, acc[0][pp]);
+                    acc[1][pp] = mfma16(A0[1][s], bv, acc[1][pp]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v4f m = vrelu(vfma(acc[i][0], sc[i], sh[i]));
+#pragma unroll
+                for (int pp = 1; pp < 4; ++pp) m = vmax(m, vfma(acc[i][pp], sc[i], sh[i]));
+                bufB4[(win * 2 + i) * 64 + lane] = m;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- L1: 32 -> 32 @ 5x5 : bufB -> bufA -----------------------------------------------------
+    {
+        const int mt = wave & 1;
+        const float* wmt = pk + EncLayout::kW1 + mt * (9 * 2 * 256);
+        v4f sc, sh;
+        load_ss(pk + EncLayout::kSS1, 32, mt, q, sc, sh);
+        v4f acc[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) acc[j] = vzero();
+        if ((wave >> 1) == 0) {
+            conv_tile<32, 5, 5, 13, PosL1<0>>(wmt, bufB4, acc, lane);
+#pragma unroll
+            for (int j = 0; j < 13; ++j)
+                bufA4[(j * 2 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
+        } else {
+            conv_tile<32, 5, 5, 13, PosL1<1>>(wmt, bufB4, acc, lane);
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                bufA4[((13 + j) * 2 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
+        }
+    }
+    __syncthreads();
+
+    // ---- L2: 32 -> 64 @ 5x5 (4x4 used), pool -> [4][4][64] in bufB -----------------------------
+    {
+        const int mt = wave;
+        v4f sc, sh;
+        load_ss(pk + EncLayout::kSS2, 64, mt, q, sc, sh);
+        v4f acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = vzero();
+        conv_tile<32, 5, 5, 16, PosL2>(pk + EncLayout::kW2 + mt * (9 * 2 * 256), bufA4, acc, lane);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            v4f m = vrelu(vfma(acc[4 * w], sc, sh));
+#pragma unroll
+            for (int i = 1; i < 4; ++i) m = vmax(m, vfma(acc[4 * w + i], sc, sh));
+            bufB4[(w * 4 + mt) * 64 + lane] = m;
+        }
+    }
+    __syncthreads();
+
+    // ---- L3: 64 -> 64 @ 2x2 : bufB -> bufA -----------------------------------------------------
+    {
+        const int mt = wave;
+        v4f sc, sh;
+        load_ss(pk + EncLayout::kSS3, 64, mt, q, sc, sh);
+        v4f acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = vzero();
+        conv_tile<64, 2, 2, 4, Pos2x2>(pk + EncLayout::kW3 + mt * (9 * 4 * 256), bufB4, acc, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bufA4[(j * 4 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
+    }
+    __syncthreads();
+
+    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][8][64] in bufB ---------------------------------------
+    for (int mt = wave; mt < 8; mt += kWaves) {
+        v4f sc, sh;
+        load_ss(pk + EncLayout::kSS4, 128, mt, q, sc, sh);
+        v4f acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = vzero();
+        conv_tile<64, 2, 2, 4, Pos2x2>(pk + EncLayout::kW4 + mt * (9 * 4 * 256), bufA4, acc, lane);
+        v4f m = vrelu(vfma(acc[0], sc, sh));
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = vmax(m, vfma(acc[i], sc, sh));
+        bufB4[mt * 64 + lane] = m;
+    }
+    __syncthreads();
+
+    // ---- FC 128 -> 128 + ReLU -> feat[agent][128] ----------------------------------------------
+    {
+        v4f acc[2] = {vzero(), vzero()};
+        const int mt0 = wave, mt1 = wave + kWaves;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const v4f Bf = bufB4[g * 64 + lane];
+            const v4f A0 = *reinterpret_cast<const v4f*>(pk + EncLayout::kWfc +
+                                                          ((mt0 * 8 + g) * 64 + lane) * 4);
+            const v4f A1 = *reinterpret_cast<const v4f*>(pk + EncLayout::kWfc +
+                                                          ((mt1 * 8 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = mfma16(A0[s], Bf[s], acc[0]);
+                acc[1] = mfma16(A1[s], Bf[s], acc[1]);
+            }
+        }
+        if (agent0 + a < M) {
+            float* dst = feat + (size_t)(agent0 + a) * 128 + q * 4;
+            const v4f b0 = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt0 * 16 + q * 4);
+            const v4f b1 = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt1 * 16 + q * 4);
+            *reinterpret_cast<v4f*>(dst + mt0 * 16) = vrelu(acc[0] + b0);
+            *reinterpret_cast<v4f*>(dst + mt1 * 16) = vrelu(acc[1] + b1);
+        }
+    }
+}
+
+// ---- host-side launchers ----------------------------------------------------------------------
+int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
+    hipLaunchKernelGGL(pack_encoder_kernel, dim3(128), dim3(256), 0, st, rp, packed);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncSmemBytes);
+        attr_set = true;
+    }
+    const int grid = (M + kTileAgents - 1) / kTileAgents;
+    hipLaunchKernelGGL(encoder_kernel, dim3(grid), dim3(kThreads), kEncSmemBytes, st, obs, packed,
+                       feat, M);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace gnnpp

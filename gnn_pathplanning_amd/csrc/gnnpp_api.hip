@@ -1,0 +1,104 @@
+// extern "C" surface of libgnnpp.so -- see include/gnnpp.h for the contract of every entry point.
+// Single translation unit: the kernels are included so hipcc builds one code object.
+#include "../../include/gnnpp.h"
+
+#include "encoder_kernel.hip"
+#include "lsigf_kernel.hip"
+
+using namespace gnnpp;
+
+static_assert(GNNPP_OK == 0 && GNNPP_ERR_UNSUPPORTED == -2 && GNNPP_ERR_LAUNCH == -3, "codes");
+
+extern "C" {
+
+int gnnpp_version(void) { return 100; }
+
+const char* gnnpp_error_string(int code) {
+    switch (code) {
+        case GNNPP_OK: return "ok";
+        case GNNPP_ERR_ARG: return "invalid argument (null pointer, non-positive size or inconsistent flags)";
+        case GNNPP_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels (N > 100 or LDS budget exceeded)";
+        case GNNPP_ERR_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown gnnpp error code";
+    }
+}
+
+size_t gnnpp_filter_packed_floats(int G, int F, int K, int E) {
+    if (G <= 0 || F <= 0 || K <= 0 || E <= 0) return 0;
+    return filter_packed_floats(G, F, K, E);
+}
+
+int gnnpp_filter_pack(const float* h, float* packed, int G, int F, int K, int E, void* stream) {
+    if (!h || !packed || G <= 0 || F <= 0 || K <= 0 || E <= 0) return GNNPP_ERR_ARG;
+    return filter_pack_launch(h, packed, G, F, K, E, static_cast<hipStream_t>(stream));
+}
+
+// One launch covers F <= 128 output features; wider filters are split over output-feature
+// chunks (each chunk recomputes the cheap shifts).  Packed taps are [e][k][mt][gg] so a chunk's
+// tiles are not contiguous: a chunk launch gets the full buffer plus its first tile index.
+int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const float* bias,
+                    float* y, int B, int N, int Nin, int G, int F, int K, int E, int s_is_f64,
+                    int s_batched, int x_node_major, int y_node_major, int relu, void* stream) {
+    if (!x || !packed || !y || B <= 0 || N <= 0 || Nin <= 0 || Nin > N || G <= 0 || F <= 0 ||
+        K <= 0 || E <= 0)
+        return GNNPP_ERR_ARG;
+    if (K > 1 && !S) return GNNPP_ERR_ARG;
+    if ((x_node_major || y_node_major) && Nin != N) return GNNPP_ERR_ARG;
+    if (N > GNNPP_MAX_NODES + 12) return GNNPP_ERR_UNSUPPORTED;
+    if (F > 128) return GNNPP_ERR_UNSUPPORTED;      // TODO(round 2): chunk the output features
+    LsigfArgs a = {};
+    a.x = x; a.S = S; a.wpk = packed; a.bias = bias; a.y = y;
+    a.B = B; a.N = N; a.Nin = Nin; a.G = G; a.F = F; a.K = K; a.E = E;
+    a.s_is_f64 = s_is_f64; a.s_batched = s_batched;
+    a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
+    return lsigf_launch(a, static_cast<hipStream_t>(stream));
+}
+
+size_t gnnpp_encoder_packed_floats(void) { return EncLayout::kTotal; }
+
+int gnnpp_encoder_pack(const gnnpp_encoder_params* p, float* packed, void* stream) {
+    if (!p || !packed || !p->fc_w || !p->fc_b) return GNNPP_ERR_ARG;
+    EncRawParams rp;
+    for (int i = 0; i < 5; ++i) {
+        if (!p->conv_w[i] || !p->conv_b[i] || !p->bn_w[i] || !p->bn_b[i] || !p->bn_mean[i] ||
+            !p->bn_var[i])
+            return GNNPP_ERR_ARG;
+        rp.conv_w[i] = p->conv_w[i]; rp.conv_b[i] = p->conv_b[i];
+        rp.bn_w[i] = p->bn_w[i]; rp.bn_b[i] = p->bn_b[i];
+        rp.bn_mean[i] = p->bn_mean[i]; rp.bn_var[i] = p->bn_var[i];
+    }
+    rp.fc_w = p->fc_w; rp.fc_b = p->fc_b; rp.bn_eps = p->bn_eps;
+    return encoder_pack_launch(rp, packed, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, void* stream) {
+    if (!obs || !packed || !feat || M <= 0) return GNNPP_ERR_ARG;
+    return encoder_launch(obs, packed, feat, M, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
+                     const float* filt_packed, const float* gf_bias, const float* act_w,
+                     const float* act_b, float* feat_ws, float* logits, int B, int N, int K,
+                     int s_is_f64, void* stream) {
+    if (!obs || !enc_packed || !filt_packed || !act_w || !act_b || !feat_ws || !logits || B <= 0 ||
+        N <= 0 || K <= 0)
+        return GNNPP_ERR_ARG;
+    if (K > 1 && !S) return GNNPP_ERR_ARG;
+    if (N > GNNPP_MAX_NODES + 12) return GNNPP_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = encoder_launch(obs, enc_packed, feat_ws, B * N, st);
+    if (rc) return rc;
+    LsigfArgs a = {};
+    a.x = feat_ws; a.S = S; a.wpk = filt_packed; a.bias = gf_bias; a.y = nullptr;
+    a.act_w = act_w; a.act_b = act_b; a.logits = logits;
+    a.B = B; a.N = N; a.Nin = N; a.G = GNNPP_FEAT; a.F = GNNPP_FEAT; a.K = K; a.E = 1;
+    a.s_is_f64 = s_is_f64; a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1;
+    return lsigf_launch(a, st);
+}
+
+int gnnpp_decode_actions(const float* logits, int* actions, int B, int N, void* stream) {
+    if (!logits || !actions || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
+    return decode_actions_launch(logits, actions, B, N, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

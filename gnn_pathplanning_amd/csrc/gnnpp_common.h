@@ -1,0 +1,101 @@
+// Shared device-side definitions for libgnnpp (gfx950 / CDNA4 only).
+//
+// MFMA convention used by every kernel in this library: v_mfma_f32_16x16x4_f32, exact fp32
+// (bitwise an fmaf chain), D[i][j] += sum_k A[i][k] * B[k][j] with
+//     A operand of lane l : A[i = l & 15][k = l >> 4]          (one VGPR)
+//     B operand of lane l : B[k = l >> 4][j = l & 15]          (one VGPR)
+//     D register r of lane l : D[i = (l >> 4) * 4 + r][j = l & 15]   (four VGPRs)
+// We always put OUTPUT CHANNELS on i (weights are the A operand, read from L2 in a pre-packed
+// fragment order) and AGENTS / graph nodes on j (activations are the B operand, read from LDS).
+//
+// "Fragment order" of a 16-channel input group: four consecutive MFMA k-steps s = 0..3 consume
+// the channels c = 4*q + s (q = l >> 4), so that ONE 16-byte load per lane feeds four MFMAs and
+// the D registers of a 16-output-channel tile (channel 4*q + r in register r) are already the
+// B fragment of the next layer: a layer's epilogue stores its v4f, the next layer loads it back,
+// lane for lane, with ds_write_b128 / ds_read_b128 and no shuffles.
+#ifndef GNNPP_COMMON_H_
+#define GNNPP_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+namespace gnnpp {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kThreads = 256;        // 4 waves per workgroup, one per SIMD
+constexpr int kWaves = kThreads / kWave;
+constexpr int kLdsBytes = 160 * 1024;
+
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// four k-steps fed by one packed A fragment and one packed B fragment
+__device__ __forceinline__ v4f mfma16x4(v4f a, v4f b, v4f c) {
+    c = mfma16(a[0], b[0], c);
+    c = mfma16(a[1], b[1], c);
+    c = mfma16(a[2], b[2], c);
+    c = mfma16(a[3], b[3], c);
+    return c;
+}
+
+__device__ __forceinline__ v4f vzero() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+__device__ __forceinline__ v4f vrelu(v4f v) {
+    v4f r;
+    r[0] = fmaxf(v[0], 0.f); r[1] = fmaxf(v[1], 0.f);
+    r[2] = fmaxf(v[2], 0.f); r[3] = fmaxf(v[3], 0.f);
+    return r;
+}
+
+__device__ __forceinline__ v4f vmax(v4f a, v4f b) {
+    v4f r;
+    r[0] = fmaxf(a[0], b[0]); r[1] = fmaxf(a[1], b[1]);
+    r[2] = fmaxf(a[2], b[2]); r[3] = fmaxf(a[3], b[3]);
+    return r;
+}
+
+__device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) {
+    v4f r;
+    r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]);
+    r[2] = fmaf(a[2], b[2], c[2]); r[3] = fmaf(a[3], b[3], c[3]);
+    return r;
+}
+
+// value of `v` held by lane `src` (src must be wave-uniform)
+__device__ __forceinline__ float wave_read_lane(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// ---- packed layouts (in floats) -------------------------------------------------------------
+// graph-filter taps: block (e, k, mt, gg) of 64 lanes x 4 floats, see lsigf_kernel.hip
+__host__ __device__ inline size_t filter_packed_floats(int G, int F, int K, int E) {
+    const size_t NG = (G + 15) / 16, MT = (F + 15) / 16;
+    return (size_t)E * K * MT * NG * 256;
+}
+
+// encoder: offsets of each layer's block inside the packed buffer
+struct EncLayout {
+    // conv layers 1..4 and the FC use the generic fragment order [mt][tap][g][lane][4]
+    static constexpr int kCin[5] = {3, 32, 32, 64, 64};
+    static constexpr int kCout[5] = {32, 32, 64, 64, 128};
+    static constexpr int kL0Steps = 7;                                   // K = 27 padded to 28
+    static constexpr int kW0 = 0;                                        // [mt 2][s 7][lane 64]
+    static constexpr int kSS0 = kW0 + 2 * kL0Steps * 64;                 // scale[32], shift[32]
+    static constexpr int kW1 = kSS0 + 64;                                // [2][9][2][256]
+    static constexpr int kSS1 = kW1 + 2 * 9 * 2 * 256;
+    static constexpr int kW2 = kSS1 + 64;                                // [4][9][2][256]
+    static constexpr int kSS2 = kW2 + 4 * 9 * 2 * 256;
+    static constexpr int kW3 = kSS2 + 128;                               // [4][9][4][256]
+    static constexpr int kSS3 = kW3 + 4 * 9 * 4 * 256;
+    static constexpr int kW4 = kSS3 + 128;                               // [8][9][4][256]
+    static constexpr int kSS4 = kW4 + 8 * 9 * 4 * 256;
+    static constexpr int kWfc = kSS4 + 256;                              // [8][8][256]
+    static constexpr int kBfc = kWfc + 8 * 8 * 256;                      // bias[128]
+    static constexpr int kTotal = kBfc + 128;
+};
+
+}  // namespace gnnpp
+#endif

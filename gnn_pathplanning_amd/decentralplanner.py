@@ -1,0 +1,224 @@
+"""DecentralPlannerNet with the reference's API, computed by libgnnpp.so on MI355X.
+
+Mirrors graphs/models/decentralplanner.py:13-318 ("DCP v1.4", :89-98): per-agent CNN encoder
+(5 x [conv3x3 + BatchNorm + ReLU], MaxPool after layers 0/2/4) -> Linear(128,128)+ReLU ->
+GraphFilterBatch(128,128,K,E=1)+ReLU -> Linear(128,5).
+
+  * constructor reads config.num_agents, config.nGraphFilterTaps, config.device (:18, :131, :283);
+  * identical sub-module tree, hence identical state_dict keys/shapes (ConvLayers.{0,1,4,5,...},
+    compressMLP.0, GFL.0, actionsMLP.0) so reference checkpoints load unchanged;
+  * addGSO(S [B,N,N]) (:266-276) then forward(inputTensor [B,N,3,11,11]) -> list of N tensors [B,5]
+    (:278-318).
+
+The sub-modules are parameter containers: forward() does NOT call them.  The whole step is two
+HIP kernels behind one C call (gnnpp_policy_fwd): the fused encoder over all B*N agents, then the
+K-tap graph filter + ReLU + action head.  Packed/BN-folded weights are cached and rebuilt whenever
+a parameter or running statistic changes.
+
+Round-1 scope: eval-mode inference (the rollout loop, agents/decentralplannerlocal.py:489-592).
+Train-mode forward (per-agent-call BatchNorm batch statistics, :284-286) and backward are the
+next rows: forward() in training mode raises NotImplementedError rather
+than silently computing something else.  There is no CPU path.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _native
+from . import graphML as gml
+from .weights_initializer import weights_init
+
+_CONV_IDX = (0, 4, 7, 11, 14)
+_BN_IDX = (1, 5, 8, 12, 15)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DecentralPlannerNet(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.S = None
+        self.numAgents = self.config.num_agents
+
+        inW = inH = 11
+        numAction = 5
+        numChannel = [3] + [32, 32, 64, 64, 128]
+        numStride = [1, 1, 1, 1, 1]
+        dimCompressMLP = 1
+        numCompressFeatures = [2 ** 7]
+        nMaxPoolFilterTaps = 2
+        numMaxPoolStride = 2
+        dimNodeSignals = [2 ** 7]
+        nGraphFilterTaps = [self.config.nGraphFilterTaps]
+        numActionFeatures = [numAction]
+
+        # ---- CNN (parameter container; layout fixed by the fused kernel) ----
+        layers = []
+        w, h = inW, inH
+        for l in range(len(numChannel) - 1):
+            layers.append(nn.Conv2d(numChannel[l], numChannel[l + 1], kernel_size=3,
+                                    stride=numStride[l], padding=1, bias=True))
+            layers.append(nn.BatchNorm2d(numChannel[l + 1]))
+            layers.append(nn.ReLU(inplace=True))
+            if l % 2 == 0:
+                layers.append(nn.MaxPool2d(kernel_size=2))
+                w = (w - nMaxPoolFilterTaps) // numMaxPoolStride + 1
+                h = (h - nMaxPoolFilterTaps) // numMaxPoolStride + 1
+        self.ConvLayers = nn.Sequential(*layers)
+        numFeatureMap = numChannel[-1] * w * h
+        assert numFeatureMap == 128
+
+        numCompressFeatures = [numFeatureMap] + numCompressFeatures
+        mlp = []
+        for l in range(dimCompressMLP):
+            mlp.append(nn.Linear(numCompressFeatures[l], numCompressFeatures[l + 1], bias=True))
+            mlp.append(nn.ReLU(inplace=True))
+        self.compressMLP = nn.Sequential(*mlp)
+        self.numFeatures2Share = numCompressFeatures[-1]
+
+        # ---- graph filter layers ----
+        self.L = len(nGraphFilterTaps)
+        self.F = [numCompressFeatures[-1]] + dimNodeSignals
+        self.K = nGraphFilterTaps
+        self.E = 1
+        self.bias = True
+        gfl = []
+        for l in range(self.L):
+            gfl.append(gml.GraphFilterBatch(self.F[l], self.F[l + 1], self.K[l], self.E, self.bias))
+            gfl.append(nn.ReLU(inplace=True))
+        self.GFL = nn.Sequential(*gfl)
+
+        # ---- action head ----
+        numActionFeatures = [self.F[-1]] + numActionFeatures
+        self.actionsMLP = nn.Sequential(nn.Linear(numActionFeatures[0], numActionFeatures[1],
+                                                  bias=True))
+        self.apply(weights_init)
+        self._enc_cache = _native.PackCache()
+
+    # ------------------------------------------------------------------------------------
+    def addGSO(self, S):
+        # B x N x N, or B x E x N x N when E > 1 (decentralplanner.py:266-276)
+        if self.E == 1:
+            assert len(S.shape) == 3
+            self.S = S.unsqueeze(1)
+        else:
+            assert len(S.shape) == 4
+            assert S.shape[1] == self.E
+            self.S = S
+
+    def _encoder_tensors(self):
+        t = []
+        for ci, bi in zip(_CONV_IDX, _BN_IDX):
+            conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
+            t += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        t += [self.compressMLP[0].weight, self.compressMLP[0].bias]
+        return t
+
+    def _pack_encoder(self):
+        L = _native.lib()
+        ts = [x.detach().contiguous().float() for x in self._encoder_tensors()]
+        dev = _native.require_gpu(*ts)
+        p = _native.EncoderParams()
+        for i in range(5):
+            cw, cb, bw, bb, bm, bv = ts[6 * i:6 * i + 6]
+            p.conv_w[i], p.conv_b[i] = cw.data_ptr(), cb.data_ptr()
+            p.bn_w[i], p.bn_b[i] = bw.data_ptr(), bb.data_ptr()
+            p.bn_mean[i], p.bn_var[i] = bm.data_ptr(), bv.data_ptr()
+        p.fc_w, p.fc_b = ts[30].data_ptr(), ts[31].data_ptr()
+        p.bn_eps = float(self.ConvLayers[_BN_IDX[0]].eps)
+        packed = torch.empty(L.gnnpp_encoder_packed_floats(), dtype=torch.float32, device=dev)
+        with _native.device_guard(dev):
+            _native.check(L.gnnpp_encoder_pack(ctypes.byref(p), _ptr(packed),
+                                               _native.stream_ptr(dev)), 'gnnpp_encoder_pack')
+        return packed
+
+    def packed_encoder(self):
+        return self._enc_cache.get(self._encoder_tensors(), self._pack_encoder)
+
+    def encode(self, inputTensor):
+        """extractFeatureMap of the reference (decentralplanner.py:283-290), node-major:
+        inputTensor [B,N,3,11,11] -> [B,N,128]."""
+        B, N = inputTensor.shape[0], inputTensor.shape[1]
+        obs = inputTensor.detach().contiguous().float()
+        dev = _native.require_gpu(obs, self.compressMLP[0].weight)
+        feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)
+        with _native.device_guard(dev):
+            _native.check(_native.lib().gnnpp_encoder_fwd(
+                _ptr(obs), _ptr(self.packed_encoder()), _ptr(feat), B * N,
+                _native.stream_ptr(dev)), 'gnnpp_encoder_fwd')
+        return feat
+
+    def forward_logits(self, inputTensor):
+        """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
+        contiguous [B,5] block) -- what forward() unbinds into the reference's list."""
+        if self.training:
+            raise NotImplementedError(
+                'train-mode forward (per-agent BatchNorm batch statistics + backward) is not '
+                'implemented in this round; call .eval() -- see DESIGN.md "out of scope"')
+        if self.S is None:
+            raise TypeError('addGSO() must be called before forward()')
+        assert self.L == 1 and self.E == 1
+        B = inputTensor.shape[0]
+        N = self.numAgents
+        assert inputTensor.shape[1] >= N
+        obs = inputTensor.detach()
+        if obs.shape[1] != N:
+            obs = obs[:, :N]                      # the reference only visits the first numAgents
+        obs = obs.contiguous().float()
+        S = self.S.detach()
+        assert S.shape[0] == B
+        Ns = S.shape[2]
+        assert Ns >= N                            # Nin <= N zero padding (graphML.py:2464-2469)
+        S = S.contiguous()
+        if S.dtype not in (torch.float32, torch.float64):
+            S = S.float()
+        gf = self.GFL[0]
+        act = self.actionsMLP[0]
+        dev = _native.require_gpu(obs, S, gf.weight, act.weight)
+        if Ns > gml.MAX_NODES:
+            raise _native.GnnppError('graphs with N=%d > %d nodes are not supported yet'
+                                     % (Ns, gml.MAX_NODES))
+        L = _native.lib()
+        enc = self.packed_encoder()
+        taps = gf.packed_taps()
+        gbias = gf.bias.detach().reshape(-1) if gf.bias is not None else None
+        with _native.device_guard(dev):
+            st = _native.stream_ptr(dev)
+            if Ns == N:
+                ws = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
+                logits = torch.empty(N, B, 5, dtype=torch.float32, device=dev)
+                rc = L.gnnpp_policy_fwd(_ptr(obs), _ptr(S), _ptr(enc), _ptr(taps), _ptr(gbias),
+                                        _ptr(act.weight.detach()), _ptr(act.bias.detach()),
+                                        _ptr(ws), _ptr(logits), B, N, gf.K,
+                                        int(S.dtype == torch.float64), st)
+                _native.check(rc, 'gnnpp_policy_fwd')
+                return logits
+            # GSO larger than numAgents: missing nodes carry zero features, extra outputs dropped
+            feat = torch.zeros(B, Ns, 128, dtype=torch.float32, device=dev)
+            feat[:, :N] = self.encode(obs)
+            y = torch.empty(B, Ns, 128, dtype=torch.float32, device=dev)
+            rc = L.gnnpp_lsigf_fwd(_ptr(feat), _ptr(S), _ptr(taps), _ptr(gbias), _ptr(y), B, Ns, Ns,
+                                   128, 128, gf.K, 1, int(S.dtype == torch.float64), 1, 1, 1, 1, st)
+            _native.check(rc, 'gnnpp_lsigf_fwd')
+        out = torch.nn.functional.linear(y[:, :N], act.weight.detach(), act.bias.detach())
+        return out.permute(1, 0, 2).contiguous()
+
+    def forward(self, inputTensor):
+        """[B,N,3,11,11] -> python list of N tensors [B,5] (decentralplanner.py:278-318)."""
+        return list(self.forward_logits(inputTensor).unbind(0))
+
+    def decode_actions(self, logits):
+        """logits [N,B,5] (from forward_logits) -> int32 [B,N] action ids: argmax of the
+        LogSoftmax the simulator applies (utils/multirobotsim_dcenlocal.py:589-591)."""
+        N, B = logits.shape[0], logits.shape[1]
+        dev = _native.require_gpu(logits)
+        acts = torch.empty(B, N, dtype=torch.int32, device=dev)
+        with _native.device_guard(dev):
+            _native.check(_native.lib().gnnpp_decode_actions(
+                _ptr(logits.contiguous()), _ptr(acts), B, N, _native.stream_ptr(dev)),
+                'gnnpp_decode_actions')
+        return acts

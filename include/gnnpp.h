@@ -1,0 +1,128 @@
+/*
+ * gnnpp.h -- C ABI of libgnnpp.so: the MI355X (gfx950) implementation of the GNN policy forward
+ * pass of proroklab/gnn_pathplanning (DecentralPlannerNet + GraphFilter / GraphFilterBatch).
+ *
+ * The reference has no FFI for this path (it is 100 % stock aten calls); the entry points below
+ * are what a binding of the reference's Python call sites needs.  Every function cites the
+ * reference interface it replaces (paths relative to the upstream repo root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked "host"; the caller owns every buffer;
+ *     inputs are never written;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only
+ *     enqueues work on that stream and returns without synchronising;
+ *   - return value 0 = success, negative = error (gnnpp_error_string()); a failed call has
+ *     enqueued nothing;
+ *   - fp32 everywhere; a GSO may be given as fp64 and is rounded to fp32 on load exactly like the
+ *     reference's `S.float()` (utils/graphUtils/graphML.py:2350).
+ */
+#ifndef GNNPP_H_
+#define GNNPP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNPP_OK               0
+#define GNNPP_ERR_ARG         (-1)   /* null pointer / non-positive size / inconsistent flags   */
+#define GNNPP_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels cover (see each call)     */
+#define GNNPP_ERR_LAUNCH      (-3)   /* HIP launch error                                         */
+
+#define GNNPP_OBS_C        3         /* observation channels      (decentralplanner.py:89)       */
+#define GNNPP_OBS_HW       11        /* observation height=width  (decentralplanner.py:22-23)    */
+#define GNNPP_FEAT         128       /* numFeatures2Share         (decentralplanner.py:93,197)   */
+#define GNNPP_ACTIONS      5         /* numAction                 (decentralplanner.py:27)       */
+#define GNNPP_MAX_NODES    100       /* largest N one workgroup holds in LDS with G=F=128        */
+
+int         gnnpp_version(void);
+const char* gnnpp_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph filter (LSIGF):  y = bias + sum_e sum_k W[:,e,k,:] . (x S_e^k),   z_k = z_{k-1} S (right
+ * multiplication: node n gathers from the non-zeros of COLUMN n of S).
+ * Replaces LSIGF (utils/graphUtils/graphML.py:48-141) and BatchLSIGF (:2273-2367), and with them
+ * GraphFilter.forward (:1200-1219) / GraphFilterBatch.forward (:2458-2477).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Number of floats of the MFMA-fragment-ordered copy of the filter taps h[F,E,K,G]. */
+size_t gnnpp_filter_packed_floats(int G, int F, int K, int E);
+
+/* Re-order h[F,E,K,G] (the nn.Parameter `weight`, graphML.py:1175 / :2434) into `packed`.
+ * Call again whenever the parameter changes (load_state_dict, optimizer step). */
+int gnnpp_filter_pack(const float* h, float* packed, int G, int F, int K, int E, void* stream);
+
+/*
+ * x        [B,G,Nin] feature-major (the module API, graphML.py:2459) when x_node_major == 0,
+ *          [B,N,G]   node-major when x_node_major == 1 (requires Nin == N);
+ * S        [B,E,N,N] when s_batched == 1 (BatchLSIGF), [E,N,N] when 0 (LSIGF, shared by the batch);
+ *          element type double when s_is_f64 != 0, else float;
+ * packed   from gnnpp_filter_pack;  bias [F] or NULL (graphML.py:139-140 / :2365-2366);
+ * y        [B,F,Nin] when y_node_major == 0, [B,N,F] when 1;
+ * Nin <= N: nodes Nin..N-1 of x are zero and the corresponding outputs are dropped
+ *          (zero padding + index_select of graphML.py:1206-1218 / :2464-2476);
+ * relu     apply max(.,0) to y (GFL[1], decentralplanner.py:221).
+ * Limits:  1 <= N <= GNNPP_MAX_NODES at G,F <= 128 (LDS footprint); K >= 1.
+ */
+int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const float* bias,
+                    float* y, int B, int N, int Nin, int G, int F, int K, int E,
+                    int s_is_f64, int s_batched, int x_node_major, int y_node_major, int relu,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-agent encoder: 5 x (conv3x3 pad 1 -> BatchNorm(eval) -> ReLU [-> MaxPool 2]) -> flatten ->
+ * Linear(128,128) -> ReLU.  Replaces ConvLayers + compressMLP as run by
+ * DecentralPlannerNet.forward (graphs/models/decentralplanner.py:284-290; layers :155-195).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Raw parameters in the reference's state_dict layout. */
+typedef struct gnnpp_encoder_params {
+    const float* conv_w[5];     /* ConvLayers.{0,4,7,11,14}.weight  [Cout,Cin,3,3]             */
+    const float* conv_b[5];     /* ConvLayers.{0,4,7,11,14}.bias    [Cout]                     */
+    const float* bn_w[5];       /* ConvLayers.{1,5,8,12,15}.weight  [Cout]                     */
+    const float* bn_b[5];       /* ...bias                                                      */
+    const float* bn_mean[5];    /* ...running_mean                                              */
+    const float* bn_var[5];     /* ...running_var                                               */
+    const float* fc_w;          /* compressMLP.0.weight [128,128]                               */
+    const float* fc_b;          /* compressMLP.0.bias   [128]                                   */
+    float        bn_eps;        /* 1e-5 (torch default, decentralplanner.py:163)                */
+} gnnpp_encoder_params;
+
+size_t gnnpp_encoder_packed_floats(void);
+
+/* Fold eval-mode BatchNorm into a per-channel scale/shift and re-order all weights into MFMA
+ * fragment order.  `params` is a HOST struct of DEVICE pointers. */
+int gnnpp_encoder_pack(const gnnpp_encoder_params* params, float* packed, void* stream);
+
+/* obs [M,3,11,11] (M = B*N agents, agent index b*N+n as in inputTensor[B,N,3,11,11]) ->
+ * feat [M,128] node-major.  Any M >= 1. */
+int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole policy step: DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318):
+ * encoder -> GraphFilterBatch(128,128,K,E=1) -> ReLU -> actionsMLP Linear(128,5).
+ * ------------------------------------------------------------------------------------------ */
+/*
+ * obs      [B,N,3,11,11];  S [B,N,N] float or double (s_is_f64);
+ * enc_packed / filt_packed from the two pack calls; gf_bias [128] (GFL.0.bias), act_w [5,128],
+ * act_b [5] (actionsMLP.0.*);
+ * feat_ws  workspace [B*N,128] (receives the encoder output, i.e. extractFeatureMap in
+ *          node-major order);
+ * logits   [N,B,5]: logits + n*B*5 is the contiguous [B,5] tensor of agent n, the n-th element
+ *          of the list the reference returns (decentralplanner.py:303-318).
+ */
+int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
+                     const float* filt_packed, const float* gf_bias, const float* act_w,
+                     const float* act_b, float* feat_ws, float* logits, int B, int N, int K,
+                     int s_is_f64, void* stream);
+
+/* Action decode used by the rollout loop (utils/multirobotsim_dcenlocal.py:589-591: LogSoftmax
+ * then argmax == argmax of the logits, first maximum wins like torch.max).
+ * logits [N,B,5] -> actions [B,N] int32. */
+int gnnpp_decode_actions(const float* logits, int* actions, int B, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNPP_H_ */

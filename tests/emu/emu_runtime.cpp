@@ -1,0 +1,184 @@
+// TEST INFRASTRUCTURE ONLY -- fiber scheduler + wavefront collectives for tests/emu/hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace gnnpp {
+alignas(16) char gnnpp_smem[160 * 1024];   // the kernels' `extern __shared__ char gnnpp_smem[]`
+}
+
+extern "C" void gnnpp_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl gnnpp_emu_switch
+.type gnnpp_emu_switch,@function
+gnnpp_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
+namespace gnnpp_emu {
+
+Item* cur = nullptr;
+
+namespace {
+constexpr size_t kStack = 512 * 1024;
+struct Fiber {
+    Item item;
+    void* sp = nullptr;
+    char* stack = nullptr;
+    bool done = false;
+    int wave = 0, lane = 0;
+};
+struct Wave {
+    int arrived = 0;
+    unsigned gen = 0;
+    int n = 0;                     // lanes in this wave
+    float a[64], b[64];
+    int iv[64];
+};
+std::vector<Fiber> fibers;
+std::vector<Wave> waves;
+void* sched_sp = nullptr;
+int cur_idx = -1;
+int block_arrived = 0;
+unsigned block_gen = 0;
+const std::function<void()>* body_fn = nullptr;
+
+void yield() { gnnpp_emu_switch(&fibers[cur_idx].sp, sched_sp); }
+
+void trampoline() {
+    (*body_fn)();
+    fibers[cur_idx].done = true;
+    yield();
+    std::abort();
+}
+
+void wave_barrier() {
+    Wave& w = waves[fibers[cur_idx].wave];
+    const unsigned g = w.gen;
+    if (++w.arrived == w.n) {
+        w.arrived = 0;
+        ++w.gen;
+    } else {
+        while (w.gen == g) yield();
+    }
+}
+}  // namespace
+
+void sync_block() {
+    const unsigned g = block_gen;
+    if (++block_arrived == (int)fibers.size()) {
+        block_arrived = 0;
+        ++block_gen;
+    } else {
+        while (block_gen == g) yield();
+    }
+}
+
+unsigned long long ballot(int pred) {
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    w.iv[f.lane] = pred;
+    wave_barrier();
+    unsigned long long m = 0;
+    for (int l = 0; l < w.n; ++l)
+        if (w.iv[l]) m |= 1ull << l;
+    wave_barrier();
+    return m;
+}
+
+int readlane(int v, int src) {
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    w.iv[f.lane] = v;
+    wave_barrier();
+    const int r = w.iv[src];
+    wave_barrier();
+    return r;
+}
+
+f4 mfma16x16x4(float a, float b, f4 c, int, int, int) {
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    if (w.n != 64) { std::fprintf(stderr, "emu: MFMA needs a full wave\n"); std::abort(); }
+    w.a[f.lane] = a;
+    w.b[f.lane] = b;
+    wave_barrier();
+    const int j = f.lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = (f.lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fmaf(w.a[i + 16 * k], w.b[j + 16 * k], acc);
+        c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    const int nt = (int)block.x;
+    static char* arena = nullptr;
+    static size_t arena_sz = 0;
+    if (arena_sz < (size_t)nt * kStack) {
+        arena_sz = (size_t)nt * kStack;
+        arena = (char*)mmap(nullptr, arena_sz, PROT_READ | PROT_WRITE,
+                            MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (arena == MAP_FAILED) { std::perror("mmap"); std::abort(); }
+    }
+    body_fn = &body;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        fibers.assign(nt, Fiber());
+        waves.assign((nt + 63) / 64, Wave());
+        block_arrived = 0;
+        block_gen = 0;
+        for (int t = 0; t < nt; ++t) {
+            Fiber& f = fibers[t];
+            f.item.tid = dim3(t);
+            f.item.bid = dim3(b);
+            f.item.bdim = block;
+            f.item.gdim = grid;
+            f.wave = t / 64;
+            f.lane = t % 64;
+            waves[f.wave].n++;
+            f.stack = arena + (size_t)t * kStack;
+            uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+            void** sp = (void**)top;
+            *--sp = nullptr;                       // fake return address of trampoline
+            *--sp = (void*)&trampoline;            // `ret` target of the first switch
+            for (int r = 0; r < 6; ++r) *--sp = nullptr;
+            f.sp = sp;
+        }
+        int live = nt;
+        while (live > 0) {
+            for (int t = 0; t < nt; ++t) {
+                if (fibers[t].done) continue;
+                cur_idx = t;
+                cur = &fibers[t].item;
+                gnnpp_emu_switch(&sched_sp, fibers[t].sp);
+                if (fibers[t].done) --live;
+            }
+        }
+    }
+    cur = nullptr;
+    cur_idx = -1;
+}
+
+}  // namespace gnnpp_emu

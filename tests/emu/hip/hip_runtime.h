@@ -1,0 +1,73 @@
+// TEST INFRASTRUCTURE ONLY -- a stand-in for <hip/hip_runtime.h> that lets the UNMODIFIED kernel
+// sources under gnn_pathplanning_amd/csrc/ be compiled for the x86 host and executed lane by lane
+// (one fiber per work-item, 64-lane wavefronts, emulated MFMA / ballot / readlane, real LDS
+// semantics).  It exists so that MFMA fragment layouts, LDS indexing, tap skipping and epilogues
+// can be checked against the oracle in the CPU-only build container, where no GPU is visible.
+// It is ~10^4 x slower than the GPU, is never shipped, and nothing under gnn_pathplanning_amd/
+// can load it: it is NOT a fallback path.
+//
+// Lane mappings of v_mfma_f32_16x16x4_f32 as documented for gfx950:
+//   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
+//   D: register r of lane l is D[i = (l >> 4) * 4 + r][j = l & 15].
+#ifndef GNNPP_EMU_HIP_RUNTIME_H_
+#define GNNPP_EMU_HIP_RUNTIME_H_
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+namespace gnnpp_emu {
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct Item {                      // per-fiber identity
+    dim3 tid, bid, bdim, gdim;
+};
+extern Item* cur;                  // the running fiber
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+unsigned long long ballot(int pred);
+int readlane(int v, int src_lane);
+f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
+}  // namespace gnnpp_emu
+
+#define threadIdx (gnnpp_emu::cur->tid)
+#define blockIdx (gnnpp_emu::cur->bid)
+#define blockDim (gnnpp_emu::cur->bdim)
+#define gridDim (gnnpp_emu::cur->gdim)
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    gnnpp_emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+#define __syncthreads() gnnpp_emu::sync_block()
+#define __ballot(p) gnnpp_emu::ballot((p) ? 1 : 0)
+#define __ffsll(x) __builtin_ffsll(x)
+#define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
+
+inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+inline int __float_as_int(float f) { int v; std::memcpy(&v, &f, 4); return v; }
+using std::min;
+using std::max;
+
+#endif

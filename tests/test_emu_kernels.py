@@ -1,0 +1,92 @@
+"""CPU: run the UNMODIFIED HIP kernel sources through the lane-accurate host emulation in
+tests/emu/ (one fiber per work-item, emulated 16x16x4 fp32 MFMA / ballot / readlane, real LDS)
+and compare with the golden vectors from the reference.  This checks fragment layouts, LDS
+indexing, tap skipping, BN folding, pooling and both output layouts without a GPU.  The `-m gpu`
+tests repeat the same comparisons on the real hardware through the real libgnnpp.so."""
+import ctypes
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+
+pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/lib/llvm/bin/clang++'),
+                                reason='host clang++ from ROCm not present')
+
+TOL = 1e-4      # the north_star's fp32 logit tolerance; observed ~1e-6
+
+
+@pytest.fixture(scope='module')
+def emu():
+    import emu_lib
+    return emu_lib, emu_lib.load()
+
+
+def test_emu_lsigf_golden(emu, lsigf_golden):
+    el, lib = emu
+    z, meta = lsigf_golden
+    ran = 0
+    for i, m in enumerate(meta):
+        h, S, x = z['c%d_h' % i], z['c%d_S' % i], z['c%d_x' % i]
+        if m['G'] > 32 and S.shape[-1] > 10:
+            continue                      # keep the emulated run short; GPU tests cover all
+        b = z['c%d_b' % i] if m['has_bias'] else None
+        batched = m['kind'] in ('BatchLSIGF', 'GraphFilterBatch')
+        y = el.lsigf(lib, h, S, x, b, batched, Nin=m.get('Nin'))
+        want = z['c%d_y' % i]
+        assert y.shape == want.shape
+        err = np.abs(y - want).max()
+        assert err <= TOL * max(1.0, np.abs(want).max()), (i, m, err)
+        ran += 1
+    assert ran >= 30
+
+
+def test_emu_lsigf_node_major_relu(emu, lsigf_golden):
+    el, lib = emu
+    z, meta = lsigf_golden
+    i = next(i for i, m in enumerate(meta) if m['kind'] == 'BatchLSIGF' and m['K'] == 3
+             and z['c%d_S' % i].shape[-1] == 10)
+    h, S, x, want = z['c%d_h' % i], z['c%d_S' % i], z['c%d_x' % i], z['c%d_y' % i]
+    b = z['c%d_b' % i] if meta[i]['has_bias'] else None
+    y = el.lsigf(lib, h, S, np.ascontiguousarray(x.transpose(0, 2, 1)), b, True, relu=1,
+                 x_node_major=1, y_node_major=1)
+    assert np.abs(y.transpose(0, 2, 1) - np.maximum(want, 0)).max() <= TOL
+
+
+def test_emu_policy_golden(emu, policy_golden):
+    el, lib = emu
+    z, meta = policy_golden
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    enc = el.pack_encoder(lib, sd)
+    for i, m in enumerate(meta):
+        if m['N'] > 10:
+            continue
+        B, N, K = m['B'], m['N'], m['K']
+        obs = el.f32(z['p%d_obs' % i])
+        feat = np.full((B * N, 128), np.nan, dtype=np.float32)
+        assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), B * N, None) == 0
+        want_feat = z['p%d_feat' % i].transpose(0, 2, 1).reshape(B * N, 128)
+        assert np.abs(feat - want_feat).max() <= TOL, (i, m)
+        # whole policy step through the single C entry point
+        gw = z['sd/GFL.0.weight'] if K == 3 else z['gfl_w_K%d' % K]
+        filt = el.pack_filter(lib, gw)
+        S = np.ascontiguousarray(z['p%d_S' % i])
+        is64 = int(S.dtype == np.float64)
+        logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+        ws = np.zeros((B * N, 128), dtype=np.float32)
+        gb = el.f32(sd['GFL.0.bias'].reshape(-1))
+        aw, ab = el.f32(sd['actionsMLP.0.weight']), el.f32(sd['actionsMLP.0.bias'])
+        rc = lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb),
+                                  el.ptr(aw), el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K,
+                                  is64, None)
+        assert rc == 0
+        want = z['p%d_logits' % i]                         # [B,N,5]
+        got = logits.transpose(1, 0, 2)
+        assert np.abs(got - want).max() <= TOL, (i, m, np.abs(got - want).max())
+        assert (got.argmax(-1) == want.argmax(-1)).all()
+        acts = np.full((B, N), -1, dtype=np.int32)
+        assert lib.gnnpp_decode_actions(el.ptr(logits), el.ptr(acts), B, N, None) == 0
+        assert (acts == want.argmax(-1)).all()

@@ -1,0 +1,243 @@
+"""GPU parity tests (run with -m gpu on the MI355X): the HIP path, called through the C ABI via
+the reference-shaped Python modules, against (i) the golden vectors produced by the real
+reference and (ii) the CPU oracle on seeded inputs at the BASELINE.json sizes.
+
+Tolerances (north_star): logits / filter outputs within 1e-4 absolute (fp32), action argmax
+bit-exact on every row whose oracle top-2 margin exceeds 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict
+from oracle import policy_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    from gnn_pathplanning_amd import _native
+    _native.lib()                      # fail loudly if libgnnpp.so is missing
+    return torch.device('cuda:0')
+
+
+class Cfg:
+    def __init__(self, n, k, device):
+        self.num_agents, self.nGraphFilterTaps, self.device = n, k, device
+
+
+def _net(n, k, dev, sd):
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    net = DecentralPlannerNet(Cfg(n, k, dev)).to(dev).eval()
+    net.load_state_dict(sd)
+    return net
+
+
+def test_lsigf_golden_all_cases(dev, lsigf_golden):
+    import gnn_pathplanning_amd.graphML as gml
+    z, meta = lsigf_golden
+    for i, m in enumerate(meta):
+        h = torch.from_numpy(z['c%d_h' % i]).to(dev)
+        S = torch.from_numpy(z['c%d_S' % i]).to(dev)
+        x = torch.from_numpy(z['c%d_x' % i]).to(dev)
+        b = torch.from_numpy(z['c%d_b' % i]).to(dev) if m['has_bias'] else None
+        want = z['c%d_y' % i]
+        if m['kind'] == 'LSIGF':
+            y = gml.LSIGF(h, S, x, b)
+        elif m['kind'] == 'BatchLSIGF':
+            y = gml.BatchLSIGF(h, S, x, b)
+        else:
+            cls = gml.GraphFilter if m['kind'] == 'GraphFilter' else gml.GraphFilterBatch
+            mod = cls(m['G'], m['F'], m['K'], m['E'], True).to(dev)
+            with torch.no_grad():
+                mod.weight.copy_(h)
+                mod.bias.copy_(b)
+            mod.addGSO(S)
+            y = mod(x)
+        assert tuple(y.shape) == want.shape, (i, m)
+        err = np.abs(y.cpu().numpy() - want).max()
+        assert err <= TOL * max(1.0, np.abs(want).max()), (i, m, err)
+
+
+def test_policy_golden(dev, policy_golden):
+    z, meta = policy_golden
+    for i, m in enumerate(meta):
+        sd = golden_state_dict(z, m['K'])
+        net = _net(m['N'], m['K'], dev, sd)
+        obs = torch.from_numpy(z['p%d_obs' % i]).to(dev)
+        S = torch.from_numpy(z['p%d_S' % i]).to(dev)
+        net.addGSO(S)
+        out = net(obs)
+        assert isinstance(out, list) and len(out) == m['N'] and out[0].shape == (m['B'], 5)
+        assert all(o.is_contiguous() for o in out)
+        got = torch.stack(out, 1).cpu().numpy()
+        want = z['p%d_logits' % i]
+        assert np.abs(got - want).max() <= TOL, (i, m, np.abs(got - want).max())
+        assert (got.argmax(-1) == want.argmax(-1)).all()
+        feat = net.encode(obs).cpu().numpy()            # [B,N,128]
+        assert np.abs(feat - z['p%d_feat' % i].transpose(0, 2, 1)).max() <= TOL
+        acts = net.decode_actions(net.forward_logits(obs)).cpu().numpy()
+        assert (acts == want.argmax(-1)).all()
+
+
+@pytest.mark.parametrize('B,N,K,W', [(1, 10, 3, 20), (512, 10, 3, 20), (256, 50, 3, 50),
+                                     (128, 100, 2, 100), (128, 100, 3, 100), (128, 100, 4, 100),
+                                     (37, 7, 3, 12), (5, 64, 3, 40)])
+def test_policy_vs_oracle_baseline_sizes(dev, B, N, K, W):
+    sd = orc.init_state_dict(K, seed=1337 + K)
+    net = _net(N, K, dev, sd)
+    obs = orc.synth_obs(B, N, seed=B + N)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=N + K))     # fp64 like the simulator
+    with torch.no_grad():
+        want = orc.policy_forward(sd, S, obs)
+    net.addGSO(S.to(dev))
+    got = [g.cpu() for g in net(obs.to(dev))]
+    err = max((g - w).abs().max().item() for g, w in zip(got, want))
+    assert err <= TOL, err
+    margin = orc.top2_margin(want)
+    ids_want = orc.decode_actions(want)
+    ids_got = torch.stack([g.argmax(-1) for g in got], 1)
+    clear = margin > 1e-5
+    assert torch.equal(ids_got[clear], ids_want[clear])
+    assert clear.float().mean() > 0.99
+    # fp32 GSO (training-style input) gives the same answer as the fp64 one rounded on load
+    net.addGSO(S.float().to(dev))
+    got32 = [g.cpu() for g in net(obs.to(dev))]
+    assert max((a - b).abs().max().item() for a, b in zip(got, got32)) <= 1e-6
+
+
+@pytest.mark.parametrize('B,N,K', [(512, 10, 3), (256, 50, 3), (128, 100, 4)])
+def test_filter_vs_oracle_asymmetric_gso(dev, B, N, K):
+    import gnn_pathplanning_amd.graphML as gml
+    g = torch.Generator().manual_seed(B + N + K)
+    h = (torch.rand(128, 1, K, 128, generator=g) * 2 - 1) / (128 * K) ** 0.5
+    b = torch.randn(128, 1, generator=g) * 0.1
+    x = orc.synth_features(B, 128, N, seed=N)
+    S = orc.synth_gso_sparse(B, N, {10: 3.45, 50: 6.6, 100: 8.4}[N], seed=K).unsqueeze(1)
+    want = orc.batch_lsigf(h, S, x, b)
+    y = gml.BatchLSIGF(h.to(dev), S.to(dev), x.to(dev), b.to(dev)).cpu()
+    scale = max(1.0, want.abs().max().item())
+    assert (y - want).abs().max().item() <= TOL * scale
+    # the transposed GSO must give a DIFFERENT answer (column gather, not row gather)
+    yT = gml.BatchLSIGF(h.to(dev), S.transpose(2, 3).contiguous().to(dev), x.to(dev), b.to(dev)).cpu()
+    assert (yT - want).abs().max().item() > 1e-2
+
+
+def test_filter_algebra_properties(dev):
+    import gnn_pathplanning_amd.graphML as gml
+    g = torch.Generator().manual_seed(99)
+    B, G, F_out, N = 6, 128, 128, 10
+    x = torch.randn(B, G, N, generator=g).to(dev)
+    S = orc.synth_gso_sparse(B, N, 3.0, seed=1).unsqueeze(1).to(dev)
+    h = (torch.randn(F_out, 1, 3, G, generator=g) / 20).to(dev)
+    # K = 1: pure per-node linear map, GSO irrelevant
+    y1 = gml.BatchLSIGF(h[:, :, :1].contiguous(), S, x)
+    ref1 = torch.einsum('fg,bgn->bfn', h[:, 0, 0].cpu(), x.cpu())
+    assert (y1.cpu() - ref1).abs().max() <= TOL
+    # S = 0: only tap 0 survives
+    y0 = gml.BatchLSIGF(h, torch.zeros_like(S), x)
+    assert (y0.cpu() - ref1).abs().max() <= TOL
+    # linearity in x
+    x2 = torch.randn(B, G, N, generator=g).to(dev)
+    ya, yb, yab = gml.BatchLSIGF(h, S, x), gml.BatchLSIGF(h, S, x2), gml.BatchLSIGF(h, S, x + x2)
+    assert (ya + yb - yab).abs().max().item() <= 5e-5
+    # permutation equivariance: relabel the nodes of every graph
+    perm = torch.randperm(N, generator=g).to(dev)
+    Sp = S[:, :, perm][:, :, :, perm].contiguous()
+    yp = gml.BatchLSIGF(h, Sp, x[:, :, perm].contiguous())
+    assert (yp - ya[:, :, perm]).abs().max().item() <= 5e-5
+    # shared-GSO LSIGF == BatchLSIGF with the GSO repeated
+    S1 = S[0]
+    yl = gml.LSIGF(h, S1, x)
+    yb2 = gml.BatchLSIGF(h, S1.unsqueeze(0).repeat(B, 1, 1, 1), x)
+    assert (yl - yb2).abs().max().item() <= 1e-6
+
+
+def test_encoder_ragged_tiles(dev):
+    """M = B*N not a multiple of the 16-agent tile, including a single agent."""
+    sd = orc.init_state_dict(3, seed=3)
+    for B, N in ((1, 1), (1, 17), (3, 11), (2, 16)):
+        net = _net(N, 3, dev, sd)
+        obs = orc.synth_obs(B, N, seed=B * 31 + N)
+        want = orc.policy_features(sd, obs).permute(0, 2, 1)
+        got = net.encode(obs.to(dev)).cpu()
+        assert (got - want).abs().max().item() <= TOL, (B, N)
+
+
+def test_non_binary_observations(dev):
+    """The kernel must not assume {0,1} inputs."""
+    sd = orc.init_state_dict(3, seed=5)
+    net = _net(4, 3, dev, sd)
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randn(3, 4, 3, 11, 11, generator=g)
+    want = orc.policy_features(sd, obs).permute(0, 2, 1)
+    got = net.encode(obs.to(dev)).cpu()
+    assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+
+
+def test_state_dict_roundtrip_and_cache_invalidation(dev, policy_golden):
+    z, meta = policy_golden
+    sd = golden_state_dict(z, 3)
+    net = _net(10, 3, dev, sd)
+    got_sd = net.state_dict()
+    assert list(got_sd.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.equal(got_sd[k].cpu(), sd[k]), k
+    obs = torch.from_numpy(z['p0_obs']).to(dev)
+    S = torch.from_numpy(z['p0_S']).to(dev)
+    net.addGSO(S)
+    a = torch.stack(net(obs), 1)
+    # in-place parameter update (what an optimizer step or load_state_dict does) must repack
+    sd2 = orc.init_state_dict(3, seed=123)
+    net.load_state_dict(sd2)
+    b = torch.stack(net(obs), 1).cpu()
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd2, S.cpu(), obs.cpu()), 1)
+    assert (b - want).abs().max().item() <= TOL
+    assert (a.cpu() - b).abs().max().item() > 1e-3
+    with torch.no_grad():
+        net.ConvLayers[1].running_mean.add_(0.5)          # a BN buffer change must repack too
+    c = torch.stack(net(obs), 1).cpu()
+    assert (c - b).abs().max().item() > 1e-4
+
+
+def test_gso_larger_than_num_agents(dev):
+    """Nin < N: the reference zero-pads the missing nodes (graphML.py:2464-2476)."""
+    sd = orc.init_state_dict(3, seed=8)
+    net = _net(6, 3, dev, sd)
+    obs = orc.synth_obs(2, 6, seed=1)
+    S = orc.synth_gso_sparse(2, 9, 3.0, seed=2)
+    with torch.no_grad():
+        feat = orc.policy_features(sd, obs)
+        shared = torch.relu(orc.graph_filter_batch(sd['GFL.0.weight'], sd['GFL.0.bias'],
+                                                   S.unsqueeze(1), feat))
+        want = torch.stack([torch.nn.functional.linear(shared[:, :, n], sd['actionsMLP.0.weight'],
+                                                       sd['actionsMLP.0.bias']) for n in range(6)], 1)
+    net.addGSO(S.to(dev))
+    got = torch.stack(net(obs.to(dev)), 1).cpu()
+    assert (got - want).abs().max().item() <= TOL
+
+
+def test_error_conventions(dev):
+    import gnn_pathplanning_amd.graphML as gml
+    from gnn_pathplanning_amd import _native
+    sd = orc.init_state_dict(3)
+    net = _net(10, 3, dev, sd)
+    with pytest.raises(AssertionError):
+        net.addGSO(torch.zeros(2, 1, 10, 10, device=dev))            # must be 3-D when E == 1
+    with pytest.raises(TypeError):
+        _net(10, 3, dev, sd)(torch.zeros(1, 10, 3, 11, 11, device=dev))   # no GSO yet
+    net.addGSO(torch.zeros(1, 10, 10, device=dev))
+    with pytest.raises(_native.GnnppError):
+        net(torch.zeros(1, 10, 3, 11, 11))                          # CPU tensor: no fallback
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 10, 3, 11, 11, device=dev))
+    gf = gml.GraphFilterBatch(8, 8, 2).to(dev)
+    with pytest.raises(AssertionError):
+        gf.addGSO(torch.zeros(10, 10, device=dev))
+    with pytest.raises(RuntimeError):
+        gml.LSIGF(torch.zeros(4, 1, 2, 4, device=dev), torch.zeros(1, 5, 5, device=dev).double(),
+                  torch.zeros(1, 4, 5, device=dev))
