@@ -37,6 +37,42 @@ FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, chip-level parame
 ENC_MACS_PER_AGENT = 1238112 + 16384    # CNN + compress MLP
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pick_cpu_threads(orc, sd, N, K, budget_s=6.0):
+    """Thread count that makes the CPU oracle fastest on a small sample (B=32) of the workload.
+    torch's default (= all logical cores) can be catastrophically oversubscribed on the GPU box."""
+    obs = orc.synth_obs(32, N, seed=1)
+    S = torch.from_numpy(orc.synth_gso_geometric(32, N, 20, seed=1)).float()
+    best_t, best = 1, float('inf')
+    t_begin = time.perf_counter()
+    for t in (1, 2, 4, 8, 16, 32, 64, 128):
+        if t > usable_cores() or time.perf_counter() - t_begin > budget_s:
+            break
+        torch.set_num_threads(t)
+        with torch.no_grad():
+            orc.policy_forward(sd, S, obs)
+            t0 = time.perf_counter()
+            orc.policy_forward(sd, S, obs)
+            dt = time.perf_counter() - t0
+        if dt < best:
+            best_t, best = t, dt
+        elif dt > 2.0 * best:
+            break
+    torch.set_num_threads(best_t)
+    return best_t
+
+
 def policy_flops_per_agent(K, mean_deg):
     return 2.0 * (1238112 + 16384 + K * 128 * 128 + (K - 1) * mean_deg * 128 + 640)
 
@@ -170,7 +206,7 @@ def main():
         result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value / world / 1e12
 
         # parity gate on the bench batch + CPU baseline (bounded sample of the same workload)
-        torch.set_num_threads(os.cpu_count() or 1)
+        threads = pick_cpu_threads(orc, sd, N, K)
         with torch.no_grad():
             want = orc.policy_forward(sd, S_cpu, obs_cpu)
         got = [o.cpu() for o in out]
@@ -184,19 +220,17 @@ def main():
                             'near_tie_rows': int((~clear).sum()), 'rows': int(clear.numel())}
         if not args.no_cpu_baseline:
             with torch.no_grad():
-                for _ in range(2):
-                    orc.policy_forward(sd, S_cpu, obs_cpu)
+                orc.policy_forward(sd, S_cpu, obs_cpu)
                 times = []
                 t_start = time.perf_counter()
-                while (time.perf_counter() - t_start < args.cpu_seconds or len(times) < 3) \
-                        and len(times) < 200:
+                while time.perf_counter() - t_start < args.cpu_seconds and len(times) < 200:
                     t1 = time.perf_counter()
                     orc.policy_forward(sd, S_cpu, obs_cpu)
                     times.append(time.perf_counter() - t1)
             times.sort()
             med = times[len(times) // 2]
             result['cpu_baseline'] = {
-                'value': B * N / med, 'unit': 'agent-steps/s', 'cores': torch.get_num_threads(),
+                'value': B * N / med, 'unit': 'agent-steps/s', 'cores': threads, 'usable_cores': usable_cores(),
                 'kind': 'port',
                 'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
                           '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'

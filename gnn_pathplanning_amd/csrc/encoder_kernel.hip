@@ -8,13 +8,20 @@
 // One workgroup (4 waves) owns a tile of 16 agents and carries them through all six layers with
 // the activations never leaving LDS:
 //
-//   obs   [16][3][13][13]  zero-padded, fp32                        (32.8 KB, buffer A)
-//   L0    3 -> 32  @ 11x11 (only the 10x10 the pool reads) -> pool -> 32 @ 5x5     (buffer B)
-//   L1   32 -> 32  @ 5x5                                                            (buffer A)
-//   L2   32 -> 64  @ 5x5  (only the 4x4 the pool reads)    -> pool -> 64 @ 2x2     (buffer B)
-//   L3   64 -> 64  @ 2x2                                                            (buffer A)
-//   L4   64 -> 128 @ 2x2                                   -> pool -> 128 @ 1x1    (buffer B)
+//   obs   [16][3][12][12]  zero-padded on top/left only, fp32           (27.7 KB, buffer Y)
+//   L0    3 -> 32  @ 11x11 (only the 10x10 the pool reads) -> pool -> 32 @ 5x5     (buffer X)
+//   L1   32 -> 32  @ 5x5                                                            (X, in place)
+//   L2   32 -> 64  @ 5x5  (only the 4x4 the pool reads)    -> pool -> 64 @ 2x2     (X, in place)
+//   L3   64 -> 64  @ 2x2                                                            (X, in place)
+//   L4   64 -> 128 @ 2x2                                   -> pool -> 128 @ 1x1    (X, in place)
 //   FC  128 -> 128 + ReLU  -> feat[agent][128] in HBM (node-major, what the filter kernel reads)
+//
+// A wave holds ALL of its layer outputs in accumulator registers before it stores any of them,
+// so every layer from L1 on runs in place (barrier, then store): LDS per workgroup is
+// 50 KB + 27.7 KB = 78.9 KB and TWO workgroups share a CU (the second hides the first's barrier,
+// staging and weight-latency bubbles, and absorbs the 320-tiles-on-256-CUs tail of config C2).
+// The earlier ping-pong layout (2 x 50 KB, one workgroup per CU) is kept as the INPLACE=false
+// instantiation for A/B measurements (gnnpp_set_tuning).
 //
 // Every layer is an implicit GEMM on the fp32 MFMA 16x16x4 (gnnpp_common.h): output channels on
 // the MFMA i axis (weights = A operand, pre-packed fragments streamed from L2), the 16 agents on
@@ -33,11 +40,16 @@ namespace gnnpp {
 
 constexpr int kTileAgents = 16;
 constexpr int kObsFloats = 3 * 11 * 11;          // 363
-constexpr int kPadHW = 13;
-constexpr int kAgentStride = 513;                // 3*13*13 = 507 -> 513 (== 1 mod 32: bank spread)
+constexpr int kPadHW = 12;                       // 11 + one zero row/column on top/left only:
+                                                 // outputs 0..9 never read below/right of row 10
+constexpr int kAgentStride = 433;                // 3*12*12 = 432 -> 433 (odd: 16 lanes, 16 banks)
 constexpr int kBufFloats = 25 * 2 * 256;         // largest activation: 25 positions x 32 channels
-constexpr size_t kEncSmemBytes = 2 * kBufFloats * sizeof(float);     // 102400
-static_assert(kTileAgents * kAgentStride <= kBufFloats, "padded observation must fit buffer A");
+constexpr int kObsFloatsLds = kTileAgents * kAgentStride;            // 6928 floats = 27712 B
+static_assert(kObsFloatsLds % 4 == 0 && kObsFloatsLds <= kBufFloats, "obs staging buffer");
+template <bool INPLACE>
+constexpr size_t enc_smem_bytes() {
+    return (INPLACE ? (kBufFloats + kObsFloatsLds) : 2 * kBufFloats) * sizeof(float);
+}
 
 // ---- weight packing (device side; inputs are the reference's state_dict tensors) --------------
 struct EncRawParams {
@@ -115,7 +127,7 @@ __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ p
 // PosFn::get(j, y, x) -> is slot j used, and its output coordinates (all constexpr-foldable).
 template <int CIN, int H, int W, int NSLOT, class PosFn>
 __device__ __forceinline__ void conv_tile(const float* __restrict__ wmt,   // [9][NG][64][4]
-                                          const v4f* __restrict__ in,      // [H*W][NG][64]
+                                          const v4f* in,                   // [H*W][NG][64]
                                           v4f (&acc)[NSLOT], int lane) {
     constexpr int NG = CIN / 16;
 #pragma unroll
@@ -178,14 +190,18 @@ __device__ __forceinline__ void load_ss(const float* __restrict__ ss, int cn, in
     sh = *reinterpret_cast<const v4f*>(ss + cn + mt * 16 + q * 4);
 }
 
-__global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restrict__ obs,
-                                                           const float* __restrict__ pk,
-                                                           float* __restrict__ feat, int M) {
+// INPLACE = true : X = activations (all layers in place), Y = observations; 2 workgroups / CU.
+// INPLACE = false: two 50 KB buffers used ping-pong (obs share the first); 1 workgroup / CU.
+template <bool INPLACE>
+__global__ __launch_bounds__(kThreads, INPLACE ? 2 : 1) void encoder_kernel(
+    const float* __restrict__ obs, const float* __restrict__ pk, float* __restrict__ feat, int M) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    float* bufA = reinterpret_cast<float*>(gnnpp_smem);
-    float* bufB = bufA + kBufFloats;
-    v4f* bufA4 = reinterpret_cast<v4f*>(bufA);
-    v4f* bufB4 = reinterpret_cast<v4f*>(bufB);
+    // ping-pong: obs,L1,L3 live in P0 and L0,L2,L4 in P1;  in place: obs in P1(=Y), the rest in P0
+    float* const P0 = reinterpret_cast<float*>(gnnpp_smem);
+    float* const P1 = P0 + kBufFloats;
+    float* const bufObs = INPLACE ? P1 : P0;
+    v4f* const act0 = reinterpret_cast<v4f*>(INPLACE ? P0 : P1);   // L0, L2, L4 outputs
+    v4f* const act1 = reinterpret_cast<v4f*>(P0);                  // L1, L3 outputs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -194,20 +210,19 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
     const int q = lane >> 4;
     const int agent0 = blockIdx.x * kTileAgents;
 
-    // ---- stage the zero-padded observations: bufA[a][c][13][13] --------------------------------
-    for (int i = tid; i < kTileAgents * kAgentStride; i += kThreads) {
+    // ---- stage the observations, zero row/column on top and left: bufObs[a][c][12][12] --------
+    for (int i = tid; i < kObsFloatsLds; i += kThreads) {
         const int ag = i / kAgentStride, rem = i - ag * kAgentStride;
         const int c = rem / (kPadHW * kPadHW), r2 = rem - c * (kPadHW * kPadHW);
         const int yy = r2 / kPadHW, xx = r2 - yy * kPadHW;
         float v = 0.f;
-        if (rem < 3 * kPadHW * kPadHW && yy >= 1 && yy <= 11 && xx >= 1 && xx <= 11 &&
-            agent0 + ag < M)
+        if (rem < 3 * kPadHW * kPadHW && yy >= 1 && xx >= 1 && agent0 + ag < M)
             v = obs[(size_t)(agent0 + ag) * kObsFloats + c * 121 + (yy - 1) * 11 + (xx - 1)];
-        bufA[i] = v;
+        bufObs[i] = v;
     }
     __syncthreads();
 
-    // ---- L0: 3 -> 32 @ 11x11, BN, ReLU, pool -> [25][2][64] v4f in bufB ------------------------
+    // ---- L0: 3 -> 32 @ 11x11, BN, ReLU, pool -> [25][2][64] v4f in act0 ------------------------
     {
         float A0[2][7];
         int offB[7];
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
         load_ss(pk + EncLayout::kSS0, 32, 1, q, sc[1], sh[1]);
         for (int win = wave; win < 25; win += kWaves) {
             const int wy = win / 5, wx = win - wy * 5;
-            const float* base = bufA + (2 * wy) * kPadHW + 2 * wx;
+            const float* base = bufObs + (2 * wy) * kPadHW + 2 * wx;
             v4f acc[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -245,13 +260,13 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
                 v4f m = vrelu(vfma(acc[i][0], sc[i], sh[i]));
 #pragma unroll
                 for (int pp = 1; pp < 4; ++pp) m = vmax(m, vfma(acc[i][pp], sc[i], sh[i]));
-                bufB4[(win * 2 + i) * 64 + lane] = m;
+                act0[(win * 2 + i) * 64 + lane] = m;
             }
         }
     }
     __syncthreads();
 
-    // ---- L1: 32 -> 32 @ 5x5 : bufB -> bufA -----------------------------------------------------
+    // ---- L1: 32 -> 32 @ 5x5 : act0 -> act1 -----------------------------------------------------
     {
         const int mt = wave & 1;
         const float* wmt = pk + EncLayout::kW1 + mt * (9 * 2 * 256);
@@ -260,21 +275,20 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
         v4f acc[13];
 #pragma unroll
         for (int j = 0; j < 13; ++j) acc[j] = vzero();
-        if ((wave >> 1) == 0) {
-            conv_tile<32, 5, 5, 13, PosL1<0>>(wmt, bufB4, acc, lane);
+        const int half = wave >> 1;
+        if (half == 0)
+            conv_tile<32, 5, 5, 13, PosL1<0>>(wmt, act0, acc, lane);
+        else
+            conv_tile<32, 5, 5, 13, PosL1<1>>(wmt, act0, acc, lane);
+        if (INPLACE) __syncthreads();                  // everyone is done reading L0's output
 #pragma unroll
-            for (int j = 0; j < 13; ++j)
-                bufA4[(j * 2 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
-        } else {
-            conv_tile<32, 5, 5, 13, PosL1<1>>(wmt, bufB4, acc, lane);
-#pragma unroll
-            for (int j = 0; j < 12; ++j)
-                bufA4[((13 + j) * 2 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
-        }
+        for (int j = 0; j < 13; ++j)
+            if (half * 13 + j < 25)
+                act1[((half * 13 + j) * 2 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
     }
     __syncthreads();
 
-    // ---- L2: 32 -> 64 @ 5x5 (4x4 used), pool -> [4][4][64] in bufB -----------------------------
+    // ---- L2: 32 -> 64 @ 5x5 (4x4 used), pool -> [4][4][64] in act0 -----------------------------
     {
         const int mt = wave;
         v4f sc, sh;
@@ -282,18 +296,19 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
         v4f acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = vzero();
-        conv_tile<32, 5, 5, 16, PosL2>(pk + EncLayout::kW2 + mt * (9 * 2 * 256), bufA4, acc, lane);
+        conv_tile<32, 5, 5, 16, PosL2>(pk + EncLayout::kW2 + mt * (9 * 2 * 256), act1, acc, lane);
+        if (INPLACE) __syncthreads();
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             v4f m = vrelu(vfma(acc[4 * w], sc, sh));
 #pragma unroll
             for (int i = 1; i < 4; ++i) m = vmax(m, vfma(acc[4 * w + i], sc, sh));
-            bufB4[(w * 4 + mt) * 64 + lane] = m;
+            act0[(w * 4 + mt) * 64 + lane] = m;
         }
     }
     __syncthreads();
 
-    // ---- L3: 64 -> 64 @ 2x2 : bufB -> bufA -----------------------------------------------------
+    // ---- L3: 64 -> 64 @ 2x2 : act0 -> act1 -----------------------------------------------------
     {
         const int mt = wave;
         v4f sc, sh;
@@ -301,24 +316,34 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
         v4f acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = vzero();
-        conv_tile<64, 2, 2, 4, Pos2x2>(pk + EncLayout::kW3 + mt * (9 * 4 * 256), bufB4, acc, lane);
+        conv_tile<64, 2, 2, 4, Pos2x2>(pk + EncLayout::kW3 + mt * (9 * 4 * 256), act0, acc, lane);
+        if (INPLACE) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bufA4[(j * 4 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
+        for (int j = 0; j < 4; ++j) act1[(j * 4 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
     }
     __syncthreads();
 
-    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][8][64] in bufB ---------------------------------------
-    for (int mt = wave; mt < 8; mt += kWaves) {
-        v4f sc, sh;
-        load_ss(pk + EncLayout::kSS4, 128, mt, q, sc, sh);
-        v4f acc[4];
+    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][8][64] in act0 (two channel tiles per wave) ----------
+    {
+        v4f res[2];
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const int mt = wave + kWaves * i;
+            v4f sc, sh;
+            load_ss(pk + EncLayout::kSS4, 128, mt, q, sc, sh);
+            v4f acc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = vzero();
-        conv_tile<64, 2, 2, 4, Pos2x2>(pk + EncLayout::kW4 + mt * (9 * 4 * 256), bufA4, acc, lane);
-        v4f m = vrelu(vfma(acc[0], sc, sh));
+            for (int j = 0; j < 4; ++j) acc[j] = vzero();
+            conv_tile<64, 2, 2, 4, Pos2x2>(pk + EncLayout::kW4 + mt * (9 * 4 * 256), act1, acc,
+                                           lane);
+            v4f m = vrelu(vfma(acc[0], sc, sh));
 #pragma unroll
-        for (int i = 1; i < 4; ++i) m = vmax(m, vfma(acc[i], sc, sh));
-        bufB4[mt * 64 + lane] = m;
+            for (int jj = 1; jj < 4; ++jj) m = vmax(m, vfma(acc[jj], sc, sh));
+            if (i == 0) res[0] = m; else res[1] = m;
+        }
+        if (INPLACE) __syncthreads();
+        act0[wave * 64 + lane] = res[0];
+        act0[(wave + kWaves) * 64 + lane] = res[1];
     }
     __syncthreads();
 
@@ -328,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void encoder_kernel(const float* __restri
         const int mt0 = wave, mt1 = wave + kWaves;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const v4f Bf = bufB4[g * 64 + lane];
+            const v4f Bf = act0[g * 64 + lane];
             const v4f A0 = *reinterpret_cast<const v4f*>(pk + EncLayout::kWfc +
                                                           ((mt0 * 8 + g) * 64 + lane) * 4);
             const v4f A1 = *reinterpret_cast<const v4f*>(pk + EncLayout::kWfc +
@@ -355,17 +380,27 @@ int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+int g_encoder_variant = 1;          // 1: in place, 2 workgroups/CU (default); 0: ping-pong
+
+template <bool INPLACE>
+static int encoder_launch_t(const float* obs, const float* packed, float* feat, int M,
+                            hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel<INPLACE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)enc_smem_bytes<INPLACE>());
         attr_set = true;
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL(encoder_kernel, dim3(grid), dim3(kThreads), kEncSmemBytes, st, obs, packed,
-                       feat, M);
+    hipLaunchKernelGGL((encoder_kernel<INPLACE>), dim3(grid), dim3(kThreads),
+                       enc_smem_bytes<INPLACE>(), st, obs, packed, feat, M);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    return g_encoder_variant ? encoder_launch_t<true>(obs, packed, feat, M, st)
+                             : encoder_launch_t<false>(obs, packed, feat, M, st);
 }
 
 }  // namespace gnnpp

@@ -96,6 +96,21 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
     return lsigf_launch(a, st);
 }
 
+int gnnpp_set_tuning(int key, int value) {
+    switch (key) {
+        case GNNPP_TUNE_ENCODER_VARIANT:
+            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            g_encoder_variant = value;
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_GPW:
+            if (value < 0) return GNNPP_ERR_ARG;
+            g_filter_gpw = value;
+            return GNNPP_OK;
+        default:
+            return GNNPP_ERR_ARG;
+    }
+}
+
 int gnnpp_decode_actions(const float* logits, int* actions, int B, int N, void* stream) {
     if (!logits || !actions || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     return decode_actions_launch(logits, actions, B, N, static_cast<hipStream_t>(stream));

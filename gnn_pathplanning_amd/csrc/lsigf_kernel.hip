@@ -65,7 +65,95 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
     }
 }
 
-template <int RT, int MTW>
+// One shift for the rows owned by this wave: z_cur[r,:] = sum_m S[m, n(r)] * z_prev[m,:].
+// Lane m reads S[m,n]; the ballot is the column's sparsity pattern; neighbours are consumed four
+// at a time so four independent LDS row reads are in flight (ILP), 2 features per lane.
+__device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
+                                            const float* __restrict__ zprev,
+                                            float* __restrict__ zcur, int R, int wave, int lane) {
+    const int N = p.N, zs = p.zstride, GP = p.NG * 16;
+    for (int r = wave; r < R; r += kWaves) {
+        const int j = r / N, n = r - j * N;
+        const float* Scol = Sl + j * N * p.Ns + n;
+        const float* zg = zprev + j * N * zs;
+        for (int c0 = 0; c0 < GP; c0 += 128) {
+            const int col = c0 + 2 * lane;
+            const bool live = col < GP;
+            const int colc = live ? col : 0;
+            v2f s2 = {0.f, 0.f};
+            for (int m0 = 0; m0 < N; m0 += 64) {
+                const int m = m0 + lane;
+                const float sv = (m < N) ? Scol[m * p.Ns] : 0.f;
+                unsigned long long mask = __ballot(sv != 0.f);
+                while (mask) {
+                    int mm[4];
+                    float sc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (mask) {
+                            mm[u] = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            sc[u] = wave_read_lane(sv, mm[u]);
+                        } else {
+                            mm[u] = mm[0];             // harmless re-read, weight 0
+                            sc[u] = 0.f;
+                        }
+                    }
+                    v2f zv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        zv[u] = *reinterpret_cast<const v2f*>(zg + (m0 + mm[u]) * zs + colc);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s2[0] = fmaf(sc[u], zv[u][0], s2[0]);
+                        s2[1] = fmaf(sc[u], zv[u][1], s2[1]);
+                    }
+                }
+            }
+            if (live) *reinterpret_cast<v2f*>(zcur + r * zs + col) = s2;
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ z0, int g0, int ng,
+                                        int tid, bool rezero) {
+    const int N = p.N, zs = p.zstride, R = ng * N;
+    if (p.x_node_major) {
+        const float* xs = p.x + (size_t)g0 * N * p.G;
+        if ((p.G & 3) == 0) {
+            const int G4 = p.G >> 2;
+            for (int i = tid; i < R * G4; i += kThreads) {
+                const int r = i / G4, c = i - r * G4;
+                *reinterpret_cast<v4f*>(z0 + r * zs + 4 * c) =
+                    *reinterpret_cast<const v4f*>(xs + (size_t)r * p.G + 4 * c);
+            }
+        } else {
+            for (int i = tid; i < R * p.G; i += kThreads) {
+                const int r = i / p.G, c = i - r * p.G;
+                z0[r * zs + c] = xs[(size_t)r * p.G + c];
+            }
+        }
+    } else {
+        // x[b][g][n], n < Nin; linear (coalesced) walk over each graph's G x Nin slab
+        const int slab = p.G * p.Nin;
+        for (int j = 0; j < ng; ++j) {
+            const float* xs = p.x + (size_t)(g0 + j) * slab;
+            for (int i = tid; i < slab; i += kThreads) {
+                const int g = i / p.Nin, n = i - g * p.Nin;
+                z0[(j * N + n) * zs + g] = xs[i];
+            }
+            if (rezero)                                 // rows n >= Nin must be zero again
+                for (int i = tid; i < (N - p.Nin) * p.G; i += kThreads) {
+                    const int n = p.Nin + i / p.G, g = i % p.G;
+                    z0[(j * N + n) * zs + g] = 0.f;
+                }
+        }
+    }
+}
+
+// RT  = 16-row MFMA tiles per workgroup, MTW = output-channel tiles per wave (1: F<=64, 2: F<=128),
+// NGT = compile-time number of 16-wide input-feature groups (8 for G = 128; 0 = run-time NG).
+template <int RT, int MTW, int NGT>
 __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     const int tid = threadIdx.x;
@@ -80,10 +168,33 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
     const int R = ng * N;                              // valid rows
     const int zs = p.zstride;
     constexpr int ROWS = RT * 16;
+    const int NG = NGT ? NGT : p.NG;
+    constexpr int NGA = NGT ? NGT : 1;
 
     float* zbuf0 = reinterpret_cast<float*>(gnnpp_smem);
     float* zbuf1 = zbuf0 + ROWS * zs;
     float* Sl = zbuf1 + ROWS * zs;                     // [gpw][N][Ns]
+
+    // Tap weights of the first tap: issued first so their L2 latency hides behind the staging.
+    // Packed block (e,k,mt,gg): 64 lanes x 4 floats = the A fragments of four MFMA k-steps.
+    const int ntaps = p.E * p.K;
+    const size_t tap_stride = (size_t)p.MT * NG * 256;
+    v4f Acur[NGA][MTW], Anxt[NGA][MTW];
+    auto load_tap = [&](v4f (&A)[NGA][MTW], int tap) {
+        if (NGT) {
+            const float* wt = p.wpk + tap * tap_stride + lane * 4;
+#pragma unroll
+            for (int gg = 0; gg < NGA; ++gg)
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    const int mt = wave + kWaves * i;
+                    A[gg][i] = (mt < p.MT) ? *reinterpret_cast<const v4f*>(
+                                                 wt + (size_t)(mt * NGA + gg) * 256)
+                                           : vzero();
+                }
+        }
+    };
+    load_tap(Acur, 0);
 
     // ---- zero both z buffers (pad rows / pad columns must be finite zeros) --------------------
     {
@@ -92,34 +203,7 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
         for (int i = tid; i < n4; i += kThreads) zz[i] = vzero();
     }
     __syncthreads();
-
-    // ---- stage x -> z_0 (node-major rows) ------------------------------------------------------
-    if (p.x_node_major) {
-        const float* xs = p.x + (size_t)g0 * N * p.G;
-        if ((p.G & 3) == 0) {
-            const int G4 = p.G >> 2;
-            for (int i = tid; i < R * G4; i += kThreads) {
-                const int r = i / G4, c = i - r * G4;
-                *reinterpret_cast<v4f*>(zbuf0 + r * zs + 4 * c) =
-                    *reinterpret_cast<const v4f*>(xs + (size_t)r * p.G + 4 * c);
-            }
-        } else {
-            for (int i = tid; i < R * p.G; i += kThreads) {
-                const int r = i / p.G, c = i - r * p.G;
-                zbuf0[r * zs + c] = xs[(size_t)r * p.G + c];
-            }
-        }
-    } else {
-        // x[b][g][n], n < Nin; linear (coalesced) walk over each graph's G x Nin slab
-        const int slab = p.G * p.Nin;
-        for (int j = 0; j < ng; ++j) {
-            const float* xs = p.x + (size_t)(g0 + j) * slab;
-            for (int i = tid; i < slab; i += kThreads) {
-                const int g = i / p.Nin, n = i - g * p.Nin;
-                zbuf0[(j * N + n) * zs + g] = xs[i];
-            }
-        }
-    }
+    stage_x(p, zbuf0, g0, ng, tid, false);             // z_0 (node-major rows)
 
     v4f acc[MTW][RT];
 #pragma unroll
@@ -128,10 +212,11 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
         for (int rt = 0; rt < RT; ++rt) acc[i][rt] = vzero();
 
     const int NN = N * N;
+    int tap = 0;
     for (int e = 0; e < p.E; ++e) {
         // ---- stage the S slabs of edge feature e (only needed when K > 1) ---------------------
         if (p.K > 1) {
-            if (e > 0) __syncthreads();                // previous e's gathers are done with Sl
+            if (e > 0) __syncthreads();                // previous e is done with Sl and the z's
             for (int j = 0; j < ng; ++j) {
                 const size_t sidx = ((size_t)(p.s_batched ? (g0 + j) * p.E : 0) + e) * NN;
                 float* dst = Sl + j * N * p.Ns;
@@ -149,98 +234,64 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
                     }
                 }
             }
+            // z_{e,0} = x: the ping-pong overwrote it when K > 2, so edge features e > 0 re-stage
+            // it (E > 1 is outside the planner's configs: simple and correct beats fast here).
+            if (e > 0 && p.K > 2) stage_x(p, zbuf0, g0, ng, tid, true);
         }
         __syncthreads();                               // z_0 (and Sl) visible
 
-        // z_{e,0} = x lives in zbuf0 for e == 0; for e > 0 it must be re-staged because the
-        // ping-pong overwrote it when K > 2.  (E > 1 is outside the planner's configs: simple
-        // and correct beats fast here.)
-        if (e > 0 && p.K > 2) {
-            // re-stage x into zbuf0
-            if (p.x_node_major) {
-                const float* xs = p.x + (size_t)g0 * N * p.G;
-                for (int i = tid; i < R * p.G; i += kThreads) {
-                    const int r = i / p.G, c = i - r * p.G;
-                    zbuf0[r * zs + c] = xs[(size_t)r * p.G + c];
-                }
-            } else {
-                const int slab = p.G * p.Nin;
-                for (int j = 0; j < ng; ++j) {
-                    const float* xs = p.x + (size_t)(g0 + j) * slab;
-                    for (int i = tid; i < slab; i += kThreads) {
-                        const int g = i / p.Nin, n = i - g * p.Nin;
-                        zbuf0[(j * N + n) * zs + g] = xs[i];
-                    }
-                    // rows n >= Nin of z_0 must be zero again
-                    for (int i = tid; i < (N - p.Nin) * p.G; i += kThreads) {
-                        const int n = p.Nin + i / p.G, g = i % p.G;
-                        zbuf0[(j * N + n) * zs + g] = 0.f;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-
-        for (int k = 0; k < p.K; ++k) {
+        for (int k = 0; k < p.K; ++k, ++tap) {
             float* zcur = (k & 1) ? zbuf1 : zbuf0;
+            if (tap + 1 < ntaps) load_tap(Anxt, tap + 1);       // in flight during the shift
             if (k > 0) {
-                // ---- shift: one wavefront per node, sparse column gather -----------------------
-                const float* zprev = (k & 1) ? zbuf0 : zbuf1;
-                const int GP = p.NG * 16;
-                for (int r = wave; r < R; r += kWaves) {
-                    const int j = r / N, n = r - j * N;
-                    const float* Scol = Sl + j * N * p.Ns + n;
-                    const float* zg = zprev + j * N * zs;
-                    for (int c0 = 0; c0 < GP; c0 += 128) {
-                        const int col = c0 + 2 * lane;
-                        const bool live = col < GP;
-                        v2f s2 = {0.f, 0.f};
-                        for (int m0 = 0; m0 < N; m0 += 64) {
-                            const int m = m0 + lane;
-                            const float sv = (m < N) ? Scol[m * p.Ns] : 0.f;
-                            unsigned long long mask = __ballot(sv != 0.f);
-                            while (mask) {
-                                const int mm = __ffsll((long long)mask) - 1;
-                                mask &= mask - 1;
-                                const float s = wave_read_lane(sv, mm);
-                                if (live) {
-                                    const v2f zv = *reinterpret_cast<const v2f*>(
-                                        zg + (m0 + mm) * zs + col);
-                                    s2[0] = fmaf(s, zv[0], s2[0]);
-                                    s2[1] = fmaf(s, zv[1], s2[1]);
-                                }
-                            }
-                        }
-                        if (live) *reinterpret_cast<v2f*>(zcur + r * zs + col) = s2;
-                    }
-                }
+                gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, lane);
                 __syncthreads();
             }
-
-            // ---- contraction of tap (e,k) on MFMA ----------------------------------------------
-            const float* wtap = p.wpk + (size_t)(e * p.K + k) * p.MT * p.NG * 256;
-            for (int gg = 0; gg < p.NG; ++gg) {
-                v4f A[MTW];
+            // ---- contraction of tap (e,k) on MFMA: D[f, row] += W[f, g] z[row, g] --------------
+            if (NGT) {
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    const int mt = wave + kWaves * i;
-                    A[i] = (mt < p.MT)
-                               ? *reinterpret_cast<const v4f*>(
-                                     wtap + ((size_t)(mt * p.NG + gg) * 64 + lane) * 4)
-                               : vzero();
+                for (int gg = 0; gg < NGA; ++gg) {
+                    v4f Bf[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        Bf[rt] = *reinterpret_cast<const v4f*>(zcur + (rt * 16 + a) * zs +
+                                                               gg * 16 + q * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                acc[i][rt] = mfma16(Acur[gg][i][s], Bf[rt][s], acc[i][rt]);
                 }
-                v4f Bf[RT];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    Bf[rt] = *reinterpret_cast<const v4f*>(zcur + (rt * 16 + a) * zs + gg * 16 +
-                                                           q * 4);
+                for (int gg = 0; gg < NGA; ++gg)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                    for (int i = 0; i < MTW; ++i) Acur[gg][i] = Anxt[gg][i];
+            } else {
+                const float* wtap = p.wpk + tap * tap_stride;
+                for (int gg = 0; gg < NG; ++gg) {
+                    v4f A[MTW];
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i)
+                    for (int i = 0; i < MTW; ++i) {
+                        const int mt = wave + kWaves * i;
+                        A[i] = (mt < p.MT) ? *reinterpret_cast<const v4f*>(
+                                                 wtap + ((size_t)(mt * NG + gg) * 64 + lane) * 4)
+                                           : vzero();
+                    }
+                    v4f Bf[RT];
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-                            acc[i][rt] = mfma16(A[i][s], Bf[rt][s], acc[i][rt]);
+                    for (int rt = 0; rt < RT; ++rt)
+                        Bf[rt] = *reinterpret_cast<const v4f*>(zcur + (rt * 16 + a) * zs +
+                                                               gg * 16 + q * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                acc[i][rt] = mfma16(A[i][s], Bf[rt][s], acc[i][rt]);
+                }
             }
         }
     }
@@ -296,16 +347,33 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
         }
     }
     if (p.act_w) {
-        // logits[n][b][a5] = act_b[a5] + sum_f act_w[a5][f] * ybuf[row][f]
-        for (int i = tid; i < R * 5; i += kThreads) {
-            const int r = i / 5, a5 = i - r * 5;
-            const float* yr = ybuf + r * zs;
-            const float* wr = p.act_w + a5 * p.F;
-            float s = 0.f;
-            for (int f = 0; f < p.F; ++f) s = fmaf(wr[f], yr[f], s);
-            s += p.act_b[a5];
-            const int j = r / N, n = r - j * N;
-            p.logits[((size_t)n * p.B + (g0 + j)) * 5 + a5] = s;
+        // Action head on MFMA: D[a5, row] = sum_f act_w[a5, f] * y[row, f]; the A fragment is read
+        // straight from act_w[5,F] (rows >= 5 are zero), the B fragment from the staged y tile.
+        const int i5 = lane & 15;
+        for (int rt = wave; rt < RT; rt += kWaves) {
+            v4f d = vzero();
+            for (int gg = 0; gg < p.MT; ++gg) {
+                const int f0 = gg * 16 + q * 4;
+                v4f A = vzero();
+                if (i5 < 5) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (f0 + s < p.F) A[s] = p.act_w[i5 * p.F + f0 + s];
+                }
+                const v4f Bv = *reinterpret_cast<const v4f*>(ybuf + (rt * 16 + a) * zs + f0);
+                d = mfma16x4(A, Bv, d);
+            }
+            const int r = rt * 16 + a;                  // this lane's row; it holds a5 = 4*q + reg
+            if (r < R && q < 2) {
+                const int j = r / N, n = r - j * N;
+                float* dst = p.logits + ((size_t)n * p.B + (g0 + j)) * 5;
+                if (q == 0) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dst[t] = d[t] + p.act_b[t];
+                } else {
+                    dst[4] = d[0] + p.act_b[4];
+                }
+            }
         }
     }
 }
@@ -326,18 +394,30 @@ __global__ void decode_actions_kernel(const float* __restrict__ logits, int* __r
 }
 
 // ---- host-side launcher -----------------------------------------------------------------------
+int g_filter_gpw = 0;               // 0: heuristic below; > 0: forced graphs per workgroup (tuning)
+
+template <int RT, int MTW, int NGT>
+static hipError_t launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RT, MTW, NGT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lsigf_kernel<RT, MTW, NGT>), dim3(grid), dim3(kThreads), smem, st, a);
+    return hipGetLastError();
+}
+
 template <int RT>
 static hipError_t launch_rt(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (a.MT <= kWaves) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RT, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipLaunchKernelGGL((lsigf_kernel<RT, 1>), dim3(grid), dim3(kThreads), smem, st, a);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RT, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipLaunchKernelGGL((lsigf_kernel<RT, 2>), dim3(grid), dim3(kThreads), smem, st, a);
-    }
-    return hipGetLastError();
+    if (a.NG == 8 && a.MT > kWaves) return launch_one<RT, 2, 8>(a, grid, smem, st);   // G = F = 128
+    if (a.MT <= kWaves) return launch_one<RT, 1, 0>(a, grid, smem, st);
+    return launch_one<RT, 2, 0>(a, grid, smem, st);
+}
+
+static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
+    const int rt = (gpw * a.N + 15) / 16;
+    return (size_t)2 * rt * 16 * a.zstride * 4 + (size_t)gpw * a.N * a.Ns * 4;
 }
 
 // Chooses graphs-per-workgroup, checks the LDS budget and launches.  Returns a GNNPP_* code.
@@ -349,23 +429,25 @@ int lsigf_launch(LsigfArgs a, hipStream_t st) {
     a.zstride = 16 * wide + 8;
     a.Ns = a.N | 1;
     if (a.N > 112) return -2;
-    // graphs per workgroup: fill the 16-row MFMA tiles, but keep >= ~256 workgroups in flight
+    // graphs per workgroup: fill the 16-row MFMA tiles, but keep the 256 CUs busy.  Cost model:
+    // rounds over the chip x (fixed staging/latency cost + MFMA work per row tile).
     int best = 1;
     double best_cost = 1e30;
     const int max_gpw = 112 / a.N;
     for (int g = 1; g <= max_gpw && g <= a.B; ++g) {
+        if (lsigf_smem(a, g) > (size_t)kLdsBytes) break;
         const int rt = (g * a.N + 15) / 16;
-        const size_t smem = (size_t)2 * rt * 16 * a.zstride * 4 + (size_t)g * a.N * a.Ns * 4;
-        if (smem > (size_t)kLdsBytes) break;
         const int wgs = (a.B + g - 1) / g;
         const int rounds = (wgs + 255) / 256;
-        // per-workgroup time ~ fixed staging cost + MFMA work per row tile
         const double cost = rounds * (1.0 + rt);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = g; }
     }
+    if (g_filter_gpw > 0 && g_filter_gpw <= max_gpw && g_filter_gpw <= a.B &&
+        lsigf_smem(a, g_filter_gpw) <= (size_t)kLdsBytes)
+        best = g_filter_gpw;
     a.gpw = best;
     const int rt = (a.gpw * a.N + 15) / 16;
-    const size_t smem = (size_t)2 * rt * 16 * a.zstride * 4 + (size_t)a.gpw * a.N * a.Ns * 4;
+    const size_t smem = lsigf_smem(a, a.gpw);
     if (smem > (size_t)kLdsBytes) return -2;
     const int grid = (a.B + a.gpw - 1) / a.gpw;
     hipError_t err;

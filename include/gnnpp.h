@@ -39,6 +39,13 @@ extern "C" {
 int         gnnpp_version(void);
 const char* gnnpp_error_string(int code);
 
+/* Process-wide tuning knobs for A/B measurements (bench.py); defaults are the fast settings.
+ * Results are identical for every setting -- only the schedule changes. */
+#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 1 (default): in-place layers, 79 KB LDS, 2 workgroups/CU;
+                                         0: ping-pong buffers, 100 KB LDS, 1 workgroup/CU        */
+#define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
+int         gnnpp_set_tuning(int key, int value);
+
 /* ------------------------------------------------------------------------------------------
  * Graph filter (LSIGF):  y = bias + sum_e sum_k W[:,e,k,:] . (x S_e^k),   z_k = z_{k-1} S (right
  * multiplication: node n gathers from the non-zeros of COLUMN n of S).

@@ -56,13 +56,15 @@ def test_emu_lsigf_node_major_relu(emu, lsigf_golden):
     assert np.abs(y.transpose(0, 2, 1) - np.maximum(want, 0)).max() <= TOL
 
 
-def test_emu_policy_golden(emu, policy_golden):
+@pytest.mark.parametrize('variant', [1, 0])
+def test_emu_policy_golden(emu, policy_golden, variant):
     el, lib = emu
+    assert lib.gnnpp_set_tuning(0, variant) == 0        # encoder: 1 = in place, 0 = ping-pong
     z, meta = policy_golden
     sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
     enc = el.pack_encoder(lib, sd)
     for i, m in enumerate(meta):
-        if m['N'] > 10:
+        if m['N'] > 10 or (variant == 0 and i > 1):
             continue
         B, N, K = m['B'], m['N'], m['K']
         obs = el.f32(z['p%d_obs' % i])
@@ -90,3 +92,21 @@ def test_emu_policy_golden(emu, policy_golden):
         acts = np.full((B, N), -1, dtype=np.int32)
         assert lib.gnnpp_decode_actions(el.ptr(logits), el.ptr(acts), B, N, None) == 0
         assert (acts == want.argmax(-1)).all()
+
+
+def test_emu_filter_forced_gpw(emu, lsigf_golden):
+    """The graphs-per-workgroup choice only changes the schedule, never the result."""
+    el, lib = emu
+    z, meta = lsigf_golden
+    i = next(i for i, m in enumerate(meta) if m['kind'] == 'BatchLSIGF' and m['K'] == 3
+             and m['G'] == 128 and z['c%d_S' % i].shape[-1] == 10)
+    h, S, x, want = z['c%d_h' % i], z['c%d_S' % i], z['c%d_x' % i], z['c%d_y' % i]
+    b = z['c%d_b' % i] if meta[i]['has_bias'] else None
+    try:
+        for gpw in (1, 2):
+            assert lib.gnnpp_set_tuning(1, gpw) == 0
+            y = el.lsigf(lib, h, S, x, b, True)
+            assert np.abs(y - want).max() <= TOL
+    finally:
+        lib.gnnpp_set_tuning(1, 0)
+    assert lib.gnnpp_set_tuning(7, 0) == -1 and lib.gnnpp_set_tuning(0, 5) == -1

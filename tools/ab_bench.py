@@ -1,0 +1,99 @@
+"""Single-process A/B timings of the libgnnpp kernels (HIP events on the launch stream).
+Prints one JSON line per measurement; used to pick defaults and to fill DESIGN.md tables."""
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnn_pathplanning_amd import _native                      # noqa: E402
+from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet   # noqa: E402
+from oracle import policy_oracle as orc                       # noqa: E402  (inputs only)
+
+dev = torch.device('cuda:0')
+L = _native.lib()
+vp = lambda t: ctypes.c_void_p(t.data_ptr())                  # noqa: E731
+st = _native.stream_ptr(dev)
+
+
+def timeit(fn, reps=40, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best                                                # us
+
+
+class Cfg:
+    def __init__(self, n, k):
+        self.num_agents, self.nGraphFilterTaps, self.device = n, k, dev
+
+
+def main():
+    sd = orc.init_state_dict(3)
+    net = DecentralPlannerNet(Cfg(10, 3)).to(dev).eval()
+    net.load_state_dict(sd)
+    enc = net.packed_encoder()
+    # ---- encoder variants over M ----
+    for M in (16, 256, 4096, 5120, 8192, 12800, 40960):
+        obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
+        feat = torch.empty(M, 128, device=dev)
+        row = {'kernel': 'encoder', 'M': M}
+        for v in (1, 0):
+            L.gnnpp_set_tuning(0, v)
+            t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
+            row['v%d_us' % v] = round(t, 2)
+            row['v%d_TFLOPs' % v] = round(2.0 * (1238112 + 16384) * M / t / 1e6, 1)
+        L.gnnpp_set_tuning(0, 1)
+        print(json.dumps(row), flush=True)
+    # ---- filter: graphs-per-workgroup sweep ----
+    for (N, B, K, W) in ((10, 512, 3, 20), (50, 256, 3, 50), (100, 128, 3, 100), (10, 4096, 3, 20)):
+        gf = DecentralPlannerNet(Cfg(N, K)).to(dev).GFL[0]
+        x = torch.relu(torch.randn(B * N, 128, device=dev))
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=1)).float().to(dev)
+        y = torch.empty(B * N, 128, device=dev)
+        gb = gf.bias.detach().reshape(-1)
+        taps = gf.packed_taps()
+        row = {'kernel': 'lsigf', 'N': N, 'B': B, 'K': K}
+        for gpw in (0, 1, 2, 3, 4, 6, 8):
+            if gpw * N > 112:
+                continue
+            L.gnnpp_set_tuning(1, gpw)
+            t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(x), vp(S), vp(taps), vp(gb), vp(y), B, N, N, 128,
+                                                 128, K, 1, 0, 1, 1, 1, 1, st))
+            row['gpw%d_us' % gpw] = round(t, 2)
+        L.gnnpp_set_tuning(1, 0)
+        # module-API layout (feature-major in/out), heuristic gpw
+        xf = x.reshape(B, N, 128).permute(0, 2, 1).contiguous()
+        yf = torch.empty(B, 128, N, device=dev)
+        S4 = S.unsqueeze(1).contiguous()
+        t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(xf), vp(S4), vp(taps), vp(gb), vp(yf), B, N, N, 128, 128,
+                                             K, 1, 0, 1, 0, 0, 0, st))
+        row['feature_major_us'] = round(t, 2)
+        print(json.dumps(row), flush=True)
+    # ---- whole policy step (python call included in the stream time) ----
+    for (N, B, W) in ((10, 1, 20), (10, 64, 20), (10, 512, 20), (50, 256, 50), (100, 128, 100)):
+        net = DecentralPlannerNet(Cfg(N, 3)).to(dev).eval()
+        net.load_state_dict(sd)
+        obs = orc.synth_obs(B, N).to(dev)
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=2)).float().to(dev)
+
+        def step():
+            net.addGSO(S)
+            return net(obs)
+        t = timeit(step, reps=30)
+        print(json.dumps({'kernel': 'policy_step', 'N': N, 'B': B, 'us': round(t, 2),
+                          'agent_steps_per_s': round(B * N / t * 1e6)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()

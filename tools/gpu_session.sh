@@ -1,38 +1,38 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel trace (+ optional PMC passes).
-# Usage (from the repo root on the GPU box): bash tools/gpu_session.sh [tag] [pmc]
-TAG=${1:-r01}
-PMC=${2:-}
+# One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
+# steps: test smoke bench ab bench35 prof pmc   (default: all but pmc)
+TAG=${1:-r01}; shift
+STEPS=${@:-test smoke bench ab bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-echo "== rocminfo" ; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4
-echo "== build check"; ls -la gnn_pathplanning_amd/libgnnpp.so
-echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee $OUT/pytest_gpu.log
-echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.log
-echo "== bench c2"
-timeout 600 python bench.py --steps 200 --warmup 20 2>&1 | tail -3 | tee $OUT/bench_c2.json
-for c in c3 c5; do
-  echo "== bench $c"
-  timeout 600 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 4 2>&1 | tail -1 | tee $OUT/bench_$c.json
-done
-echo "== rocprofv3 kernel trace"
+has() { [[ " $STEPS " == *" $1 "* ]]; }
+T0=$(date +%s)
+stamp() { echo "== [$(( $(date +%s) - T0 ))s] $1"; }
+if has test; then stamp "pytest -m gpu"
+  timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 | tee $OUT/pytest_gpu.log; fi
+if has smoke; then stamp smoke
+  timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log; fi
+if has bench; then stamp "bench c2"
+  timeout 300 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
+if has ab; then stamp "ab_bench"
+  timeout 400 python tools/ab_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_bench.jsonl; fi
+if has bench35; then for c in c3 c5; do stamp "bench $c"
+  timeout 300 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 5 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/prof_run.log 2>&1
-find $OUT/prof -name "*kernel_stats*" | head -3
-f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -12 "$f" | tee $OUT/kernel_stats_head.csv
-if [ -n "$PMC" ]; then
-  echo "== rocprofv3 pmc passes"
-  timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o pmc -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
-  ls $OUT/pmc_*/ 2>/dev/null | head
-fi
-# keep the merged-back payload small
-find $OUT -name "*.csv" -size +8M -delete
+if has prof; then stamp "rocprofv3 kernel trace"
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/prof_run.log 2>&1
+  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && head -12 "$f" | tee $OUT/kernel_stats_head.csv
+  find $OUT/prof -name "*kernel_trace.csv" -size +6M -delete; fi
+if has pmc; then stamp "rocprofv3 pmc passes"
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+    name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+    timeout 200 rocprofv3 --pmc $grp -d $OUT/pmc_$name -o pmc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1
+    python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt
+    find $OUT/pmc_$name -name "*.csv" -size +2M -delete
+  done; fi
+stamp done
 du -sh $OUT
