@@ -141,11 +141,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = world * B * N * args.steps / elapsed
+    from gnn_pathplanning_amd.sharding import aggregate_throughput
+    value, _, elapsed = aggregate_throughput(B * N * args.steps, elapsed, device=dev)
 
     result = {
         'metric': 'agent-steps/sec (policy fwd)', 'value': value, 'unit': 'agent-steps/s',

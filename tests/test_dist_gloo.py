@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the N>1 launch path of bench.py (sharding + aggregation).
+No GPU and no data-path collective is involved; the GPU box runs the same code over nccl/RCCL."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gnn_pathplanning_amd.sharding import aggregate_throughput, shard_batch, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        B = 7
+        obs = torch.arange(B * 3, dtype=torch.float32).reshape(B, 3)
+        gso = torch.arange(B, dtype=torch.float32)
+        o, g = shard_batch((obs, gso), rank, world)
+        dist.barrier()
+        # rank 1 is "slower": whole-job time is the max, units are summed
+        thr, units, t = aggregate_throughput(o.shape[0] * 10, 1.0 + rank)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, g.tolist())
+        q.put((rank, thr, units, t, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_exactly():
+    for total in (0, 1, 5, 8, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_sharding_and_aggregation():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, thr, units, t, gathered in res:
+        assert units == 70.0 and t == 2.0 and abs(thr - 35.0) < 1e-9
+        assert gathered == [[0.0, 1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]      # disjoint, complete, ordered
+
+
+def test_single_process_aggregation_without_group():
+    thr, units, t = aggregate_throughput(100, 0.5)
+    assert (thr, units, t) == (200.0, 100, 0.5)
