@@ -106,6 +106,10 @@ int gnnpp_set_tuning(int key, int value) {
             if (value < 0) return GNNPP_ERR_ARG;
             g_filter_gpw = value;
             return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_WAVES:
+            if (value != 0 && value != 8 && value != 16) return GNNPP_ERR_ARG;
+            g_filter_waves = value;
+            return GNNPP_OK;
         default:
             return GNNPP_ERR_ARG;
     }

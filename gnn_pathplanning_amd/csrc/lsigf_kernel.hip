@@ -38,6 +38,7 @@ struct LsigfArgs {
     int NG, MT;            // ceil(G/16), ceil(F/16)   (F <= 128 per launch -> MT <= 8)
     int zstride;           // LDS row stride in floats = 16*max(NG,MT) + 8
     int gpw;               // graphs per workgroup
+    int rt_total;          // 16-row MFMA tiles per workgroup = ceil(gpw*N / 16)
     int Ns;                // LDS row stride of an S slab (odd)
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
 };
@@ -70,9 +71,10 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
 // at a time so four independent LDS row reads are in flight (ILP), 2 features per lane.
 __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
                                             const float* __restrict__ zprev,
-                                            float* __restrict__ zcur, int R, int wave, int lane) {
+                                            float* __restrict__ zcur, int R, int wave, int nwaves,
+                                            int lane) {
     const int N = p.N, zs = p.zstride, GP = p.NG * 16;
-    for (int r = wave; r < R; r += kWaves) {
+    for (int r = wave; r < R; r += nwaves) {
         const int j = r / N, n = r - j * N;
         const float* Scol = Sl + j * N * p.Ns + n;
         const float* zg = zprev + j * N * zs;
@@ -115,20 +117,22 @@ __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __r
     }
 }
 
+// x -> z_0 rows (node-major in LDS) by the threads [t0, t0+nt) of the workgroup.
 __device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ z0, int g0, int ng,
-                                        int tid, bool rezero) {
+                                        int t0, int nt, bool rezero) {
     const int N = p.N, zs = p.zstride, R = ng * N;
+    if (t0 < 0) return;
     if (p.x_node_major) {
         const float* xs = p.x + (size_t)g0 * N * p.G;
         if ((p.G & 3) == 0) {
             const int G4 = p.G >> 2;
-            for (int i = tid; i < R * G4; i += kThreads) {
+            for (int i = t0; i < R * G4; i += nt) {
                 const int r = i / G4, c = i - r * G4;
                 *reinterpret_cast<v4f*>(z0 + r * zs + 4 * c) =
                     *reinterpret_cast<const v4f*>(xs + (size_t)r * p.G + 4 * c);
             }
         } else {
-            for (int i = tid; i < R * p.G; i += kThreads) {
+            for (int i = t0; i < R * p.G; i += nt) {
                 const int r = i / p.G, c = i - r * p.G;
                 z0[r * zs + c] = xs[(size_t)r * p.G + c];
             }
@@ -138,12 +142,12 @@ __device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ 
         const int slab = p.G * p.Nin;
         for (int j = 0; j < ng; ++j) {
             const float* xs = p.x + (size_t)(g0 + j) * slab;
-            for (int i = tid; i < slab; i += kThreads) {
+            for (int i = t0; i < slab; i += nt) {
                 const int g = i / p.Nin, n = i - g * p.Nin;
                 z0[(j * N + n) * zs + g] = xs[i];
             }
             if (rezero)                                 // rows n >= Nin must be zero again
-                for (int i = tid; i < (N - p.Nin) * p.G; i += kThreads) {
+                for (int i = t0; i < (N - p.Nin) * p.G; i += nt) {
                     const int n = p.Nin + i / p.G, g = i % p.G;
                     z0[(j * N + n) * zs + g] = 0.f;
                 }
@@ -151,11 +155,39 @@ __device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ 
     }
 }
 
-// RT  = 16-row MFMA tiles per workgroup, MTW = output-channel tiles per wave (1: F<=64, 2: F<=128),
-// NGT = compile-time number of 16-wide input-feature groups (8 for G = 128; 0 = run-time NG).
-template <int RT, int MTW, int NGT>
-__global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
+// dense S slabs of edge feature e -> LDS (fp64 -> fp32 like `S.float()`), threads [t0, t0+nt)
+__device__ __forceinline__ void stage_s(const LsigfArgs& p, float* __restrict__ Sl, int g0, int ng,
+                                        int e, int t0, int nt) {
+    const int N = p.N, NN = N * N;
+    if (t0 < 0) return;
+    for (int j = 0; j < ng; ++j) {
+        const size_t sidx = ((size_t)(p.s_batched ? (g0 + j) * p.E : 0) + e) * NN;
+        float* dst = Sl + j * N * p.Ns;
+        if (p.s_is_f64) {
+            const double* src = reinterpret_cast<const double*>(p.S) + sidx;
+            for (int i = t0; i < NN; i += nt) {
+                const int m = i / N, n = i - m * N;
+                dst[m * p.Ns + n] = (float)src[i];
+            }
+        } else {
+            const float* src = reinterpret_cast<const float*>(p.S) + sidx;
+            for (int i = t0; i < NN; i += nt) {
+                const int m = i / N, n = i - m * N;
+                dst[m * p.Ns + n] = src[i];
+            }
+        }
+    }
+}
+
+// NW   = waves per workgroup (8 or 16).  A wave owns ONE 16-channel output tile, mt = wave % MTP
+//        (MTP = 8, or 4 when F <= 64), and the row-tile chunk  wave / MTP  of RTW row tiles;
+// RTW  = 16-row MFMA tiles per wave;  NGT = compile-time number of 16-wide input-feature groups
+//        (8 for G = 128: the whole tap's A fragments live in registers and the next tap's are
+//        prefetched during the shift; 0 = run-time NG, fragments loaded inside the loop).
+template <int RTW, int NW, int NGT>
+__global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    constexpr int NT = NW * 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -167,9 +199,13 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
     const int N = p.N;
     const int R = ng * N;                              // valid rows
     const int zs = p.zstride;
-    constexpr int ROWS = RT * 16;
+    const int ROWS = p.rt_total * 16;
     const int NG = NGT ? NGT : p.NG;
     constexpr int NGA = NGT ? NGT : 1;
+    const int mtp = p.MT > 4 ? 8 : 4;
+    const int mt = wave & (mtp - 1);
+    const int rt0 = (wave / mtp) * RTW;                // first row tile of this wave
+    const bool has_mfma = mt < p.MT && rt0 < p.rt_total;
 
     float* zbuf0 = reinterpret_cast<float*>(gnnpp_smem);
     float* zbuf1 = zbuf0 + ROWS * zs;
@@ -179,64 +215,45 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
     // Packed block (e,k,mt,gg): 64 lanes x 4 floats = the A fragments of four MFMA k-steps.
     const int ntaps = p.E * p.K;
     const size_t tap_stride = (size_t)p.MT * NG * 256;
-    v4f Acur[NGA][MTW], Anxt[NGA][MTW];
-    auto load_tap = [&](v4f (&A)[NGA][MTW], int tap) {
-        if (NGT) {
-            const float* wt = p.wpk + tap * tap_stride + lane * 4;
+    v4f Acur[NGA], Anxt[NGA];
+    auto load_tap = [&](v4f (&A)[NGA], int tap) {
+        if (NGT && has_mfma) {
+            const float* wt = p.wpk + tap * tap_stride + ((size_t)mt * NGA * 64 + lane) * 4;
 #pragma unroll
-            for (int gg = 0; gg < NGA; ++gg)
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    const int mt = wave + kWaves * i;
-                    A[gg][i] = (mt < p.MT) ? *reinterpret_cast<const v4f*>(
-                                                 wt + (size_t)(mt * NGA + gg) * 256)
-                                           : vzero();
-                }
+            for (int gg = 0; gg < NGA; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
         }
     };
     load_tap(Acur, 0);
 
-    // ---- zero both z buffers (pad rows / pad columns must be finite zeros) --------------------
+    // ---- zero the pad rows of both z buffers (pad columns are never read when G % 16 == 0) -----
     {
-        v4f* zz = reinterpret_cast<v4f*>(zbuf0);
-        const int n4 = (2 * ROWS * zs) >> 2;           // zs is a multiple of 8
-        for (int i = tid; i < n4; i += kThreads) zz[i] = vzero();
+        const bool all = (p.G & 15) != 0 || (p.F & 15) != 0 || p.Nin < N;
+        const int r_lo = all ? 0 : R;
+        const int n4 = ((ROWS - r_lo) * zs) >> 2;      // zs is a multiple of 8
+        v4f* z0 = reinterpret_cast<v4f*>(zbuf0 + r_lo * zs);
+        v4f* z1 = reinterpret_cast<v4f*>(zbuf1 + r_lo * zs);
+        for (int i = tid; i < n4; i += NT) { z0[i] = vzero(); z1[i] = vzero(); }
+        if (all) __syncthreads();                      // the x staging below overwrites zeroed cells
     }
-    __syncthreads();
-    stage_x(p, zbuf0, g0, ng, tid, false);             // z_0 (node-major rows)
+    // x and S(e=0) are staged by disjoint thread ranges so their load latencies overlap
+    {
+        const int ns = (p.K > 1) ? (NT / 4) : 0;       // last quarter of the threads stage S
+        stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
+        if (ns) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
+    }
 
-    v4f acc[MTW][RT];
+    v4f acc[RTW];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[i][rt] = vzero();
+    for (int t = 0; t < RTW; ++t) acc[t] = vzero();
 
-    const int NN = N * N;
     int tap = 0;
     for (int e = 0; e < p.E; ++e) {
-        // ---- stage the S slabs of edge feature e (only needed when K > 1) ---------------------
-        if (p.K > 1) {
-            if (e > 0) __syncthreads();                // previous e is done with Sl and the z's
-            for (int j = 0; j < ng; ++j) {
-                const size_t sidx = ((size_t)(p.s_batched ? (g0 + j) * p.E : 0) + e) * NN;
-                float* dst = Sl + j * N * p.Ns;
-                if (p.s_is_f64) {
-                    const double* src = reinterpret_cast<const double*>(p.S) + sidx;
-                    for (int i = tid; i < NN; i += kThreads) {
-                        const int m = i / N, n = i - m * N;
-                        dst[m * p.Ns + n] = (float)src[i];
-                    }
-                } else {
-                    const float* src = reinterpret_cast<const float*>(p.S) + sidx;
-                    for (int i = tid; i < NN; i += kThreads) {
-                        const int m = i / N, n = i - m * N;
-                        dst[m * p.Ns + n] = src[i];
-                    }
-                }
-            }
+        if (e > 0 && p.K > 1) {
+            __syncthreads();                           // previous e is done with Sl and the z's
+            stage_s(p, Sl, g0, ng, e, tid, NT);
             // z_{e,0} = x: the ping-pong overwrote it when K > 2, so edge features e > 0 re-stage
             // it (E > 1 is outside the planner's configs: simple and correct beats fast here).
-            if (e > 0 && p.K > 2) stage_x(p, zbuf0, g0, ng, tid, true);
+            if (p.K > 2) stage_x(p, zbuf0, g0, ng, tid, NT, true);
         }
         __syncthreads();                               // z_0 (and Sl) visible
 
@@ -244,53 +261,41 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
             float* zcur = (k & 1) ? zbuf1 : zbuf0;
             if (tap + 1 < ntaps) load_tap(Anxt, tap + 1);       // in flight during the shift
             if (k > 0) {
-                gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, lane);
+                gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, NW, lane);
                 __syncthreads();
             }
             // ---- contraction of tap (e,k) on MFMA: D[f, row] += W[f, g] z[row, g] --------------
-            if (NGT) {
+            if (has_mfma) {
+                const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
+                if (NGT) {
 #pragma unroll
-                for (int gg = 0; gg < NGA; ++gg) {
-                    v4f Bf[RT];
+                    for (int gg = 0; gg < NGA; ++gg) {
+                        v4f Bf[RTW];
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        Bf[rt] = *reinterpret_cast<const v4f*>(zcur + (rt * 16 + a) * zs +
-                                                               gg * 16 + q * 4);
+                        for (int t = 0; t < RTW; ++t)
+                            Bf[t] = *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + gg * 16);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                            for (int rt = 0; rt < RT; ++rt)
-                                acc[i][rt] = mfma16(Acur[gg][i][s], Bf[rt][s], acc[i][rt]);
-                }
-#pragma unroll
-                for (int gg = 0; gg < NGA; ++gg)
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) Acur[gg][i] = Anxt[gg][i];
-            } else {
-                const float* wtap = p.wpk + tap * tap_stride;
-                for (int gg = 0; gg < NG; ++gg) {
-                    v4f A[MTW];
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) {
-                        const int mt = wave + kWaves * i;
-                        A[i] = (mt < p.MT) ? *reinterpret_cast<const v4f*>(
-                                                 wtap + ((size_t)(mt * NG + gg) * 64 + lane) * 4)
-                                           : vzero();
+                            for (int t = 0; t < RTW; ++t)
+                                acc[t] = mfma16(Acur[gg][s], Bf[t][s], acc[t]);
                     }
-                    v4f Bf[RT];
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        Bf[rt] = *reinterpret_cast<const v4f*>(zcur + (rt * 16 + a) * zs +
-                                                               gg * 16 + q * 4);
+                    for (int gg = 0; gg < NGA; ++gg) Acur[gg] = Anxt[gg];
+                } else {
+                    const float* wt = p.wpk + tap * tap_stride + ((size_t)mt * NG * 64 + lane) * 4;
+                    for (int gg = 0; gg < NG; ++gg) {
+                        const v4f A = *reinterpret_cast<const v4f*>(wt + gg * 256);
+                        v4f Bf[RTW];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                        for (int t = 0; t < RTW; ++t)
+                            Bf[t] = *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + gg * 16);
 #pragma unroll
-                        for (int i = 0; i < MTW; ++i)
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int rt = 0; rt < RT; ++rt)
-                                acc[i][rt] = mfma16(A[i][s], Bf[rt][s], acc[i][rt]);
+                            for (int t = 0; t < RTW; ++t)
+                                acc[t] = mfma16(A[s], Bf[t][s], acc[t]);
+                    }
                 }
             }
         }
@@ -299,21 +304,22 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
     // ---- epilogue: bias (+ReLU) -> LDS [row][f] -> coalesced store / fused action head --------
     __syncthreads();                                   // every wave is done reading z
     float* ybuf = zbuf0;
+    float* actw = zbuf1;                               // act_w staged here: [5][F]
+    if (p.act_w)
+        for (int i = tid; i < 5 * p.F; i += NT) actw[i] = p.act_w[i];
+    if (has_mfma) {
+        const int f0 = mt * 16 + q * 4;
+        v4f bv = vzero();
+        if (p.bias) {
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int mt = wave + kWaves * i;
-        if (mt < p.MT) {
-            const int f0 = mt * 16 + q * 4;
-            v4f bv = vzero();
-            if (p.bias) {
+            for (int r = 0; r < 4; ++r) bv[r] = (f0 + r < p.F) ? p.bias[f0 + r] : 0.f;
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bv[r] = (f0 + r < p.F) ? p.bias[f0 + r] : 0.f;
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                v4f v = acc[i][rt] + bv;
+        for (int t = 0; t < RTW; ++t) {
+            if (rt0 + t < p.rt_total) {
+                v4f v = acc[t] + bv;
                 if (p.relu) v = vrelu(v);
-                *reinterpret_cast<v4f*>(ybuf + (rt * 16 + a) * zs + f0) = v;
+                *reinterpret_cast<v4f*>(ybuf + ((rt0 + t) * 16 + a) * zs + f0) = v;
             }
         }
     }
@@ -324,13 +330,13 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
             float* yd = p.y + (size_t)g0 * N * p.F;
             if ((p.F & 3) == 0) {
                 const int F4 = p.F >> 2;
-                for (int i = tid; i < R * F4; i += kThreads) {
+                for (int i = tid; i < R * F4; i += NT) {
                     const int r = i / F4, c = i - r * F4;
                     *reinterpret_cast<v4f*>(yd + (size_t)r * p.F + 4 * c) =
                         *reinterpret_cast<const v4f*>(ybuf + r * zs + 4 * c);
                 }
             } else {
-                for (int i = tid; i < R * p.F; i += kThreads) {
+                for (int i = tid; i < R * p.F; i += NT) {
                     const int r = i / p.F, c = i - r * p.F;
                     yd[(size_t)r * p.F + c] = ybuf[r * zs + c];
                 }
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
             const int slab = p.F * p.Nin;
             for (int j = 0; j < ng; ++j) {
                 float* yd = p.y + (size_t)(g0 + j) * slab;
-                for (int i = tid; i < slab; i += kThreads) {
+                for (int i = tid; i < slab; i += NT) {
                     const int f = i / p.Nin, n = i - f * p.Nin;
                     yd[i] = ybuf[(j * N + n) * zs + f];
                 }
@@ -347,10 +353,10 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
         }
     }
     if (p.act_w) {
-        // Action head on MFMA: D[a5, row] = sum_f act_w[a5, f] * y[row, f]; the A fragment is read
-        // straight from act_w[5,F] (rows >= 5 are zero), the B fragment from the staged y tile.
+        // Action head on MFMA: D[a5, row] = sum_f act_w[a5, f] * y[row, f]; A fragment from the
+        // staged act_w (rows >= 5 are zero), B fragment from the staged y tile.
         const int i5 = lane & 15;
-        for (int rt = wave; rt < RT; rt += kWaves) {
+        for (int rt = wave; rt < p.rt_total; rt += NW) {
             v4f d = vzero();
             for (int gg = 0; gg < p.MT; ++gg) {
                 const int f0 = gg * 16 + q * 4;
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void lsigf_kernel(const LsigfArgs p) {
                 if (i5 < 5) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        if (f0 + s < p.F) A[s] = p.act_w[i5 * p.F + f0 + s];
+                        if (f0 + s < p.F) A[s] = actw[i5 * p.F + f0 + s];
                 }
                 const v4f Bv = *reinterpret_cast<const v4f*>(ybuf + (rt * 16 + a) * zs + f0);
                 d = mfma16x4(A, Bv, d);
@@ -395,24 +401,38 @@ __global__ void decode_actions_kernel(const float* __restrict__ logits, int* __r
 
 // ---- host-side launcher -----------------------------------------------------------------------
 int g_filter_gpw = 0;               // 0: heuristic below; > 0: forced graphs per workgroup (tuning)
+int g_filter_waves = 0;             // 0: heuristic; 8 or 16: forced waves per workgroup (tuning)
 
-template <int RT, int MTW, int NGT>
+template <int RTW, int NW, int NGT>
 static hipError_t launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RT, MTW, NGT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RTW, NW, NGT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lsigf_kernel<RT, MTW, NGT>), dim3(grid), dim3(kThreads), smem, st, a);
+    hipLaunchKernelGGL((lsigf_kernel<RTW, NW, NGT>), dim3(grid), dim3(NW * 64), smem, st, a);
     return hipGetLastError();
 }
 
-template <int RT>
-static hipError_t launch_rt(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (a.NG == 8 && a.MT > kWaves) return launch_one<RT, 2, 8>(a, grid, smem, st);   // G = F = 128
-    if (a.MT <= kWaves) return launch_one<RT, 1, 0>(a, grid, smem, st);
-    return launch_one<RT, 2, 0>(a, grid, smem, st);
+template <int RTW, int NW>
+static hipError_t launch_ng(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
+    return a.NG == 8 ? launch_one<RTW, NW, 8>(a, grid, smem, st)
+                     : launch_one<RTW, NW, 0>(a, grid, smem, st);
+}
+
+template <int NW>
+static hipError_t launch_rtw(int rtw, const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
+    switch (rtw) {
+        case 1: return launch_ng<1, NW>(a, grid, smem, st);
+        case 2: return launch_ng<2, NW>(a, grid, smem, st);
+        case 3: return launch_ng<3, NW>(a, grid, smem, st);
+        case 4: return launch_ng<4, NW>(a, grid, smem, st);
+        case 5: return launch_ng<5, NW>(a, grid, smem, st);
+        case 6: return launch_ng<6, NW>(a, grid, smem, st);
+        case 7: return launch_ng<7, NW>(a, grid, smem, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
@@ -420,11 +440,12 @@ static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
     return (size_t)2 * rt * 16 * a.zstride * 4 + (size_t)gpw * a.N * a.Ns * 4;
 }
 
-// Chooses graphs-per-workgroup, checks the LDS budget and launches.  Returns a GNNPP_* code.
+// Chooses graphs-per-workgroup and waves-per-workgroup, checks the LDS budget and launches.
+// Returns a GNNPP_* code.
 int lsigf_launch(LsigfArgs a, hipStream_t st) {
     a.NG = (a.G + 15) / 16;
     a.MT = (a.F + 15) / 16;
-    if (a.MT > 2 * kWaves) return -2;                 // F > 128: the caller splits F
+    if (a.MT > 8) return -2;                          // F > 128: the caller splits F
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;
     a.Ns = a.N | 1;
@@ -446,21 +467,18 @@ int lsigf_launch(LsigfArgs a, hipStream_t st) {
         lsigf_smem(a, g_filter_gpw) <= (size_t)kLdsBytes)
         best = g_filter_gpw;
     a.gpw = best;
-    const int rt = (a.gpw * a.N + 15) / 16;
+    a.rt_total = (a.gpw * a.N + 15) / 16;
     const size_t smem = lsigf_smem(a, a.gpw);
     if (smem > (size_t)kLdsBytes) return -2;
     const int grid = (a.B + a.gpw - 1) / a.gpw;
-    hipError_t err;
-    switch (rt) {
-        case 1: err = launch_rt<1>(a, grid, smem, st); break;
-        case 2: err = launch_rt<2>(a, grid, smem, st); break;
-        case 3: err = launch_rt<3>(a, grid, smem, st); break;
-        case 4: err = launch_rt<4>(a, grid, smem, st); break;
-        case 5: err = launch_rt<5>(a, grid, smem, st); break;
-        case 6: err = launch_rt<6>(a, grid, smem, st); break;
-        case 7: err = launch_rt<7>(a, grid, smem, st); break;
-        default: return -2;
-    }
+    // waves per workgroup: 16 when there are enough rows / row tiles to feed them
+    const int mtp = a.MT > 4 ? 8 : 4;
+    int nw = (a.gpw * a.N > 24) ? 16 : 8;
+    if (g_filter_waves == 8 || g_filter_waves == 16) nw = g_filter_waves;
+    const int chunks = nw / mtp;
+    const int rtw = (a.rt_total + chunks - 1) / chunks;
+    const hipError_t err = nw == 16 ? launch_rtw<16>(rtw, a, grid, smem, st)
+                                    : launch_rtw<8>(rtw, a, grid, smem, st);
     return err == hipSuccess ? 0 : -3;
 }
 

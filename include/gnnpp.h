@@ -44,6 +44,7 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_ENCODER_VARIANT 0  /* 1 (default): in-place layers, 79 KB LDS, 2 workgroups/CU;
                                          0: ping-pong buffers, 100 KB LDS, 1 workgroup/CU        */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
+#define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
 int         gnnpp_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

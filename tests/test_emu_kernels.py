@@ -103,10 +103,11 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
     h, S, x, want = z['c%d_h' % i], z['c%d_S' % i], z['c%d_x' % i], z['c%d_y' % i]
     b = z['c%d_b' % i] if meta[i]['has_bias'] else None
     try:
-        for gpw in (1, 2):
-            assert lib.gnnpp_set_tuning(1, gpw) == 0
+        for gpw, waves in ((1, 8), (2, 16), (2, 8), (1, 16)):
+            assert lib.gnnpp_set_tuning(1, gpw) == 0 and lib.gnnpp_set_tuning(2, waves) == 0
             y = el.lsigf(lib, h, S, x, b, True)
-            assert np.abs(y - want).max() <= TOL
+            assert np.abs(y - want).max() <= TOL, (gpw, waves)
     finally:
         lib.gnnpp_set_tuning(1, 0)
+        lib.gnnpp_set_tuning(2, 0)
     assert lib.gnnpp_set_tuning(7, 0) == -1 and lib.gnnpp_set_tuning(0, 5) == -1

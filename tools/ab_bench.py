@@ -44,7 +44,7 @@ def main():
     net.load_state_dict(sd)
     enc = net.packed_encoder()
     # ---- encoder variants over M ----
-    for M in (16, 256, 4096, 5120, 8192, 12800, 40960):
+    for M in (16, 5120, 12800, 40960):
         obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
@@ -64,14 +64,17 @@ def main():
         gb = gf.bias.detach().reshape(-1)
         taps = gf.packed_taps()
         row = {'kernel': 'lsigf', 'N': N, 'B': B, 'K': K}
-        for gpw in (0, 1, 2, 3, 4, 6, 8):
-            if gpw * N > 112:
-                continue
-            L.gnnpp_set_tuning(1, gpw)
-            t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(x), vp(S), vp(taps), vp(gb), vp(y), B, N, N, 128,
-                                                 128, K, 1, 0, 1, 1, 1, 1, st))
-            row['gpw%d_us' % gpw] = round(t, 2)
+        for waves in (0, 8, 16):
+            L.gnnpp_set_tuning(2, waves)
+            for gpw in (0, 1, 2, 3, 4, 6, 8):
+                if gpw * N > 112 or (waves == 0 and gpw != 0):
+                    continue
+                L.gnnpp_set_tuning(1, gpw)
+                t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(x), vp(S), vp(taps), vp(gb), vp(y), B, N, N,
+                                                     128, 128, K, 1, 0, 1, 1, 1, 1, st))
+                row['w%d_gpw%d_us' % (waves, gpw)] = round(t, 2)
         L.gnnpp_set_tuning(1, 0)
+        L.gnnpp_set_tuning(2, 0)
         # module-API layout (feature-major in/out), heuristic gpw
         xf = x.reshape(B, N, 128).permute(0, 2, 1).contiguous()
         yf = torch.empty(B, 128, N, device=dev)
