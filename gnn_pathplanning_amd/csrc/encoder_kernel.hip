@@ -380,7 +380,8 @@ int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int g_encoder_variant = 1;          // 1: in place, 2 workgroups/CU (default); 0: ping-pong
+int g_encoder_variant = 2;          // 2: schedule v2 (default); 1: v1 in place; 0: v1 ping-pong
+int encoder_launch_v2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 
 template <bool INPLACE>
 static int encoder_launch_t(const float* obs, const float* packed, float* feat, int M,
@@ -399,6 +400,7 @@ static int encoder_launch_t(const float* obs, const float* packed, float* feat, 
 }
 
 int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    if (g_encoder_variant == 2) return encoder_launch_v2(obs, packed, feat, M, st);
     return g_encoder_variant ? encoder_launch_t<true>(obs, packed, feat, M, st)
                              : encoder_launch_t<false>(obs, packed, feat, M, st);
 }

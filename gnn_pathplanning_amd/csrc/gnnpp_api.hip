@@ -3,6 +3,7 @@
 #include "../../include/gnnpp.h"
 
 #include "encoder_kernel.hip"
+#include "encoder_kernel_v2.hip"
 #include "lsigf_kernel.hip"
 
 using namespace gnnpp;
@@ -99,7 +100,7 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT:
-            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
             g_encoder_variant = value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_GPW:

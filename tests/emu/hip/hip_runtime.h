@@ -65,6 +65,9 @@ f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 #define __ffsll(x) __builtin_ffsll(x)
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 1
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 
 inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 inline int __float_as_int(float f) { int v; std::memcpy(&v, &f, 4); return v; }

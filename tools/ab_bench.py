@@ -44,16 +44,16 @@ def main():
     net.load_state_dict(sd)
     enc = net.packed_encoder()
     # ---- encoder variants over M ----
-    for M in (16, 5120, 12800, 40960):
+    for M in (16, 4096, 5120, 12800, 40960):
         obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
-        for v in (1, 0):
+        for v in (2, 1):
             L.gnnpp_set_tuning(0, v)
             t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
             row['v%d_us' % v] = round(t, 2)
             row['v%d_TFLOPs' % v] = round(2.0 * (1238112 + 16384) * M / t / 1e6, 1)
-        L.gnnpp_set_tuning(0, 1)
+        L.gnnpp_set_tuning(0, 2)
         print(json.dumps(row), flush=True)
     # ---- filter: graphs-per-workgroup sweep ----
     for (N, B, K, W) in ((10, 512, 3, 20), (50, 256, 3, 50), (100, 128, 3, 100), (10, 4096, 3, 20)):
