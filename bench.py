@@ -176,13 +176,21 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / reps
 
+        traffic = args.traffic_bytes
+        pmc_file = os.path.join(ROOT, 'profiles', 'pmc_encoder_%s.json' % args.config)
+        if traffic is None and os.path.exists(pmc_file):
+            # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command,
+            # gfx950 correction of the microarch guide: FETCH_SIZE counts half of wide reads
+            pmc = json.load(open(pmc_file))
+            traffic = (2.0 * pmc['FETCH_SIZE_KB_per_dispatch'] + pmc['WRITE_SIZE_KB_per_dispatch']) * 1024.0
         t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
         flops = 2.0 * ENC_MACS_PER_AGENT * M
         achieved = flops / t_enc / 1e12
         result['roofline'] = {
             'kernel': 'gnnpp::encoder_kernel', 'bound': 'mfma', 'achieved': achieved,
             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-            'traffic': args.traffic_bytes, 'avg_launch_us': t_enc * 1e6,
+            'traffic': traffic, 'algorithmic_bytes': M * (363 + 128) * 4.0 + 156288 * 4.0,
+            'avg_launch_us': t_enc * 1e6,
             'flops_per_launch': flops,
         }
         # secondary: the graph-filter kernel alone (node-major features in, ReLU'd features out)
