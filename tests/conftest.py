@@ -37,3 +37,8 @@ def golden_state_dict(z, K=3):
     if K != 3:
         sd['GFL.0.weight'] = torch.from_numpy(np.array(z['gfl_w_K%d' % K]))
     return sd
+
+
+@pytest.fixture(scope='session')
+def rollout_golden():
+    return _load('rollout_traces.npz')
