@@ -20,7 +20,8 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
 
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_encoder_packed_floats',
-           'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_decode_actions')
+           'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
+           'gnnpp_rollout_move')
 
 
 class GnnppError(RuntimeError):
@@ -54,6 +55,20 @@ class EncoderParams(ctypes.Structure):
                 ('fc_w', ctypes.c_void_p), ('fc_b', ctypes.c_void_p), ('bn_eps', ctypes.c_float)]
 
 
+class RolloutStruct(ctypes.Structure):
+    """struct gnnpp_rollout (include/gnnpp.h)."""
+    _fields_ = [('grid', ctypes.c_void_p), ('grid_batched', ctypes.c_int), ('goal', ctypes.c_void_p),
+                ('pos', ctypes.c_void_p), ('B', ctypes.c_int), ('N', ctypes.c_int),
+                ('H', ctypes.c_int), ('W', ctypes.c_int), ('obs', ctypes.c_void_p),
+                ('radius', ctypes.c_void_p), ('S', ctypes.c_void_p), ('connected', ctypes.c_void_p),
+                ('grow', ctypes.c_int), ('logits', ctypes.c_void_p), ('actions', ctypes.c_void_p),
+                ('reached', ctypes.c_void_p), ('start_step', ctypes.c_void_p),
+                ('end_step', ctypes.c_void_p), ('maxstep', ctypes.c_void_p),
+                ('flags', ctypes.c_void_p), ('stats', ctypes.c_void_p), ('currentstep', ctypes.c_int),
+                ('tie_mode', ctypes.c_int), ('seed', ctypes.c_uint), ('choices', ctypes.c_void_p),
+                ('choice_count', ctypes.c_void_p), ('max_choices', ctypes.c_int)]
+
+
 _lib = None
 
 
@@ -83,8 +98,12 @@ def lib():
     L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, vp]
     L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 4 + [vp]
     L.gnnpp_decode_actions.argtypes = [vp, vp, ci, ci, vp]
+    for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move'):
+        getattr(L, f).argtypes = [ctypes.POINTER(RolloutStruct), vp]
+        getattr(L, f).restype = ci
     for f in ('gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_encoder_pack', 'gnnpp_encoder_fwd',
-              'gnnpp_policy_fwd', 'gnnpp_decode_actions'):
+              'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
+           'gnnpp_rollout_move'):
         getattr(L, f).restype = ci
     _lib = L
     return L

@@ -5,6 +5,7 @@
 #include "encoder_kernel.hip"
 #include "encoder_kernel_v2.hip"
 #include "lsigf_kernel.hip"
+#include "rollout_kernels.hip"
 
 using namespace gnnpp;
 
@@ -119,6 +120,31 @@ int gnnpp_set_tuning(int key, int value) {
 int gnnpp_decode_actions(const float* logits, int* actions, int B, int N, void* stream) {
     if (!logits || !actions || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     return decode_actions_launch(logits, actions, B, N, static_cast<hipStream_t>(stream));
+}
+
+static int rollout_common_ok(const gnnpp_rollout* r) {
+    return r && r->pos && r->B > 0 && r->N > 0 && r->N <= GNNPP_ROLLOUT_MAX_AGENTS;
+}
+
+int gnnpp_rollout_observe(const gnnpp_rollout* r, void* stream) {
+    if (!rollout_common_ok(r) || !r->grid || !r->goal || !r->obs || r->H <= 0 || r->W <= 0)
+        return GNNPP_ERR_ARG;
+    return rollout_observe_launch(*r, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_rollout_gso(const gnnpp_rollout* r, void* stream) {
+    if (!rollout_common_ok(r) || !r->radius || !r->S) return GNNPP_ERR_ARG;
+    return rollout_gso_launch(*r, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream) {
+    if (!rollout_common_ok(r) || !r->grid || !r->goal || (!r->logits && !r->actions) ||
+        !r->reached || !r->start_step || !r->end_step || !r->maxstep || !r->flags || !r->stats ||
+        r->H <= 0 || r->W <= 0)
+        return GNNPP_ERR_ARG;
+    if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
+    if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
+    return rollout_move_launch(*r, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

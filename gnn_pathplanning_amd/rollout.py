@@ -1,0 +1,142 @@
+"""Batched on-device rollouts: B independent MAPF episodes stepped together on one MI355X.
+
+Mirrors what the reference does per test case on the host (agents/decentralplannerlocal.py:534-592
+driving utils/multirobotsim_dcenlocal.py), with the episode state resident in HBM:
+
+    sim.getCurrentState()  -> BatchedRollout.observe()   AgentState.toInputTensor (statetransformer.py:82-130)
+    sim.getGSO(step)       -> BatchedRollout.gso(step)   computeAdjacencyMatrix (multirobotsim_dcenlocal.py:320-394)
+    model.addGSO / model() -> DecentralPlannerNet.forward_logits
+    sim.move(actionVec, t) -> BatchedRollout.move(...)   move + interRobotCollision (:462-723)
+
+A step is four kernel launches and no host synchronisation; `run()` only reads back a "finished"
+flag every few steps.  The reference's random.choice tie-break among colliding agents (:489) is
+replaced by a deterministic rule (`tie_mode`): 'lowest' index, 'hashed' counter-based RNG, or
+'replay' of recorded choices (parity tests).  Positions are (row, col) integers.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+
+_TIE = {'lowest': 0, 'hashed': 1, 'replay': 2}
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+class BatchedRollout:
+    def __init__(self, grid, starts, goals, maxstep, device, commR=6.0, tie_mode='lowest', seed=0):
+        """grid [B,H,W] or [H,W] (1 = obstacle); starts, goals [B,N,2]; maxstep int or [B]."""
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise _native.GnnppError('BatchedRollout needs a HIP device (no CPU fallback)')
+        _native.lib()
+        self.device = dev
+        g = torch.as_tensor(grid)
+        self.grid_batched = int(g.dim() == 3)
+        self.grid = g.to(torch.uint8).contiguous().to(dev)
+        self.H, self.W = int(g.shape[-2]), int(g.shape[-1])
+        self.pos = torch.as_tensor(starts).to(torch.int32).contiguous().to(dev)
+        self.goal = torch.as_tensor(goals).to(torch.int32).contiguous().to(dev)
+        self.B, self.N = int(self.pos.shape[0]), int(self.pos.shape[1])
+        assert self.goal.shape == self.pos.shape and self.pos.shape[2] == 2
+        assert not self.grid_batched or self.grid.shape[0] == self.B
+        if self.N > 128:
+            raise _native.GnnppError('at most 128 agents per episode')
+        ms = torch.as_tensor(maxstep, dtype=torch.int32)
+        self.maxstep = (ms if ms.dim() else ms.repeat(self.B)).contiguous().to(dev)
+        B, N = self.B, self.N
+        self.obs = torch.empty(B, N, 3, 11, 11, dtype=torch.float32, device=dev)
+        self.radius = torch.full((B,), float(commR), dtype=torch.float64, device=dev)
+        self.S = torch.empty(B, N, N, dtype=torch.float32, device=dev)
+        self.connected = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.reached = torch.zeros(B, N, dtype=torch.int32, device=dev)
+        self.start_step = torch.full((B, N), -1, dtype=torch.int32, device=dev)
+        self.end_step = torch.full((B, N), -1, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(B, 3, dtype=torch.int32, device=dev)
+        self.stats = torch.zeros(B, 2, dtype=torch.int32, device=dev)
+        self.choice_count = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.tie_mode = _TIE[tie_mode]
+        self.seed = int(seed) & 0xffffffff
+        self.t = 0                                            # steps taken so far
+        r = _native.RolloutStruct()
+        r.grid, r.grid_batched, r.goal, r.pos = _p(self.grid), self.grid_batched, _p(self.goal), _p(self.pos)
+        r.B, r.N, r.H, r.W = B, N, self.H, self.W
+        r.obs, r.radius, r.S, r.connected = _p(self.obs), _p(self.radius), _p(self.S), _p(self.connected)
+        r.reached, r.start_step, r.end_step = _p(self.reached), _p(self.start_step), _p(self.end_step)
+        r.maxstep, r.flags, r.stats = _p(self.maxstep), _p(self.flags), _p(self.stats)
+        r.tie_mode, r.seed, r.choice_count = self.tie_mode, self.seed, _p(self.choice_count)
+        self._r = r
+
+    # -- the three simulator calls -------------------------------------------------------------
+    def _call(self, fn, what):
+        with _native.device_guard(self.device):
+            _native.check(fn(ctypes.byref(self._r), _native.stream_ptr(self.device)), what)
+
+    def observe(self):
+        """[B,N,3,11,11] float32 observations of the current positions (buffer reused each step)."""
+        self._call(_native.lib().gnnpp_rollout_observe, 'gnnpp_rollout_observe')
+        return self.obs
+
+    def gso(self, step=None):
+        """[B,N,N] float32 GSO of the current positions.  step 0 grows the radius until connected."""
+        step = self.t if step is None else step
+        self._r.grow = int(step == 0)
+        self._call(_native.lib().gnnpp_rollout_gso, 'gnnpp_rollout_gso')
+        return self.S
+
+    def move(self, logits=None, actions=None, choices=None, currentstep=None):
+        """Apply one joint action.  logits [N,B,5] (DecentralPlannerNet.forward_logits) or action
+        ids [B,N] int32; `choices` [B,C] int16 only for tie_mode='replay'.  Returns flags [B,3]
+        (allReachGoal at entry, moveCollision, predictCollision) -- a device tensor."""
+        r = self._r
+        keep = []
+        if logits is not None:
+            lg = logits.detach().contiguous().float()
+            assert lg.shape == (self.N, self.B, 5)
+            keep.append(lg)
+            r.logits, r.actions = _p(lg), None
+        else:
+            ac = actions.to(torch.int32).contiguous()
+            assert ac.shape == (self.B, self.N)
+            keep.append(ac)
+            r.logits, r.actions = None, _p(ac)
+        if self.tie_mode == 2:
+            ch = choices.to(torch.int16).contiguous().to(self.device)
+            keep.append(ch)
+            r.choices, r.max_choices = _p(ch), int(ch.shape[1])
+        self.t += 1
+        r.currentstep = self.t if currentstep is None else int(currentstep)
+        self._call(_native.lib().gnnpp_rollout_move, 'gnnpp_rollout_move')
+        return self.flags
+
+    # -- whole episodes ------------------------------------------------------------------------------
+    def step(self, model):
+        """One rollout step of all episodes: observe -> gso -> policy forward -> move."""
+        obs = self.observe()
+        S = self.gso()
+        model.addGSO(S)
+        return self.move(logits=model.forward_logits(obs))
+
+    def run(self, model, max_steps=None, check_every=8):
+        """Step until every episode has finished (all agents at their goals, or maxstep reached).
+        Like the reference loop (agents/decentralplannerlocal.py:560-599) an episode needs one more
+        move() after its last agent arrives for its statistics to be written."""
+        limit = int(self.maxstep.max().item()) if max_steps is None else int(max_steps)
+        steps = 0
+        while steps < limit:
+            self.step(model)
+            steps += 1
+            if steps % check_every == 0 and bool((self.flags[:, 0] == 1).all().item()):
+                break
+        return self.results()
+
+    def results(self):
+        torch.cuda.synchronize(self.device)
+        reached = self.reached.bool()
+        return {'steps': self.t, 'reached': reached.cpu(), 'success': reached.all(dim=1).cpu(),
+                'makespan': self.stats[:, 0].cpu(), 'flowtime': self.stats[:, 1].cpu(),
+                'end_step': self.end_step.cpu(), 'start_step': self.start_step.cpu(),
+                'positions': self.pos.cpu(), 'radius': self.radius.cpu()}

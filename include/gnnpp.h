@@ -131,6 +131,55 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
  * logits [N,B,5] -> actions [B,N] int32. */
 int gnnpp_decode_actions(const float* logits, int* actions, int B, int N, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Batched rollout step around the forward (B independent episodes resident on the device):
+ *   gnnpp_rollout_observe  AgentState.toInputTensor             dataloader/statetransformer.py:82-130
+ *   gnnpp_rollout_gso      multiRobotSim.computeAdjacencyMatrix utils/multirobotsim_dcenlocal.py:320-365
+ *                          (+ getGSO :367-394: radius bookkeeping)
+ *   gnnpp_rollout_move     multiRobotSim.move :562-723 with interRobotCollision :462-555
+ * One struct (HOST struct of DEVICE pointers) carries the episode state; each call reads the
+ * fields of its section.  Integer / boolean / fp64 work: bit-exact against the simulator.
+ * ------------------------------------------------------------------------------------------ */
+#define GNNPP_ROLLOUT_MAX_AGENTS 128
+#define GNNPP_TIE_LOWEST  0   /* colliding agent with the lowest index keeps its move          */
+#define GNNPP_TIE_HASHED  1   /* counter-based hash of (seed, episode, step, call)             */
+#define GNNPP_TIE_REPLAY  2   /* replay recorded random.choice outcomes (parity tests)         */
+
+typedef struct gnnpp_rollout {
+    /* episode state shared by the three calls */
+    const unsigned char* grid;  /* [B,H,W] when grid_batched else [H,W]; 1 = obstacle           */
+    int          grid_batched;
+    const int*   goal;          /* [B,N,2] (row, col)                                           */
+    int*         pos;           /* [B,N,2] current positions; updated by move                   */
+    int          B, N, H, W;
+    /* observe */
+    float*       obs;           /* out [B,N,3,11,11]: obstacle FOV, goal / projected goal, agents */
+    /* gso */
+    double*      radius;        /* [B] communication radius, in/out (commR at step 0)           */
+    float*       S;             /* out [B,N,N] = float(D^-1/2 A D^-1/2)                          */
+    int*         connected;     /* out [B] or NULL                                              */
+    int          grow;          /* 1 at step 0: radius /= 1.1, then *= 1.1 until connected      */
+    /* move */
+    const float* logits;        /* [N,B,5] from gnnpp_policy_fwd (argmax decoded here), or NULL */
+    const int*   actions;       /* [B,N] action ids when logits == NULL                         */
+    int*         reached;       /* [B,N] 0/1                 (count_reachgoal)                   */
+    int*         start_step;    /* [B,N], -1 = None          (startStep_action_predict)          */
+    int*         end_step;      /* [B,N], -1 = None          (endStep_action_predict)            */
+    const int*   maxstep;       /* [B]                                                           */
+    int*         flags;         /* out [B,3]: allReachGoal at entry, moveCollision, predictCollision */
+    int*         stats;         /* out [B,2]: makespan, flowtime (written when the episode ends) */
+    int          currentstep;   /* 1-based step index, as the agent passes it (:588)            */
+    int          tie_mode;      /* GNNPP_TIE_*: stands in for random.choice (:489)              */
+    unsigned     seed;
+    const short* choices;       /* [B,max_choices] recorded outcomes for GNNPP_TIE_REPLAY       */
+    int*         choice_count;  /* out [B] tie-breaks consumed in this call, or NULL            */
+    int          max_choices;
+} gnnpp_rollout;
+
+int gnnpp_rollout_observe(const gnnpp_rollout* r, void* stream);
+int gnnpp_rollout_gso(const gnnpp_rollout* r, void* stream);
+int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""CPU: the HIP rollout kernels (observe / gso / move), compiled unmodified for the host emulation,
+replay the traces recorded from the real simulator bit-exactly (tie-breaks replayed)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/lib/llvm/bin/clang++'),
+                                reason='host clang++ from ROCm not present')
+
+
+def replay_case(lib, Struct, z, ci, m):
+    N, W, T = m['N'], m['W'], m['T']
+    grid = np.ascontiguousarray(z['t%d_grid' % ci].astype(np.uint8))
+    goal = np.ascontiguousarray(z['t%d_goal' % ci].astype(np.int32))[None]
+    pos_all = z['t%d_pos' % ci].astype(np.int32)
+    pos = np.ascontiguousarray(pos_all[0][None])
+    obs = np.zeros((1, N, 3, 11, 11), np.float32)
+    radius = np.array([float(m['commR'])], np.float64)
+    S = np.zeros((1, N, N), np.float32)
+    conn = np.zeros(1, np.int32)
+    reached = np.zeros((1, N), np.int32)
+    start = np.full((1, N), -1, np.int32)
+    end = np.full((1, N), -1, np.int32)
+    maxstep = np.array([m['maxstep']], np.int32)
+    flags = np.zeros((1, 3), np.int32)
+    stats = np.zeros((1, 2), np.int32)
+    ccount = np.zeros(1, np.int32)
+    all_choices = z['t%d_choices' % ci]
+    used = 0
+    r = Struct()
+    r.grid, r.grid_batched, r.goal, r.pos = grid.ctypes.data, 0, goal.ctypes.data, pos.ctypes.data
+    r.B, r.N, r.H, r.W = 1, N, W, W
+    r.obs, r.radius, r.S, r.connected = obs.ctypes.data, radius.ctypes.data, S.ctypes.data, conn.ctypes.data
+    r.reached, r.start_step, r.end_step = reached.ctypes.data, start.ctypes.data, end.ctypes.data
+    r.maxstep, r.flags, r.stats = maxstep.ctypes.data, flags.ctypes.data, stats.ctypes.data
+    r.tie_mode, r.choice_count = 2, ccount.ctypes.data
+    for t in range(T):
+        assert (pos[0] == pos_all[t]).all(), (ci, t)
+        assert lib.gnnpp_rollout_observe(ctypes.byref(r), None) == 0
+        assert (obs[0] == z['t%d_obs' % ci][t].astype(np.float32)).all(), (ci, t)
+        r.grow = int(t == 0)
+        assert lib.gnnpp_rollout_gso(ctypes.byref(r), None) == 0
+        assert radius[0] == z['t%d_radius' % ci][t], (ci, t)
+        assert (S[0] == z['t%d_gso' % ci][t].astype(np.float32)).all(), (ci, t)
+        assert conn[0] in (0, 1)
+        # move: logits in the [N,B,5] layout of gnnpp_policy_fwd; recorded tie-breaks for this step
+        logits = np.ascontiguousarray(z['t%d_logits' % ci][t][:, None, :])
+        nch = int(z['t%d_nchoices' % ci][t])
+        ch = np.zeros((1, max(nch, 1)), np.int16)
+        ch[0, :nch] = all_choices[used:used + nch]
+        used += nch
+        r.logits, r.actions, r.currentstep = logits.ctypes.data, None, t + 1
+        r.choices, r.max_choices = ch.ctypes.data, ch.shape[1]
+        assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == 0
+        assert ccount[0] == nch, (ci, t, ccount[0], nch)
+        assert list(flags[0]) == [int(v) for v in z['t%d_flags' % ci][t]], (ci, t)
+        assert (reached[0] == z['t%d_reached' % ci][t]).all(), (ci, t)
+    assert (pos[0] == pos_all[T]).all()
+    assert list(stats[0]) == [m['makespan'], m['flowtime']], (ci, list(stats[0]), m)
+    assert list(end[0]) == m['end_step'] and list(start[0]) == m['start_step']
+
+
+def test_emu_rollout_traces(rollout_golden):
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    lib = emu_lib.load()
+    z, meta = rollout_golden
+    for ci, m in enumerate(meta):
+        replay_case(lib, RolloutStruct, z, ci, m)
+
+
+def test_emu_rollout_argument_checks():
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    lib = emu_lib.load()
+    r = RolloutStruct()
+    assert lib.gnnpp_rollout_observe(ctypes.byref(r), None) == -1
+    assert lib.gnnpp_rollout_gso(None, None) == -1
+    r.B, r.N = 1, 200
+    assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == -1

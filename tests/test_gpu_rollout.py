@@ -1,0 +1,134 @@
+"""GPU (-m gpu): the batched rollout step through the C ABI / BatchedRollout against (i) the traces
+of the real simulator, (ii) the CPU rollout oracle on fresh random episodes, (iii) the policy oracle
+inside a closed-loop rollout.  Integer/boolean/fp64 stages are bit-exact; logits within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import policy_oracle as orc
+from oracle import rollout_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from gnn_pathplanning_amd import _native
+    _native.lib()
+    return torch.device('cuda:0')
+
+
+def random_episodes(rng, B, N, W, density):
+    grids, starts, goals = [], [], []
+    for _ in range(B):
+        g = (rng.random((W, W)) < density).astype(np.uint8)
+        free = np.argwhere(g == 0)
+        idx = rng.choice(len(free), size=2 * N, replace=False)
+        grids.append(g); starts.append(free[idx[:N]]); goals.append(free[idx[N:]])
+    return np.stack(grids), np.stack(starts), np.stack(goals)
+
+
+def test_replay_simulator_traces(dev, rollout_golden):
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    z, meta = rollout_golden
+    for ci, m in enumerate(meta):
+        pos_all = z['t%d_pos' % ci].astype(np.int64)
+        env = BatchedRollout(z['t%d_grid' % ci], pos_all[0][None], z['t%d_goal' % ci][None],
+                             m['maxstep'], dev, commR=m['commR'], tie_mode='replay')
+        used = 0
+        for t in range(m['T']):
+            assert (env.pos[0].cpu().numpy() == pos_all[t]).all(), (ci, t)
+            assert (env.observe()[0].cpu().numpy() == z['t%d_obs' % ci][t]).all(), (ci, t)
+            S = env.gso(t)[0].cpu().numpy()
+            assert (S == z['t%d_gso' % ci][t].astype(np.float32)).all(), (ci, t)
+            assert env.radius[0].item() == z['t%d_radius' % ci][t]
+            nch = int(z['t%d_nchoices' % ci][t])
+            ch = torch.zeros(1, max(nch, 1), dtype=torch.int16)
+            ch[0, :nch] = torch.from_numpy(z['t%d_choices' % ci][used:used + nch].astype(np.int16))
+            used += nch
+            logits = torch.from_numpy(z['t%d_logits' % ci][t]).unsqueeze(1).to(dev)     # [N,1,5]
+            flags = env.move(logits=logits, choices=ch)
+            assert flags[0].cpu().tolist() == [int(v) for v in z['t%d_flags' % ci][t]], (ci, t)
+            assert env.choice_count[0].item() == nch
+            assert (env.reached[0].cpu().numpy() == z['t%d_reached' % ci][t]).all()
+        res = env.results()
+        assert (res['positions'][0].numpy() == pos_all[m['T']]).all()
+        assert res['makespan'][0].item() == m['makespan'] and res['flowtime'][0].item() == m['flowtime']
+        assert res['end_step'][0].tolist() == m['end_step']
+        assert res['start_step'][0].tolist() == m['start_step']
+
+
+@pytest.mark.parametrize('B,N,W,dens', [(64, 10, 20, 0.1), (16, 40, 24, 0.05), (8, 100, 40, 0.05)])
+def test_batched_steps_vs_oracle_random_actions(dev, B, N, W, dens):
+    """Many episodes at once, random joint actions (lots of collisions), lowest-index tie-break."""
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    rng = np.random.default_rng(B + N)
+    grids, starts, goals = random_episodes(rng, B, N, W, dens)
+    maxstep = 12
+    env = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode='lowest')
+    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], maxstep) for b in range(B)]
+    radius = [6.0] * B
+    lowest = lambda c: c[0]                                              # noqa: E731
+    for t in range(maxstep + 1):
+        obs = env.observe().cpu().numpy()
+        S = env.gso(t).cpu().numpy()
+        rad = env.radius.cpu().numpy()
+        acts = rng.integers(0, 5, size=(B, N))
+        flags = env.move(actions=torch.from_numpy(acts).to(dev)).cpu().numpy()
+        pos = env.pos.cpu().numpy()
+        for b in range(B):
+            assert (obs[b] == ro.build_observations(grids[b], goals[b], eps[b].cur)).all(), (t, b)
+            Sb, radius[b], _ = ro.communication_gso(eps[b].cur, radius[b], grow=(t == 0))
+            assert radius[b] == rad[b] and (S[b] == Sb.astype(np.float32)).all(), (t, b)
+            f = ro.move_step(eps[b], acts[b], t + 1, lowest)
+            assert [int(v) for v in f] == flags[b].tolist(), (t, b)
+            assert (pos[b] == eps[b].cur).all(), (t, b)
+    res = env.results()
+    for b in range(B):
+        assert res['makespan'][b].item() == eps[b].makespan
+        assert res['flowtime'][b].item() == eps[b].flowtime
+
+
+def test_closed_loop_rollout_with_policy(dev):
+    """observe -> gso -> forward -> move on the GPU; every stage checked against the CPU oracles
+    fed with the GPU's own state, so a near-tie in the logits cannot make the trajectories drift."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    B, N, W = 6, 10, 20
+    rng = np.random.default_rng(5)
+    grids, starts, goals = random_episodes(rng, B, N, W, 0.1)
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    sd = orc.init_state_dict(3, seed=21)
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(sd)
+    env = BatchedRollout(grids, starts, goals, 10, dev, tie_mode='lowest')
+    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], 10) for b in range(B)]
+    for t in range(10):
+        obs = env.observe()
+        S = env.gso()
+        net.addGSO(S)
+        logits = net.forward_logits(obs)                                  # [N,B,5]
+        with torch.no_grad():
+            want = torch.stack(orc.policy_forward(sd, S.cpu(), obs.cpu()), 0)   # [N,B,5]
+        assert (logits.cpu() - want).abs().max().item() <= 1e-4
+        acts = net.decode_actions(logits).cpu().numpy()                   # [B,N]
+        margin = torch.topk(want, 2, dim=-1).values
+        clear = ((margin[..., 0] - margin[..., 1]) > 1e-5).numpy().T      # [B,N]
+        assert (acts[clear] == want.argmax(-1).numpy().T[clear]).all()
+        env.move(logits=logits)
+        pos = env.pos.cpu().numpy()
+        for b in range(B):
+            ro.move_step(eps[b], acts[b], t + 1, lambda c: c[0])
+            assert (pos[b] == eps[b].cur).all(), (t, b)
+    out = BatchedRollout(grids, starts, goals, 24, dev).run(net, check_every=4)
+    assert out['steps'] <= 24 and out['reached'].shape == (B, N)
+
+
+def test_rollout_needs_gpu():
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    with pytest.raises(_native.GnnppError):
+        BatchedRollout(np.zeros((4, 4)), np.zeros((1, 2, 2)), np.ones((1, 2, 2)), 4, 'cpu')

@@ -98,5 +98,35 @@ def main():
                           'agent_steps_per_s': round(B * N / t * 1e6)}), flush=True)
 
 
+def rollout_bench():
+    import numpy as np
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    sd = orc.init_state_dict(3)
+    for (N, B, W) in ((10, 512, 20), (50, 256, 50), (100, 128, 100)):
+        rng = np.random.default_rng(N)
+        grids = (rng.random((B, W, W)) < 0.08).astype(np.uint8)
+        starts = np.zeros((B, N, 2), np.int64); goals = np.zeros((B, N, 2), np.int64)
+        for b in range(B):
+            free = np.argwhere(grids[b] == 0)
+            idx = rng.choice(len(free), size=2 * N, replace=False)
+            starts[b], goals[b] = free[idx[:N]], free[idx[N:]]
+        net = DecentralPlannerNet(Cfg(N, 3)).to(dev).eval()
+        net.load_state_dict(sd)
+        env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed')
+        env.step(net)
+        row = {'kernel': 'rollout_step', 'N': N, 'B': B}
+        row['observe_us'] = round(timeit(env.observe, reps=20), 2)
+        row['gso_us'] = round(timeit(lambda: env.gso(5), reps=20), 2)
+        lg = net.forward_logits(env.obs)
+        row['move_us'] = round(timeit(lambda: env.move(logits=lg), reps=20), 2)
+        t = timeit(lambda: env.step(net), reps=20)
+        row['step_us'] = round(t, 2)
+        row['agent_steps_per_s'] = round(B * N / t * 1e6)
+        print(json.dumps(row), flush=True)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'rollout':
+        rollout_bench()
+        sys.exit(0)
     main()

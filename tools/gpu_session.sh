@@ -19,6 +19,8 @@ if has bench; then stamp "bench c2"
   timeout 300 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
 if has ab; then stamp "ab_bench"
   timeout 400 python tools/ab_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_bench.jsonl; fi
+if has rollout; then stamp "rollout bench"
+  timeout 300 python tools/ab_bench.py rollout 2>&1 | grep -v amdgpu.ids | tee $OUT/rollout_bench.jsonl; fi
 if has bench35; then for c in c3 c5; do stamp "bench $c"
   timeout 300 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 5 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
