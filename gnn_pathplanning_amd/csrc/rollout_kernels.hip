@@ -147,26 +147,44 @@ __global__ __launch_bounds__(64) void rollout_gso_kernel(const RolloutArgs p) {
 }
 
 // ---- move + collision shielding -------------------------------------------------------------------
-struct MoveScratch {             // all in LDS, N <= kMaxAgents
-    int cur[kMaxAgents][2];
-    int nxt[kMaxAgents][2];
-    int snap[kMaxAgents][2];     // allagents_pos: snapshot, never updated inside one call
-    int lpos[kMaxAgents][2];     // list_pos: updated as agents are stopped
-    int last_action[kMaxAgents];
-    int collided[kMaxAgents];
-};
+// One wavefront per episode; lane l holds agents l and l + 64 in registers (N <= 128).  The
+// reference's python is sequential, but only its outer `for i in range(N)` loops carry a true
+// dependence; everything inside them is a search or a set update that a ballot does in one step:
+//   * list_pos.count(pos) > 1            -> popcount(ballot(lpos == pos_i))
+//   * collided = [j : allagents_pos[j] == pos] (ascending) -> ballot mask; random.choice -> k-th bit
+//   * `for name in collided: if last action is STOP: everybody in collided stops
+//                            elif name != chosen: it stops`
+//     == "if ANY collided agent already stands still, all of them (the chosen one too) stop,
+//        otherwise all but the chosen one stop"  (an agent's own flag can only flip through the
+//        stop-everybody branch, which is idempotent) -- checked against the simulator's traces;
+//   * list_nextpos.index(cur_i)          -> ffs(ballot(snapshot == cur_i)).
+struct Pos2 { int x, y; };
+
+__device__ __forceinline__ int lane_get(const int (&v)[2], int agent) {
+    return __builtin_amdgcn_readlane(agent < 64 ? v[0] : v[1], agent & 63);
+}
+
+struct MaskPair { unsigned long long lo, hi; };
+
+__device__ __forceinline__ MaskPair ballot2(bool p0, bool p1) {
+    MaskPair m;
+    m.lo = __ballot(p0);
+    m.hi = __ballot(p1);
+    return m;
+}
 
 __device__ __forceinline__ unsigned hash_u32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
 
-// random.choice(collided_agents) of the reference (:489): index into the collided list.
-__device__ int choose_mover(const RolloutArgs& p, int b, int ncol, int& calls) {
+// random.choice(collided_agents) of the reference (:489): index into the (ascending) collided list.
+__device__ __forceinline__ int choose_mover(const RolloutArgs& p, int b, int ncol, int& calls) {
     int k = 0;
     if (p.tie_mode == 1) {
-        k = (int)(hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u + (unsigned)p.currentstep * 0x85EBCA6Bu +
-                                             (unsigned)calls)) % (unsigned)ncol);
+        k = (int)(hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u +
+                                             (unsigned)p.currentstep * 0x85EBCA6Bu + (unsigned)calls)) %
+                  (unsigned)ncol);
     } else if (p.tie_mode == 2) {
         const int c = calls < p.max_choices ? (int)p.choices[(size_t)b * p.max_choices + calls] : 0;
         k = c < ncol ? c : 0;
@@ -175,50 +193,75 @@ __device__ int choose_mover(const RolloutArgs& p, int b, int ncol, int& calls) {
     return k;
 }
 
-__device__ bool inter_robot_collision(const RolloutArgs& p, MoveScratch& s, int b, int N, int& calls) {
+// index of the k-th set bit (k < popcount) of a 128-bit mask
+__device__ __forceinline__ int kth_set_bit(MaskPair m, int k) {
+    const int nlo = __popcll(m.lo);
+    unsigned long long w = m.lo;
+    int base = 0;
+    if (k >= nlo) { w = m.hi; k -= nlo; base = 64; }
+    for (int i = 0; i < k; ++i) w &= w - 1;
+    return base + __ffsll((long long)w) - 1;
+}
+
+struct AgentRegs {               // per lane: agents `lane` and `lane + 64`
+    int curx[2], cury[2], nxtx[2], nxty[2], last[2];
+};
+
+__device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
+                                      int& calls) {
     bool collision = false;
-    for (int i = 0; i < N; ++i) {
-        s.snap[i][0] = s.nxt[i][0]; s.snap[i][1] = s.nxt[i][1];
-        s.lpos[i][0] = s.nxt[i][0]; s.lpos[i][1] = s.nxt[i][1];
+    const bool live[2] = {lane < N, lane + 64 < N};
+    int snx[2], sny[2], lpx[2], lpy[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        snx[h] = r.nxtx[h]; sny[h] = r.nxty[h];              // allagents_pos (never updated)
+        lpx[h] = r.nxtx[h]; lpy[h] = r.nxty[h];              // list_pos (updated)
     }
     for (int i = 0; i < N; ++i) {
-        const int px = s.lpos[i][0], py = s.lpos[i][1];
-        int count = 0;
-        for (int j = 0; j < N; ++j) count += (s.lpos[j][0] == px && s.lpos[j][1] == py);
-        if (count > 1) {
+        const int px = lane_get(lpx, i), py = lane_get(lpy, i);
+        const MaskPair same = ballot2(live[0] && lpx[0] == px && lpy[0] == py,
+                                      live[1] && lpx[1] == px && lpy[1] == py);
+        if (__popcll(same.lo) + __popcll(same.hi) > 1) {
             collision = true;
-            int ncol = 0;
-            for (int j = 0; j < N; ++j)
-                if (s.snap[j][0] == px && s.snap[j][1] == py) s.collided[ncol++] = j;
-            const int mover = s.collided[choose_mover(p, b, ncol, calls)];
-            for (int c = 0; c < ncol; ++c) {
-                const int j = s.collided[c];
-                if (s.last_action[j] == 4) {
-                    for (int c2 = 0; c2 < ncol; ++c2) {           // one stands still: all stop
-                        const int k = s.collided[c2];
-                        s.last_action[k] = 4;
-                        s.nxt[k][0] = s.cur[k][0]; s.nxt[k][1] = s.cur[k][1];
-                        s.lpos[k][0] = s.nxt[k][0]; s.lpos[k][1] = s.nxt[k][1];
-                    }
-                } else if (j != mover) {
-                    s.last_action[j] = 4;
-                    s.nxt[j][0] = s.cur[j][0]; s.nxt[j][1] = s.cur[j][1];
-                    s.lpos[j][0] = s.nxt[j][0]; s.lpos[j][1] = s.nxt[j][1];
+            const bool in0 = live[0] && snx[0] == px && sny[0] == py;
+            const bool in1 = live[1] && snx[1] == px && sny[1] == py;
+            const MaskPair col = ballot2(in0, in1);
+            const int ncol = __popcll(col.lo) + __popcll(col.hi);
+            const int mover = kth_set_bit(col, choose_mover(p, b, ncol, calls));
+            const MaskPair still = ballot2(in0 && r.last[0] == 4, in1 && r.last[1] == 4);
+            const bool all_stop = (still.lo | still.hi) != 0;
+            const bool in[2] = {in0, in1};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (in[h] && (all_stop || lane + 64 * h != mover)) {
+                    r.last[h] = 4;
+                    r.nxtx[h] = r.curx[h]; r.nxty[h] = r.cury[h];
+                    lpx[h] = r.curx[h]; lpy[h] = r.cury[h];
                 }
             }
         }
     }
-    // position swaps (:524-553): list_nextpos is a snapshot taken here
-    for (int i = 0; i < N; ++i) { s.snap[i][0] = s.nxt[i][0]; s.snap[i][1] = s.nxt[i][1]; }
+    // position swaps (:524-553); list_nextpos is a snapshot taken here
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { snx[h] = r.nxtx[h]; sny[h] = r.nxty[h]; }
     for (int i = 0; i < N; ++i) {
-        int sidx = -1;
-        for (int j = 0; j < N; ++j)
-            if (s.snap[j][0] == s.cur[i][0] && s.snap[j][1] == s.cur[i][1]) { sidx = j; break; }
-        if (sidx >= 0 && sidx != i && s.cur[sidx][0] == s.nxt[i][0] && s.cur[sidx][1] == s.nxt[i][1]) {
-            s.nxt[i][0] = s.cur[i][0]; s.nxt[i][1] = s.cur[i][1];
-            s.nxt[sidx][0] = s.cur[sidx][0]; s.nxt[sidx][1] = s.cur[sidx][1];
-            s.last_action[i] = 4; s.last_action[sidx] = 4;
-            collision = true;
+        const int cx = lane_get(r.curx, i), cy = lane_get(r.cury, i);
+        const MaskPair hit = ballot2(live[0] && snx[0] == cx && sny[0] == cy,
+                                     live[1] && snx[1] == cx && sny[1] == cy);
+        if (hit.lo | hit.hi) {
+            const int sidx = hit.lo ? __ffsll((long long)hit.lo) - 1 : 64 + __ffsll((long long)hit.hi) - 1;
+            if (sidx != i && lane_get(r.curx, sidx) == lane_get(r.nxtx, i) &&
+                lane_get(r.cury, sidx) == lane_get(r.nxty, i)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int me = lane + 64 * h;
+                    if (me == i || me == sidx) {
+                        r.nxtx[h] = r.curx[h]; r.nxty[h] = r.cury[h];
+                        r.last[h] = 4;
+                    }
+                }
+                collision = true;
+            }
         }
     }
     return collision;
@@ -226,90 +269,122 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, MoveScratch& s, int 
 
 __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    MoveScratch& s = *reinterpret_cast<MoveScratch*>(gnnpp_smem);
+    int* red = reinterpret_cast<int*>(gnnpp_smem);              // [3][kMaxAgents] for the statistics
     const int b = blockIdx.x, lane = threadIdx.x, N = p.N;
     int* pos = p.pos + (size_t)b * N * 2;
-    // decode the actions in parallel (argmax of the logits == argmax of LogSoftmax, first max wins)
-    for (int n = lane; n < N; n += 64) {
-        int key;
-        if (p.logits) {
-            const float* l = p.logits + ((size_t)n * p.B + b) * 5;
-            key = 0;
-            float best = l[0];
-#pragma unroll
-            for (int k = 1; k < 5; ++k)
-                if (l[k] > best) { best = l[k]; key = k; }
-        } else {
-            key = p.actions[(size_t)b * N + n];
-        }
-        s.collided[n] = key;                                    // staging slot for the decoded key
-        s.cur[n][0] = pos[2 * n]; s.cur[n][1] = pos[2 * n + 1];
-    }
-    __syncthreads();
-    if (lane != 0) return;                                      // the shielding logic is sequential
-
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * p.H * p.W : 0);
     const int* goal = p.goal + (size_t)b * N * 2;
     int* reached = p.reached + (size_t)b * N;
     int* start_step = p.start_step + (size_t)b * N;
     int* end_step = p.end_step + (size_t)b * N;
     const int step = p.currentstep, maxstep = p.maxstep[b];
-    const int dxs[5] = {-1, 0, 1, 0, 0}, dys[5] = {0, -1, 0, 1, 0};
-    bool all_reached = true;
-    for (int n = 0; n < N; ++n) all_reached = all_reached && reached[n];
+
+    AgentRegs r;
+    int key[2], rch[2], sst[2], est[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = lane + 64 * h;
+        live[h] = n < N;
+        key[h] = 4; rch[h] = 1; sst[h] = -1; est[h] = -1;
+        r.curx[h] = r.cury[h] = r.nxtx[h] = r.nxty[h] = -1 - n;          // distinct dummies
+        r.last[h] = 4;
+        if (live[h]) {
+            if (p.logits) {         // argmax of the logits == argmax of LogSoftmax, first max wins
+                const float* l = p.logits + ((size_t)n * p.B + b) * 5;
+                int kk = 0;
+                float best = l[0];
+#pragma unroll
+                for (int k = 1; k < 5; ++k)
+                    if (l[k] > best) { best = l[k]; kk = k; }
+                key[h] = kk;
+            } else {
+                key[h] = p.actions[(size_t)b * N + n];
+            }
+            r.curx[h] = pos[2 * n]; r.cury[h] = pos[2 * n + 1];
+            rch[h] = reached[n]; sst[h] = start_step[n]; est[h] = end_step[n];
+        }
+    }
+    const MaskPair not_reached = ballot2(live[0] && !rch[0], live[1] && !rch[1]);
+    const bool all_reached = !(not_reached.lo | not_reached.hi);
     bool predict_collision = false, move_collision = false;
     int calls = 0;
     if (!all_reached || step < maxstep) {
-        for (int n = 0; n < N; ++n) {
-            const int key = s.collided[n];
-            if (key != 4 && start_step[n] < 0) start_step[n] = step - 1;
-            const int nx = s.cur[n][0] + dxs[key], ny = s.cur[n][1] + dys[key];
-            const bool edge = nx >= p.H || nx < 0 || ny >= p.W || ny < 0;
-            if (edge || grid[nx * p.W + ny] == 1) {
-                predict_collision = true;
-                s.last_action[n] = 4;
-                s.nxt[n][0] = s.cur[n][0]; s.nxt[n][1] = s.cur[n][1];
-            } else {
-                s.last_action[n] = key;
-                s.nxt[n][0] = nx; s.nxt[n][1] = ny;
+        bool bumped[2] = {false, false};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (live[h]) {
+                if (key[h] != 4 && sst[h] < 0) sst[h] = step - 1;
+                const int dx = key[h] == 0 ? -1 : key[h] == 2 ? 1 : 0;
+                const int dy = key[h] == 1 ? -1 : key[h] == 3 ? 1 : 0;
+                const int nx = r.curx[h] + dx, ny = r.cury[h] + dy;
+                const bool edge = nx >= p.H || nx < 0 || ny >= p.W || ny < 0;
+                if (edge || grid[nx * p.W + ny] == 1) {
+                    bumped[h] = true;
+                    r.last[h] = 4;
+                    r.nxtx[h] = r.curx[h]; r.nxty[h] = r.cury[h];
+                } else {
+                    r.last[h] = key[h];
+                    r.nxtx[h] = nx; r.nxty[h] = ny;
+                }
             }
         }
-        bool detect = inter_robot_collision(p, s, b, N, calls);
+        const MaskPair bm = ballot2(bumped[0], bumped[1]);
+        predict_collision = (bm.lo | bm.hi) != 0;
+        bool detect = inter_robot_collision(p, r, b, N, lane, calls);
         for (int it = 0; it < N; ++it) {
             if (!detect) break;
-            detect = inter_robot_collision(p, s, b, N, calls);
+            detect = inter_robot_collision(p, r, b, N, lane, calls);
             predict_collision = true;
         }
-        move_collision = inter_robot_collision(p, s, b, N, calls);
-        for (int n = 0; n < N; ++n) {
-            pos[2 * n] = s.nxt[n][0]; pos[2 * n + 1] = s.nxt[n][1];
-            if (s.nxt[n][0] == goal[2 * n] && s.nxt[n][1] == goal[2 * n + 1] && !reached[n]) {
-                reached[n] = 1;
-                end_step[n] = step;
-            }
-            if (step >= maxstep && !reached[n]) {
-                end_step[n] = step;
-                if (start_step[n] < 0) start_step[n] = 0;
+        move_collision = inter_robot_collision(p, r, b, N, lane, calls);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (live[h]) {
+                const int n = lane + 64 * h;
+                pos[2 * n] = r.nxtx[h]; pos[2 * n + 1] = r.nxty[h];
+                if (r.nxtx[h] == goal[2 * n] && r.nxty[h] == goal[2 * n + 1] && !rch[h]) {
+                    rch[h] = 1;
+                    est[h] = step;
+                }
+                if (step >= maxstep && !rch[h]) {
+                    est[h] = step;
+                    if (sst[h] < 0) sst[h] = 0;
+                }
+                reached[n] = rch[h]; start_step[n] = sst[h]; end_step[n] = est[h];
             }
         }
     }
     if (all_reached || step >= maxstep) {
         // An agent that reached its goal without ever issuing a move keeps start_step = None in
         // the reference (which then raises TypeError on `end - None`); we count it from step 0.
-        int flow = 0, emax = -(1 << 30), smin = 1 << 30;
-        for (int n = 0; n < N; ++n) {
-            const int st = start_step[n] < 0 ? 0 : start_step[n];
-            flow += end_step[n] - st;
-            emax = end_step[n] > emax ? end_step[n] : emax;
-            smin = st < smin ? st : smin;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (live[h]) {
+                const int n = lane + 64 * h;
+                red[n] = est[h];
+                red[kMaxAgents + n] = sst[h] < 0 ? 0 : sst[h];
+            }
         }
-        p.stats[2 * b] = emax - smin;
-        p.stats[2 * b + 1] = flow;
+        __syncthreads();
+        if (lane == 0) {
+            int flow = 0, emax = -(1 << 30), smin = 1 << 30;
+            for (int n = 0; n < N; ++n) {
+                const int e = red[n], st = red[kMaxAgents + n];
+                flow += e - st;
+                emax = e > emax ? e : emax;
+                smin = st < smin ? st : smin;
+            }
+            p.stats[2 * b] = emax - smin;
+            p.stats[2 * b + 1] = flow;
+        }
     }
-    p.flags[3 * b] = all_reached;
-    p.flags[3 * b + 1] = move_collision;
-    p.flags[3 * b + 2] = predict_collision;
-    if (p.choice_count) p.choice_count[b] = calls;
+    if (lane == 0) {
+        p.flags[3 * b] = all_reached;
+        p.flags[3 * b + 1] = move_collision;
+        p.flags[3 * b + 2] = predict_collision;
+        if (p.choice_count) p.choice_count[b] = calls;
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -327,7 +402,7 @@ int rollout_gso_launch(const RolloutArgs& a, hipStream_t st) {
 }
 
 int rollout_move_launch(const RolloutArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(rollout_move_kernel, dim3(a.B), dim3(64), sizeof(MoveScratch), st, a);
+    hipLaunchKernelGGL(rollout_move_kernel, dim3(a.B), dim3(64), 2 * kMaxAgents * sizeof(int), st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
