@@ -19,7 +19,7 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
                '-Wno-unused-result']
 
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_filter_packed_floats',
-           'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_encoder_packed_floats',
+           'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move')
 
@@ -92,6 +92,8 @@ def lib():
     L.gnnpp_filter_packed_floats.argtypes = [ci] * 4
     L.gnnpp_filter_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     L.gnnpp_lsigf_fwd.argtypes = [vp] * 5 + [ci] * 12 + [vp]
+    L.gnnpp_lsigf_fwd_save.argtypes = [vp] * 6 + [ci] * 13 + [vp]
+    L.gnnpp_lsigf_fwd_save.restype = ci
     L.gnnpp_encoder_packed_floats.restype = cs
     L.gnnpp_encoder_packed_floats.argtypes = []
     L.gnnpp_encoder_pack.argtypes = [ctypes.POINTER(EncoderParams), vp, vp]

@@ -56,6 +56,24 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
+int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
+                         float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
+                         int s_is_f64, int s_batched, int s_transposed, int x_node_major,
+                         int y_node_major, int relu, void* stream) {
+    if (!x || !packed || !y || B <= 0 || N <= 0 || Nin <= 0 || Nin > N || G <= 0 || F <= 0 ||
+        K <= 0 || E <= 0)
+        return GNNPP_ERR_ARG;
+    if (K > 1 && !S) return GNNPP_ERR_ARG;
+    if ((x_node_major || y_node_major) && Nin != N) return GNNPP_ERR_ARG;
+    if (N > GNNPP_MAX_NODES + 12 || F > 128) return GNNPP_ERR_UNSUPPORTED;
+    LsigfArgs a = {};
+    a.x = x; a.S = S; a.wpk = packed; a.bias = bias; a.y = y; a.zs = zs;
+    a.B = B; a.N = N; a.Nin = Nin; a.G = G; a.F = F; a.K = K; a.E = E;
+    a.s_is_f64 = s_is_f64; a.s_batched = s_batched; a.s_transposed = s_transposed;
+    a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
+    return lsigf_launch(a, static_cast<hipStream_t>(stream));
+}
+
 size_t gnnpp_encoder_packed_floats(void) { return EncLayout::kTotal; }
 
 int gnnpp_encoder_pack(const gnnpp_encoder_params* p, float* packed, void* stream) {

@@ -41,6 +41,8 @@ struct LsigfArgs {
     int rt_total;          // 16-row MFMA tiles per workgroup = ceil(gpw*N / 16)
     int Ns;                // LDS row stride of an S slab (odd)
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
+    int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
+    float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
 };
 
 // Re-order h[F,E,K,G] into MFMA A fragments: block (e,k,mt,gg) holds, for lane l = q*16 + i and
@@ -167,13 +169,13 @@ __device__ __forceinline__ void stage_s(const LsigfArgs& p, float* __restrict__ 
             const double* src = reinterpret_cast<const double*>(p.S) + sidx;
             for (int i = t0; i < NN; i += nt) {
                 const int m = i / N, n = i - m * N;
-                dst[m * p.Ns + n] = (float)src[i];
+                dst[p.s_transposed ? n * p.Ns + m : m * p.Ns + n] = (float)src[i];
             }
         } else {
             const float* src = reinterpret_cast<const float*>(p.S) + sidx;
             for (int i = t0; i < NN; i += nt) {
                 const int m = i / N, n = i - m * N;
-                dst[m * p.Ns + n] = src[i];
+                dst[p.s_transposed ? n * p.Ns + m : m * p.Ns + n] = src[i];
             }
         }
     }
@@ -263,6 +265,13 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             if (k > 0) {
                 gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, NW, lane);
                 __syncthreads();
+            }
+            if (p.zs) {                                  // training: keep z_{e,k} for dW = dy . z^T
+                float* zd = p.zs + ((size_t)tap * p.B + g0) * N * p.G;
+                for (int i = tid; i < R * p.G; i += NT) {
+                    const int r = i / p.G, c = i - r * p.G;
+                    zd[i] = zcur[r * zs + c];
+                }
             }
             // ---- contraction of tap (e,k) on MFMA: D[f, row] += W[f, g] z[row, g] --------------
             if (has_mfma) {

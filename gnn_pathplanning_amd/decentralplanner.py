@@ -15,10 +15,14 @@ HIP kernels behind one C call (gnnpp_policy_fwd): the fused encoder over all B*N
 K-tap graph filter + ReLU + action head.  Packed/BN-folded weights are cached and rebuilt whenever
 a parameter or running statistic changes.
 
-Round-1 scope: eval-mode inference (the rollout loop, agents/decentralplannerlocal.py:489-592).
-Train-mode forward (per-agent-call BatchNorm batch statistics, :284-286) and backward are the
-next rows: forward() in training mode raises NotImplementedError rather
-than silently computing something else.  There is no CPU path.
+Eval mode (the rollout loop, agents/decentralplannerlocal.py:489-592) is the fully fused HIP path.
+
+Train mode (agents/decentralplannerlocal.py:283-317) keeps the reference's exact semantics: the
+encoder runs once per agent so BatchNorm normalises with per-agent-call batch statistics and
+updates its running statistics N times per forward (decentralplanner.py:284-290).  That needs
+batch-wide reductions per agent, so in train mode the encoder and the action head are stock aten /
+MIOpen ops on the GPU with autograd, while the graph filter (forward, input gradient, tap
+gradient) runs on the gnnpp HIP kernels through graphML._LSIGFFunction.  There is no CPU path.
 """
 import ctypes
 
@@ -156,9 +160,7 @@ class DecentralPlannerNet(nn.Module):
         """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
         contiguous [B,5] block) -- what forward() unbinds into the reference's list."""
         if self.training:
-            raise NotImplementedError(
-                'train-mode forward (per-agent BatchNorm batch statistics + backward) is not '
-                'implemented in this round; call .eval() -- see DESIGN.md "out of scope"')
+            return torch.stack(self._forward_train(inputTensor), 0)
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
         assert self.L == 1 and self.E == 1
@@ -207,8 +209,26 @@ class DecentralPlannerNet(nn.Module):
         out = torch.nn.functional.linear(y[:, :N], act.weight.detach(), act.bias.detach())
         return out.permute(1, 0, 2).contiguous()
 
+    def _forward_train(self, inputTensor):
+        """Differentiable forward with the reference's op sequence (decentralplanner.py:278-318)."""
+        if self.S is None:
+            raise TypeError('addGSO() must be called before forward()')
+        _native.require_gpu(inputTensor, self.S, self.compressMLP[0].weight)
+        B = inputTensor.shape[0]
+        feats = []
+        for n in range(self.numAgents):
+            fm = self.ConvLayers(inputTensor[:, n])
+            feats.append(self.compressMLP(fm.view(fm.size(0), -1)))
+        x = torch.stack(feats, dim=2)                              # B x F x N
+        for l in range(self.L):
+            self.GFL[2 * l].addGSO(self.S)
+        shared = self.GFL(x)                                       # HIP filter fwd/bwd + ReLU
+        return [self.actionsMLP(shared[:, :, n].reshape(B, -1)) for n in range(self.numAgents)]
+
     def forward(self, inputTensor):
         """[B,N,3,11,11] -> python list of N tensors [B,5] (decentralplanner.py:278-318)."""
+        if self.training:
+            return self._forward_train(inputTensor)
         return list(self.forward_logits(inputTensor).unbind(0))
 
     def decode_actions(self, logits):

@@ -12,8 +12,12 @@ Same names, argument meaning, shape asserts, parameter names/shapes (`weight [F,
 callers run unchanged.  Layouts at this boundary are the reference's feature-major
 x[B,G,N] -> y[B,F,N]; the kernel transposes through LDS on load/store (no extra HBM pass).
 
-Forward only in this round: outputs carry no autograd graph (backward is SURVEY.md section 8f
-row 2).  There is no CPU path: tensors must be on a HIP device.
+Autograd: when gradients are enabled and an input requires grad, the call goes through
+`_LSIGFFunction`: forward = the HIP kernel (also dumping the tap signals z_k), backward =
+  dx = the SAME kernel on dy with taps h.permute(3,1,2,0) and S^T (the input gradient of a graph
+       filter is a graph filter), dW = one library GEMM per tap (dy . z_k^T), db = sum(dy).
+No gradient flows to S (it is data in the reference too).  There is no CPU path: tensors must be
+on a HIP device.
 """
 import ctypes
 import math
@@ -48,8 +52,12 @@ def pack_filter_taps(h):
     return packed
 
 
-def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False):
-    """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]."""
+def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
+                  save_taps=False):
+    """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
+    (and, with save_taps, zs [E*K, B*N, G])."""
+    if transposed or save_taps:
+        return _lsigf_device_ex(h, S, x, b, batched, Nin, packed, transposed, save_taps)
     dev = _native.require_gpu(h, S, x, b)
     L = _native.lib()
     F_out, E, K, G = h.shape
@@ -90,6 +98,70 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False):
     return y
 
 
+def _lsigf_device_ex(h, S, x, b, batched, Nin, packed, transposed, save_taps):
+    """gnnpp_lsigf_fwd_save: optional S^T and tap dump (training path).  F <= 128 per call."""
+    dev = _native.require_gpu(h, S, x, b)
+    L = _native.lib()
+    F_out, E, K, G = h.shape
+    N, B = S.shape[-1], x.shape[0]
+    if N > MAX_NODES or F_out > _MAX_F_PER_LAUNCH:
+        raise _native.GnnppError('training path supports N <= %d and F <= %d' % (MAX_NODES, _MAX_F_PER_LAUNCH))
+    xc = x.detach().contiguous().float()
+    Sc = S.detach().contiguous()
+    if Sc.dtype not in (torch.float32, torch.float64):
+        Sc = Sc.float()
+    if packed is None:
+        packed = pack_filter_taps(h)
+    bias = None
+    if b is not None:
+        assert b.numel() == F_out, 'per-node bias is not supported on the training path'
+        bias = b.detach().contiguous().float().reshape(-1)
+    y = torch.empty(B, F_out, Nin, dtype=torch.float32, device=dev)
+    zs = torch.empty(E * K, B * N, G, dtype=torch.float32, device=dev) if save_taps else None
+    with _native.device_guard(dev):
+        rc = L.gnnpp_lsigf_fwd_save(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y), _ptr(zs),
+                                    B, N, Nin, G, F_out, K, E, int(Sc.dtype == torch.float64),
+                                    int(batched), int(transposed), 0, 0, 0, _native.stream_ptr(dev))
+    _native.check(rc, 'gnnpp_lsigf_fwd_save')
+    return (y, zs) if save_taps else y
+
+
+class _LSIGFFunction(torch.autograd.Function):
+    """y = LSIGF(h, S, x, b) with gradients for h, x and b (none for S)."""
+
+    @staticmethod
+    def forward(ctx, h, S, x, b, batched, packed):
+        Nin = x.shape[2]
+        y, zs = _lsigf_device_ex(h, S, x, b, batched, Nin, packed, False, True)
+        ctx.save_for_backward(h, S, zs)
+        ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, S, zs = ctx.saved_tensors
+        F_out, E, K, G = h.shape
+        N = S.shape[-1]
+        B = dy.shape[0]
+        dy = dy.contiguous().float()
+        dh = dx = db = None
+        if ctx.needs_input_grad[2]:
+            hT = h.detach().permute(3, 1, 2, 0).contiguous()             # [G,E,K,F]
+            dx = _lsigf_device_ex(hT, S, dy, None, ctx.batched, ctx.Nin, None, True, False)
+        if ctx.needs_input_grad[0]:
+            dyp = dy if ctx.Nin == N else torch.nn.functional.pad(dy, (0, N - ctx.Nin))
+            dy2 = dyp.permute(1, 0, 2).reshape(F_out, B * N)             # [F, B*N]
+            dh = torch.matmul(dy2.unsqueeze(0), zs)                      # [E*K, F, G]
+            dh = dh.reshape(E, K, F_out, G).permute(2, 0, 1, 3).contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = dy.sum(dim=(0, 2)).reshape(F_out, 1)
+        return dh, None, dx, db, None, None
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def LSIGF(h, S, x, b=None):
     """Linear shift-invariant graph filter, one GSO for the whole batch (graphML.py:48-141).
 
@@ -105,6 +177,8 @@ def LSIGF(h, S, x, b=None):
         # the reference multiplies x @ S without a cast (:124) and torch refuses mixed dtypes
         raise RuntimeError('expected S and x to have the same dtype, but got: %s != %s'
                            % (x.dtype, S.dtype))
+    if _wants_grad(h, x, b):
+        return _LSIGFFunction.apply(h, S, x, b, False, None)
     return _lsigf_device(h, S, x, b, batched=False, Nin=N)
 
 
@@ -118,6 +192,8 @@ def BatchLSIGF(h, S, x, b=None):
     assert x.shape[1] == G
     assert x.shape[2] == N
     assert S.shape[0] == x.shape[0]
+    if _wants_grad(h, x, b):
+        return _LSIGFFunction.apply(h, S, x, b, True, None)
     return _lsigf_device(h, S, x, b, batched=True, Nin=N)
 
 
@@ -164,6 +240,9 @@ class _GraphFilterBase(nn.Module):
             assert self.S.shape[0] == x.shape[0]
         # zero padding of the missing nodes and the final index_select (graphML.py:1206-1218 /
         # :2464-2476) are folded into the kernel through Nin
+        if _wants_grad(self.weight, x, self.bias):
+            return _LSIGFFunction.apply(self.weight, self.S, x, self.bias, self._batched,
+                                        self.packed_taps())
         return _lsigf_device(self.weight, self.S, x, self.bias, self._batched, Nin,
                              packed=self.packed_taps())
 

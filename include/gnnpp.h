@@ -79,6 +79,19 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
                     int s_is_f64, int s_batched, int x_node_major, int y_node_major, int relu,
                     void* stream);
 
+/*
+ * Training variant of gnnpp_lsigf_fwd (loss.backward() at agents/decentralplannerlocal.py:314):
+ *   zs            optional out [E*K, B*N, G] node-major: every tap signal z_{e,k} = x S_e^k, so that
+ *                 dW[f,e,k,g] = sum_{b,n} dy[b,f,n] z_{e,k}[b,n,g] is one library GEMM per tap;
+ *   s_transposed  use S^T.  The input gradient of the filter is itself a filter,
+ *                 dx = sum_k W_k^T . dy . (S^T)^k, i.e. this call with x := dy, taps packed from
+ *                 h.permute(3,1,2,0) and s_transposed = 1.
+ */
+int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
+                         float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
+                         int s_is_f64, int s_batched, int s_transposed, int x_node_major,
+                         int y_node_major, int relu, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-agent encoder: 5 x (conv3x3 pad 1 -> BatchNorm(eval) -> ReLU [-> MaxPool 2]) -> flatten ->
  * Linear(128,128) -> ReLU.  Replaces ConvLayers + compressMLP as run by

@@ -159,9 +159,91 @@ def gen_policy(DecentralPlannerNet):
     print('policy_model: %d cases' % len(meta))
 
 
+def gen_training(DecentralPlannerNet, gml):
+    """Train-mode forward + backward of the reference (agents/decentralplannerlocal.py:283-317) and
+    standalone graph-filter gradients -> tests/golden/training_grads.npz."""
+    from oracle.policy_oracle import synth_gso_geometric, synth_gso_sparse, synth_obs
+    z = np.load(os.path.join(OUT, 'policy_model.npz'))
+    sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith('sd/')}
+    store, meta = {}, []
+    FULL = ('GFL.0.weight', 'GFL.0.bias', 'actionsMLP.0.weight', 'actionsMLP.0.bias',
+            'compressMLP.0.bias', 'ConvLayers.0.weight', 'ConvLayers.0.bias', 'ConvLayers.1.weight',
+            'ConvLayers.15.weight', 'ConvLayers.15.bias', 'ConvLayers.11.bias')
+    for ci, (N, K, B) in enumerate(((10, 3, 4), (3, 2, 6))):
+        net = DecentralPlannerNet(Cfg(N, K))
+        sdk = dict(sd)
+        if K != 3:
+            sdk['GFL.0.weight'] = torch.from_numpy(np.array(z['gfl_w_K%d' % K]))
+        net.load_state_dict(sdk)
+        net.train()
+        obs = synth_obs(B, N, seed=900 + ci)
+        S = torch.from_numpy(synth_gso_geometric(B, N, 20, seed=800 + ci)).float()
+        g = torch.Generator().manual_seed(700 + ci)
+        tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=g), 5).float()
+        net.addGSO(S)
+        predict = net(obs)
+        bt = tgt.permute(1, 0, 2)
+        loss = 0
+        ce = torch.nn.CrossEntropyLoss()
+        for n in range(N):
+            loss = loss + ce(predict[n], torch.max(bt[n], 1)[1])
+        loss = loss / N
+        loss.backward()
+        store['g%d_obs' % ci] = obs.numpy().astype(np.uint8)
+        store['g%d_S' % ci] = S.numpy()
+        store['g%d_target' % ci] = tgt.numpy().astype(np.uint8)
+        store['g%d_logits' % ci] = torch.stack([p.detach() for p in predict], 1).numpy()
+        store['g%d_loss' % ci] = np.array(loss.item(), dtype=np.float64)
+        names, summ = [], []
+        for name, p in net.named_parameters():
+            names.append(name)
+            gr = p.grad.double()
+            summ.append([gr.sum().item(), gr.abs().sum().item(), gr.norm().item()])
+            if name in FULL:
+                store['g%d_grad/%s' % (ci, name)] = p.grad.numpy()
+        store['g%d_gradsum' % ci] = np.array(summ)
+        for name, b in net.named_buffers():
+            if name.startswith(('ConvLayers.1.', 'ConvLayers.15.')):
+                store['g%d_buf/%s' % (ci, name)] = b.numpy()
+        meta.append({'kind': 'policy', 'N': N, 'K': K, 'B': B, 'param_names': names})
+    # standalone graph-filter gradients
+    g = torch.Generator().manual_seed(4711)
+    for ci, (cls, G, F_out, K, E, N, Nin, B) in enumerate((('GraphFilterBatch', 16, 24, 3, 2, 7, 5, 3),
+                                                          ('GraphFilter', 128, 128, 3, 1, 10, 10, 2),
+                                                          ('GraphFilterBatch', 128, 128, 4, 1, 10, 10, 2))):
+        mod = getattr(gml, cls)(G, F_out, K, E, True)
+        x = torch.randn(B, G, Nin, generator=g, requires_grad=True)
+        if cls == 'GraphFilter':
+            S = synth_gso_sparse(E, N, 3.0, seed=50 + ci)
+        else:
+            S = synth_gso_sparse(B * E, N, 3.0, seed=50 + ci).reshape(B, E, N, N)
+        cot = torch.randn(B, F_out, Nin, generator=g)
+        mod.addGSO(S)
+        y = mod(x)
+        (y * cot).sum().backward()
+        k = 'f%d_' % ci
+        store[k + 'h'] = mod.weight.detach().numpy()
+        store[k + 'b'] = mod.bias.detach().numpy()
+        store[k + 'S'] = S.numpy()
+        store[k + 'x'] = x.detach().numpy()
+        store[k + 'cot'] = cot.numpy()
+        store[k + 'y'] = y.detach().numpy()
+        store[k + 'dx'] = x.grad.numpy()
+        store[k + 'dh'] = mod.weight.grad.numpy()
+        store[k + 'db'] = mod.bias.grad.numpy()
+        meta.append({'kind': cls, 'G': G, 'F': F_out, 'K': K, 'E': E, 'N': N, 'Nin': Nin, 'B': B})
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'training_grads.npz'), **store)
+    print('training_grads: %d cases' % len(meta))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     Net, gml = import_reference()
     sys.path.insert(0, os.path.dirname(HERE))
+    if len(sys.argv) > 1 and sys.argv[1] == 'training':
+        gen_training(Net, gml)
+        sys.exit(0)
     gen_lsigf(gml)
     gen_policy(Net)
+    gen_training(Net, gml)

@@ -142,16 +142,19 @@ def lsigf_f64(h, S, x, b=None):
 # --------------------------------------------------------------------------------------------
 # full policy
 # --------------------------------------------------------------------------------------------
-def encoder_one_agent(sd, obs_agent):
+def encoder_one_agent(sd, obs_agent, training=False):
     """ConvLayers + flatten + compressMLP for one agent's mini-batch [B,3,11,11] -> [B,128].
-    decentralplanner.py:286-289 with the Sequential of :155-177 (eval-mode BatchNorm)."""
+    decentralplanner.py:286-289 with the Sequential of :155-177.  training=True reproduces the
+    reference's train mode: BatchNorm uses THIS call's batch statistics and updates the running
+    statistics in `sd` in place (momentum 0.1), once per agent call."""
     t = obs_agent
     for li in range(5):
         t = tF.conv2d(t, sd['ConvLayers.%d.weight' % CONV_KEYS[li]],
                       sd['ConvLayers.%d.bias' % CONV_KEYS[li]], stride=1, padding=1)
         bn = 'ConvLayers.%d.' % BN_KEYS[li]
         t = tF.batch_norm(t, sd[bn + 'running_mean'], sd[bn + 'running_var'],
-                          sd[bn + 'weight'], sd[bn + 'bias'], training=False, eps=BN_EPS)
+                          sd[bn + 'weight'], sd[bn + 'bias'], training=training, momentum=0.1,
+                          eps=BN_EPS)
         t = tF.relu(t)
         if POOL_AFTER[li]:
             t = tF.max_pool2d(t, kernel_size=2)
@@ -159,8 +162,8 @@ def encoder_one_agent(sd, obs_agent):
     return tF.relu(tF.linear(flat, sd['compressMLP.0.weight'], sd['compressMLP.0.bias']))
 
 
-def policy_forward(sd, S, obs):
-    """DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318), eval mode.
+def policy_forward(sd, S, obs, training=False):
+    """DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318); eval mode by default.
 
     sd: state_dict (CPU tensors), S: [B,N,N] (fp32 or fp64), obs: [B,N,3,11,11] fp32.
     Returns a list of N tensors [B,5] exactly like the reference.
@@ -170,13 +173,21 @@ def policy_forward(sd, S, obs):
     S4 = S.unsqueeze(1)
     feat = torch.zeros(B, 128, N)
     for n in range(N):
-        feat[:, :, n] = encoder_one_agent(sd, obs[:, n])
+        feat[:, :, n] = encoder_one_agent(sd, obs[:, n], training)
     shared = tF.relu(graph_filter_batch(sd['GFL.0.weight'], sd['GFL.0.bias'], S4, feat))
     out = []
     for n in range(N):
         out.append(tF.linear(shared[:, :, n].reshape(B, -1),
                              sd['actionsMLP.0.weight'], sd['actionsMLP.0.bias']))
     return out
+
+
+def policy_loss(out, target):
+    """agents/decentralplannerlocal.py:305-312: mean over agents of CE(predict[n], argmax target)."""
+    loss = 0
+    for n in range(len(out)):
+        loss = loss + tF.cross_entropy(out[n], target[:, n].argmax(-1))
+    return loss / len(out)
 
 
 def policy_features(sd, obs):

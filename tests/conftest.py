@@ -42,3 +42,8 @@ def golden_state_dict(z, K=3):
 @pytest.fixture(scope='session')
 def rollout_golden():
     return _load('rollout_traces.npz')
+
+
+@pytest.fixture(scope='session')
+def training_golden():
+    return _load('training_grads.npz')

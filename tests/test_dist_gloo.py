@@ -63,6 +63,46 @@ def test_two_rank_gloo_sharding_and_aggregation():
         assert gathered == [[0.0, 1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]      # disjoint, complete, ordered
 
 
+def _dp_worker(rank, world, port, q):
+    import torch.nn as nn
+    from gnn_pathplanning_amd.training import FlatBucketDP
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                       # different init per rank on purpose
+        model = nn.Sequential(nn.Linear(6, 5), nn.BatchNorm1d(5), nn.Linear(5, 3))
+        dp = FlatBucketDP(model)                            # broadcast params + buffers from rank 0
+        w0 = model[0].weight.detach().clone()
+        x = torch.full((4, 6), float(rank + 1))
+        model(x).sum().backward()
+        local = [p.grad.clone() for p in model.parameters()]
+        dp.reduce_gradients()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [g.tolist() for g in local])
+        mean = [(torch.tensor(a) + torch.tensor(b)) / 2 for a, b in zip(*gathered)]
+        ok = all(torch.allclose(p.grad, m, atol=1e-6) for p, m in zip(model.parameters(), mean))
+        q.put((rank, ok, w0.tolist(), dp.bucket.numel()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_bucket_dp_two_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)                             # gradients are the cross-rank mean
+    assert res[0][2] == res[1][2]                             # parameters were broadcast from rank 0
+    assert res[0][3] == 6 * 5 + 5 + 5 + 5 + 5 * 3 + 3         # ONE bucket holds every gradient
+
+
 def test_single_process_aggregation_without_group():
     thr, units, t = aggregate_throughput(100, 0.5)
     assert (thr, units, t) == (200.0, 100, 0.5)

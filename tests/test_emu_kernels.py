@@ -112,3 +112,40 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
         lib.gnnpp_set_tuning(2, 0)
     assert lib.gnnpp_set_tuning(7, 0) == -1 and lib.gnnpp_set_tuning(0, 5) == -1
     assert lib.gnnpp_set_tuning(0, 2) == 0
+
+
+def test_emu_lsigf_transposed_and_tap_dump(emu, lsigf_golden):
+    """gnnpp_lsigf_fwd_save: (i) s_transposed == running on S^T, (ii) zs holds z_{e,k} = x S_e^k."""
+    el, lib = emu
+    g = np.random.default_rng(3)
+    B, G, F_out, K, E, N = 3, 20, 12, 3, 2, 7
+    h = g.standard_normal((F_out, E, K, G)).astype(np.float32) / 8
+    x = g.standard_normal((B, G, N)).astype(np.float32)
+    S = (g.random((B, E, N, N)) < 0.4) * g.random((B, E, N, N))
+    S = S.astype(np.float32)
+    packed = el.pack_filter(lib, h)
+
+    def run(Smat, transposed, want_zs):
+        y = np.full((B, F_out, N), np.nan, np.float32)
+        zs = np.full((E * K, B * N, G), np.nan, np.float32) if want_zs else None
+        Sc = np.ascontiguousarray(Smat)
+        rc = lib.gnnpp_lsigf_fwd_save(el.ptr(x), el.ptr(Sc), el.ptr(packed), None, el.ptr(y),
+                                      el.ptr(zs) if want_zs else None, B, N, N, G, F_out, K, E, 0, 1,
+                                      transposed, 0, 0, 0, None)
+        assert rc == 0
+        return y, zs
+    y_t, _ = run(S, 1, False)
+    y_ref, zs = run(np.ascontiguousarray(S.transpose(0, 1, 3, 2)), 0, True)
+    assert np.abs(y_t - y_ref).max() <= 1e-6
+    from oracle import policy_oracle as orc
+    want = orc.lsigf_f64(h, S.transpose(0, 1, 3, 2), x)
+    assert np.abs(y_ref - want).max() <= 1e-4
+    # tap signals of the run on S^T
+    St = S.transpose(0, 1, 3, 2).astype(np.float64)
+    for e in range(E):
+        z = x.astype(np.float64)
+        for k in range(K):
+            if k > 0:
+                z = np.einsum('bgm,bmn->bgn', z, St[:, e])
+            got = zs[e * K + k].reshape(B, N, G).transpose(0, 2, 1)
+            assert np.abs(got - z).max() <= 1e-4, (e, k)

@@ -1,0 +1,138 @@
+"""GPU (-m gpu): training path -- graph-filter forward/backward on the HIP kernels (autograd
+Function), train-mode DecentralPlannerNet, loss/gradient/BN-statistics parity with the REAL
+reference (tests/golden/training_grads.npz) and with the CPU oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict
+from oracle import policy_oracle as orc
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-4        # gradients: relative to the tensor's max magnitude (fp32, different summation order)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from gnn_pathplanning_amd import _native
+    _native.lib()
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol=RTOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() <= rtol * max(1e-6, np.abs(b).max())
+
+
+def test_graph_filter_gradients_match_reference(dev, training_golden):
+    import gnn_pathplanning_amd.graphML as gml
+    z, meta = training_golden
+    idx = 0
+    for m in meta:
+        if m['kind'] == 'policy':
+            continue
+        k = 'f%d_' % idx
+        idx += 1
+        mod = getattr(gml, m['kind'])(m['G'], m['F'], m['K'], m['E'], True).to(dev)
+        with torch.no_grad():
+            mod.weight.copy_(torch.from_numpy(z[k + 'h']))
+            mod.bias.copy_(torch.from_numpy(z[k + 'b']))
+        x = torch.from_numpy(z[k + 'x']).to(dev).requires_grad_(True)
+        mod.addGSO(torch.from_numpy(z[k + 'S']).to(dev))
+        y = mod(x)
+        assert y.requires_grad
+        (y * torch.from_numpy(z[k + 'cot']).to(dev)).sum().backward()
+        assert close(y.detach().cpu(), z[k + 'y'], 1e-4), m
+        assert close(x.grad.cpu(), z[k + 'dx']), m
+        assert close(mod.weight.grad.cpu(), z[k + 'dh']), m
+        assert close(mod.bias.grad.cpu(), z[k + 'db']), m
+
+
+@pytest.mark.parametrize('B,N,K,E,G,F_out', [(8, 10, 3, 1, 128, 128), (3, 50, 2, 1, 128, 128),
+                                             (2, 100, 3, 1, 128, 128), (5, 6, 4, 2, 24, 40)])
+def test_lsigf_autograd_vs_oracle(dev, B, N, K, E, G, F_out):
+    import gnn_pathplanning_amd.graphML as gml
+    g = torch.Generator().manual_seed(B * N + K)
+    h = (torch.randn(F_out, E, K, G, generator=g) / (G * K) ** 0.5)
+    b = torch.randn(F_out, 1, generator=g) * 0.1
+    x = torch.randn(B, G, N, generator=g)
+    S = orc.synth_gso_sparse(B * E, N, 4.0, seed=K).reshape(B, E, N, N)
+    cot = torch.randn(B, F_out, N, generator=g)
+    hc, bc, xc = h.clone().requires_grad_(True), b.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    (orc.batch_lsigf(hc, S, xc, bc) * cot).sum().backward()
+    hg, bg, xg = (t.to(dev).requires_grad_(True) for t in (h, b, x))
+    (gml.BatchLSIGF(hg, S.to(dev), xg, bg) * cot.to(dev)).sum().backward()
+    assert close(xg.grad.cpu(), xc.grad) and close(hg.grad.cpu(), hc.grad) and close(bg.grad.cpu(), bc.grad)
+    # only some inputs require grad
+    x2 = x.to(dev).requires_grad_(True)
+    y2 = gml.BatchLSIGF(h.to(dev), S.to(dev), x2, b.to(dev))
+    (y2 * cot.to(dev)).sum().backward()
+    assert close(x2.grad.cpu(), xc.grad)
+
+
+def test_policy_training_step_matches_reference(dev, training_golden, policy_golden):
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import policy_loss
+    z, meta = training_golden
+    zp, _ = policy_golden
+    for ci, m in enumerate(meta):
+        if m['kind'] != 'policy':
+            continue
+
+        class Cfg:
+            num_agents, nGraphFilterTaps, device = m['N'], m['K'], dev
+        net = DecentralPlannerNet(Cfg()).to(dev)
+        net.load_state_dict(golden_state_dict(zp, m['K']))
+        net.train()
+        obs = torch.from_numpy(z['g%d_obs' % ci].astype(np.float32)).to(dev)
+        S = torch.from_numpy(z['g%d_S' % ci]).to(dev)
+        tgt = torch.from_numpy(z['g%d_target' % ci].astype(np.float32)).to(dev)
+        net.addGSO(S)
+        out = net(obs)
+        assert isinstance(out, list) and len(out) == m['N'] and out[0].requires_grad
+        loss = policy_loss(out, tgt)
+        loss.backward()
+        assert abs(loss.item() - float(z['g%d_loss' % ci])) <= 1e-5
+        assert np.abs(torch.stack(out, 1).detach().cpu().numpy() - z['g%d_logits' % ci]).max() <= 1e-4
+        grads = dict((n, p.grad) for n, p in net.named_parameters())
+        assert list(grads) == m['param_names']
+        for j, name in enumerate(m['param_names']):
+            want = z['g%d_gradsum' % ci][j]
+            assert abs(grads[name].double().norm().item() - want[2]) <= 5e-4 * max(1e-3, want[2]), name
+            key = 'g%d_grad/%s' % (ci, name)
+            if key in z.files:
+                assert close(grads[name].cpu(), z[key], 5e-4), name
+        bufs = dict(net.named_buffers())
+        for key in z.files:
+            if key.startswith('g%d_buf/' % ci):
+                name = key.split('/', 1)[1]
+                assert close(bufs[name].cpu().float(), z[key].astype(np.float32), 1e-4), name
+
+
+def test_train_step_reduces_loss_and_eval_repacks(dev):
+    """A few Adam steps on one batch (agents/decentralplannerlocal.py:59 settings) lower the loss,
+    and the fused eval path afterwards uses the UPDATED weights (pack cache invalidation)."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import train_step
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    torch.manual_seed(0)
+    net = DecentralPlannerNet(Cfg()).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    B = 16
+    obs = orc.synth_obs(B, 10, seed=2).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, 10, 20, seed=2)).float().to(dev)
+    g = torch.Generator().manual_seed(1)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, 10), generator=g), 5).float().to(dev)
+    net.train()
+    losses = [train_step(net, opt, obs, tgt, S).item() for _ in range(12)]
+    assert losses[-1] < losses[0] - 0.05, losses
+    net.eval()
+    net.addGSO(S)
+    got = torch.stack(net(obs), 1).cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd, S.cpu(), obs.cpu()), 1)
+    assert (got - want).abs().max().item() <= 1e-4
