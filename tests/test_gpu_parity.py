@@ -57,7 +57,7 @@ def test_lsigf_golden_all_cases(dev, lsigf_golden):
             mod.addGSO(S)
             y = mod(x)
         assert tuple(y.shape) == want.shape, (i, m)
-        err = np.abs(y.cpu().numpy() - want).max()
+        err = np.abs(y.detach().cpu().numpy() - want).max()
         assert err <= TOL * max(1.0, np.abs(want).max()), (i, m, err)
 
 
@@ -232,9 +232,10 @@ def test_error_conventions(dev):
     net.addGSO(torch.zeros(1, 10, 10, device=dev))
     with pytest.raises(_native.GnnppError):
         net(torch.zeros(1, 10, 3, 11, 11))                          # CPU tensor: no fallback
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 10, 3, 11, 11, device=dev))
+    net.train()                                                     # train mode: differentiable
+    net.addGSO(torch.zeros(2, 10, 10, device=dev))
+    out = net(torch.zeros(2, 10, 3, 11, 11, device=dev))
+    assert isinstance(out, list) and len(out) == 10 and out[0].requires_grad
     gf = gml.GraphFilterBatch(8, 8, 2).to(dev)
     with pytest.raises(AssertionError):
         gf.addGSO(torch.zeros(10, 10, device=dev))

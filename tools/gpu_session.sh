@@ -12,7 +12,7 @@ has() { [[ " $STEPS " == *" $1 "* ]]; }
 T0=$(date +%s)
 stamp() { echo "== [$(( $(date +%s) - T0 ))s] $1"; }
 if has test; then stamp "pytest -m gpu"
-  timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 | tee $OUT/pytest_gpu.log; fi
+  timeout 600 python -m pytest tests -q -m gpu --maxfail=6 2>&1 | tail -40 | tee $OUT/pytest_gpu.log; fi
 if has smoke; then stamp smoke
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log; fi
 if has bench; then stamp "bench c2"
