@@ -6,6 +6,9 @@ Mirrors the part of utils/graphUtils/graphML.py that the path planner uses:
     BatchLSIGF(h, S, x, b=None)       graphML.py:2273-2367   one GSO per sample
     GraphFilter(G, F, K, E=1, bias)   graphML.py:1111-1230
     GraphFilterBatch(G, F, K, E, b)   graphML.py:2369-2488
+    matrixPowersBatch(S, K)           graphML.py:2063-2113   S^k, k = 0..K-1, per sample
+    batchLSIGF(h, SK, x, bias=None)   graphML.py:2115-2178   filter on pre-powered GSOs
+    GraphFilterBatchGSO(G, F, K, E,b) graphML.py:2180-2271
 
 Same names, argument meaning, shape asserts, parameter names/shapes (`weight [F,E,K,G]`,
 `bias [F,1]`), init rule and `addGSO` / `forward` / `extra_repr` behaviour, so the reference's
@@ -278,3 +281,74 @@ class GraphFilterBatch(_GraphFilterBase):
         self.N = S.shape[2]
         assert S.shape[3] == self.N
         self.S = S
+
+
+def matrixPowersBatch(S, K):
+    """S^k for k = 0..K-1 per batch element (graphML.py:2063-2113).  S [B,N,N] -> [B,K,N,N];
+    S [B,E,N,N] -> [B,E,K,N,N].  A chain of batched library GEMMs, run once per addGSO."""
+    if len(S.shape) == 3:
+        B, N = S.shape[0], S.shape[1]
+        assert S.shape[2] == N
+        E, S, scalar = 1, S.unsqueeze(1), True
+    else:
+        assert len(S.shape) == 4
+        B, E, N = S.shape[0], S.shape[1], S.shape[2]
+        assert S.shape[3] == N
+        scalar = False
+    cur = torch.eye(N, device=S.device).repeat([B, E, 1, 1])
+    SK = cur.unsqueeze(2)
+    for _ in range(1, K):
+        cur = torch.matmul(cur, S)
+        SK = torch.cat((SK, cur.unsqueeze(2)), dim=2)
+    return SK.squeeze(1) if scalar else SK
+
+
+def batchLSIGF(h, SK, x, bias=None):
+    """Graph filter on given per-sample matrices SK [B,E,K,N,N] (graphML.py:2115-2178):
+    y[b] = bias + sum_{e,k} h[:,e,k,:] . (x[b] SK[b,e,k]).  Each (e,k) pair is an independent
+    one-hop shift of x, i.e. the LSIGF kernel with E*K "edge features", two taps and a zero tap 0."""
+    F_out, E, K, G = h.shape
+    B = SK.shape[0]
+    assert SK.shape[1] == E
+    assert SK.shape[2] == K
+    N = SK.shape[3]
+    assert SK.shape[4] == N
+    assert x.shape[0] == B
+    assert x.shape[1] == G
+    assert x.shape[2] == N
+    h2 = torch.zeros(F_out, E * K, 2, G, dtype=h.dtype, device=h.device)
+    h2[:, :, 1, :] = h.reshape(F_out, E * K, G)
+    S2 = SK.reshape(B, E * K, N, N)
+    if _wants_grad(h, x, bias):
+        return _LSIGFFunction.apply(h2, S2, x, bias, True, None)
+    return _lsigf_device(h2, S2, x, bias, batched=True, Nin=N)
+
+
+class GraphFilterBatchGSO(GraphFilter):
+    """Graph filtering layer with a different GSO per sample, powers precomputed at addGSO
+    (graphML.py:2180-2271).  addGSO(S [B,N,N] | [B,E,N,N]); forward(x [B,G,N]) -> [B,F,N]."""
+
+    def __init__(self, G, F, K, E=1, bias=True):
+        super().__init__(G, F, K, E, bias)
+
+    def addGSO(self, S):
+        if len(S.shape) == 3 and S.shape[1] == S.shape[2]:
+            self.S = S.unsqueeze(1)
+        elif len(S.shape) == 4 and S.shape[1] == self.E and S.shape[2] == S.shape[3]:
+            self.S = S
+        self.N = self.S.shape[2]
+        self.B = self.S.shape[0]
+        self.SK = matrixPowersBatch(self.S, self.K)
+
+    def forward(self, x):
+        return batchLSIGF(self.weight, self.SK, x, self.bias)
+
+    def extra_repr(self):
+        s = 'in_features=%d, out_features=%d, ' % (self.G, self.F)
+        s += 'filter_taps=%d, ' % self.K + 'edge_features=%d, ' % self.E
+        s += 'bias=%s, ' % (self.bias is not None)
+        if self.S is not None:
+            s += 'GSO stored: number_nodes=%d, batch_size=%d' % (self.N, self.B)
+        else:
+            s += 'no GSO stored'
+        return s

@@ -232,6 +232,25 @@ def gen_training(DecentralPlannerNet, gml):
         store[k + 'dh'] = mod.weight.grad.numpy()
         store[k + 'db'] = mod.bias.grad.numpy()
         meta.append({'kind': cls, 'G': G, 'F': F_out, 'K': K, 'E': E, 'N': N, 'Nin': Nin, 'B': B})
+    # pre-powered GSO family: matrixPowersBatch / batchLSIGF / GraphFilterBatchGSO
+    for ci, (G, F_out, K, E, N, B) in enumerate(((12, 20, 3, 1, 9, 3), (128, 128, 3, 1, 10, 2),
+                                                 (8, 8, 4, 2, 6, 2))):
+        mod = gml.GraphFilterBatchGSO(G, F_out, K, E, True)
+        S = synth_gso_sparse(B * E, N, 3.0, seed=70 + ci).reshape(B, E, N, N)
+        if E == 1 and ci == 0:
+            S = S.squeeze(1)                                       # the 3-D addGSO form
+        x = torch.randn(B, G, N, generator=g)
+        with torch.no_grad():
+            mod.addGSO(S)
+            y = mod(x)
+        k = 'p%d_' % ci
+        store[k + 'h'] = mod.weight.detach().numpy()
+        store[k + 'b'] = mod.bias.detach().numpy()
+        store[k + 'S'] = S.numpy()
+        store[k + 'SK'] = mod.SK.numpy()
+        store[k + 'x'] = x.numpy()
+        store[k + 'y'] = y.numpy()
+        meta.append({'kind': 'GraphFilterBatchGSO', 'G': G, 'F': F_out, 'K': K, 'E': E, 'N': N, 'B': B})
     store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, 'training_grads.npz'), **store)
     print('training_grads: %d cases' % len(meta))

@@ -138,3 +138,16 @@ def test_pack_cache_keying():
     assert len(calls) == 1
     t.add_(1)                                                # in-place update bumps _version
     assert c.get((t,), lambda: calls.append(1) or 'c') == 'c' and len(calls) == 2
+
+
+def test_prepowered_gso_api_surface():
+    import gnn_pathplanning_amd.graphML as gml
+    m = gml.GraphFilterBatchGSO(4, 6, 3, 2, bias=False)
+    assert isinstance(m, gml.GraphFilter) and m.weight.shape == (6, 2, 3, 4)
+    SK = gml.matrixPowersBatch(torch.rand(2, 5, 5), 3)
+    assert SK.shape == (2, 3, 5, 5) and torch.equal(SK[:, 0], torch.eye(5).repeat(2, 1, 1))
+    S = torch.rand(2, 2, 5, 5)
+    SK = gml.matrixPowersBatch(S, 3)
+    assert SK.shape == (2, 2, 3, 5, 5) and torch.allclose(SK[:, :, 2], S @ S, atol=1e-6)
+    m.addGSO(S)
+    assert m.N == 5 and m.B == 2 and 'number_nodes=5' in m.extra_repr()

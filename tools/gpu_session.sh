@@ -21,6 +21,8 @@ if has ab; then stamp "ab_bench"
   timeout 400 python tools/ab_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_bench.jsonl; fi
 if has rollout; then stamp "rollout bench"
   timeout 300 python tools/ab_bench.py rollout 2>&1 | grep -v amdgpu.ids | tee $OUT/rollout_bench.jsonl; fi
+if has train; then stamp "train bench"
+  timeout 300 python tools/train_bench.py --steps 50 2>&1 | tail -1 | tee $OUT/train_bench.json; fi
 if has bench35; then for c in c3 c5; do stamp "bench $c"
   timeout 300 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 5 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp

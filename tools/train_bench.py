@@ -1,0 +1,71 @@
+"""Training throughput for BASELINE config 4 (dcp_onlineExpert: 10 agents, K=3, batch 64 per GPU,
+Adam lr 1e-3 wd 1e-5), 1 GPU or data parallel:
+    python tools/train_bench.py --steps 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        tools/train_bench.py --steps 50
+Prints one JSON line on rank 0 (agent-steps/s of full train steps, all ranks)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64)
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.sharding import aggregate_throughput
+    from gnn_pathplanning_amd.training import FlatBucketDP, train_step
+    from oracle import policy_oracle as orc                   # synthetic inputs only
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    torch.manual_seed(1337)
+    net = DecentralPlannerNet(Cfg()).to(dev).train()
+    dp = FlatBucketDP(net) if world > 1 else None
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    B, N = args.batch, 10
+    obs = orc.synth_obs(B, N, seed=1337 + rank).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337 + rank)).float().to(dev)
+    g = torch.Generator().manual_seed(rank)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=g), 5).float().to(dev)
+    for _ in range(args.warmup):
+        loss = train_step(net, opt, obs, tgt, S, dp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(net, opt, obs, tgt, S, dp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    thr, units, el = aggregate_throughput(B * N * args.steps, el, device=dev)
+    if rank == 0:
+        print(json.dumps({'metric': 'training agent-steps/s (fwd+bwd+Adam, config 4)', 'value': thr,
+                          'n_gpus': world, 'batch_per_gpu': B, 'ms_per_step': 1e3 * el / args.steps,
+                          'final_loss': float(loss.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
