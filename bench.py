@@ -191,6 +191,9 @@ def main():
             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
             'traffic': traffic, 'algorithmic_bytes': M * (363 + 128) * 4.0 + 156288 * 4.0,
             'avg_launch_us': t_enc * 1e6,
+            # the kernel skips zero-padding taps and pooled-away positions: MFMA work it executes
+            'executed_flops_per_launch': 11300 * 2048.0 * ((M + 15) // 16),
+            'executed_frac': 11300 * 2048.0 * ((M + 15) // 16) / t_enc / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             'flops_per_launch': flops,
         }
         # secondary: the graph-filter kernel alone (node-major features in, ReLU'd features out)

@@ -32,7 +32,7 @@ def test_graph_filter_gradients_match_reference(dev, training_golden):
     z, meta = training_golden
     idx = 0
     for m in meta:
-        if m['kind'] == 'policy':
+        if m['kind'] not in ('GraphFilter', 'GraphFilterBatch'):
             continue
         k = 'f%d_' % idx
         idx += 1
