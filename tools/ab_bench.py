@@ -125,7 +125,43 @@ def rollout_bench():
         print(json.dumps(row), flush=True)
 
 
+def pipelined_bench():
+    """Two independent batches in flight: step i of batch A overlaps step i of batch B on a second
+    stream (what a rollout driver with two episode batches per GPU does)."""
+    import time
+    sd = orc.init_state_dict(3)
+    for (N, B, W) in ((10, 512, 20), (50, 256, 50)):
+        nets, obs, gso, streams = [], [], [], []
+        for i in range(3):
+            net = DecentralPlannerNet(Cfg(N, 3)).to(dev).eval()
+            net.load_state_dict(sd)
+            nets.append(net)
+            obs.append(orc.synth_obs(B, N, seed=i).to(dev))
+            gso.append(torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=i)).float().to(dev))
+            streams.append(torch.cuda.Stream())
+        row = {'kernel': 'pipelined_steps', 'N': N, 'B': B}
+        for ns in (1, 2, 3):
+            def go(steps):
+                for k in range(steps):
+                    i = k % ns
+                    with torch.cuda.stream(streams[i]):
+                        nets[i].addGSO(gso[i])
+                        nets[i](obs[i])
+            go(12)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            go(120)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / 120
+            row['streams%d_us_per_step' % ns] = round(t * 1e6, 2)
+            row['streams%d_agent_steps_per_s' % ns] = round(B * N / t)
+        print(json.dumps(row), flush=True)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'pipelined':
+        pipelined_bench()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'rollout':
         rollout_bench()
         sys.exit(0)

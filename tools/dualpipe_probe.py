@@ -1,0 +1,76 @@
+"""Feasibility probe: MFMA encoder kernel and a VALU-saturating kernel on two streams at once."""
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gnn_pathplanning_amd import _native                      # noqa: E402
+from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet   # noqa: E402
+from oracle import policy_oracle as orc                       # noqa: E402
+
+dev = torch.device('cuda:0')
+L = _native.lib()
+P = ctypes.CDLL(os.path.join(ROOT, 'tools', 'probe', 'libprobe.so'))
+P.probe_valu_burn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+vp = lambda t: ctypes.c_void_p(t.data_ptr())                  # noqa: E731
+
+
+class Cfg:
+    num_agents, nGraphFilterTaps, device = 10, 3, dev
+
+
+net = DecentralPlannerNet(Cfg()).to(dev).eval()
+net.load_state_dict(orc.init_state_dict(3))
+enc = net.packed_encoder()
+sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+burn_out = torch.empty(1024 * 256, device=dev)
+
+
+def run(M, blocks, iters, mode, reps=20):
+    obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
+    feat = torch.empty(M, 128, device=dev)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        ea0, ea1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        sA.wait_event(t0); sB.wait_event(t0)
+        with torch.cuda.stream(sA):
+            ea0.record()
+            if mode in ('mfma', 'both'):
+                for _ in range(reps):
+                    L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, ctypes.c_void_p(sA.cuda_stream))
+            ea1.record()
+        with torch.cuda.stream(sB):
+            eb0.record()
+            if mode in ('valu', 'both'):
+                for _ in range(reps):
+                    P.probe_valu_burn(vp(burn_out), blocks, iters, ctypes.c_void_p(sB.cuda_stream))
+            eb1.record()
+        torch.cuda.current_stream().wait_stream(sA)
+        torch.cuda.current_stream().wait_stream(sB)
+        t1.record()
+        torch.cuda.synchronize()
+        r = (ea0.elapsed_time(ea1) * 1e3 / reps, eb0.elapsed_time(eb1) * 1e3 / reps,
+             t0.elapsed_time(t1) * 1e3 / reps)
+        best = r if best is None or r[2] < best[2] else best
+    return [round(x, 1) for x in best]
+
+
+for M in (4096, 5120):
+    for blocks, iters in ((256, 600), (1024, 150), (256, 1200)):
+        row = {'M': M, 'valu_blocks': blocks, 'valu_iters': iters}
+        row['mfma_alone_us'] = run(M, blocks, iters, 'mfma')[0]
+        row['valu_alone_us'] = run(M, blocks, iters, 'valu')[1]
+        b = run(M, blocks, iters, 'both')
+        row['both_mfma_us'], row['both_valu_us'], row['both_wall_us'] = b
+        # VALU work done: blocks*256 threads * iters*64 FMAs
+        row['valu_TFLOPs_alone'] = round(2.0 * blocks * 256 * iters * 64 / row['valu_alone_us'] / 1e6, 1)
+        print(json.dumps(row), flush=True)

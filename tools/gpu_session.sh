@@ -23,6 +23,10 @@ if has rollout; then stamp "rollout bench"
   timeout 300 python tools/ab_bench.py rollout 2>&1 | grep -v amdgpu.ids | tee $OUT/rollout_bench.jsonl; fi
 if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 2>&1 | tail -1 | tee $OUT/train_bench.json; fi
+if has pipelined; then stamp "pipelined steps"
+  timeout 300 python tools/ab_bench.py pipelined 2>&1 | grep -v amdgpu.ids | tee $OUT/pipelined.jsonl; fi
+if has dualpipe; then stamp "dual-pipe probe"
+  timeout 300 python tools/dualpipe_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/dualpipe_probe.jsonl; fi
 if has bench35; then for c in c3 c5; do stamp "bench $c"
   timeout 300 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 5 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
