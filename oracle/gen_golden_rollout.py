@@ -176,6 +176,36 @@ def main():
     store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, 'rollout_traces.npz'), **store)
 
+    # ---- a dataset case in the reference's .mat format, read back by the REFERENCE's loader ------
+    import scipy.io as sio
+    from dataloader.statetransformer import AgentState
+    ed = types.ModuleType('easydict')
+    ed.EasyDict = dict
+    sys.modules.setdefault('easydict', ed)             # imported by the loader module, unused here
+    import dataloader.Dataloader_dcplocal_notTF_onlineExpert as dl
+    ci = 2                                                 # the 6-agent 8x8 trace
+    T = meta[ci]['T']
+    acts = store['t%d_actions' % ci].astype(np.int64)      # [T,N]
+    case = {'map': store['t%d_grid' % ci].astype(np.float64), 'goal': store['t%d_goal' % ci].astype(np.int64),
+            'inputState': store['t%d_pos' % ci][:T].astype(np.int64),
+            'inputTensor': store['t%d_obs' % ci].astype(np.float64),
+            'target': np.eye(5, dtype=np.int64)[acts], 'GSO': store['t%d_gso' % ci],
+            'makespan': T}
+    mat = os.path.join(OUT, 'case_fixture.mat')
+    sio.savemat(mat, case, do_compression=True)
+
+    class FakeLoader:
+        pass
+    fl = FakeLoader()
+    fl.AgentState = AgentState(meta[ci]['N'])
+    tr = dl.CreateDataset.load_train_data(fl, mat, 3)
+    te = dl.CreateDataset.load_data_during_training(fl, mat, 0)
+    np.savez_compressed(os.path.join(OUT, 'case_fixture_expected.npz'),
+                        train_input=tr[0].numpy(), train_target=tr[1].numpy(), train_gso=tr[2].numpy(),
+                        train_map=tr[3].numpy(), test_input=te[0].numpy(), test_target=te[1].numpy(),
+                        test_map=te[3].numpy())
+    print('case fixture written', os.path.getsize(mat))
+
 
 if __name__ == '__main__':
     main()

@@ -132,3 +132,18 @@ def test_rollout_needs_gpu():
     from gnn_pathplanning_amd.rollout import BatchedRollout
     with pytest.raises(_native.GnnppError):
         BatchedRollout(np.zeros((4, 4)), np.zeros((1, 2, 2)), np.ones((1, 2, 2)), 4, 'cpu')
+
+
+def test_rollout_from_reference_case_files(dev, rollout_golden):
+    """A dataset case in the reference's .mat format feeds the batched rollout directly."""
+    import os
+    from conftest import GOLDEN
+    from gnn_pathplanning_amd.formats import rollout_from_cases
+    z, meta = rollout_golden
+    mat = os.path.join(GOLDEN, 'case_fixture.mat')                   # = trace 2 (6 agents, 8x8)
+    env = rollout_from_cases([mat, mat], dev, tie_mode='lowest')
+    assert (env.B, env.N, env.H, env.W) == (2, 6, 8, 8)
+    assert env.maxstep.tolist() == [2 * meta[2]['T']] * 2
+    obs = env.observe().cpu().numpy()
+    assert (obs[0] == z['t2_obs'][0]).all() and (obs[1] == z['t2_obs'][0]).all()
+    assert (env.gso(0)[1].cpu().numpy() == z['t2_gso'][0].astype(np.float32)).all()
