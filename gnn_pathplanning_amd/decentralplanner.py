@@ -21,8 +21,9 @@ Train mode (agents/decentralplannerlocal.py:283-317) keeps the reference's exact
 encoder runs once per agent so BatchNorm normalises with per-agent-call batch statistics and
 updates its running statistics N times per forward (decentralplanner.py:284-290).  That needs
 batch-wide reductions per agent, so in train mode the encoder and the action head are stock aten /
-MIOpen ops on the GPU with autograd, while the graph filter (forward, input gradient, tap
-gradient) runs on the gnnpp HIP kernels through graphML._LSIGFFunction.  There is no CPU path.
+MIOpen ops on the GPU with autograd (agents as convolution groups instead of a python loop), while
+the graph filter (forward, input gradient, tap gradient) runs on the gnnpp HIP kernels through
+graphML._LSIGFFunction.  There is no CPU path.
 """
 import ctypes
 
@@ -210,20 +211,50 @@ class DecentralPlannerNet(nn.Module):
         return out.permute(1, 0, 2).contiguous()
 
     def _forward_train(self, inputTensor):
-        """Differentiable forward with the reference's op sequence (decentralplanner.py:278-318)."""
+        """Differentiable train-mode forward with the reference's semantics
+        (decentralplanner.py:278-318) but without its N-fold python loop: the agents become
+        convolution GROUPS and BatchNorm runs over N*C channels, so the batch statistics of
+        channel (n, c) are exactly those of the reference's n-th ConvLayers call; the N sequential
+        running-statistics updates (momentum m) collapse to
+            r <- (1-m)^N r + m * sum_n (1-m)^(N-1-n) stat_n .
+        Weight gradients accumulate over the N expanded copies, as they do over the N calls."""
+        import torch.nn.functional as tF
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
         _native.require_gpu(inputTensor, self.S, self.compressMLP[0].weight)
-        B = inputTensor.shape[0]
-        feats = []
-        for n in range(self.numAgents):
-            fm = self.ConvLayers(inputTensor[:, n])
-            feats.append(self.compressMLP(fm.view(fm.size(0), -1)))
-        x = torch.stack(feats, dim=2)                              # B x F x N
+        B, N = inputTensor.shape[0], self.numAgents
+        x = inputTensor[:, :N].reshape(B, N * 3, 11, 11)
+        for ci, bi in zip(_CONV_IDX, _BN_IDX):
+            conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
+            C = conv.out_channels
+            x = tF.conv2d(x, conv.weight.repeat(N, 1, 1, 1), conv.bias.repeat(N), stride=1,
+                          padding=1, groups=N)
+            bmean = torch.zeros(N * C, device=x.device, dtype=x.dtype)
+            bvar = torch.ones(N * C, device=x.device, dtype=x.dtype)
+            # momentum 1 => the dummy buffers receive the batch mean / unbiased variance
+            x = tF.batch_norm(x, bmean, bvar, bn.weight.repeat(N), bn.bias.repeat(N), training=True,
+                              momentum=1.0, eps=bn.eps)
+            if bn.track_running_stats and bn.momentum is not None:
+                with torch.no_grad():
+                    m = float(bn.momentum)
+                    w = m * (1.0 - m) ** torch.arange(N - 1, -1, -1, device=x.device, dtype=x.dtype)
+                    keep = (1.0 - m) ** N
+                    bn.running_mean.mul_(keep).add_((w[:, None] * bmean.view(N, C)).sum(0))
+                    bn.running_var.mul_(keep).add_((w[:, None] * bvar.view(N, C)).sum(0))
+                    bn.num_batches_tracked.add_(N)
+            x = tF.relu(x)
+            if isinstance(self.ConvLayers[bi + 2] if bi + 2 < len(self.ConvLayers) else None,
+                          nn.MaxPool2d):
+                x = tF.max_pool2d(x, 2)
+        feat = x.reshape(B, N, self.numFeatures2Share)
+        fc = self.compressMLP[0]
+        comp = tF.relu(tF.linear(feat, fc.weight, fc.bias))          # B x N x F
         for l in range(self.L):
             self.GFL[2 * l].addGSO(self.S)
-        shared = self.GFL(x)                                       # HIP filter fwd/bwd + ReLU
-        return [self.actionsMLP(shared[:, :, n].reshape(B, -1)) for n in range(self.numAgents)]
+        shared = self.GFL(comp.permute(0, 2, 1).contiguous())       # HIP filter fwd/bwd + ReLU
+        act = self.actionsMLP[0]
+        logits = tF.linear(shared.permute(0, 2, 1), act.weight, act.bias)      # B x N x 5
+        return [logits[:, n] for n in range(N)]
 
     def forward(self, inputTensor):
         """[B,N,3,11,11] -> python list of N tensors [B,5] (decentralplanner.py:278-318)."""
