@@ -88,6 +88,9 @@ def main():
                     help='extra measurement: independent batches in flight on this many HIP streams '
                          '(reported under "pipelined", never as "value"); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--dist-backend', default='nccl',
+                    help='nccl (= RCCL, default); gloo only to exercise the multi-rank code path '
+                         'on a box with fewer GPUs than ranks (with GNNPP_BENCH_DEVICE=0)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per encoder launch from a separate rocprofv3 --pmc pass')
     args = ap.parse_args()
@@ -97,13 +100,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = int(os.environ.get('GNNPP_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from gnn_pathplanning_amd import _native
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
