@@ -179,12 +179,14 @@ def main():
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
-            t0 = time.perf_counter()
-            run_pipelined(args.steps)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            el_p = time.perf_counter() - t0
+            el_p = float('inf')
+            for _ in range(2):                      # best of two: the enqueue side is host-bound-ish
+                t0 = time.perf_counter()
+                run_pipelined(args.steps)
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                el_p = min(el_p, time.perf_counter() - t0)
         v_p, _, el_p = aggregate_throughput(B * N * args.steps, el_p, device=dev)
         pipelined = {'streams': S_n, 'value': v_p, 'ms_per_step': 1e3 * el_p / args.steps,
                      'note': 'K independent batches round-robin on %d HIP streams; not the headline' % S_n}

@@ -103,6 +103,8 @@ class DecentralPlannerNet(nn.Module):
                                                   bias=True))
         self.apply(weights_init)
         self._enc_cache = _native.PackCache()
+        self._head_cache = _native.PackCache()
+        self._ws = None
 
     # ------------------------------------------------------------------------------------
     def addGSO(self, S):
@@ -157,6 +159,12 @@ class DecentralPlannerNet(nn.Module):
                 _native.stream_ptr(dev)), 'gnnpp_encoder_fwd')
         return feat
 
+    @staticmethod
+    def _head_pointers(gf, act):
+        gb = gf.bias.detach().reshape(-1).contiguous() if gf.bias is not None else None
+        aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
+        return (gb.data_ptr() if gb is not None else None, aw.data_ptr(), ab.data_ptr(), (gb, aw, ab))
+
     def forward_logits(self, inputTensor):
         """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
         contiguous [B,5] block) -- what forward() unbinds into the reference's list."""
@@ -171,12 +179,14 @@ class DecentralPlannerNet(nn.Module):
         obs = inputTensor.detach()
         if obs.shape[1] != N:
             obs = obs[:, :N]                      # the reference only visits the first numAgents
-        obs = obs.contiguous().float()
+        if obs.dtype is not torch.float32 or not obs.is_contiguous():
+            obs = obs.contiguous().float()
         S = self.S.detach()
         assert S.shape[0] == B
         Ns = S.shape[2]
         assert Ns >= N                            # Nin <= N zero padding (graphML.py:2464-2469)
-        S = S.contiguous()
+        if not S.is_contiguous():
+            S = S.contiguous()
         if S.dtype not in (torch.float32, torch.float64):
             S = S.float()
         gf = self.GFL[0]
@@ -188,16 +198,21 @@ class DecentralPlannerNet(nn.Module):
         L = _native.lib()
         enc = self.packed_encoder()
         taps = gf.packed_taps()
-        gbias = gf.bias.detach().reshape(-1) if gf.bias is not None else None
+        # raw pointers of the small head tensors, refreshed only when one of them changes
+        gb_p, aw_p, ab_p, _keep = self._head_cache.get(
+            (gf.bias, act.weight, act.bias) if gf.bias is not None else (act.weight, act.bias),
+            lambda: self._head_pointers(gf, act))
+        gbias = _keep[0]
         with _native.device_guard(dev):
             st = _native.stream_ptr(dev)
             if Ns == N:
-                ws = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
+                # the feature workspace is internal (one model instance per stream)
+                if self._ws is None or self._ws.shape[0] != B * N or self._ws.device != dev:
+                    self._ws = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
                 logits = torch.empty(N, B, 5, dtype=torch.float32, device=dev)
-                rc = L.gnnpp_policy_fwd(_ptr(obs), _ptr(S), _ptr(enc), _ptr(taps), _ptr(gbias),
-                                        _ptr(act.weight.detach()), _ptr(act.bias.detach()),
-                                        _ptr(ws), _ptr(logits), B, N, gf.K,
-                                        int(S.dtype == torch.float64), st)
+                rc = L.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc.data_ptr(), taps.data_ptr(),
+                                        gb_p, aw_p, ab_p, self._ws.data_ptr(), logits.data_ptr(),
+                                        B, N, gf.K, int(S.dtype is torch.float64), st)
                 _native.check(rc, 'gnnpp_policy_fwd')
                 return logits
             # GSO larger than numAgents: missing nodes carry zero features, extra outputs dropped
