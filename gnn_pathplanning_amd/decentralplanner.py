@@ -118,12 +118,32 @@ class DecentralPlannerNet(nn.Module):
             self.S = S
 
     def _encoder_tensors(self):
-        t = []
-        for ci, bi in zip(_CONV_IDX, _BN_IDX):
-            conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
-            t += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        t += [self.compressMLP[0].weight, self.compressMLP[0].bias]
+        """The 32 tensors the packed encoder depends on.  Walking nn.Sequential / __getattr__ costs
+        ~40 us per call, so the list is memoised; _apply() (.to/.cuda/.float), load_state_dict()
+        and a periodic refresh invalidate it (replacing a Parameter OBJECT by hand is caught at the
+        latest after 256 forwards -- call invalidate_packed() to force it)."""
+        self._calls = getattr(self, '_calls', 0) + 1
+        t = getattr(self, '_enc_tensors', None)
+        if t is None or (self._calls & 255) == 0:
+            t = []
+            for ci, bi in zip(_CONV_IDX, _BN_IDX):
+                conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
+                t += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            t += [self.compressMLP[0].weight, self.compressMLP[0].bias]
+            self._enc_tensors = t
+            self._mods = (self.GFL[0], self.actionsMLP[0])
         return t
+
+    def invalidate_packed(self):
+        self._enc_tensors = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._enc_tensors = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._enc_tensors = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _pack_encoder(self):
         L = _native.lib()
@@ -189,14 +209,13 @@ class DecentralPlannerNet(nn.Module):
             S = S.contiguous()
         if S.dtype not in (torch.float32, torch.float64):
             S = S.float()
-        gf = self.GFL[0]
-        act = self.actionsMLP[0]
+        enc = self.packed_encoder()
+        gf, act = self._mods
         dev = _native.require_gpu(obs, S, gf.weight, act.weight)
         if Ns > gml.MAX_NODES:
             raise _native.GnnppError('graphs with N=%d > %d nodes are not supported yet'
                                      % (Ns, gml.MAX_NODES))
         L = _native.lib()
-        enc = self.packed_encoder()
         taps = gf.packed_taps()
         # raw pointers of the small head tensors, refreshed only when one of them changes
         gb_p, aw_p, ab_p, _keep = self._head_cache.get(
