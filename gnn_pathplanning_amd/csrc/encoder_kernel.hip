@@ -73,9 +73,36 @@ __device__ __forceinline__ int enc_ss_off(int layer) {
          : layer == 3 ? EncLayout::kSS3 : EncLayout::kSS4;
 }
 
+// Winograd F(2x2,3x3) weight transform, element (a,b) of U = G g G^T with
+// G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]];  g = 3x3 kernel (row-major, cross-correlation).
+__device__ __forceinline__ float winograd_u(const float* __restrict__ g, int a, int b) {
+    float t[3];                                                  // row a of (G g)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        t[c] = a == 0 ? g0 : a == 1 ? 0.5f * (g0 + g1 + g2) : a == 2 ? 0.5f * (g0 - g1 + g2) : g2;
+    }
+    return b == 0 ? t[0] : b == 1 ? 0.5f * (t[0] + t[1] + t[2]) : b == 2 ? 0.5f * (t[0] - t[1] + t[2])
+                                                                        : t[2];
+}
+
 __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ packed) {
     const int stride = gridDim.x * blockDim.x;
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // Winograd L0: [mt 2][wpos 16][lane 64] = U[cout = mt*16+i][cin = q][wpos], 0 for q = 3
+    for (int idx = t0; idx < 2 * 16 * 64; idx += stride) {
+        const int l = idx & 63, wp = (idx >> 6) & 15, mt = idx >> 10;
+        const int co = mt * 16 + (l & 15), ci = l >> 4;
+        packed[EncLayout::kU0 + idx] =
+            ci < 3 ? winograd_u(rp.conv_w[0] + (co * 3 + ci) * 9, wp >> 2, wp & 3) : 0.f;
+    }
+    // Winograd L2: [mt 4][g 2][wpos 16][lane 64][s 4] = U[cout][cin = g*16 + q*4 + s][wpos]
+    for (int idx = t0; idx < 4 * 2 * 16 * 256; idx += stride) {
+        const int s = idx & 3, l = (idx >> 2) & 63, wp = (idx >> 8) & 15, g = (idx >> 12) & 1,
+                  mt = idx >> 13;
+        const int co = mt * 16 + (l & 15), ci = g * 16 + (l >> 4) * 4 + s;
+        packed[EncLayout::kU2 + idx] = winograd_u(rp.conv_w[2] + (co * 32 + ci) * 9, wp >> 2, wp & 3);
+    }
     // L0: [mt 2][s 7][lane 64];  k = 4*s + q  ->  (c, ky, kx) = (k/9, (k%9)/3, k%3);  k = 27 -> 0
     for (int idx = t0; idx < 2 * 7 * 64; idx += stride) {
         const int l = idx & 63, s = (idx >> 6) % 7, mt = idx / (7 * 64);
@@ -380,8 +407,9 @@ int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int g_encoder_variant = 2;          // 2: schedule v2 (default); 1: v1 in place; 0: v1 ping-pong
+int g_encoder_variant = 3;          // 3: v3 Winograd L0/L2 (default); 2: v2; 1: v1 in place; 0: ping-pong
 int encoder_launch_v2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
+int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 
 template <bool INPLACE>
 static int encoder_launch_t(const float* obs, const float* packed, float* feat, int M,
@@ -400,6 +428,7 @@ static int encoder_launch_t(const float* obs, const float* packed, float* feat, 
 }
 
 int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    if (g_encoder_variant == 3) return encoder_launch_v3(obs, packed, feat, M, st);
     if (g_encoder_variant == 2) return encoder_launch_v2(obs, packed, feat, M, st);
     return g_encoder_variant ? encoder_launch_t<true>(obs, packed, feat, M, st)
                              : encoder_launch_t<false>(obs, packed, feat, M, st);

@@ -38,7 +38,12 @@ struct WStream {                 // per-wave segment bases, already offset by la
 
 // Address of stream item `idx` (compile-time after unrolling).  Conv segments are traversed
 // group-major: local item j -> (g = j / 9, tap = j % 9), stored at [(tap * NG + g)].
-__device__ __forceinline__ const float* item_ptr(const WStream& ws, int idx) {
+struct ItemsV2 {
+    typedef WStream Stream;
+    static constexpr int kEnd = kI_END;
+    static __device__ __forceinline__ const float* ptr(const WStream& ws, int idx);
+};
+__device__ __forceinline__ const float* ItemsV2::ptr(const WStream& ws, int idx) {
     if (idx < kI_L2) { const int j = idx - kI_L1; return ws.l1 + ((j % 9) * 2 + j / 9) * 256; }
     if (idx < kI_L3) { const int j = idx - kI_L2; return ws.l2 + ((j % 9) * 2 + j / 9) * 256; }
     if (idx < kI_L4A) { const int j = idx - kI_L3; return ws.l3 + ((j % 9) * 4 + j / 9) * 256; }
@@ -51,10 +56,12 @@ __device__ __forceinline__ const float* item_ptr(const WStream& ws, int idx) {
 // Ring loads are relaxed wavefront-scope ATOMIC loads (two 8-byte halves): same instruction and
 // cache policy as a plain global_load, but "ordered" for the compiler, so they are issued where
 // the source puts them instead of being sunk next to their first use 12 items later.
-__device__ __forceinline__ void ring_load(const WStream& ws, v4f (&ring)[kRing], int idx) {
-    if (idx < kI_END) {
+template <class Items>
+__device__ __forceinline__ void ring_load(const typename Items::Stream& ws, v4f (&ring)[kRing],
+                                          int idx) {
+    if (idx < Items::kEnd) {
         typedef unsigned long long u64;
-        u64* p = reinterpret_cast<u64*>(const_cast<float*>(item_ptr(ws, idx)));
+        u64* p = reinterpret_cast<u64*>(const_cast<float*>(Items::ptr(ws, idx)));
         const u64 lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const u64 hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         v4f r;
@@ -67,9 +74,10 @@ __device__ __forceinline__ void ring_load(const WStream& ws, v4f (&ring)[kRing],
 }
 
 // One output-channel tile over a compile-time position set, weights from the ring.
-template <int START, int CIN, int H, int W, int NSLOT, class PosFn>
-__device__ __forceinline__ void conv_tile_ring(const WStream& ws, v4f (&ring)[kRing],
-                                               const v4f* in, v4f (&acc)[NSLOT], int lane) {
+template <class Items, int START, int CIN, int H, int W, int NSLOT, class PosFn>
+__device__ __forceinline__ void conv_tile_ring(const typename Items::Stream& ws,
+                                               v4f (&ring)[kRing], const v4f* in,
+                                               v4f (&acc)[NSLOT], int lane) {
     constexpr int NG = CIN / 16;
 #pragma unroll
     for (int it = 0; it < 9 * NG; ++it) {
@@ -79,7 +87,7 @@ __device__ __forceinline__ void conv_tile_ring(const WStream& ws, v4f (&ring)[kR
         // operations may), otherwise the scheduler sinks each refill next to its consumer.
         __builtin_amdgcn_sched_barrier(kSchedItemMask);
         const v4f A = ring[(START + it) % kRing];
-        ring_load(ws, ring, START + it + kRing);       // refill the slot just consumed
+        ring_load<Items>(ws, ring, START + it + kRing);   // refill the slot just consumed
         v4f Bf[NSLOT];
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v2(const float* __
     ws.fcb = pk + EncLayout::kWfc + (wave + kWaves) * (8 * 256) + lane * 4;
     v4f ring[kRing];
 #pragma unroll
-    for (int i = 0; i < kRing; ++i) ring_load(ws, ring, i);
+    for (int i = 0; i < kRing; ++i) ring_load<ItemsV2>(ws, ring, i);
 
     // ---- observations: all loads first, zero-fill while they fly, then scatter ------------------
     {
@@ -237,9 +245,9 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v2(const float* __
 #pragma unroll
         for (int j = 0; j < 13; ++j) acc[j] = vzero();
         if (half == 0)
-            conv_tile_ring<kI_L1, 32, 5, 5, 13, PosL1<0>>(ws, ring, X4, acc, lane);
+            conv_tile_ring<ItemsV2, kI_L1, 32, 5, 5, 13, PosL1<0>>(ws, ring, X4, acc, lane);
         else
-            conv_tile_ring<kI_L1, 32, 5, 5, 13, PosL1<1>>(ws, ring, X4, acc, lane);
+            conv_tile_ring<ItemsV2, kI_L1, 32, 5, 5, 13, PosL1<1>>(ws, ring, X4, acc, lane);
         __syncthreads();                               // everyone is done reading L0's output
 #pragma unroll
         for (int j = 0; j < 13; ++j)
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v2(const float* __
         v4f acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = vzero();
-        conv_tile_ring<kI_L2, 32, 5, 5, 16, PosL2>(ws, ring, X4, acc, lane);
+        conv_tile_ring<ItemsV2, kI_L2, 32, 5, 5, 16, PosL2>(ws, ring, X4, acc, lane);
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v2(const float* __
         v4f acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = vzero();
-        conv_tile_ring<kI_L3, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc, lane);
+        conv_tile_ring<ItemsV2, kI_L3, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc, lane);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) X4[(j * 4 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
@@ -291,8 +299,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v2(const float* __
         v4f acc0[4], acc1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc0[j] = vzero(); acc1[j] = vzero(); }
-        conv_tile_ring<kI_L4A, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc0, lane);
-        conv_tile_ring<kI_L4B, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc1, lane);
+        conv_tile_ring<ItemsV2, kI_L4A, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc0, lane);
+        conv_tile_ring<ItemsV2, kI_L4B, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc1, lane);
         v4f m0 = vrelu(vfma(acc0[0], sc0, sh0)), m1 = vrelu(vfma(acc1[0], sc1, sh1));
 #pragma unroll
         for (int j = 1; j < 4; ++j) {
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v2(const float* __
                 const int idx = (t == 0 ? kI_FCA : kI_FCB) + g;
                 __builtin_amdgcn_sched_barrier(kSchedItemMask);
                 const v4f A = ring[idx % kRing];
-                ring_load(ws, ring, idx + kRing);
+                ring_load<ItemsV2>(ws, ring, idx + kRing);
                 acc[t][g & 1] = mfma16x4(A, Bf[g], acc[t][g & 1]);
             }
         }

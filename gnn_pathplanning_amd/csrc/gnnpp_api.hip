@@ -4,6 +4,7 @@
 
 #include "encoder_kernel.hip"
 #include "encoder_kernel_v2.hip"
+#include "encoder_kernel_v3.hip"
 #include "lsigf_kernel.hip"
 #include "rollout_kernels.hip"
 
@@ -119,7 +120,7 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT:
-            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 3) return GNNPP_ERR_ARG;
             g_encoder_variant = value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_GPW:

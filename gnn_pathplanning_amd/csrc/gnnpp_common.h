@@ -94,7 +94,10 @@ struct EncLayout {
     static constexpr int kSS4 = kW4 + 8 * 9 * 4 * 256;
     static constexpr int kWfc = kSS4 + 256;                              // [8][8][256]
     static constexpr int kBfc = kWfc + 8 * 8 * 256;                      // bias[128]
-    static constexpr int kTotal = kBfc + 128;
+    // Winograd F(2x2,3x3) weights U = G g G^T (16 values per 3x3 kernel) for L0 and L2
+    static constexpr int kU0 = kBfc + 128;                               // [mt 2][wpos 16][lane 64]
+    static constexpr int kU2 = kU0 + 2 * 16 * 64;                        // [mt 4][g 2][wpos 16][lane 64][4]
+    static constexpr int kTotal = kU2 + 4 * 2 * 16 * 256;
 };
 
 }  // namespace gnnpp

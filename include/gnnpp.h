@@ -41,9 +41,10 @@ const char* gnnpp_error_string(int code);
 
 /* Process-wide tuning knobs for A/B measurements (bench.py); defaults are the fast settings.
  * Results are identical for every setting -- only the schedule changes. */
-#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 2 (default): schedule v2 (weight-fragment register ring,
-                                         up-front observation loads); 1: v1, in-place layers,
-                                         79 KB LDS; 0: v1, ping-pong buffers, 100 KB LDS          */
+#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 3 (default): v2 + Winograd F(2x2,3x3) in L0 and L2;
+                                         2: schedule v2 (weight-fragment register ring, up-front
+                                         observation loads); 1: v1, in-place layers, 79 KB LDS;
+                                         0: v1, ping-pong buffers, 100 KB LDS                      */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
 #define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
 int         gnnpp_set_tuning(int key, int value);

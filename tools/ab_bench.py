@@ -48,13 +48,15 @@ def main():
         obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
-        for v in (2, 1):
+        for v in (3, 2):
             L.gnnpp_set_tuning(0, v)
             t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
             row['v%d_us' % v] = round(t, 2)
             row['v%d_TFLOPs' % v] = round(2.0 * (1238112 + 16384) * M / t / 1e6, 1)
-        L.gnnpp_set_tuning(0, 2)
+        L.gnnpp_set_tuning(0, 3)
         print(json.dumps(row), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'encoder':
+        return
     # ---- filter: graphs-per-workgroup sweep ----
     for (N, B, K, W) in ((10, 512, 3, 20), (50, 256, 3, 50), (100, 128, 3, 100), (10, 4096, 3, 20)):
         gf = DecentralPlannerNet(Cfg(N, K)).to(dev).GFL[0]
