@@ -76,6 +76,9 @@ __device__ __forceinline__ void winograd_output(const v4f (&m)[16], v4f (&y)[4])
     y[3] = r1[1] - r1[2] - r1[3];
 }
 
+// WINO_L0 = false keeps v2's direct L0 (28 ds_read_b32 + 56 MFMAs per pool window) and uses
+// Winograd for L2 only; selectable through gnnpp_set_tuning for A/B measurements.
+template <bool WINO_L0>
 __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M) {
@@ -83,6 +86,10 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     float* const X = reinterpret_cast<float*>(gnnpp_smem);          // activations, in place
     float* const bufObs = X + kBufFloats;                            // padded observations
     v4f* const X4 = reinterpret_cast<v4f*>(X);
+    // The observation buffer is dead after L0 and big enough (27.7 KB) for the pooled L2 / L3 / L4
+    // outputs (<= 16 KB): the late layers ping-pong X <-> Y instead of running in place, which
+    // drops three barriers and the registers that held a layer's outputs across them.
+    v4f* const Y4 = reinterpret_cast<v4f*>(bufObs);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,6 +151,59 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     }
     __syncthreads();
 
+    if (!WINO_L0) {
+        // ---- L0 direct (as v2): 3 -> 32 @ 11x11 (10x10 used), BN, ReLU, pool ------------------------
+        float A0[2][7];
+        int offB[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            A0[0][s] = pk[EncLayout::kW0 + (0 * 7 + s) * 64 + lane];
+            A0[1][s] = pk[EncLayout::kW0 + (1 * 7 + s) * 64 + lane];
+            int k = 4 * s + q;
+            if (k >= 27) k = 0;
+            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
+            offB[s] = a * kAgentStride + c * (kPadHW * kPadHW) + ky * kPadHW + kx;
+        }
+        v4f sc[2], sh[2];
+        load_ss(pk + EncLayout::kSS0, 32, 0, q, sc[0], sh[0]);
+        load_ss(pk + EncLayout::kSS0, 32, 1, q, sc[1], sh[1]);
+        float Bc[28], Bn[28];
+        auto load_window = [&](float (&B)[28], int win) {
+            const int wy = win / 5, wx = win - wy * 5;
+            const float* base = bufObs + (2 * wy) * kPadHW + 2 * wx;
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+                    B[s * 4 + pp] = base[offB[s] + (pp >> 1) * kPadHW + (pp & 1)];
+        };
+        load_window(Bc, wave);
+        for (int win = wave; win < 25; win += kWaves) {
+            if (win + kWaves < 25) load_window(Bn, win + kWaves);
+            v4f acc[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) acc[i][pp] = vzero();
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    acc[0][pp] = mfma16(A0[0][s], Bc[s * 4 + pp], acc[0][pp]);
+                    acc[1][pp] = mfma16(A0[1][s], Bc[s * 4 + pp], acc[1][pp]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v4f m = vrelu(vfma(acc[i][0], sc[i], sh[i]));
+#pragma unroll
+                for (int pp = 1; pp < 4; ++pp) m = vmax(m, vfma(acc[i][pp], sc[i], sh[i]));
+                X4[(win * 2 + i) * 64 + lane] = m;
+            }
+#pragma unroll
+            for (int i = 0; i < 28; ++i) Bc[i] = Bn[i];
+        }
+    } else
     // ---- L0 (Winograd): one 4x4 input patch per pool window, 16 MFMAs per channel tile ------------
     {
         float U0[2][16];
@@ -212,7 +272,6 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
         const int mt = wave;
         v4f sc, sh;
         load_ss(pk + EncLayout::kSS2, 64, mt, q, sc, sh);
-        v4f res[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ty = t >> 1, tx = t & 1;
@@ -252,15 +311,12 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
             v4f r = vrelu(vfma(y[0], sc, sh));
 #pragma unroll
             for (int pp = 1; pp < 4; ++pp) r = vmax(r, vfma(y[pp], sc, sh));
-            res[t] = r;
+            Y4[(t * 4 + mt) * 64 + lane] = r;
         }
-        __syncthreads();                               // everyone is done reading L1's output
-#pragma unroll
-        for (int t = 0; t < 4; ++t) X4[(t * 4 + mt) * 64 + lane] = res[t];
     }
     __syncthreads();
 
-    // ---- L3: 64 -> 64 @ 2x2, in place ----------------------------------------------------------------
+    // ---- L3: 64 -> 64 @ 2x2 : Y -> X -----------------------------------------------------------------
     {
         const int mt = wave;
         v4f sc, sh;
@@ -268,14 +324,13 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
         v4f acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = vzero();
-        conv_tile_ring<ItemsV3, k3_L3, 64, 2, 2, 4, Pos2x2>(ws, ring, X4, acc, lane);
-        __syncthreads();
+        conv_tile_ring<ItemsV3, k3_L3, 64, 2, 2, 4, Pos2x2>(ws, ring, Y4, acc, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) X4[(j * 4 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
     }
     __syncthreads();
 
-    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][8][64], two channel tiles per wave, in place -----------
+    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][8][64], two channel tiles per wave : X -> Y -------------
     {
         v4f sc0, sh0, sc1, sh1;
         load_ss(pk + EncLayout::kSS4, 128, wave, q, sc0, sh0);
@@ -291,9 +346,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
             m0 = vmax(m0, vfma(acc0[j], sc0, sh0));
             m1 = vmax(m1, vfma(acc1[j], sc1, sh1));
         }
-        __syncthreads();
-        X4[wave * 64 + lane] = m0;
-        X4[(wave + kWaves) * 64 + lane] = m1;
+        Y4[wave * 64 + lane] = m0;
+        Y4[(wave + kWaves) * 64 + lane] = m1;
     }
     __syncthreads();
 
@@ -301,7 +355,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     {
         v4f Bf[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) Bf[g] = X4[g * 64 + lane];
+        for (int g = 0; g < 8; ++g) Bf[g] = Y4[g * 64 + lane];
         v4f acc[2][2] = {{vzero(), vzero()}, {vzero(), vzero()}};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -325,17 +379,26 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     }
 }
 
-int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+template <bool WINO_L0>
+static int encoder_launch_v3_t(const float* obs, const float* packed, float* feat, int M,
+                               hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_v3),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_v3<WINO_L0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL(encoder_kernel_v3, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M);
+    hipLaunchKernelGGL((encoder_kernel_v3<WINO_L0>), dim3(grid), dim3(kThreads), smem, st, obs, packed,
+                       feat, M);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
+                      int wino_l0) {
+    return wino_l0 ? encoder_launch_v3_t<true>(obs, packed, feat, M, st)
+                   : encoder_launch_v3_t<false>(obs, packed, feat, M, st);
 }
 
 }  // namespace gnnpp

@@ -56,7 +56,7 @@ def test_emu_lsigf_node_major_relu(emu, lsigf_golden):
     assert np.abs(y.transpose(0, 2, 1) - np.maximum(want, 0)).max() <= TOL
 
 
-@pytest.mark.parametrize('variant', [3, 2, 1, 0])
+@pytest.mark.parametrize('variant', [3, 4, 2, 1, 0])
 def test_emu_policy_golden(emu, policy_golden, variant):
     el, lib = emu
     assert lib.gnnpp_set_tuning(0, variant) == 0        # encoder schedule: 3 = v3 Winograd, 2 = v2, 1 = v1 in place, 0 = ping-pong

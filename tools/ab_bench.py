@@ -48,7 +48,7 @@ def main():
         obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
-        for v in (3, 2):
+        for v in (3, 4, 2):
             L.gnnpp_set_tuning(0, v)
             t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
             row['v%d_us' % v] = round(t, 2)
