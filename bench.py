@@ -241,8 +241,9 @@ def main():
             'traffic': traffic, 'algorithmic_bytes': M * (363 + 128) * 4.0 + 156288 * 4.0,
             'avg_launch_us': t_enc * 1e6,
             # the kernel skips zero-padding taps and pooled-away positions: MFMA work it executes
-            'executed_flops_per_launch': 11300 * 2048.0 * ((M + 15) // 16),
-            'executed_frac': 11300 * 2048.0 * ((M + 15) // 16) / t_enc / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            # (v3: 8876 MFMAs of 2048 FLOP per 16-agent tile; v2: 11300; nominal: 12544)
+            'executed_flops_per_launch': 8876 * 2048.0 * ((M + 15) // 16),
+            'executed_frac': 8876 * 2048.0 * ((M + 15) // 16) / t_enc / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             'flops_per_launch': flops,
         }
         # secondary: the graph-filter kernel alone (node-major features in, ReLU'd features out)

@@ -407,10 +407,11 @@ int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int g_encoder_variant = 3;          // 3: v3 Winograd L0+L2 (default); 4: Winograd L2 only; 2: v2; 1: v1 in place; 0: ping-pong
+int g_encoder_variant = 5;          // 5: v3 Winograd L0+L2, late layers in place (default); 3: same,
+                                    // late layers via the obs buffer; 4/6: Winograd L2 only (Y / in place); 2: v2; 1: v1 in place; 0: ping-pong
 int encoder_launch_v2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
-                      int wino_l0);
+                      int wino_l0, int late_y);
 
 template <bool INPLACE>
 static int encoder_launch_t(const float* obs, const float* packed, float* feat, int M,
@@ -429,8 +430,10 @@ static int encoder_launch_t(const float* obs, const float* packed, float* feat, 
 }
 
 int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
-    if (g_encoder_variant == 3) return encoder_launch_v3(obs, packed, feat, M, st, 1);
-    if (g_encoder_variant == 4) return encoder_launch_v3(obs, packed, feat, M, st, 0);
+    if (g_encoder_variant == 3) return encoder_launch_v3(obs, packed, feat, M, st, 1, 1);
+    if (g_encoder_variant == 4) return encoder_launch_v3(obs, packed, feat, M, st, 0, 1);
+    if (g_encoder_variant == 5) return encoder_launch_v3(obs, packed, feat, M, st, 1, 0);
+    if (g_encoder_variant == 6) return encoder_launch_v3(obs, packed, feat, M, st, 0, 0);
     if (g_encoder_variant == 2) return encoder_launch_v2(obs, packed, feat, M, st);
     return g_encoder_variant ? encoder_launch_t<true>(obs, packed, feat, M, st)
                              : encoder_launch_t<false>(obs, packed, feat, M, st);

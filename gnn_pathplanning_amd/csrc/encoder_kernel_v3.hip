@@ -78,7 +78,9 @@ __device__ __forceinline__ void winograd_output(const v4f (&m)[16], v4f (&y)[4])
 
 // WINO_L0 = false keeps v2's direct L0 (28 ds_read_b32 + 56 MFMAs per pool window) and uses
 // Winograd for L2 only; selectable through gnnpp_set_tuning for A/B measurements.
-template <bool WINO_L0>
+// LATE_Y = true: L2/L3/L4 outputs ping-pong X <-> Y (the dead observation buffer);
+// LATE_Y = false: they stay in X, in place, held in registers across a barrier (as v2).
+template <bool WINO_L0, bool LATE_Y>
 __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     // The observation buffer is dead after L0 and big enough (27.7 KB) for the pooled L2 / L3 / L4
     // outputs (<= 16 KB): the late layers ping-pong X <-> Y instead of running in place, which
     // drops three barriers and the registers that held a layer's outputs across them.
-    v4f* const Y4 = reinterpret_cast<v4f*>(bufObs);
+    v4f* const Y4 = LATE_Y ? reinterpret_cast<v4f*>(bufObs) : X4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
         const int mt = wave;
         v4f sc, sh;
         load_ss(pk + EncLayout::kSS2, 64, mt, q, sc, sh);
+        v4f res[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ty = t >> 1, tx = t & 1;
@@ -311,7 +314,13 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
             v4f r = vrelu(vfma(y[0], sc, sh));
 #pragma unroll
             for (int pp = 1; pp < 4; ++pp) r = vmax(r, vfma(y[pp], sc, sh));
-            Y4[(t * 4 + mt) * 64 + lane] = r;
+            if (LATE_Y) Y4[(t * 4 + mt) * 64 + lane] = r;
+            else res[t] = r;
+        }
+        if (!LATE_Y) {
+            __syncthreads();                           // everyone is done reading L1's output
+#pragma unroll
+            for (int t = 0; t < 4; ++t) X4[(t * 4 + mt) * 64 + lane] = res[t];
         }
     }
     __syncthreads();
@@ -325,6 +334,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = vzero();
         conv_tile_ring<ItemsV3, k3_L3, 64, 2, 2, 4, Pos2x2>(ws, ring, Y4, acc, lane);
+        if (!LATE_Y) __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) X4[(j * 4 + mt) * 64 + lane] = vrelu(vfma(acc[j], sc, sh));
     }
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
             m0 = vmax(m0, vfma(acc0[j], sc0, sh0));
             m1 = vmax(m1, vfma(acc1[j], sc1, sh1));
         }
+        if (!LATE_Y) __syncthreads();
         Y4[wave * 64 + lane] = m0;
         Y4[(wave + kWaves) * 64 + lane] = m1;
     }
@@ -379,26 +390,28 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     }
 }
 
-template <bool WINO_L0>
+template <bool WINO_L0, bool LATE_Y>
 static int encoder_launch_v3_t(const float* obs, const float* packed, float* feat, int M,
                                hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_v3<WINO_L0>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_v3<WINO_L0, LATE_Y>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL((encoder_kernel_v3<WINO_L0>), dim3(grid), dim3(kThreads), smem, st, obs, packed,
+    hipLaunchKernelGGL((encoder_kernel_v3<WINO_L0, LATE_Y>), dim3(grid), dim3(kThreads), smem, st, obs, packed,
                        feat, M);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
-                      int wino_l0) {
-    return wino_l0 ? encoder_launch_v3_t<true>(obs, packed, feat, M, st)
-                   : encoder_launch_v3_t<false>(obs, packed, feat, M, st);
+                      int wino_l0, int late_y) {
+    if (wino_l0) return late_y ? encoder_launch_v3_t<true, true>(obs, packed, feat, M, st)
+                               : encoder_launch_v3_t<true, false>(obs, packed, feat, M, st);
+    return late_y ? encoder_launch_v3_t<false, true>(obs, packed, feat, M, st)
+                  : encoder_launch_v3_t<false, false>(obs, packed, feat, M, st);
 }
 
 }  // namespace gnnpp

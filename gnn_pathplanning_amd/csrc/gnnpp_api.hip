@@ -120,7 +120,7 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT:
-            if (value < 0 || value > 4) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 6) return GNNPP_ERR_ARG;
             g_encoder_variant = value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_GPW:

@@ -41,7 +41,9 @@ const char* gnnpp_error_string(int code);
 
 /* Process-wide tuning knobs for A/B measurements (bench.py); defaults are the fast settings.
  * Results are identical for every setting -- only the schedule changes. */
-#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 3 (default): v2 + Winograd F(2x2,3x3) in L0 and L2;
+#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 5 (default): v3 = v2 + Winograd F(2x2,3x3) in L0 and L2,
+                                         late layers in place; 3: v3 with the late layers through
+                                         the observation buffer; 4 / 6: Winograd in L2 only;
                                          2: schedule v2 (weight-fragment register ring, up-front
                                          observation loads); 1: v1, in-place layers, 79 KB LDS;
                                          0: v1, ping-pong buffers, 100 KB LDS                      */

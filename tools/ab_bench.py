@@ -48,12 +48,11 @@ def main():
         obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
-        for v in (3, 4, 2):
+        for v in (5, 3, 2):
             L.gnnpp_set_tuning(0, v)
             t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
-            row['v%d_us' % v] = round(t, 2)
-            row['v%d_TFLOPs' % v] = round(2.0 * (1238112 + 16384) * M / t / 1e6, 1)
-        L.gnnpp_set_tuning(0, 3)
+            row['v%d_us' % v] = min(round(t, 2), row.get('v%d_us' % v, 1e9))
+        L.gnnpp_set_tuning(0, 5)
         print(json.dumps(row), flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'encoder':
         return
