@@ -37,14 +37,14 @@ if has bench35; then for c in c3 c5; do stamp "bench $c"
   timeout 300 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 5 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then stamp "rocprofv3 kernel trace"
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/prof_run.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --pipeline-streams 0 > $OUT/prof_run.log 2>&1
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -12 "$f" | tee $OUT/kernel_stats_head.csv
   find $OUT/prof -name "*kernel_trace.csv" -size +6M -delete; fi
 if has pmc; then stamp "rocprofv3 pmc passes"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-    timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1
+    timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --pipeline-streams 0 > $OUT/pmc_$name.log 2>&1
     python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt
     find $OUT/pmc_$name -name "*.csv" -size +2M -delete
   done; fi
