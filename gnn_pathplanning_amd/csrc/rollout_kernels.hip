@@ -42,10 +42,16 @@ __device__ __forceinline__ void projected_goal(int dx, int dy, int& px, int& py)
     }
 }
 
+constexpr int kObsAgentsPerWg = 16;
+
+// grid = (ceil(N / 16), B): a workgroup builds the episode's occupancy grid in LDS and writes the
+// observations of 16 agents.
 __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     unsigned char* occ = reinterpret_cast<unsigned char*>(gnnpp_smem);     // [H*W] agents present
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n0 = blockIdx.x * kObsAgentsPerWg;
+    const int n1 = min(p.N, n0 + kObsAgentsPerWg);
     const int HW = p.H * p.W;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * HW : 0);
     const int* pos = p.pos + (size_t)b * p.N * 2;
@@ -54,9 +60,9 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
     __syncthreads();
     for (int n = tid; n < p.N; n += 256) occ[pos[2 * n] * p.W + pos[2 * n + 1]] = 1;
     __syncthreads();
-    float* out = p.obs + (size_t)b * p.N * 363;
-    for (int e = tid; e < p.N * 363; e += 256) {
-        const int n = e / 363, r = e - n * 363;
+    float* out = p.obs + ((size_t)b * p.N + n0) * 363;
+    for (int e = tid; e < (n1 - n0) * 363; e += 256) {
+        const int n = n0 + e / 363, r = e - (e / 363) * 363;
         const int ch = r / 121, r2 = r - ch * 121;
         const int i = r2 / 11, j = r2 - i * 11;
         const int cx = pos[2 * n], cy = pos[2 * n + 1];
@@ -82,15 +88,26 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
 // until the graph is connected; S = D^-1/2 A D^-1/2 in fp64 (isolated nodes -> 0), rounded to fp32
 // (what `S.float()` does to the simulator's float64 GSO).  Connectivity by graph search on
 // adjacency bit masks -- the same boolean as the reference's Laplacian-spectrum test.
-__global__ __launch_bounds__(64) void rollout_gso_kernel(const RolloutArgs p) {
+// Largest integer d2 with sqrt((double)d2) < R, i.e. the exact integer form of the reference's
+// `distance < R` test on integer positions (-1 if none).  Evaluated with the same correctly rounded
+// fp64 sqrt the reference's pdist uses, once per radius instead of once per agent pair.
+__device__ __forceinline__ long long dist2_threshold(double R) {
+    if (!(R > 0.0)) return -1;
+    long long t = (long long)(R * R) + 2;
+    while (t >= 0 && !(sqrt((double)t) < R)) --t;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     unsigned long long* adj = reinterpret_cast<unsigned long long*>(gnnpp_smem);   // [N][2]
     double* inv = reinterpret_cast<double*>(adj + 2 * kMaxAgents);                  // [N]
     double* shared_r = inv + kMaxAgents;                                            // [1]
-    int* shared_flag = reinterpret_cast<int*>(shared_r + 1);                        // [1]
-    const int b = blockIdx.x, lane = threadIdx.x, N = p.N;
+    long long* shared_t = reinterpret_cast<long long*>(shared_r + 1);               // [1]
+    int* shared_flag = reinterpret_cast<int*>(shared_t + 1);                        // [1]
+    const int b = blockIdx.x, tid = threadIdx.x, N = p.N;
     const int* pos = p.pos + (size_t)b * N * 2;
-    if (lane == 0) {
+    if (tid == 0) {
         double r = p.radius[b];
         if (p.grow) r = r / 1.1;
         *shared_r = r;
@@ -98,21 +115,24 @@ __global__ __launch_bounds__(64) void rollout_gso_kernel(const RolloutArgs p) {
     }
     __syncthreads();
     for (;;) {
-        if (lane == 0 && p.grow) *shared_r = *shared_r * 1.1;
+        if (tid == 0) {
+            if (p.grow) *shared_r = *shared_r * 1.1;
+            *shared_t = dist2_threshold(*shared_r);
+        }
         __syncthreads();
-        const double R = *shared_r;
-        for (int i = lane; i < N; i += 64) {
+        const long long T = *shared_t;
+        for (int i = tid; i < N; i += 256) {
             unsigned long long w0 = 0, w1 = 0;
             const int xi = pos[2 * i], yi = pos[2 * i + 1];
             for (int j = 0; j < N; ++j) {
                 const int dx = xi - pos[2 * j], dy = yi - pos[2 * j + 1];
-                const bool e = (j != i) && (sqrt((double)(dx * dx + dy * dy)) < R);
+                const bool e = (j != i) && ((long long)(dx * dx + dy * dy) <= T);
                 if (e) { if (j < 64) w0 |= 1ull << j; else w1 |= 1ull << (j - 64); }
             }
             adj[2 * i] = w0; adj[2 * i + 1] = w1;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             unsigned long long r0 = 1ull, r1 = 0, d0 = 0, d1 = 0;      // reached / expanded
             for (;;) {
                 const unsigned long long f0 = r0 & ~d0, f1 = r1 & ~d1;
@@ -129,18 +149,21 @@ __global__ __launch_bounds__(64) void rollout_gso_kernel(const RolloutArgs p) {
         if (*shared_flag || !p.grow) break;
         __syncthreads();
     }
-    for (int i = lane; i < N; i += 64) {
+    for (int i = tid; i < N; i += 256) {
         const int deg = __popcll(adj[2 * i]) + __popcll(adj[2 * i + 1]);
         inv[i] = deg ? sqrt(1.0 / (double)deg) : 0.0;
     }
     __syncthreads();
     float* S = p.S + (size_t)b * N * N;
-    for (int e = lane; e < N * N; e += 64) {
-        const int i = e / N, j = e - i * N;
-        const bool on = j < 64 ? (adj[2 * i] >> j) & 1ull : (adj[2 * i + 1] >> (j - 64)) & 1ull;
-        S[e] = on ? (float)(inv[i] * inv[j]) : 0.f;
+    for (int i = tid / 16; i < N; i += 16) {                    // 16 rows in flight, 16 lanes per row
+        const unsigned long long w0 = adj[2 * i], w1 = adj[2 * i + 1];
+        const double ii = inv[i];
+        for (int j = tid & 15; j < N; j += 16) {
+            const bool on = j < 64 ? (w0 >> j) & 1ull : (w1 >> (j - 64)) & 1ull;
+            S[i * N + j] = on ? (float)(ii * inv[j]) : 0.f;
+        }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         p.radius[b] = *shared_r;
         if (p.connected) p.connected[b] = *shared_flag;
     }
@@ -391,13 +414,15 @@ __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
 int rollout_observe_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t smem = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (smem > 64 * 1024) return -2;
-    hipLaunchKernelGGL(rollout_observe_kernel, dim3(a.B), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(rollout_observe_kernel,
+                       dim3((a.N + kObsAgentsPerWg - 1) / kObsAgentsPerWg, a.B), dim3(256), smem, st,
+                       a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int rollout_gso_launch(const RolloutArgs& a, hipStream_t st) {
-    const size_t smem = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 16;
-    hipLaunchKernelGGL(rollout_gso_kernel, dim3(a.B), dim3(64), smem, st, a);
+    const size_t smem = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;
+    hipLaunchKernelGGL(rollout_gso_kernel, dim3(a.B), dim3(256), smem, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

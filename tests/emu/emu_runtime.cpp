@@ -144,15 +144,16 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         if (arena == MAP_FAILED) { std::perror("mmap"); std::abort(); }
     }
     body_fn = &body;
-    for (unsigned b = 0; b < grid.x; ++b) {
+    for (unsigned bb = 0; bb < grid.x * grid.y; ++bb) {
+        const unsigned b = bb % grid.x, by = bb / grid.x;
         fibers.assign(nt, Fiber());
         waves.assign((nt + 63) / 64, Wave());
         block_arrived = 0;
         block_gen = 0;
         for (int t = 0; t < nt; ++t) {
             Fiber& f = fibers[t];
-            f.item.tid = dim3(t);
-            f.item.bid = dim3(b);
+            f.item.tid = dim3(t, 0, 0);
+            f.item.bid = dim3(b, by, 0);
             f.item.bdim = block;
             f.item.gdim = grid;
             f.wave = t / 64;
