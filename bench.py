@@ -263,6 +263,25 @@ def main():
                                        'whole_step_wall': 1e6 * elapsed / args.steps}
         result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value / world / 1e12
 
+        # secondary: one whole rollout step on the device (observation builder + communication GSO
+        # + this forward + action decode / collision shielding), B episodes on random maps
+        import numpy as np
+        from gnn_pathplanning_amd.rollout import BatchedRollout
+        rng = np.random.default_rng(1337)
+        grids = (rng.random((B, W, W)) < 0.08).astype(np.uint8)
+        starts = np.zeros((B, N, 2), np.int64)
+        goals = np.zeros((B, N, 2), np.int64)
+        for b_i in range(B):
+            free = np.argwhere(grids[b_i] == 0)
+            pick = rng.choice(len(free), size=2 * N, replace=False)
+            starts[b_i], goals[b_i] = free[pick[:N]], free[pick[N:]]
+        env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed', seed=1337)
+        with torch.no_grad():
+            t_roll = time_kernel(lambda: env.step(net), reps=30)
+        result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
+                                  'what': 'observe + gso + policy forward + move (collision shielding), '
+                                          'all on the device, %d episodes' % B}
+
         # parity gate on the bench batch + CPU baseline (bounded sample of the same workload)
         threads = pick_cpu_threads(orc, sd, N, K)
         with torch.no_grad():
