@@ -38,6 +38,41 @@ def train_step(model, optimizer, batch_input, batch_target, batch_GSO, dp=None):
     return loss.detach()
 
 
+class GraphedTrainStep:
+    """The whole optimisation step (forward, loss, backward, optimizer) captured once in a HIP graph
+    and replayed: at the reference's batch size (64) the step is launch-bound (~250 kernels), and a
+    replay costs one launch.  The libgnnpp kernels are enqueued on torch's capture stream through
+    the C ABI like any other launch, so they are captured too (including the re-packing of the
+    filter taps after each weight update).  Inputs are copied into static buffers before replay.
+
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
+        step = GraphedTrainStep(model, opt, batch_input, batch_target, batch_GSO)
+        loss = step(batch_input, batch_target, batch_GSO)          # device tensor, no sync
+
+    Single GPU only in this round (the gradient all-reduce is not captured)."""
+
+    def __init__(self, model, optimizer, batch_input, batch_target, batch_GSO, warmup=3):
+        self.inp = batch_input.clone()
+        self.tgt = batch_target.clone()
+        self.gso = batch_GSO.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                                 # warm allocator, packs, MIOpen
+                train_step(model, optimizer, self.inp, self.tgt, self.gso)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model, optimizer, self.inp, self.tgt, self.gso)
+
+    def __call__(self, batch_input, batch_target, batch_GSO):
+        self.inp.copy_(batch_input)
+        self.tgt.copy_(batch_target)
+        self.gso.copy_(batch_GSO)
+        self.graph.replay()
+        return self.loss
+
+
 class FlatBucketDP:
     def __init__(self, module, group=None, broadcast_from=0):
         self.module = module

@@ -174,3 +174,37 @@ def test_prepowered_gso_family_matches_reference(dev, training_golden):
         xr = x.clone().requires_grad_(True)
         ref(xr).sum().backward()
         assert close(xg.grad.cpu(), xr.grad.cpu(), 1e-3)
+
+
+def test_graphed_train_step_equals_eager(dev):
+    """HIP-graph replay of the train step follows the eager step exactly (same kernels, same order)."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import GraphedTrainStep, train_step
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    B = 8
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for i in range(6):
+        obs = orc.synth_obs(B, 10, seed=40 + i).to(dev)
+        S = torch.from_numpy(orc.synth_gso_geometric(B, 10, 20, seed=40 + i)).float().to(dev)
+        tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, 10), generator=g), 5).float().to(dev)
+        batches.append((obs, tgt, S))
+    sd0 = orc.init_state_dict(3, seed=9)
+
+    def fresh():
+        net = DecentralPlannerNet(Cfg()).to(dev).train()
+        net.load_state_dict(sd0)
+        return net, torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
+    net_e, opt_e = fresh()
+    for _ in range(4):                       # GraphedTrainStep spends 3 warm-up + 1 captured step
+        train_step(net_e, opt_e, *batches[0])
+    eager = [train_step(net_e, opt_e, *b).item() for b in batches[1:]]
+    net_g, opt_g = fresh()
+    step = GraphedTrainStep(net_g, opt_g, *batches[0])
+    graphed = [step(*b).item() for b in batches[1:]]
+    assert np.allclose(eager, graphed, rtol=2e-4, atol=1e-6), (eager, graphed)
+    for (k, a), (_, b) in zip(net_e.state_dict().items(), net_g.state_dict().items()):
+        if a.dtype.is_floating_point:
+            assert (a - b).abs().max().item() <= 2e-4 * max(1.0, a.abs().max().item()), k

@@ -24,7 +24,10 @@ if has ab; then stamp "ab_bench"
 if has rollout; then stamp "rollout bench"
   timeout 300 python tools/ab_bench.py rollout 2>&1 | grep -v amdgpu.ids | tee $OUT/rollout_bench.jsonl; fi
 if has train; then stamp "train bench"
-  timeout 300 python tools/train_bench.py --steps 50 2>&1 | tail -1 | tee $OUT/train_bench.json; fi
+  timeout 300 python tools/train_bench.py --steps 50 2>&1 | tail -1 | tee $OUT/train_bench.json
+  timeout 300 python tools/train_bench.py --steps 50 --graph 2>&1 | tail -3 | tee $OUT/train_bench_graph.json
+  timeout 300 python tools/train_bench.py --steps 50 --graph --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench_graph.json
+  timeout 300 python tools/train_bench.py --steps 50 --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench.json; fi
 if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path check only)"
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
   stamp "1-rank torchrun nccl"

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--graph', action='store_true', help='capture the train step in a HIP graph')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -40,20 +41,35 @@ def main():
     torch.manual_seed(1337)
     net = DecentralPlannerNet(Cfg()).to(dev).train()
     dp = FlatBucketDP(net) if world > 1 else None
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, capturable=args.graph)
     B, N = args.batch, 10
     obs = orc.synth_obs(B, N, seed=1337 + rank).to(dev)
     S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337 + rank)).float().to(dev)
     g = torch.Generator().manual_seed(rank)
     tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=g), 5).float().to(dev)
+    step = lambda: train_step(net, opt, obs, tgt, S, dp)      # noqa: E731
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                loss = step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def step():                                           # noqa: F811
+            graph.replay()
+            return static_loss
     for _ in range(args.warmup):
-        loss = train_step(net, opt, obs, tgt, S, dp)
+        loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(net, opt, obs, tgt, S, dp)
+        loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -62,7 +78,7 @@ def main():
     if rank == 0:
         print(json.dumps({'metric': 'training agent-steps/s (fwd+bwd+Adam, config 4)', 'value': thr,
                           'n_gpus': world, 'batch_per_gpu': B, 'ms_per_step': 1e3 * el / args.steps,
-                          'final_loss': float(loss.item())}))
+                          'final_loss': float(loss.item()), 'hip_graph': bool(args.graph)}))
     if world > 1:
         dist.destroy_process_group()
 
