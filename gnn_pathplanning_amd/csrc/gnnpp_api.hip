@@ -127,6 +127,9 @@ int gnnpp_set_tuning(int key, int value) {
             if (value < 0) return GNNPP_ERR_ARG;
             g_filter_gpw = value;
             return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_ABLATE:
+            g_filter_ablate = value;
+            return GNNPP_OK;
         case GNNPP_TUNE_FILTER_WAVES:
             if (value != 0 && value != 8 && value != 16) return GNNPP_ERR_ARG;
             g_filter_waves = value;

@@ -43,6 +43,8 @@ struct LsigfArgs {
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
+    int ablate;            // MEASUREMENT ONLY (tools/ab_bench.py): bit 0 skip the shifts, bit 1 skip
+                           // the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
 
 // Re-order h[F,E,K,G] into MFMA A fragments: block (e,k,mt,gg) holds, for lane l = q*16 + i and
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     {
         const int ns = (p.K > 1) ? (NT / 4) : 0;       // last quarter of the threads stage S
         stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
-        if (ns) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
+        if (ns && !(p.ablate & 4)) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
     }
 
     v4f acc[RTW];
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             float* zcur = (k & 1) ? zbuf1 : zbuf0;
             if (tap + 1 < ntaps) load_tap(Anxt, tap + 1);       // in flight during the shift
             if (k > 0) {
-                gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, NW, lane);
+                if (!(p.ablate & 1))
+                    gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, NW, lane);
                 __syncthreads();
             }
             if (p.zs) {                                  // training: keep z_{e,k} for dW = dy . z^T
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                 }
             }
             // ---- contraction of tap (e,k) on MFMA: D[f, row] += W[f, g] z[row, g] --------------
-            if (has_mfma) {
+            if (has_mfma && !(p.ablate & 2)) {
                 const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
                 if (NGT) {
 #pragma unroll
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     }
 
     // ---- epilogue: bias (+ReLU) -> LDS [row][f] -> coalesced store / fused action head --------
+    if (p.ablate & 8) return;
     __syncthreads();                                   // every wave is done reading z
     float* ybuf = zbuf0;
     float* actw = zbuf1;                               // act_w staged here: [5][F]
@@ -411,6 +415,7 @@ __global__ void decode_actions_kernel(const float* __restrict__ logits, int* __r
 // ---- host-side launcher -----------------------------------------------------------------------
 int g_filter_gpw = 0;               // 0: heuristic below; > 0: forced graphs per workgroup (tuning)
 int g_filter_waves = 0;             // 0: heuristic; 8 or 16: forced waves per workgroup (tuning)
+int g_filter_ablate = 0;            // measurement-only phase ablation mask (see LsigfArgs::ablate)
 
 template <int RTW, int NW, int NGT>
 static hipError_t launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
@@ -454,6 +459,7 @@ static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
 int lsigf_launch(LsigfArgs a, hipStream_t st) {
     a.NG = (a.G + 15) / 16;
     a.MT = (a.F + 15) / 16;
+    a.ablate = g_filter_ablate;
     if (a.MT > 8) return -2;                          // F > 128: the caller splits F
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;

@@ -49,6 +49,9 @@ const char* gnnpp_error_string(int code);
                                          0: v1, ping-pong buffers, 100 KB LDS                      */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
 #define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
+#define GNNPP_TUNE_FILTER_ABLATE   3  /* MEASUREMENT ONLY, results become wrong: bit mask of filter
+                                         phases to skip (1 shifts, 2 contraction, 4 GSO staging,
+                                         8 epilogue); 0 (default) = the real kernel               */
 int         gnnpp_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -198,7 +198,7 @@ def test_graphed_train_step_equals_eager(dev):
         net.load_state_dict(sd0)
         return net, torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)
     net_e, opt_e = fresh()
-    for _ in range(4):                       # GraphedTrainStep spends 3 warm-up + 1 captured step
+    for _ in range(3):                       # GraphedTrainStep runs 3 warm-up steps (capture only records)
         train_step(net_e, opt_e, *batches[0])
     eager = [train_step(net_e, opt_e, *b).item() for b in batches[1:]]
     net_g, opt_g = fresh()

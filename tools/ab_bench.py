@@ -126,6 +126,26 @@ def rollout_bench():
         print(json.dumps(row), flush=True)
 
 
+def filter_ablation():
+    """Phase timing of the filter kernel by ablation (results of ablated runs are meaningless)."""
+    for (N, B, K, W) in ((10, 512, 3, 20), (50, 256, 3, 50), (100, 128, 3, 100)):
+        gf = DecentralPlannerNet(Cfg(N, K)).to(dev).GFL[0]
+        x = torch.relu(torch.randn(B * N, 128, device=dev))
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=1)).float().to(dev)
+        y = torch.empty(B * N, 128, device=dev)
+        gb = gf.bias.detach().reshape(-1)
+        taps = gf.packed_taps()
+        row = {'kernel': 'lsigf_ablation', 'N': N, 'B': B}
+        for name, mask in (('full', 0), ('no_shift', 1), ('no_mfma', 2), ('no_S', 4), ('no_epilogue', 8),
+                           ('no_shift_no_mfma', 3), ('staging_only', 15), ('no_shift_mfma_S', 7)):
+            L.gnnpp_set_tuning(3, mask)
+            t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(x), vp(S), vp(taps), vp(gb), vp(y), B, N, N, 128,
+                                                 128, K, 1, 0, 1, 1, 1, 1, st))
+            row[name] = round(t, 2)
+        L.gnnpp_set_tuning(3, 0)
+        print(json.dumps(row), flush=True)
+
+
 def pipelined_bench():
     """Two independent batches in flight: step i of batch A overlaps step i of batch B on a second
     stream (what a rollout driver with two episode batches per GPU does)."""
@@ -160,6 +180,9 @@ def pipelined_bench():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'filter_ablation':
+        filter_ablation()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'pipelined':
         pipelined_bench()
         sys.exit(0)
