@@ -10,10 +10,11 @@
 //   1. the feature rows x[b] are staged ONCE into LDS, node-major, row stride G+8 floats
 //      (coalesced 512-byte row reads; the +8 makes the MFMA B-fragment ds_read_b128 conflict free);
 //   2. the dense S slabs are staged into LDS (fp64 -> fp32 on the fly, like `S.float()`);
-//   3. shift k: ONE WAVEFRONT PER NODE.  Lane m reads S[m,n], a ballot compacts the column to its
-//      non-zeros (exact: structural zeros contribute nothing), and for each neighbour the wave
-//      reads that neighbour's 512-byte feature row from LDS (ds_read_b64 per lane, conflict free)
-//      and accumulates 2 features per lane.  z ping-pongs between two LDS buffers;
+//   3. shift k: one half-wavefront per node (two nodes in flight per wave).  Lane m reads S[m,n], a
+//      ballot compacts the column to its non-zeros (exact: structural zeros contribute nothing),
+//      and for each neighbour the half-wave reads that neighbour's 512-byte feature row from LDS
+//      (ds_read_b128 per lane) and accumulates 4 features per lane.  z ping-pongs between two
+//      LDS buffers;
 //   4. contraction of tap k right after its shift: D[f, row] += W_k[f, g] z_k[row, g] on fp32 MFMA
 //      16x16x4 with the accumulators living in registers across all taps; W_k fragments stream
 //      from L2 in a pre-packed order (one 16-byte load per lane per four MFMAs);
@@ -70,53 +71,61 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
     }
 }
 
-// One shift for the rows owned by this wave: z_cur[r,:] = sum_m S[m, n(r)] * z_prev[m,:].
-// Lane m reads S[m,n]; the ballot is the column's sparsity pattern; neighbours are consumed four
-// at a time so four independent LDS row reads are in flight (ILP), 2 features per lane.
+// One shift: z_cur[r,:] = sum_m S[m, n(r)] * z_prev[m,:]   (node n gathers COLUMN n of S).
+// ONE HALF-WAVE PER NODE, two nodes in flight per wavefront.  The 32 lanes of a half scan 32
+// candidate neighbours m at a time (lane <-> m reads S[m,n]); the ballot of the non-zeros is the
+// column's sparsity pattern (exact: structural zeros contribute nothing).  Each lane then walks its
+// half's mask four neighbours at a time -- index by ffs on the mask, weight S[m,n] and the
+// neighbour's feature row (4 features per lane, one ds_read_b128) straight from LDS, so eight row
+// reads are in flight per wave and no scalar readlane chain sits between them.  fmaf in ascending m.
 __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
                                             const float* __restrict__ zprev,
                                             float* __restrict__ zcur, int R, int wave, int nwaves,
                                             int lane) {
     const int N = p.N, zs = p.zstride, GP = p.NG * 16;
-    for (int r = wave; r < R; r += nwaves) {
-        const int j = r / N, n = r - j * N;
-        const float* Scol = Sl + j * N * p.Ns + n;
+    const int half = lane >> 5, hl = lane & 31;
+    for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {          // wave-uniform trip count
+        const int r = rb + half;
+        const bool rv = r < R;
+        const int rr = rv ? r : rb;
+        const int j = rr / N, n = rr - j * N;
+        const float* Sg = Sl + j * N * p.Ns + n;                 // column n of this graph's slab
         const float* zg = zprev + j * N * zs;
         for (int c0 = 0; c0 < GP; c0 += 128) {
-            const int col = c0 + 2 * lane;
-            const bool live = col < GP;
-            const int colc = live ? col : 0;
-            v2f s2 = {0.f, 0.f};
-            for (int m0 = 0; m0 < N; m0 += 64) {
-                const int m = m0 + lane;
-                const float sv = (m < N) ? Scol[m * p.Ns] : 0.f;
-                unsigned long long mask = __ballot(sv != 0.f);
-                while (mask) {
-                    int mm[4];
-                    float sc[4];
+            const int col = c0 + 4 * hl;
+            const bool live = rv && col < GP;
+            const int colc = col < GP ? col : 0;
+            v4f acc = vzero();
+            for (int m0 = 0; m0 < N; m0 += 32) {
+                const int m = m0 + hl;
+                const float sv = (rv && m < N) ? Sg[m * p.Ns] : 0.f;
+                const unsigned long long bal = __ballot(sv != 0.f);
+                unsigned mine = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+                while (__ballot(mine != 0u)) {                   // any half still has neighbours
+                    int src[4];
+                    float w[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (mask) {
-                            mm[u] = __ffsll((long long)mask) - 1;
-                            mask &= mask - 1;
-                            sc[u] = wave_read_lane(sv, mm[u]);
-                        } else {
-                            mm[u] = mm[0];             // harmless re-read, weight 0
-                            sc[u] = 0.f;
-                        }
+                        const bool ok = mine != 0u;
+                        const int mm = ok ? __ffs((int)mine) - 1 : 0;
+                        if (ok) mine &= mine - 1u;
+                        src[u] = m0 + mm;
+                        w[u] = ok ? Sg[src[u] * p.Ns] : 0.f;     // weight 0: harmless re-read
                     }
-                    v2f zv[4];
+                    v4f zv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        zv[u] = *reinterpret_cast<const v2f*>(zg + (m0 + mm[u]) * zs + colc);
+                        zv[u] = *reinterpret_cast<const v4f*>(zg + src[u] * zs + colc);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        s2[0] = fmaf(sc[u], zv[u][0], s2[0]);
-                        s2[1] = fmaf(sc[u], zv[u][1], s2[1]);
+                        acc[0] = fmaf(w[u], zv[u][0], acc[0]);
+                        acc[1] = fmaf(w[u], zv[u][1], acc[1]);
+                        acc[2] = fmaf(w[u], zv[u][2], acc[2]);
+                        acc[3] = fmaf(w[u], zv[u][3], acc[3]);
                     }
                 }
             }
-            if (live) *reinterpret_cast<v2f*>(zcur + r * zs + col) = s2;
+            if (live) *reinterpret_cast<v4f*>(zcur + r * zs + col) = acc;
         }
     }
 }

@@ -63,6 +63,7 @@ f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 #define __syncthreads() gnnpp_emu::sync_block()
 #define __ballot(p) gnnpp_emu::ballot((p) ? 1 : 0)
 #define __ffsll(x) __builtin_ffsll(x)
+#define __ffs(x) __builtin_ffs(x)
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
