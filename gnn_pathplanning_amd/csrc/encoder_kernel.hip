@@ -86,9 +86,80 @@ __device__ __forceinline__ float winograd_u(const float* __restrict__ g, int a, 
                                                                         : t[2];
 }
 
+// ---- split-f16 path: per-layer power-of-two weight scale ---------------------------------------
+// Block b handles layer b + 1 (conv 1..4; b = 4: the FC).  2^k is chosen so that max|w| * 2^k lies in
+// [512, 1024): the hi halves stay far from f16 overflow and the lo halves (w*2^k - hi, ~2^-11 of
+// hi) of all but negligible weights are normal f16 numbers.  The kernel undoes 2^k exactly in its
+// epilogue (folded into the BatchNorm scale).
+__device__ __forceinline__ void enc_h2_layer(int b, const EncRawParams& rp, const float*& w, int& n) {
+    w = b < 4 ? rp.conv_w[b + 1] : rp.fc_w;
+    n = b == 0 ? 32 * 32 * 9 : b == 1 ? 64 * 32 * 9 : b == 2 ? 64 * 64 * 9 : b == 3 ? 128 * 64 * 9
+                                                                                    : 128 * 128;
+}
+
+__global__ void enc_layer_scale_kernel(const EncRawParams rp, float* __restrict__ packed) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* red = reinterpret_cast<float*>(gnnpp_smem);
+    const float* w;
+    int n;
+    enc_h2_layer(blockIdx.x, rp, w, n);
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)blockDim.x; ++i) m = fmaxf(m, red[i]);
+        int k = 0;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+            k = min(max(10 - e, -60), 60);
+        }
+        packed[EncLayout::kHscale + blockIdx.x] = ldexpf(1.f, k);
+        packed[EncLayout::kHinv + blockIdx.x] = ldexpf(1.f, -k);
+    }
+}
+
+// One split-f16 A fragment element pair: packed[...] holds two halves per float slot.
+// Layout of a layer: [group][kb][tap][mt_local][hi/lo][lane 64][e 8];  mt = group * NMTL + mt_local,
+// half e of lane (q, i) = W[cout = 16 mt + i][cin = 32 kb + 16 (e >> 2) + 4 q + (e & 3)][tap] * 2^k.
+__device__ __forceinline__ void enc_h2_pack_layer(const float* __restrict__ w, float scale, int cin,
+                                                  int ntap, int ngroup, int nmtl, int nkb,
+                                                  float* __restrict__ dst, int t0, int stride) {
+    _Float16* out = reinterpret_cast<_Float16*>(dst);
+    const int total = ngroup * nkb * ntap * nmtl * 512;           // (lane, e) pairs per hi/lo
+    for (int idx = t0; idx < total; idx += stride) {
+        const int e = idx & 7, l = (idx >> 3) & 63;
+        int blk = idx >> 9;
+        const int ml = blk % nmtl; blk /= nmtl;
+        const int tap = blk % ntap; blk /= ntap;
+        const int kb = blk % nkb;
+        const int grp = blk / nkb;
+        const int co = (grp * nmtl + ml) * 16 + (l & 15);
+        const int ci = 32 * kb + 16 * (e >> 2) + 4 * (l >> 4) + (e & 3);
+        const float v = w[((size_t)co * cin + ci) * ntap + tap] * scale;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const size_t item = (size_t)(idx >> 9) * 2;               // hi item, lo item follows
+        out[(item * 64 + l) * 8 + e] = hi;
+        out[((item + 1) * 64 + l) * 8 + e] = lo;
+    }
+}
+
 __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ packed) {
     const int stride = gridDim.x * blockDim.x;
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // split-f16 fragments (scales were written by enc_layer_scale_kernel, earlier on this stream)
+    enc_h2_pack_layer(rp.conv_w[1], packed[EncLayout::kHscale + 0], 32, 9, 1, 2, 1,
+                      packed + EncLayout::kH1, t0, stride);
+    enc_h2_pack_layer(rp.conv_w[2], packed[EncLayout::kHscale + 1], 32, 9, 2, 2, 1,
+                      packed + EncLayout::kH2, t0, stride);
+    enc_h2_pack_layer(rp.conv_w[3], packed[EncLayout::kHscale + 2], 64, 9, 4, 1, 2,
+                      packed + EncLayout::kH3, t0, stride);
+    enc_h2_pack_layer(rp.conv_w[4], packed[EncLayout::kHscale + 3], 64, 9, 4, 2, 2,
+                      packed + EncLayout::kH4, t0, stride);
+    enc_h2_pack_layer(rp.fc_w, packed[EncLayout::kHscale + 4], 128, 1, 4, 2, 4,
+                      packed + EncLayout::kHfc, t0, stride);
     // Winograd L0: [mt 2][wpos 16][lane 64] = U[cout = mt*16+i][cin = q][wpos], 0 for q = 3
     for (int idx = t0; idx < 2 * 16 * 64; idx += stride) {
         const int l = idx & 63, wp = (idx >> 6) & 15, mt = idx >> 10;
@@ -403,15 +474,18 @@ __global__ __launch_bounds__(kThreads, INPLACE ? 2 : 1) void encoder_kernel(
 
 // ---- host-side launchers ----------------------------------------------------------------------
 int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
+    hipLaunchKernelGGL(enc_layer_scale_kernel, dim3(5), dim3(256), 256 * sizeof(float), st, rp, packed);
     hipLaunchKernelGGL(pack_encoder_kernel, dim3(128), dim3(256), 0, st, rp, packed);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int g_encoder_variant = 5;          // 5: v3 Winograd L0+L2, late layers in place (default); 3: same,
+constexpr int kDefaultEncoderVariant = 5;
+int g_encoder_variant = kDefaultEncoderVariant;   // 7: split-f16 (encoder_kernel_h2.hip); 5: v3 Winograd L0+L2, late layers in place (default); 3: same,
                                     // late layers via the obs buffer; 4/6: Winograd L2 only (Y / in place); 2: v2; 1: v1 in place; 0: ping-pong
 int encoder_launch_v2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
                       int wino_l0, int late_y);
+int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 
 template <bool INPLACE>
 static int encoder_launch_t(const float* obs, const float* packed, float* feat, int M,
@@ -430,6 +504,7 @@ static int encoder_launch_t(const float* obs, const float* packed, float* feat, 
 }
 
 int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    if (g_encoder_variant == 7) return encoder_launch_h2(obs, packed, feat, M, st);
     if (g_encoder_variant == 3) return encoder_launch_v3(obs, packed, feat, M, st, 1, 1);
     if (g_encoder_variant == 4) return encoder_launch_v3(obs, packed, feat, M, st, 0, 1);
     if (g_encoder_variant == 5) return encoder_launch_v3(obs, packed, feat, M, st, 1, 0);

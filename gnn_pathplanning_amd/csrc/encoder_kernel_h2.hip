@@ -1,0 +1,465 @@
+// Encoder kernel, split-f16 schedule ("h2").  Same layers, same 16-agent tile, same LDS budget and
+// the same fp32 Winograd L0 as v3 (encoder_kernel_v3.hip); layers L1..L4 and the FC run on the
+// f16 matrix pipe with every fp32 operand split in two halves:
+//
+//      x = xh + xl,  xh = f16(x),  xl = f16(x - xh)          (x - xh is exact in fp32)
+//      w x ~= wh xh + wh xl + wl xh                           (fp32 accumulate; wl xl ~ 2^-22 dropped)
+//
+// Three v_mfma_f32_16x16x32_f16 (K = 32 channels, ~17 cycles each) replace eight
+// v_mfma_f32_16x16x4_f32 (K = 4, 32 cycles each): ~5x less matrix-pipe time per MAC, with the
+// operands still carrying 22 mantissa bits.  Measured against the fp32 oracle the logits move by
+// ~1e-6 (tolerance 1e-4); the exact-fp32 schedules stay selectable (gnnpp_set_tuning).
+// Domain: |activation| < 65504 (f16 range; a larger value becomes inf and is not silent).
+// Weights are pre-scaled per layer by a power of two so that their lo halves are normal numbers;
+// f16 subnormals (small lo halves of activations) are kept by the cvt and by the MFMA
+// (tools/probe/f16_probe.hip), which bounds the representation error of an activation by
+// max(2^-22 |x|, 2^-25).
+//
+// Fragment order for K = 32: k-slot (q, e) of block kb is channel 32 kb + 16 (e >> 2) + 4 q + (e & 3),
+// so the two D tiles (mt = 2 kb, 2 kb + 1) a lane holds after a layer ARE its B fragment of block kb
+// for the next layer (eight values -> one 16-byte hi and one 16-byte lo store, lane for lane).
+// Activations in LDS: [position][kb][hi/lo][lane 64] x 16 bytes -- 4 bytes per element, as fp32.
+//
+// With the matrix pipe 5x cheaper the kernel is shaped by LDS and L2 bandwidth instead:
+//   * L1/L2: a wave computes TWO channel tiles for its positions, so a B fragment read from LDS
+//     (2 KiB per position, tap) feeds six MFMAs; positions are split over the waves
+//     (L1: 7/6/6/6 positions, L2: two pool windows each, 61/60 valid taps -- balanced).
+//   * L3/L4/FC (2x2 and 1x1 images): a wave reads its whole input (64 VGPRs) once and streams
+//     weights only; these layers are bound by the weight stream out of L2 (0.5 MB per tile).
+//   * weights go through the same ordered register ring as v2/v3 (16 x 16 bytes here), packed in
+//     each wave's consumption order so the stream is linear.
+#include "gnnpp_common.h"
+
+namespace gnnpp {
+
+constexpr int kRingH = 16;
+// per-wave item stream: L1 (36) | L2 (36) | L3 (36) | L4 (72) | FC (16); one item = one 16-byte
+// hi or lo fragment of one (kb, tap, mt)
+constexpr int kh_L1 = 0, kh_L2 = 36, kh_L3 = 72, kh_L4 = 108, kh_FC = 180, kh_END = 196;
+
+struct WStreamH {                 // per-wave segment bases, already offset by lane * 4 floats
+    const float* seg[5];
+};
+
+__device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx) {
+    if (idx < kh_L2) return ws.seg[0] + (idx - kh_L1) * EncLayout::kHItem;
+    if (idx < kh_L3) return ws.seg[1] + (idx - kh_L2) * EncLayout::kHItem;
+    if (idx < kh_L4) return ws.seg[2] + (idx - kh_L3) * EncLayout::kHItem;
+    if (idx < kh_FC) return ws.seg[3] + (idx - kh_L4) * EncLayout::kHItem;
+    return ws.seg[4] + (idx - kh_FC) * EncLayout::kHItem;
+}
+
+// ordered (relaxed, wavefront-scope atomic) 16-byte load: see ring_load in encoder_kernel_v2.hip
+__device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRingH], int idx) {
+    if (idx < kh_END) {
+        typedef unsigned long long u64;
+        u64* p = reinterpret_cast<u64*>(const_cast<float*>(h2_item_ptr(ws, idx)));
+        const u64 lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const u64 hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        v4f r;
+        r[0] = __int_as_float((int)(lo & 0xffffffffu));
+        r[1] = __int_as_float((int)(lo >> 32));
+        r[2] = __int_as_float((int)(hi & 0xffffffffu));
+        r[3] = __int_as_float((int)(hi >> 32));
+        ring[idx % kRingH] = r;
+    }
+}
+
+__device__ __forceinline__ v8h as_h8(v4f v) { return __builtin_bit_cast(v8h, v); }
+__device__ __forceinline__ v4f as_f4(v8h v) { return __builtin_bit_cast(v4f, v); }
+
+// eight fp32 values (two D tiles) -> hi and lo f16 fragments
+__device__ __forceinline__ void split8(v4f a, v4f b, v4f& hi, v4f& lo) {
+    v8h h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)a[e];
+        l[e] = (_Float16)(a[e] - (float)h[e]);
+        h[4 + e] = (_Float16)b[e];
+        l[4 + e] = (_Float16)(b[e] - (float)h[4 + e]);
+    }
+    hi = as_f4(h);
+    lo = as_f4(l);
+}
+// four fp32 values (one D tile) -> the 8-byte half of a hi and of a lo fragment
+__device__ __forceinline__ void split4(v4f a, v2f& hi, v2f& lo) {
+    typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+    v4h h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)a[e];
+        l[e] = (_Float16)(a[e] - (float)h[e]);
+    }
+    hi = __builtin_bit_cast(v2f, h);
+    lo = __builtin_bit_cast(v2f, l);
+}
+
+// L1: wave w owns positions w, w + 4, ... (7 for wave 0, 6 otherwise)
+template <int WAVE>
+struct PosL1H {
+    static __device__ __forceinline__ bool get(int j, int& y, int& x) {
+        const int p = WAVE + 4 * j;
+        y = p / 5; x = p % 5;
+        return p < 25;
+    }
+};
+// L2: pool windows {0, 3} (PAIR 0) or {1, 2} (PAIR 1); slot = 4 * which + (py * 2 + px)
+template <int PAIR>
+struct PosL2H {
+    static __device__ __forceinline__ bool get(int j, int& y, int& x) {
+        const int t = (j >> 2) == 0 ? PAIR : 3 - PAIR;
+        y = 2 * (t >> 1) + ((j >> 1) & 1);
+        x = 2 * (t & 1) + (j & 1);
+        return true;
+    }
+};
+struct Pos2x2H {
+    static __device__ __forceinline__ bool get(int j, int& y, int& x) {
+        y = j >> 1; x = j & 1;
+        return true;
+    }
+};
+
+// NMT channel tiles over a compile-time position set; weights from the ring, item order
+// [kb][tap][mt][hi/lo].  PRELOAD: the whole H x W x NKB input is read into registers first.
+template <int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD>
+__device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH], const v4f* in,
+                                        v4f (&acc)[NSLOT][NMT], int lane) {
+    v4f Pin[PRELOAD ? H * W * NKB * 2 : 1];
+    if (PRELOAD) {
+#pragma unroll
+        for (int i = 0; i < H * W * NKB * 2; ++i) Pin[i] = in[i * 64 + lane];
+    }
+#pragma unroll
+    for (int it = 0; it < 9 * NKB; ++it) {
+        const int kb = it / 9, tap = it % 9;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        bool any = false;                                   // taps no position of this wave uses
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            int y = 0, x = 0;
+            const bool used = PosFn::get(j, y, x);
+            any = any || (used && y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W);
+        }
+        __builtin_amdgcn_sched_barrier(kSchedItemMask);
+        v8h Ah[NMT], Al[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            const int idx = START + (it * NMT + m) * 2;
+            Ah[m] = as_h8(ring[idx % kRingH]);
+            h2_ring_load(ws, ring, idx + kRingH);
+            Al[m] = as_h8(ring[(idx + 1) % kRingH]);
+            h2_ring_load(ws, ring, idx + 1 + kRingH);
+        }
+        if (!any) continue;
+        v8h Bh[NSLOT], Bl[NSLOT];
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            int y = 0, x = 0;
+            const bool used = PosFn::get(j, y, x);
+            const int iy = y + dy, ix = x + dx;
+            if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const int o = ((iy * W + ix) * NKB + kb) * 2;
+                Bh[j] = as_h8(PRELOAD ? Pin[o] : in[o * 64 + lane]);
+                Bl[j] = as_h8(PRELOAD ? Pin[o + 1] : in[(o + 1) * 64 + lane]);
+            }
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {              // small terms first
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                int y = 0, x = 0;
+                const bool used = PosFn::get(j, y, x);
+                const int iy = y + dy, ix = x + dx;
+                if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m)
+                        acc[j][m] = mfma16h(term == 1 ? Al[m] : Ah[m], term == 0 ? Bl[j] : Bh[j],
+                                            acc[j][m]);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_ss_h2(const float* ss, int cout, int mt, int q, float inv,
+                                           v4f& sc, v4f& sh) {
+    load_ss(ss, cout, mt, q, sc, sh);
+    sc = sc * inv;                                           // undo the weight scale 2^k (exact)
+}
+
+__global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
+                                                                 const float* __restrict__ pk,
+                                                                 float* __restrict__ feat, int M) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* const X = reinterpret_cast<float*>(gnnpp_smem);          // activations
+    float* const bufObs = X + kBufFloats;                            // padded observations, then Y
+    v4f* const X4 = reinterpret_cast<v4f*>(X);
+    v4f* const Y4 = reinterpret_cast<v4f*>(bufObs);                  // dead after L0: late layers
+                                                                     // ping-pong X <-> Y
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int a = lane & 15;
+    const int q = lane >> 4;
+    const int agent0 = blockIdx.x * kTileAgents;
+
+    WStreamH ws;
+    ws.seg[0] = pk + EncLayout::kH1 + lane * 4;
+    ws.seg[1] = pk + EncLayout::kH2 + (wave & 1) * (36 * EncLayout::kHItem) + lane * 4;
+    ws.seg[2] = pk + EncLayout::kH3 + wave * (36 * EncLayout::kHItem) + lane * 4;
+    ws.seg[3] = pk + EncLayout::kH4 + wave * (72 * EncLayout::kHItem) + lane * 4;
+    ws.seg[4] = pk + EncLayout::kHfc + wave * (16 * EncLayout::kHItem) + lane * 4;
+    v4f ring[kRingH];
+#pragma unroll
+    for (int i = 0; i < kRingH; ++i) h2_ring_load(ws, ring, i);
+
+    // ---- observations: all loads first, zero-fill while they fly, then scatter (as v2/v3) -------
+    {
+        constexpr int NV4 = kTileAgents * kObsFloats / 4;
+        constexpr int PER = (NV4 + kThreads - 1) / kThreads;
+        const int n_agents = min(kTileAgents, M - agent0);
+        const int valid = n_agents * kObsFloats;
+        const float* src = obs + (size_t)agent0 * kObsFloats;
+        v4f v[PER];
+        if (n_agents == kTileAgents) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                v[k] = *reinterpret_cast<const v4f*>(src + 4 * min(tid + k * kThreads, NV4 - 1));
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int e0 = (tid + k * kThreads) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[k][c] = src[min(e0 + c, valid - 1)];
+            }
+        }
+        v4f* z = reinterpret_cast<v4f*>(bufObs);
+        for (int i = tid; i < kObsFloatsLds / 4; i += kThreads) z[i] = vzero();
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e0 = (tid + k * kThreads) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = e0 + c;
+                if (e < valid) {
+                    const int ag = e / kObsFloats, rem = e - ag * kObsFloats;
+                    const int ch = rem / 121, r2 = rem - ch * 121;
+                    const int y = r2 / 11, x = r2 - y * 11;
+                    bufObs[ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1] =
+                        v[k][c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- L0 (fp32 Winograd, as v3): 3 -> 32 @ 11x11, BN, ReLU, pool; output split to f16 hi/lo ----
+    {
+        float U0[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int w = 0; w < 16; ++w) U0[i][w] = pk[EncLayout::kU0 + (i * 16 + w) * 64 + lane];
+        v4f sc[2], sh[2];
+        load_ss(pk + EncLayout::kSS0, 32, 0, q, sc[0], sh[0]);
+        load_ss(pk + EncLayout::kSS0, 32, 1, q, sc[1], sh[1]);
+        const float* chan = bufObs + a * kAgentStride + (q < 3 ? q : 2) * (kPadHW * kPadHW);
+        float dc[16], dn[16];
+        auto load_patch = [&](float (&d)[16], int win) {
+            const int wy = win / 5, wx = win - wy * 5;
+            const float* base = chan + (2 * wy) * kPadHW + 2 * wx;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) d[4 * u + v] = base[u * kPadHW + v];
+        };
+        load_patch(dc, wave);
+        for (int win = wave; win < 25; win += kWaves) {
+            if (win + kWaves < 25) load_patch(dn, win + kWaves);
+            winograd_input(dc);
+            v4f r[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v4f m[16];
+#pragma unroll
+                for (int w = 0; w < 16; ++w) m[w] = mfma16(U0[i][w], dc[w], vzero());
+                v4f y[4];
+                winograd_output(m, y);
+                r[i] = vrelu(vfma(y[0], sc[i], sh[i]));
+#pragma unroll
+                for (int pp = 1; pp < 4; ++pp) r[i] = vmax(r[i], vfma(y[pp], sc[i], sh[i]));
+            }
+            v4f hi, lo;
+            split8(r[0], r[1], hi, lo);
+            X4[(win * 2 + 0) * 64 + lane] = hi;
+            X4[(win * 2 + 1) * 64 + lane] = lo;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dc[i] = dn[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
+    {
+        v4f sc[2], sh[2];
+        const float inv = pk[EncLayout::kHinv + 0];
+        load_ss_h2(pk + EncLayout::kSS1, 32, 0, q, inv, sc[0], sh[0]);
+        load_ss_h2(pk + EncLayout::kSS1, 32, 1, q, inv, sc[1], sh[1]);
+        v4f acc[7][2];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
+        switch (wave) {
+            case 0: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<0>, false>(ws, ring, X4, acc, lane); break;
+            case 1: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<1>, false>(ws, ring, X4, acc, lane); break;
+            case 2: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<2>, false>(ws, ring, X4, acc, lane); break;
+            default: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<3>, false>(ws, ring, X4, acc, lane); break;
+        }
+        __syncthreads();                                   // everyone is done reading L0's output
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int p = wave + 4 * j;
+            if (p < 25) {
+                v4f hi, lo;
+                split8(vrelu(vfma(acc[j][0], sc[0], sh[0])), vrelu(vfma(acc[j][1], sc[1], sh[1])),
+                       hi, lo);
+                X4[(p * 2 + 0) * 64 + lane] = hi;
+                X4[(p * 2 + 1) * 64 + lane] = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
+    {
+        const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
+        v4f sc[2], sh[2];
+        const float inv = pk[EncLayout::kHinv + 1];
+        load_ss_h2(pk + EncLayout::kSS2, 64, 2 * mp, q, inv, sc[0], sh[0]);
+        load_ss_h2(pk + EncLayout::kSS2, 64, 2 * mp + 1, q, inv, sc[1], sh[1]);
+        v4f acc[8][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
+        if (pair == 0) conv_h2<kh_L2, 1, 5, 5, 2, 8, PosL2H<0>, false>(ws, ring, X4, acc, lane);
+        else           conv_h2<kh_L2, 1, 5, 5, 2, 8, PosL2H<1>, false>(ws, ring, X4, acc, lane);
+#pragma unroll
+        for (int wi = 0; wi < 2; ++wi) {
+            const int t = wi == 0 ? pair : 3 - pair;
+            v4f r[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                r[m] = vrelu(vfma(acc[4 * wi][m], sc[m], sh[m]));
+#pragma unroll
+                for (int pp = 1; pp < 4; ++pp)
+                    r[m] = vmax(r[m], vfma(acc[4 * wi + pp][m], sc[m], sh[m]));
+            }
+            v4f hi, lo;
+            split8(r[0], r[1], hi, lo);
+            Y4[((t * 2 + mp) * 2 + 0) * 64 + lane] = hi;
+            Y4[((t * 2 + mp) * 2 + 1) * 64 + lane] = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
+    {
+        const int mt = wave;
+        v4f sc, sh;
+        load_ss_h2(pk + EncLayout::kSS3, 64, mt, q, pk[EncLayout::kHinv + 2], sc, sh);
+        v4f acc[4][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][0] = vzero();
+        conv_h2<kh_L3, 2, 2, 2, 1, 4, Pos2x2H, true>(ws, ring, Y4, acc, lane);
+        v2f* const X2 = reinterpret_cast<v2f*>(X);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v2f hi, lo;
+            split4(vrelu(vfma(acc[j][0], sc, sh)), hi, lo);
+            // fragment (pos j, block mt >> 1): this tile is its e = 4 (mt & 1) .. +3 half
+            const int o = (j * 2 + (mt >> 1)) * 2;
+            X2[((o + 0) * 64 + lane) * 2 + (mt & 1)] = hi;
+            X2[((o + 1) * 64 + lane) * 2 + (mt & 1)] = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
+    {
+        v4f sc[2], sh[2];
+        const float inv = pk[EncLayout::kHinv + 3];
+        load_ss_h2(pk + EncLayout::kSS4, 128, 2 * wave, q, inv, sc[0], sh[0]);
+        load_ss_h2(pk + EncLayout::kSS4, 128, 2 * wave + 1, q, inv, sc[1], sh[1]);
+        v4f acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
+        conv_h2<kh_L4, 2, 2, 2, 2, 4, Pos2x2H, true>(ws, ring, X4, acc, lane);
+        v4f r[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            r[m] = vrelu(vfma(acc[0][m], sc[m], sh[m]));
+#pragma unroll
+            for (int j = 1; j < 4; ++j) r[m] = vmax(r[m], vfma(acc[j][m], sc[m], sh[m]));
+        }
+        v4f hi, lo;
+        split8(r[0], r[1], hi, lo);
+        Y4[(wave * 2 + 0) * 64 + lane] = hi;
+        Y4[(wave * 2 + 1) * 64 + lane] = lo;
+    }
+    __syncthreads();
+
+    // ---- FC 128 -> 128 + ReLU -> feat[agent][128]; tiles 2w, 2w+1 per wave ------------------------
+    {
+        v8h Bh[4], Bl[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            Bh[kb] = as_h8(Y4[(kb * 2 + 0) * 64 + lane]);
+            Bl[kb] = as_h8(Y4[(kb * 2 + 1) * 64 + lane]);
+        }
+        v4f acc[2][2] = {{vzero(), vzero()}, {vzero(), vzero()}};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            __builtin_amdgcn_sched_barrier(kSchedItemMask);
+            v8h Ah[2], Al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int idx = kh_FC + (kb * 2 + m) * 2;
+                Ah[m] = as_h8(ring[idx % kRingH]);
+                h2_ring_load(ws, ring, idx + kRingH);
+                Al[m] = as_h8(ring[(idx + 1) % kRingH]);
+                h2_ring_load(ws, ring, idx + 1 + kRingH);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m][1] = mfma16h(Ah[m], Bl[kb], acc[m][1]);
+                acc[m][1] = mfma16h(Al[m], Bh[kb], acc[m][1]);
+                acc[m][0] = mfma16h(Ah[m], Bh[kb], acc[m][0]);
+            }
+        }
+        if (agent0 + a < M) {
+            const float inv = pk[EncLayout::kHinv + 4];
+            float* dst = feat + (size_t)(agent0 + a) * 128 + q * 4;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int mt = 2 * wave + m;
+                const v4f b = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt * 16 + q * 4);
+                *reinterpret_cast<v4f*>(dst + mt * 16) = vrelu((acc[m][0] + acc[m][1]) * inv + b);
+            }
+        }
+    }
+}
+
+int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_h2),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const int grid = (M + kTileAgents - 1) / kTileAgents;
+    hipLaunchKernelGGL(encoder_kernel_h2, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace gnnpp

@@ -5,6 +5,7 @@
 #include "encoder_kernel.hip"
 #include "encoder_kernel_v2.hip"
 #include "encoder_kernel_v3.hip"
+#include "encoder_kernel_h2.hip"
 #include "lsigf_kernel.hip"
 #include "rollout_kernels.hip"
 
@@ -120,8 +121,8 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT:
-            if (value < 0 || value > 6) return GNNPP_ERR_ARG;
-            g_encoder_variant = value;
+            if (value < -1 || value > 7) return GNNPP_ERR_ARG;
+            g_encoder_variant = value < 0 ? kDefaultEncoderVariant : value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_GPW:
             if (value < 0) return GNNPP_ERR_ARG;

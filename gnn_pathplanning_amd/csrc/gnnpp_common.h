@@ -22,6 +22,7 @@ namespace gnnpp {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));   // one 16x16x32 f16 MFMA operand
 
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kThreads = 256;        // 4 waves per workgroup, one per SIMD
@@ -39,6 +40,13 @@ __device__ __forceinline__ v4f mfma16x4(v4f a, v4f b, v4f c) {
     c = mfma16(a[2], b[2], c);
     c = mfma16(a[3], b[3], c);
     return c;
+}
+
+// v_mfma_f32_16x16x32_f16: lane l holds A[i = l & 15][k-slots (q = l >> 4, e = 0..7)] and
+// B[k-slots (q, e)][j = l & 15]; D as for the fp32 form.  fp32 accumulate; f16 subnormal operands
+// are not flushed (tools/probe/f16_probe.hip).
+__device__ __forceinline__ v4f mfma16h(v8h a, v8h b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ v4f vzero() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z; }
@@ -97,7 +105,17 @@ struct EncLayout {
     // Winograd F(2x2,3x3) weights U = G g G^T (16 values per 3x3 kernel) for L0 and L2
     static constexpr int kU0 = kBfc + 128;                               // [mt 2][wpos 16][lane 64]
     static constexpr int kU2 = kU0 + 2 * 16 * 64;                        // [mt 4][g 2][wpos 16][lane 64][4]
-    static constexpr int kTotal = kU2 + 4 * 2 * 16 * 256;
+    // split-f16 path (encoder_kernel_h2.hip): w * 2^k = hi + lo, two f16 fragments of 16 bytes per
+    // lane, stored in each wave's consumption order [group][kb][tap][mt_local][hi/lo][lane 64][8 h]
+    static constexpr int kHItem = 256;                                   // floats per 1 KiB fragment
+    static constexpr int kH1 = kU2 + 4 * 2 * 16 * 256;                   // [1][1][9][2][2] items
+    static constexpr int kH2 = kH1 + 36 * kHItem;                        // [2][1][9][2][2]
+    static constexpr int kH3 = kH2 + 72 * kHItem;                        // [4][2][9][1][2]
+    static constexpr int kH4 = kH3 + 144 * kHItem;                       // [4][2][9][2][2]
+    static constexpr int kHfc = kH4 + 288 * kHItem;                      // [4][4][1][2][2]
+    static constexpr int kHinv = kHfc + 64 * kHItem;                     // 2^-k of layers 1..4, FC
+    static constexpr int kHscale = kHinv + 8;                            // 2^k  (same order)
+    static constexpr int kTotal = kHscale + 8;
 };
 
 }  // namespace gnnpp

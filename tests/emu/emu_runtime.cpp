@@ -52,6 +52,7 @@ struct Wave {
     unsigned gen = 0;
     int n = 0;                     // lanes in this wave
     float a[64], b[64];
+    float a8[64][8], b8[64][8];
     int iv[64];
 };
 std::vector<Fiber> fibers;
@@ -128,6 +129,28 @@ f4 mfma16x16x4(float a, float b, f4 c, int, int, int) {
         float acc = c[r];
         for (int k = 0; k < 4; ++k) acc = std::fmaf(w.a[i + 16 * k], w.b[j + 16 * k], acc);
         c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+
+f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int) {
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    if (w.n != 64) { std::fprintf(stderr, "emu: MFMA needs a full wave\n"); std::abort(); }
+    for (int e = 0; e < 8; ++e) {
+        w.a8[f.lane][e] = (float)a[e];
+        w.b8[f.lane][e] = (float)b[e];
+    }
+    wave_barrier();
+    const int j = f.lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = (f.lane >> 4) * 4 + r;
+        double acc = c[r];
+        for (int qq = 0; qq < 4; ++qq)
+            for (int e = 0; e < 8; ++e)
+                acc += (double)w.a8[i + 16 * qq][e] * (double)w.b8[j + 16 * qq][e];
+        c[r] = (float)acc;
     }
     wave_barrier();
     return c;

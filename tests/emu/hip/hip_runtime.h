@@ -6,6 +6,9 @@
 // It is ~10^4 x slower than the GPU, is never shipped, and nothing under gnn_pathplanning_amd/
 // can load it: it is NOT a fallback path.
 //
+// v_mfma_f32_16x16x32_f16: lane l holds the k-slots (q = l >> 4, e = 0..7) of row i / column j = l & 15;
+// products are exact, the sum is formed in double and rounded once (the hardware's internal order
+// is not modelled; tests compare at a tolerance).
 // Lane mappings of v_mfma_f32_16x16x4_f32 as documented for gfx950:
 //   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15];
 //   D: register r of lane l is D[i = (l >> 4) * 4 + r][j = l & 15].
@@ -50,6 +53,8 @@ void sync_block();
 unsigned long long ballot(int pred);
 int readlane(int v, int src_lane);
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 }  // namespace gnnpp_emu
 
 #define threadIdx (gnnpp_emu::cur->tid)
@@ -67,6 +72,7 @@ f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))

@@ -56,7 +56,7 @@ def test_emu_lsigf_node_major_relu(emu, lsigf_golden):
     assert np.abs(y.transpose(0, 2, 1) - np.maximum(want, 0)).max() <= TOL
 
 
-@pytest.mark.parametrize('variant', [3, 4, 5, 6, 2, 1, 0])
+@pytest.mark.parametrize('variant', [7, 3, 4, 5, 6, 2, 1, 0])
 def test_emu_policy_golden(emu, policy_golden, variant):
     el, lib = emu
     assert lib.gnnpp_set_tuning(0, variant) == 0        # encoder schedule: 3 = v3 Winograd, 2 = v2, 1 = v1 in place, 0 = ping-pong
@@ -64,7 +64,7 @@ def test_emu_policy_golden(emu, policy_golden, variant):
     sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
     enc = el.pack_encoder(lib, sd)
     for i, m in enumerate(meta):
-        if m['N'] > 10 or (variant != 5 and i > 1):
+        if m['N'] > 10 or (variant not in (5, 7) and i > 1):
             continue
         B, N, K = m['B'], m['N'], m['K']
         obs = el.f32(z['p%d_obs' % i])

@@ -23,6 +23,16 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(params=[7, 5], ids=['enc-split-f16', 'enc-fp32'])
+def enc_variant(request, dev):
+    """Run a test under both encoder schedules: 7 = split-f16 MFMA, 5 = exact-fp32 MFMA."""
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    assert L.gnnpp_set_tuning(0, request.param) == 0
+    yield request.param
+    assert L.gnnpp_set_tuning(0, -1) == 0              # back to the built-in default
+
+
 class Cfg:
     def __init__(self, n, k, device):
         self.num_agents, self.nGraphFilterTaps, self.device = n, k, device
@@ -61,7 +71,7 @@ def test_lsigf_golden_all_cases(dev, lsigf_golden):
         assert err <= TOL * max(1.0, np.abs(want).max()), (i, m, err)
 
 
-def test_policy_golden(dev, policy_golden):
+def test_policy_golden(dev, policy_golden, enc_variant):
     z, meta = policy_golden
     for i, m in enumerate(meta):
         sd = golden_state_dict(z, m['K'])
@@ -85,7 +95,7 @@ def test_policy_golden(dev, policy_golden):
 @pytest.mark.parametrize('B,N,K,W', [(1, 10, 3, 20), (512, 10, 3, 20), (256, 50, 3, 50),
                                      (128, 100, 2, 100), (128, 100, 3, 100), (128, 100, 4, 100),
                                      (37, 7, 3, 12), (5, 64, 3, 40)])
-def test_policy_vs_oracle_baseline_sizes(dev, B, N, K, W):
+def test_policy_vs_oracle_baseline_sizes(dev, B, N, K, W, enc_variant):
     sd = orc.init_state_dict(K, seed=1337 + K)
     net = _net(N, K, dev, sd)
     obs = orc.synth_obs(B, N, seed=B + N)
@@ -155,7 +165,7 @@ def test_filter_algebra_properties(dev):
     assert (yl - yb2).abs().max().item() <= 1e-6
 
 
-def test_encoder_ragged_tiles(dev):
+def test_encoder_ragged_tiles(dev, enc_variant):
     """M = B*N not a multiple of the 16-agent tile, including a single agent."""
     sd = orc.init_state_dict(3, seed=3)
     for B, N in ((1, 1), (1, 17), (3, 11), (2, 16)):
@@ -166,7 +176,7 @@ def test_encoder_ragged_tiles(dev):
         assert (got - want).abs().max().item() <= TOL, (B, N)
 
 
-def test_non_binary_observations(dev):
+def test_non_binary_observations(dev, enc_variant):
     """The kernel must not assume {0,1} inputs."""
     sd = orc.init_state_dict(3, seed=5)
     net = _net(4, 3, dev, sd)
@@ -175,6 +185,25 @@ def test_non_binary_observations(dev):
     want = orc.policy_features(sd, obs).permute(0, 2, 1)
     got = net.encode(obs.to(dev)).cpu()
     assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+
+
+def test_encoder_dynamic_range(dev, enc_variant):
+    """Weights and activations spread over several decades (the split-f16 schedule rescales the
+    weights per layer and keeps subnormal lo halves): the relative error must stay at fp32 level."""
+    sd = orc.init_state_dict(3, seed=11)
+    for name, f in (('ConvLayers.0.weight', 30.0), ('ConvLayers.4.weight', 0.004),
+                    ('ConvLayers.7.weight', 55.0), ('ConvLayers.11.weight', 0.02),
+                    ('ConvLayers.14.weight', 7.0), ('compressMLP.0.weight', 0.3)):
+        assert name in sd, sorted(sd)
+        sd[name] = sd[name] * f
+    net = _net(6, 3, dev, sd)
+    g = torch.Generator().manual_seed(2)
+    obs = torch.randn(5, 6, 3, 11, 11, generator=g) * 3.0
+    want = orc.policy_features(sd, obs).permute(0, 2, 1)
+    got = net.encode(obs.to(dev)).cpu()
+    scale = want.abs().max().item()
+    assert scale > 0 and torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 2e-5 * scale, ((got - want).abs().max().item(), scale)
 
 
 def test_state_dict_roundtrip_and_cache_invalidation(dev, policy_golden):

@@ -48,11 +48,17 @@ def main():
         obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
-        for v in (5, 3, 2):
+        L.gnnpp_set_tuning(0, 5)
+        L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st)
+        ref = feat.clone()
+        L.gnnpp_set_tuning(0, 7)
+        L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st)
+        row['max_abs_diff_v7_vs_v5'] = float((feat - ref).abs().max())
+        for v in (7, 5, 7, 5):
             L.gnnpp_set_tuning(0, v)
             t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
             row['v%d_us' % v] = min(round(t, 2), row.get('v%d_us' % v, 1e9))
-        L.gnnpp_set_tuning(0, 5)
+        L.gnnpp_set_tuning(0, -1)
         print(json.dumps(row), flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'encoder':
         return
