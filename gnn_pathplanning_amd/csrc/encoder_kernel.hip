@@ -87,14 +87,14 @@ __device__ __forceinline__ float winograd_u(const float* __restrict__ g, int a, 
 }
 
 // ---- split-f16 path: per-layer power-of-two weight scale ---------------------------------------
-// Block b handles layer b + 1 (conv 1..4; b = 4: the FC).  2^k is chosen so that max|w| * 2^k lies in
+// Block b handles layer b + 1 (conv 1..4; b = 4: the FC; b = 5: conv 0).  2^k is chosen so that max|w| * 2^k lies in
 // [512, 1024): the hi halves stay far from f16 overflow and the lo halves (w*2^k - hi, ~2^-11 of
 // hi) of all but negligible weights are normal f16 numbers.  The kernel undoes 2^k exactly in its
 // epilogue (folded into the BatchNorm scale).
 __device__ __forceinline__ void enc_h2_layer(int b, const EncRawParams& rp, const float*& w, int& n) {
-    w = b < 4 ? rp.conv_w[b + 1] : rp.fc_w;
+    w = b < 4 ? rp.conv_w[b + 1] : b == 4 ? rp.fc_w : rp.conv_w[0];
     n = b == 0 ? 32 * 32 * 9 : b == 1 ? 64 * 32 * 9 : b == 2 ? 64 * 64 * 9 : b == 3 ? 128 * 64 * 9
-                                                                                    : 128 * 128;
+      : b == 4 ? 128 * 128 : 32 * 3 * 9;
 }
 
 __global__ void enc_layer_scale_kernel(const EncRawParams rp, float* __restrict__ packed) {
@@ -160,6 +160,21 @@ __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ p
                       packed + EncLayout::kH4, t0, stride);
     enc_h2_pack_layer(rp.fc_w, packed[EncLayout::kHscale + 4], 128, 1, 4, 2, 4,
                       packed + EncLayout::kHfc, t0, stride);
+    {   // L0: [mt 2][hi/lo][lane 64][e 8]
+        _Float16* out = reinterpret_cast<_Float16*>(packed + EncLayout::kH0);
+        const float scale = packed[EncLayout::kHscale + 5];
+        for (int idx = t0; idx < 2 * 512; idx += stride) {
+            const int e = idx & 7, l = (idx >> 3) & 63, mt = idx >> 9, qq = l >> 4;
+            const int co = mt * 16 + (l & 15);
+            float v = 0.f;
+            if (qq < 3) v = rp.conv_w[0][(co * 3 + qq) * 9 + e];
+            else if (e < 3) v = rp.conv_w[0][(co * 3 + e) * 9 + 8];
+            v *= scale;
+            const _Float16 hi = (_Float16)v;
+            out[((mt * 2 + 0) * 64 + l) * 8 + e] = hi;
+            out[((mt * 2 + 1) * 64 + l) * 8 + e] = (_Float16)(v - (float)hi);
+        }
+    }
     // Winograd L0: [mt 2][wpos 16][lane 64] = U[cout = mt*16+i][cin = q][wpos], 0 for q = 3
     for (int idx = t0; idx < 2 * 16 * 64; idx += stride) {
         const int l = idx & 63, wp = (idx >> 6) & 15, mt = idx >> 10;
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(kThreads, INPLACE ? 2 : 1) void encoder_kernel(
 
 // ---- host-side launchers ----------------------------------------------------------------------
 int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
-    hipLaunchKernelGGL(enc_layer_scale_kernel, dim3(5), dim3(256), 256 * sizeof(float), st, rp, packed);
+    hipLaunchKernelGGL(enc_layer_scale_kernel, dim3(6), dim3(256), 256 * sizeof(float), st, rp, packed);
     hipLaunchKernelGGL(pack_encoder_kernel, dim3(128), dim3(256), 0, st, rp, packed);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -1,6 +1,6 @@
-// Encoder kernel, split-f16 schedule ("h2").  Same layers, same 16-agent tile, same LDS budget and
-// the same fp32 Winograd L0 as v3 (encoder_kernel_v3.hip); layers L1..L4 and the FC run on the
-// f16 matrix pipe with every fp32 operand split in two halves:
+// Encoder kernel, split-f16 schedule ("h2").  Same layers, same 16-agent tile and the same LDS
+// budget as v3 (encoder_kernel_v3.hip); every layer runs on the f16 matrix pipe with each fp32
+// operand split in two halves:
 //
 //      x = xh + xl,  xh = f16(x),  xl = f16(x - xh)          (x - xh is exact in fp32)
 //      w x ~= wh xh + wh xl + wl xh                           (fp32 accumulate; wl xl ~ 2^-22 dropped)
@@ -80,6 +80,14 @@ __device__ __forceinline__ void split8(v4f a, v4f b, v4f& hi, v4f& lo) {
     }
     hi = as_f4(h);
     lo = as_f4(l);
+}
+// one fp32 value -> the word (lo half << 16 | hi half), stored bit-for-bit in a float slot
+__device__ __forceinline__ float split_word(float x) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    v2h p = {h, l};
+    return __builtin_bit_cast(float, p);
 }
 // four fp32 values (one D tile) -> the 8-byte half of a hi and of a lo fragment
 __device__ __forceinline__ void split4(v4f a, v2f& hi, v2f& lo) {
@@ -190,7 +198,10 @@ __device__ __forceinline__ void load_ss_h2(const float* ss, int cout, int mt, in
 
 __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
-                                                                 float* __restrict__ feat, int M) {
+                                                                 float* __restrict__ feat, int M,
+                                                                 int stop) {
+    // `stop` (measurement only, gnnpp_set_tuning): return after phase 1 = staging, 2 = L0, 3 = L1,
+    // 4 = L2, 5 = L3, 6 = L4; 0 = the whole encoder
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* const X = reinterpret_cast<float*>(gnnpp_smem);          // activations
     float* const bufObs = X + kBufFloats;                            // padded observations, then Y
@@ -248,58 +259,90 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
                     const int ch = rem / 121, r2 = rem - ch * 121;
                     const int y = r2 / 11, x = r2 - y * 11;
                     bufObs[ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1] =
-                        v[k][c];
+                        split_word(v[k][c]);
                 }
             }
         }
     }
     __syncthreads();
+    if (stop == 1) return;
 
-    // ---- L0 (fp32 Winograd, as v3): 3 -> 32 @ 11x11, BN, ReLU, pool; output split to f16 hi/lo ----
+    // ---- L0: 3 -> 32 @ 11x11 (the 10x10 the pool reads), direct, K = 27 in ONE 32-slot block -------
+    // A pixel sits in LDS as the word (lo half << 16 | hi half).  Lane (q, agent) owns k-slots
+    // (q, e): eight word reads at per-lane offsets (position offset = instruction immediate), two
+    // pack operations per register pair, then 3 MFMAs per channel tile -- no im2col buffer.
     {
-        float U0[2][16];
+        const unsigned* const obsw = reinterpret_cast<const unsigned*>(bufObs);
+        v8h A0h[2], A0l[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int w = 0; w < 16; ++w) U0[i][w] = pk[EncLayout::kU0 + (i * 16 + w) * 64 + lane];
+        for (int i = 0; i < 2; ++i) {
+            A0h[i] = as_h8(*reinterpret_cast<const v4f*>(pk + EncLayout::kH0 + ((i * 2 + 0) * 64 + lane) * 4));
+            A0l[i] = as_h8(*reinterpret_cast<const v4f*>(pk + EncLayout::kH0 + ((i * 2 + 1) * 64 + lane) * 4));
+        }
         v4f sc[2], sh[2];
-        load_ss(pk + EncLayout::kSS0, 32, 0, q, sc[0], sh[0]);
-        load_ss(pk + EncLayout::kSS0, 32, 1, q, sc[1], sh[1]);
-        const float* chan = bufObs + a * kAgentStride + (q < 3 ? q : 2) * (kPadHW * kPadHW);
-        float dc[16], dn[16];
-        auto load_patch = [&](float (&d)[16], int win) {
+        const float inv = pk[EncLayout::kHinv + 5];
+        load_ss_h2(pk + EncLayout::kSS0, 32, 0, q, inv, sc[0], sh[0]);
+        load_ss_h2(pk + EncLayout::kSS0, 32, 1, q, inv, sc[1], sh[1]);
+        int aoff[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            aoff[e] = a * kAgentStride + (q < 3 ? q * (kPadHW * kPadHW) + (e / 3) * kPadHW + e % 3
+                                                : e < 3 ? e * (kPadHW * kPadHW) + 2 * kPadHW + 2 : 0);
+        unsigned dcur[4][8], dnxt[4][8];
+        auto load_window = [&](unsigned (&d)[4][8], int win) {
             const int wy = win / 5, wx = win - wy * 5;
-            const float* base = chan + (2 * wy) * kPadHW + 2 * wx;
+            const unsigned* base = obsw + (2 * wy) * kPadHW + 2 * wx;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) d[4 * u + v] = base[u * kPadHW + v];
+                for (int e = 0; e < 8; ++e) d[pp][e] = base[aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
         };
-        load_patch(dc, wave);
+        load_window(dcur, wave);
         for (int win = wave; win < 25; win += kWaves) {
-            if (win + kWaves < 25) load_patch(dn, win + kWaves);
-            winograd_input(dc);
+            if (win + kWaves < 25) load_window(dnxt, win + kWaves);
+            v4f acc[4][2];
+            v8h Bh[4], Bl[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u h, l;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    h[w] = (dcur[pp][2 * w] & 0xffffu) | (dcur[pp][2 * w + 1] << 16);
+                    l[w] = (dcur[pp][2 * w] >> 16) | (dcur[pp][2 * w + 1] & 0xffff0000u);
+                }
+                Bh[pp] = __builtin_bit_cast(v8h, h);
+                Bl[pp] = __builtin_bit_cast(v8h, l);
+                acc[pp][0] = vzero();
+                acc[pp][1] = vzero();
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[pp][i] = mfma16h(term == 1 ? A0l[i] : A0h[i], term == 0 ? Bl[pp] : Bh[pp],
+                                             acc[pp][i]);
             v4f r[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                v4f m[16];
+                r[i] = vrelu(vfma(acc[0][i], sc[i], sh[i]));
 #pragma unroll
-                for (int w = 0; w < 16; ++w) m[w] = mfma16(U0[i][w], dc[w], vzero());
-                v4f y[4];
-                winograd_output(m, y);
-                r[i] = vrelu(vfma(y[0], sc[i], sh[i]));
-#pragma unroll
-                for (int pp = 1; pp < 4; ++pp) r[i] = vmax(r[i], vfma(y[pp], sc[i], sh[i]));
+                for (int pp = 1; pp < 4; ++pp) r[i] = vmax(r[i], vfma(acc[pp][i], sc[i], sh[i]));
             }
             v4f hi, lo;
             split8(r[0], r[1], hi, lo);
             X4[(win * 2 + 0) * 64 + lane] = hi;
             X4[(win * 2 + 1) * 64 + lane] = lo;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dc[i] = dn[i];
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dcur[pp][e] = dnxt[pp][e];
         }
     }
     __syncthreads();
+    if (stop == 2) return;
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
     {
@@ -330,6 +373,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
         }
     }
     __syncthreads();
+    if (stop == 3) return;
 
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
     {
@@ -361,6 +405,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
         }
     }
     __syncthreads();
+    if (stop == 4) return;
 
     // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
     {
@@ -383,6 +428,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
         }
     }
     __syncthreads();
+    if (stop == 5) return;
 
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
@@ -407,6 +453,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
         Y4[(wave * 2 + 1) * 64 + lane] = lo;
     }
     __syncthreads();
+    if (stop == 6) return;
 
     // ---- FC 128 -> 128 + ReLU -> feat[agent][128]; tiles 2w, 2w+1 per wave ------------------------
     {
@@ -449,6 +496,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
     }
 }
 
+int g_encoder_stop = 0;              // measurement only (GNNPP_TUNE_ENCODER_STOP)
+
 int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
@@ -458,7 +507,8 @@ int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M,
         attr_set = true;
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL(encoder_kernel_h2, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M);
+    hipLaunchKernelGGL(encoder_kernel_h2, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
+                       g_encoder_stop);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -128,6 +128,10 @@ int gnnpp_set_tuning(int key, int value) {
             if (value < 0) return GNNPP_ERR_ARG;
             g_filter_gpw = value;
             return GNNPP_OK;
+        case GNNPP_TUNE_ENCODER_STOP:
+            if (value < 0 || value > 6) return GNNPP_ERR_ARG;
+            g_encoder_stop = value;
+            return GNNPP_OK;
         case GNNPP_TUNE_FILTER_ABLATE:
             g_filter_ablate = value;
             return GNNPP_OK;

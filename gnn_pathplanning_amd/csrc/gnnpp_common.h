@@ -113,9 +113,12 @@ struct EncLayout {
     static constexpr int kH3 = kH2 + 72 * kHItem;                        // [4][2][9][1][2]
     static constexpr int kH4 = kH3 + 144 * kHItem;                       // [4][2][9][2][2]
     static constexpr int kHfc = kH4 + 288 * kHItem;                      // [4][4][1][2][2]
-    static constexpr int kHinv = kHfc + 64 * kHItem;                     // 2^-k of layers 1..4, FC
+    static constexpr int kHinv = kHfc + 64 * kHItem;                     // 2^-k of layers 1..4, FC, 0
     static constexpr int kHscale = kHinv + 8;                            // 2^k  (same order)
-    static constexpr int kTotal = kHscale + 8;
+    // L0 (K = 27 in one 32-slot block): [mt 2][hi/lo][lane 64][e 8]; k-slot (q, e) is
+    // (channel q, tap e) for q < 3, (channel e, tap 8) for q = 3 and e < 3, unused (zero) otherwise
+    static constexpr int kH0 = kHscale + 8;
+    static constexpr int kTotal = kH0 + 4 * kHItem;
 };
 
 }  // namespace gnnpp

@@ -40,8 +40,11 @@ int         gnnpp_version(void);
 const char* gnnpp_error_string(int code);
 
 /* Process-wide tuning knobs for A/B measurements (bench.py); defaults are the fast settings.
- * Results are identical for every setting -- only the schedule changes. */
-#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 5 (default): v3 = v2 + Winograd F(2x2,3x3) in L0 and L2,
+ * Every setting computes the same function; the fp32 schedules (0..6) agree to summation order,
+ * the split-f16 schedule (7) to ~2^-22 per operand (measured: |dfeature| <= 2e-7, as the others). */
+#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 7: split-f16 MFMA for L1..FC (encoder_kernel_h2.hip);
+                                         -1: restore the built-in default;
+                                         5: v3 = v2 + Winograd F(2x2,3x3) in L0 and L2,
                                          late layers in place; 3: v3 with the late layers through
                                          the observation buffer; 4 / 6: Winograd in L2 only;
                                          2: schedule v2 (weight-fragment register ring, up-front
@@ -52,6 +55,8 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_FILTER_ABLATE   3  /* MEASUREMENT ONLY, results become wrong: bit mask of filter
                                          phases to skip (1 shifts, 2 contraction, 4 GSO staging,
                                          8 epilogue); 0 (default) = the real kernel               */
+#define GNNPP_TUNE_ENCODER_STOP     4  /* MEASUREMENT ONLY (schedule 7): return after phase 1 staging,
+                                         2 L0, 3 L1, 4 L2, 5 L3, 6 L4; 0 (default) = whole encoder */
 int         gnnpp_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------

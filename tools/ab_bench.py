@@ -38,7 +38,30 @@ class Cfg:
         self.num_agents, self.nGraphFilterTaps, self.device = n, k, dev
 
 
+def encoder_phases():
+    """Split-f16 encoder truncated after each phase (GNNPP_TUNE_ENCODER_STOP): cumulative us."""
+    net = DecentralPlannerNet(Cfg(10, 3)).to(dev).eval()
+    net.load_state_dict(orc.init_state_dict(3))
+    enc = net.packed_encoder()
+    L.gnnpp_set_tuning(0, 7)
+    names = {1: 'staging', 2: 'L0', 3: 'L1', 4: 'L2', 5: 'L3', 6: 'L4', 0: 'full'}
+    for M in (16, 4096, 5120, 40960):
+        obs = (torch.rand(M, 3, 11, 11, device=dev) < 0.1).float()
+        feat = torch.empty(M, 128, device=dev)
+        row = {'kernel': 'encoder_h2_phases', 'M': M}
+        for rep in range(2):
+            for stop in (1, 2, 3, 4, 5, 6, 0):
+                L.gnnpp_set_tuning(4, stop)
+                t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
+                row[names[stop]] = min(round(t, 2), row.get(names[stop], 1e9))
+        L.gnnpp_set_tuning(4, 0)
+        print(json.dumps(row), flush=True)
+    L.gnnpp_set_tuning(0, -1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'encoder_phases':
+        return encoder_phases()
     sd = orc.init_state_dict(3)
     net = DecentralPlannerNet(Cfg(10, 3)).to(dev).eval()
     net.load_state_dict(sd)
