@@ -18,7 +18,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'gnnpp.h')
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
                '-Wno-unused-result']
 
-EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_filter_packed_floats',
+EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move')
@@ -88,6 +88,8 @@ def lib():
     L.gnnpp_error_string.argtypes = [ci]
     L.gnnpp_set_tuning.argtypes = [ci, ci]
     L.gnnpp_set_tuning.restype = ci
+    L.gnnpp_get_tuning.argtypes = [ci]
+    L.gnnpp_get_tuning.restype = ci
     L.gnnpp_filter_packed_floats.restype = cs
     L.gnnpp_filter_packed_floats.argtypes = [ci] * 4
     L.gnnpp_filter_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp]

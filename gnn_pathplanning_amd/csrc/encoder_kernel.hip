@@ -494,7 +494,7 @@ int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-constexpr int kDefaultEncoderVariant = 5;
+constexpr int kDefaultEncoderVariant = 7;
 int g_encoder_variant = kDefaultEncoderVariant;   // 7: split-f16 (encoder_kernel_h2.hip); 5: v3 Winograd L0+L2, late layers in place (default); 3: same,
                                     // late layers via the obs buffer; 4/6: Winograd L2 only (Y / in place); 2: v2; 1: v1 in place; 0: ping-pong
 int encoder_launch_v2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);

@@ -118,6 +118,17 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
     return lsigf_launch(a, st);
 }
 
+int gnnpp_get_tuning(int key) {
+    switch (key) {
+        case GNNPP_TUNE_ENCODER_VARIANT: return g_encoder_variant;
+        case GNNPP_TUNE_FILTER_GPW: return g_filter_gpw;
+        case GNNPP_TUNE_FILTER_WAVES: return g_filter_waves;
+        case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate;
+        case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop;
+        default: return GNNPP_ERR_ARG;
+    }
+}
+
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT:

@@ -58,6 +58,7 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_ENCODER_STOP     4  /* MEASUREMENT ONLY (schedule 7): return after phase 1 staging,
                                          2 L0, 3 L1, 4 L2, 5 L3, 6 L4; 0 (default) = whole encoder */
 int         gnnpp_set_tuning(int key, int value);
+int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 
 /* ------------------------------------------------------------------------------------------
  * Graph filter (LSIGF):  y = bias + sum_e sum_k W[:,e,k,:] . (x S_e^k),   z_k = z_{k-1} S (right

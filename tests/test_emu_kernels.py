@@ -111,7 +111,7 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
         lib.gnnpp_set_tuning(1, 0)
         lib.gnnpp_set_tuning(2, 0)
     assert lib.gnnpp_set_tuning(7, 0) == -1 and lib.gnnpp_set_tuning(0, 9) == -1
-    assert lib.gnnpp_set_tuning(0, 5) == 0
+    assert lib.gnnpp_set_tuning(0, -1) == 0 and lib.gnnpp_get_tuning(0) == 7
 
 
 def test_emu_lsigf_transposed_and_tap_dump(emu, lsigf_golden):
