@@ -229,9 +229,16 @@ __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ p
         const int off = enc_ss_off(layer);
         for (int c = t0; c < c_n; c += stride) {
             const float sc = rp.bn_w[layer][c] / sqrtf(rp.bn_var[layer][c] + rp.bn_eps);
+            const float shf = rp.bn_b[layer][c] + (rp.conv_b[layer][c] - rp.bn_mean[layer][c]) * sc;
             packed[off + c] = sc;
-            packed[off + c_n + c] =
-                rp.bn_b[layer][c] + (rp.conv_b[layer][c] - rp.bn_mean[layer][c]) * sc;
+            packed[off + c_n + c] = shf;
+            // split-f16 path: the accumulators carry the weight scale 2^k of their layer
+            const float inv = packed[EncLayout::kHinv + (layer == 0 ? 5 : layer - 1)];
+            const int hoff = layer == 0 ? EncLayout::kHss0
+                           : EncLayout::kHss + (layer == 1 ? EncLayout::kHssL1 : layer == 2 ? EncLayout::kHssL2
+                                                : layer == 3 ? EncLayout::kHssL3 : EncLayout::kHssL4);
+            packed[hoff + c] = sc * inv;
+            packed[hoff + c_n + c] = shf;
         }
     }
 }

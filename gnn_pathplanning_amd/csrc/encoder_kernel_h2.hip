@@ -28,6 +28,8 @@
 //     weights only; these layers are bound by the weight stream out of L2 (0.5 MB per tile).
 //   * weights go through the same ordered register ring as v2/v3 (16 x 16 bytes here), packed in
 //     each wave's consumption order so the stream is linear.
+#include <utility>
+
 #include "gnnpp_common.h"
 
 namespace gnnpp {
@@ -37,8 +39,9 @@ constexpr int kRingH = 16;
 // hi or lo fragment of one (kb, tap, mt)
 constexpr int kh_L1 = 0, kh_L2 = 36, kh_L3 = 72, kh_L4 = 108, kh_FC = 180, kh_END = 196;
 
-struct WStreamH {                 // per-wave segment bases, already offset by lane * 4 floats
+struct WStreamH {                 // per-wave segment bases (wave-uniform: SGPRs) + this lane's offset
     const float* seg[5];
+    int lane_bytes;               // lane * 16: the lane's 16 bytes inside every 1 KiB fragment
 };
 
 __device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx) {
@@ -49,20 +52,75 @@ __device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx)
     return ws.seg[4] + (idx - kh_FC) * EncLayout::kHItem;
 }
 
-// ordered (relaxed, wavefront-scope atomic) 16-byte load: see ring_load in encoder_kernel_v2.hip
+// The weight stream is what bounds this kernel (tools/probe/wstream_probe.hip: a CU pulls ~70 GB/s
+// out of L2 with 8-byte loads, ~125 GB/s with 16-byte loads), so the ring uses global_load_dwordx4.
+// The loads must stay where the source puts them (a ring that runs ahead of its consumers); hipcc
+// sinks plain loads to their uses, a volatile load is encoded sc0 sc1 (slower), and a register the
+// compiler allocates may be copied or spilled while its load is still in flight.  So the ring
+// lives in sixteen register quads the compiler never sees: the kernel is compiled with a VGPR
+// budget that ends at v191 and v[192:255] belong to the inline asm below (they still count towards
+// the kernel's 256-register allocation).  Loads return in order: when item idx is consumed,
+// min(kRingH - 1, kh_END - 1 - idx) ring loads are younger than it, which is the vmcnt to wait for
+// (loads the compiler issues itself only make that wait conservative).  The fragment is then
+// copied out with two v_mov_b64.  tools/check_ring_isa.py verifies on the generated ISA that
+// nothing else touches v[192:255] and that loads and takes follow the ring discipline.
+#define GNNPP_RING_SLOTS(X)                                                                    \
+    X(0, 192, 193, 194, 195) X(1, 196, 197, 198, 199) X(2, 200, 201, 202, 203)                \
+    X(3, 204, 205, 206, 207) X(4, 208, 209, 210, 211) X(5, 212, 213, 214, 215)                \
+    X(6, 216, 217, 218, 219) X(7, 220, 221, 222, 223) X(8, 224, 225, 226, 227)                \
+    X(9, 228, 229, 230, 231) X(10, 232, 233, 234, 235) X(11, 236, 237, 238, 239)              \
+    X(12, 240, 241, 242, 243) X(13, 244, 245, 246, 247) X(14, 248, 249, 250, 251)             \
+    X(15, 252, 253, 254, 255)
+
 __device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRingH], int idx) {
     if (idx < kh_END) {
-        typedef unsigned long long u64;
-        u64* p = reinterpret_cast<u64*>(const_cast<float*>(h2_item_ptr(ws, idx)));
-        const u64 lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const u64 hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        v4f r;
-        r[0] = __int_as_float((int)(lo & 0xffffffffu));
-        r[1] = __int_as_float((int)(lo >> 32));
-        r[2] = __int_as_float((int)(hi & 0xffffffffu));
-        r[3] = __int_as_float((int)(hi >> 32));
-        ring[idx % kRingH] = r;
+        const float* p = h2_item_ptr(ws, idx);             // wave-uniform (scalar) fragment base
+#if defined(__HIP_DEVICE_COMPILE__)
+        (void)ring;
+        switch (idx % kRingH) {                          // folds: idx is a constant after unrolling
+#define GNNPP_X(s, a, b, c, d)                                                                 \
+    case s:                                                                                    \
+        asm volatile("global_load_dwordx4 v[" #a ":" #d "], %0, %1 ; RINGLOAD " #s             \
+                     :: "v"(ws.lane_bytes), "s"(p) : "v" #a, "v" #b, "v" #c, "v" #d);          \
+        break;
+            GNNPP_RING_SLOTS(GNNPP_X)
+#undef GNNPP_X
+        }
+#else
+        ring[idx % kRingH] = *reinterpret_cast<const v4f*>(
+            reinterpret_cast<const char*>(p) + ws.lane_bytes);
+#endif
     }
+}
+
+// the fragment of item idx, once it has landed
+__device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)ring;
+    const int younger = kh_END - 1 - idx < kRingH - 1 ? kh_END - 1 - idx : kRingH - 1;
+    switch (younger) {
+#define GNNPP_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ") ; RINGWAIT" ::: "memory"); break;
+        GNNPP_W(0) GNNPP_W(1) GNNPP_W(2) GNNPP_W(3) GNNPP_W(4) GNNPP_W(5) GNNPP_W(6) GNNPP_W(7)
+        GNNPP_W(8) GNNPP_W(9) GNNPP_W(10) GNNPP_W(11) GNNPP_W(12) GNNPP_W(13) GNNPP_W(14)
+        default: asm volatile("s_waitcnt vmcnt(15) ; RINGWAIT" ::: "memory"); break;
+#undef GNNPP_W
+    }
+    v2f lo, hi;
+    switch (idx % kRingH) {
+#define GNNPP_X(s, a, b, c, d)                                                                 \
+    case s:                                                                                    \
+        asm volatile("v_mov_b64 %0, v[" #a ":" #b "] ; RINGTAKE " #s                           \
+                     "\n\tv_mov_b64 %1, v[" #c ":" #d "] ; RINGTAKE " #s                        \
+                     : "=v"(lo), "=v"(hi));                                                    \
+        break;
+        GNNPP_RING_SLOTS(GNNPP_X)
+#undef GNNPP_X
+    }
+    v4f r = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(v8h, r);
+#else
+    return __builtin_bit_cast(v8h, ring[idx % kRingH]);
+#endif
 }
 
 __device__ __forceinline__ v8h as_h8(v4f v) { return __builtin_bit_cast(v8h, v); }
@@ -128,8 +186,73 @@ struct Pos2x2H {
     }
 };
 
-// NMT channel tiles over a compile-time position set; weights from the ring, item order
-// [kb][tap][mt][hi/lo].  PRELOAD: the whole H x W x NKB input is read into registers first.
+// One (kb, tap) step IT of NMT channel tiles over a compile-time position set: B fragments of the
+// positions the tap reaches (from LDS, or from the preloaded registers Pin), 3 MFMAs per pair.
+template <int IT, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD, int CH = NSLOT>
+__device__ __forceinline__ void tap_mfma(const v4f* in, const v4f* Pin, const v8h (&Ah)[NMT],
+                                         const v8h (&Al)[NMT], v4f (&acc)[NSLOT][NMT], int lane) {
+    constexpr int kb = IT / 9, tap = IT % 9;
+    constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int j0 = 0; j0 < NSLOT; j0 += CH) {               // CH slots at a time bounds the B registers
+        v8h Bh[CH], Bl[CH];
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = j0 + jj;
+            int y = 0, x = 0;
+            const bool used = j < NSLOT && PosFn::get(j, y, x);
+            const int iy = y + dy, ix = x + dx;
+            if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const int o = ((iy * W + ix) * NKB + kb) * 2;
+                Bh[jj] = as_h8(PRELOAD ? Pin[o] : in[o * 64 + lane]);
+                Bl[jj] = as_h8(PRELOAD ? Pin[o + 1] : in[(o + 1) * 64 + lane]);
+            }
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {              // small terms first
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+                const int j = j0 + jj;
+                int y = 0, x = 0;
+                const bool used = j < NSLOT && PosFn::get(j, y, x);
+                const int iy = y + dy, ix = x + dx;
+                if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m)
+                        acc[j][m] = mfma16h(term == 1 ? Al[m] : Ah[m], term == 0 ? Bl[jj] : Bh[jj],
+                                            acc[j][m]);
+                }
+            }
+        }
+    }
+}
+
+// The weight stream of a layer: for every step IT (item order [kb][tap][mt][hi/lo]) take the
+// 2 NMT fragments off the ring, refill the slots, and hand them to body(IT, Ah, Al).  All ring
+// traffic is issued from this wave-uniform, branch-free code; per-wave specialisation (which
+// positions a wave owns) lives inside `body`, so every path through the kernel performs the same
+// ring sequence (tools/check_ring_isa.py relies on that).
+template <int START, int NMT, class Body, int... IT>
+__device__ __forceinline__ void stream_steps(const WStreamH& ws, v4f (&ring)[kRingH], Body&& body,
+                                             std::integer_sequence<int, IT...>) {
+    auto step = [&](auto itc) {
+        constexpr int it = decltype(itc)::value;
+        __builtin_amdgcn_sched_barrier(kSchedItemMask);
+        v8h Ah[NMT], Al[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            const int idx = START + (it * NMT + m) * 2;
+            Ah[m] = h2_ring_take(ring, idx);
+            h2_ring_load(ws, ring, idx + kRingH);
+            Al[m] = h2_ring_take(ring, idx + 1);
+            h2_ring_load(ws, ring, idx + 1 + kRingH);
+        }
+        body(itc, Ah, Al);
+    };
+    (step(std::integral_constant<int, IT>{}), ...);
+}
+
+// a whole layer for one position set (no per-wave specialisation)
 template <int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD>
 __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH], const v4f* in,
                                         v4f (&acc)[NSLOT][NMT], int lane) {
@@ -138,65 +261,19 @@ __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH],
 #pragma unroll
         for (int i = 0; i < H * W * NKB * 2; ++i) Pin[i] = in[i * 64 + lane];
     }
-#pragma unroll
-    for (int it = 0; it < 9 * NKB; ++it) {
-        const int kb = it / 9, tap = it % 9;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        bool any = false;                                   // taps no position of this wave uses
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j) {
-            int y = 0, x = 0;
-            const bool used = PosFn::get(j, y, x);
-            any = any || (used && y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W);
-        }
-        __builtin_amdgcn_sched_barrier(kSchedItemMask);
-        v8h Ah[NMT], Al[NMT];
-#pragma unroll
-        for (int m = 0; m < NMT; ++m) {
-            const int idx = START + (it * NMT + m) * 2;
-            Ah[m] = as_h8(ring[idx % kRingH]);
-            h2_ring_load(ws, ring, idx + kRingH);
-            Al[m] = as_h8(ring[(idx + 1) % kRingH]);
-            h2_ring_load(ws, ring, idx + 1 + kRingH);
-        }
-        if (!any) continue;
-        v8h Bh[NSLOT], Bl[NSLOT];
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j) {
-            int y = 0, x = 0;
-            const bool used = PosFn::get(j, y, x);
-            const int iy = y + dy, ix = x + dx;
-            if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const int o = ((iy * W + ix) * NKB + kb) * 2;
-                Bh[j] = as_h8(PRELOAD ? Pin[o] : in[o * 64 + lane]);
-                Bl[j] = as_h8(PRELOAD ? Pin[o + 1] : in[(o + 1) * 64 + lane]);
-            }
-        }
-#pragma unroll
-        for (int term = 0; term < 3; ++term) {              // small terms first
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                int y = 0, x = 0;
-                const bool used = PosFn::get(j, y, x);
-                const int iy = y + dy, ix = x + dx;
-                if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-#pragma unroll
-                    for (int m = 0; m < NMT; ++m)
-                        acc[j][m] = mfma16h(term == 1 ? Al[m] : Ah[m], term == 0 ? Bl[j] : Bh[j],
-                                            acc[j][m]);
-                }
-            }
-        }
-    }
+    stream_steps<START, NMT>(ws, ring, [&](auto itc, const v8h (&Ah)[NMT], const v8h (&Al)[NMT]) {
+        tap_mfma<decltype(itc)::value, NKB, H, W, NMT, NSLOT, PosFn, PRELOAD>(in, Pin, Ah, Al, acc, lane);
+    }, std::make_integer_sequence<int, 9 * NKB>{});
 }
 
-__device__ __forceinline__ void load_ss_h2(const float* ss, int cout, int mt, int q, float inv,
-                                           v4f& sc, v4f& sh) {
-    load_ss(ss, cout, mt, q, sc, sh);
-    sc = sc * inv;                                           // undo the weight scale 2^k (exact)
-}
-
-__global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
+#if defined(__HIP_DEVICE_COMPILE__)
+// v[192:255] = the weight ring.  On gfx90a+ the backend doubles "amdgpu-num-vgpr" (the unified
+// VGPR+AGPR file), so 96 is what caps the compiler at v191; check_ring_isa.py verifies it.
+#define GNNPP_H2_VGPR_BUDGET __attribute__((amdgpu_num_vgpr(96)))
+#else
+#define GNNPP_H2_VGPR_BUDGET
+#endif
+__global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M,
                                                                  int stop) {
@@ -210,17 +287,25 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
                                                                      // ping-pong X <-> Y
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: real branches per wave
     const int a = lane & 15;
     const int q = lane >> 4;
     const int agent0 = blockIdx.x * kTileAgents;
 
     WStreamH ws;
-    ws.seg[0] = pk + EncLayout::kH1 + lane * 4;
-    ws.seg[1] = pk + EncLayout::kH2 + (wave & 1) * (36 * EncLayout::kHItem) + lane * 4;
-    ws.seg[2] = pk + EncLayout::kH3 + wave * (36 * EncLayout::kHItem) + lane * 4;
-    ws.seg[3] = pk + EncLayout::kH4 + wave * (72 * EncLayout::kHItem) + lane * 4;
-    ws.seg[4] = pk + EncLayout::kHfc + wave * (16 * EncLayout::kHItem) + lane * 4;
+    ws.seg[0] = pk + EncLayout::kH1;
+    ws.seg[1] = pk + EncLayout::kH2 + (wave & 1) * (36 * EncLayout::kHItem);
+    ws.seg[2] = pk + EncLayout::kH3 + wave * (36 * EncLayout::kHItem);
+    ws.seg[3] = pk + EncLayout::kH4 + wave * (72 * EncLayout::kHItem);
+    ws.seg[4] = pk + EncLayout::kHfc + wave * (16 * EncLayout::kHItem);
+    ws.lane_bytes = lane * 16;
+    // BatchNorm scale/shift of L1..L4: fetched now, parked in LDS after L0 (behind Y's live part), so
+    // that no compiler-issued global load (whose wait would drain the ring) sits between the layers
+    float ssv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        ssv[i] = pk[EncLayout::kHss + min(tid + i * kThreads, EncLayout::kHssFloats - 1)];
+    float* const sstab = bufObs + 16 * 256;                          // Y holds <= 16 fragments
     v4f ring[kRingH];
 #pragma unroll
     for (int i = 0; i < kRingH; ++i) h2_ring_load(ws, ring, i);
@@ -280,9 +365,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
             A0l[i] = as_h8(*reinterpret_cast<const v4f*>(pk + EncLayout::kH0 + ((i * 2 + 1) * 64 + lane) * 4));
         }
         v4f sc[2], sh[2];
-        const float inv = pk[EncLayout::kHinv + 5];
-        load_ss_h2(pk + EncLayout::kSS0, 32, 0, q, inv, sc[0], sh[0]);
-        load_ss_h2(pk + EncLayout::kSS0, 32, 1, q, inv, sc[1], sh[1]);
+        load_ss(pk + EncLayout::kHss0, 32, 0, q, sc[0], sh[0]);
+        load_ss(pk + EncLayout::kHss0, 32, 1, q, sc[1], sh[1]);
         int aoff[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -343,23 +427,29 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
     }
     __syncthreads();
     if (stop == 2) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (tid + i * kThreads < EncLayout::kHssFloats) sstab[tid + i * kThreads] = ssv[i];
+    // (first read after L1's mid-layer barrier)
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
     {
         v4f sc[2], sh[2];
-        const float inv = pk[EncLayout::kHinv + 0];
-        load_ss_h2(pk + EncLayout::kSS1, 32, 0, q, inv, sc[0], sh[0]);
-        load_ss_h2(pk + EncLayout::kSS1, 32, 1, q, inv, sc[1], sh[1]);
         v4f acc[7][2];
 #pragma unroll
         for (int j = 0; j < 7; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
-        switch (wave) {
-            case 0: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<0>, false>(ws, ring, X4, acc, lane); break;
-            case 1: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<1>, false>(ws, ring, X4, acc, lane); break;
-            case 2: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<2>, false>(ws, ring, X4, acc, lane); break;
-            default: conv_h2<kh_L1, 1, 5, 5, 2, 7, PosL1H<3>, false>(ws, ring, X4, acc, lane); break;
-        }
+        stream_steps<kh_L1, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
+            constexpr int IT = decltype(itc)::value;
+            switch (wave) {
+                case 0: tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<0>, false>(X4, nullptr, Ah, Al, acc, lane); break;
+                case 1: tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<1>, false>(X4, nullptr, Ah, Al, acc, lane); break;
+                case 2: tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<2>, false>(X4, nullptr, Ah, Al, acc, lane); break;
+                default: tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<3>, false>(X4, nullptr, Ah, Al, acc, lane); break;
+            }
+        }, std::make_integer_sequence<int, 9>{});
         __syncthreads();                                   // everyone is done reading L0's output
+        load_ss(sstab + EncLayout::kHssL1, 32, 0, q, sc[0], sh[0]);
+        load_ss(sstab + EncLayout::kHssL1, 32, 1, q, sc[1], sh[1]);
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int p = wave + 4 * j;
@@ -378,15 +468,17 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
     {
         const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
-        v4f sc[2], sh[2];
-        const float inv = pk[EncLayout::kHinv + 1];
-        load_ss_h2(pk + EncLayout::kSS2, 64, 2 * mp, q, inv, sc[0], sh[0]);
-        load_ss_h2(pk + EncLayout::kSS2, 64, 2 * mp + 1, q, inv, sc[1], sh[1]);
         v4f acc[8][2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
-        if (pair == 0) conv_h2<kh_L2, 1, 5, 5, 2, 8, PosL2H<0>, false>(ws, ring, X4, acc, lane);
-        else           conv_h2<kh_L2, 1, 5, 5, 2, 8, PosL2H<1>, false>(ws, ring, X4, acc, lane);
+        stream_steps<kh_L2, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
+            constexpr int IT = decltype(itc)::value;
+            if (pair == 0) tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<0>, false, 4>(X4, nullptr, Ah, Al, acc, lane);
+            else           tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<1>, false, 4>(X4, nullptr, Ah, Al, acc, lane);
+        }, std::make_integer_sequence<int, 9>{});
+        v4f sc[2], sh[2];
+        load_ss(sstab + EncLayout::kHssL2, 64, 2 * mp, q, sc[0], sh[0]);
+        load_ss(sstab + EncLayout::kHssL2, 64, 2 * mp + 1, q, sc[1], sh[1]);
 #pragma unroll
         for (int wi = 0; wi < 2; ++wi) {
             const int t = wi == 0 ? pair : 3 - pair;
@@ -410,12 +502,12 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
     // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
     {
         const int mt = wave;
-        v4f sc, sh;
-        load_ss_h2(pk + EncLayout::kSS3, 64, mt, q, pk[EncLayout::kHinv + 2], sc, sh);
         v4f acc[4][1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j][0] = vzero();
         conv_h2<kh_L3, 2, 2, 2, 1, 4, Pos2x2H, true>(ws, ring, Y4, acc, lane);
+        v4f sc, sh;
+        load_ss(sstab + EncLayout::kHssL3, 64, mt, q, sc, sh);
         v2f* const X2 = reinterpret_cast<v2f*>(X);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -432,14 +524,13 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
 
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
-        v4f sc[2], sh[2];
-        const float inv = pk[EncLayout::kHinv + 3];
-        load_ss_h2(pk + EncLayout::kSS4, 128, 2 * wave, q, inv, sc[0], sh[0]);
-        load_ss_h2(pk + EncLayout::kSS4, 128, 2 * wave + 1, q, inv, sc[1], sh[1]);
         v4f acc[4][2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
         conv_h2<kh_L4, 2, 2, 2, 2, 4, Pos2x2H, true>(ws, ring, X4, acc, lane);
+        v4f sc[2], sh[2];
+        load_ss(sstab + EncLayout::kHssL4, 128, 2 * wave, q, sc[0], sh[0]);
+        load_ss(sstab + EncLayout::kHssL4, 128, 2 * wave + 1, q, sc[1], sh[1]);
         v4f r[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -471,9 +562,9 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int idx = kh_FC + (kb * 2 + m) * 2;
-                Ah[m] = as_h8(ring[idx % kRingH]);
+                Ah[m] = h2_ring_take(ring, idx);
                 h2_ring_load(ws, ring, idx + kRingH);
-                Al[m] = as_h8(ring[(idx + 1) % kRingH]);
+                Al[m] = h2_ring_take(ring, idx + 1);
                 h2_ring_load(ws, ring, idx + 1 + kRingH);
             }
 #pragma unroll

@@ -118,7 +118,12 @@ struct EncLayout {
     // L0 (K = 27 in one 32-slot block): [mt 2][hi/lo][lane 64][e 8]; k-slot (q, e) is
     // (channel q, tap e) for q < 3, (channel e, tap 8) for q = 3 and e < 3, unused (zero) otherwise
     static constexpr int kH0 = kHscale + 8;
-    static constexpr int kTotal = kH0 + 4 * kHItem;
+    // BatchNorm scale/shift with the weight scale undone (scale * 2^-k): L0 [sc 32][sh 32], then the
+    // table the kernel keeps in LDS: L1 [32][32] | L2 [64][64] | L3 [64][64] | L4 [128][128]
+    static constexpr int kHss0 = kH0 + 4 * kHItem;
+    static constexpr int kHss = kHss0 + 64;
+    static constexpr int kHssL1 = 0, kHssL2 = 64, kHssL3 = 192, kHssL4 = 320, kHssFloats = 576;
+    static constexpr int kTotal = kHss + kHssFloats;
 };
 
 }  // namespace gnnpp

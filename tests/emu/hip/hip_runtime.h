@@ -74,6 +74,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)          // only used on wave-uniform values
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 

@@ -1,0 +1,58 @@
+"""Static safety check of the split-f16 encoder's inline-asm weight ring (CPU only: hipcc
+cross-compiles gfx950 without a GPU).  The ring lives in v[192:255], registers the compiler must
+never touch; tools/check_ring_isa.py walks the kernel's control-flow graph in the generated ISA and
+verifies that, plus the load -> wait -> take discipline and the register/occupancy budget."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='needs hipcc')
+def test_ring_registers_are_private_to_the_asm(tmp_path):
+    import check_ring_isa
+    out = str(tmp_path / 'gnnpp.s')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
+                           '-Wno-unused-result', '-w',
+                           os.path.join(ROOT, 'gnn_pathplanning_amd', 'csrc', 'gnnpp_api.hip'), '-o', out])
+    errors, stats, meta = check_ring_isa.check(out)
+    assert not errors, errors[:10]
+    assert stats['loads'] == 196 and stats['takes'] == 196          # every stream item, exactly once
+    assert meta == {'NumVgprs': 256, 'ScratchSize': 0, 'Occupancy': 2}
+
+
+def test_checker_catches_violations(tmp_path):
+    """The checker itself: a compiler-looking instruction that touches a ring register, a take
+    with too weak a wait, and a reload of a pending slot must all be reported."""
+    import check_ring_isa
+    good = '''_ZN5gnnpp17encoder_kernel_h2EPKfS1_Pfii:
+\tglobal_load_dwordx4 v[192:195], v1, s[0:1] ; RINGLOAD 0
+\tglobal_load_dwordx4 v[196:199], v1, s[0:1] ; RINGLOAD 1
+\ts_waitcnt vmcnt(1) ; RINGWAIT
+\tv_mov_b64 v[2:3], v[192:193] ; RINGTAKE 0
+\tv_mov_b64 v[4:5], v[194:195] ; RINGTAKE 0
+\ts_waitcnt vmcnt(0) ; RINGWAIT
+\tv_mov_b64 v[2:3], v[196:197] ; RINGTAKE 1
+\tv_mov_b64 v[4:5], v[198:199] ; RINGTAKE 1
+\ts_endpgm
+.Lfunc_end0:
+; NumVgprs: 256
+; ScratchSize: 0
+; Occupancy: 2
+'''
+    f = tmp_path / 'a.s'
+    f.write_text(good)
+    assert check_ring_isa.check(str(f))[0] == []
+    for bad in (good.replace('\ts_waitcnt vmcnt(1) ; RINGWAIT', '\tv_add_f32 v200, v193, v193\n\ts_waitcnt vmcnt(1) ; RINGWAIT'),
+                good.replace('vmcnt(1) ; RINGWAIT', 'vmcnt(2) ; RINGWAIT'),
+                good.replace('\ts_waitcnt vmcnt(1) ; RINGWAIT',
+                             '\tglobal_load_dwordx4 v[192:195], v1, s[0:1] ; RINGLOAD 0\n\ts_waitcnt vmcnt(1) ; RINGWAIT'),
+                good.replace('; ScratchSize: 0', '; ScratchSize: 16')):
+        f.write_text(bad)
+        assert check_ring_isa.check(str(f))[0], bad
