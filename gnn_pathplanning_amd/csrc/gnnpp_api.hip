@@ -125,6 +125,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_WAVES: return g_filter_waves;
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate;
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop;
+        case GNNPP_TUNE_FILTER_F16: return g_filter_f16;
         default: return GNNPP_ERR_ARG;
     }
 }
@@ -142,6 +143,10 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_ENCODER_STOP:
             if (value < 0 || value > 6) return GNNPP_ERR_ARG;
             g_encoder_stop = value;
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_F16:
+            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            g_filter_f16 = value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_ABLATE:
             g_filter_ablate = value;

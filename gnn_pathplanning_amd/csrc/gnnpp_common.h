@@ -78,10 +78,19 @@ __device__ __forceinline__ float wave_read_lane(float v, int src) {
 }
 
 // ---- packed layouts (in floats) -------------------------------------------------------------
-// graph-filter taps: block (e, k, mt, gg) of 64 lanes x 4 floats, see lsigf_kernel.hip
-__host__ __device__ inline size_t filter_packed_floats(int G, int F, int K, int E) {
+// graph-filter taps: [fp32 fragments: block (e, k, mt, gg) of 64 lanes x 4 floats]
+//                    [split-f16 fragments: block (e, k, mt, kb, hi/lo) of 64 lanes x 8 halves]
+//                    [2^k, 2^-k]                                         see lsigf_kernel.hip
+__host__ __device__ inline size_t filter_packed_f32_floats(int G, int F, int K, int E) {
     const size_t NG = (G + 15) / 16, MT = (F + 15) / 16;
     return (size_t)E * K * MT * NG * 256;
+}
+__host__ __device__ inline size_t filter_packed_h2_floats(int G, int F, int K, int E) {
+    const size_t KB = (G + 31) / 32, MT = (F + 15) / 16;
+    return (size_t)E * K * MT * KB * 512;
+}
+__host__ __device__ inline size_t filter_packed_floats(int G, int F, int K, int E) {
+    return filter_packed_f32_floats(G, F, K, E) + filter_packed_h2_floats(G, F, K, E) + 4;
 }
 
 // encoder: offsets of each layer's block inside the packed buffer

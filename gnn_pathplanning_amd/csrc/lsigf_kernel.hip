@@ -30,6 +30,7 @@ struct LsigfArgs {
     const float* x;
     const void* S;
     const float* wpk;      // packed taps, see pack_filter_kernel
+    const float* wpk_h;    // split-f16 fragments + {2^k, 2^-k} (inside the same packed buffer)
     const float* bias;     // [F] or nullptr
     float* y;              // may be nullptr when only the action head is wanted
     const float* act_w;    // [5,F] or nullptr: fused action head
@@ -50,6 +51,29 @@ struct LsigfArgs {
 
 // Re-order h[F,E,K,G] into MFMA A fragments: block (e,k,mt,gg) holds, for lane l = q*16 + i and
 // k-step s, h[f = mt*16 + i][e][k][g = gg*16 + q*4 + s]  (0 outside F x G).
+// 2^k with max|h| * 2^k in [512, 1024) (as the encoder: the lo halves of the weights stay normal
+// f16 numbers); one block.  packed_h points at the split-f16 region, its last 4 floats hold 2^k, 2^-k.
+__global__ void filter_scale_kernel(const float* __restrict__ h, float* __restrict__ scale_out,
+                                    size_t n) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* red = reinterpret_cast<float*>(gnnpp_smem);
+    float m = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(h[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)blockDim.x; ++i) m = fmaxf(m, red[i]);
+        int k = 0;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            (void)frexpf(m, &e);
+            k = min(max(10 - e, -60), 60);
+        }
+        scale_out[0] = ldexpf(1.f, k);
+        scale_out[1] = ldexpf(1.f, -k);
+    }
+}
+
 __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restrict__ packed,
                                    int G, int F, int K, int E) {
     const int NG = (G + 15) / 16, MT = (F + 15) / 16;
@@ -69,15 +93,60 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
         if (f < F && g < G) v = h[(((size_t)f * E + e) * K + k) * G + g];
         packed[idx] = v;
     }
+    // split-f16 fragments: block (e, k, mt, kb) = [hi/lo][lane 64][8 halves]; half e8 of lane (q, i)
+    // is W[f = 16 mt + i][g = 32 kb + 8 q + e8] * 2^k (natural channel order: the B operand is a
+    // row-major z row in LDS)
+    const int KB = (G + 31) / 32;
+    float* ph = packed + total;
+    const float scale = ph[filter_packed_h2_floats(G, F, K, E)];
+    _Float16* out = reinterpret_cast<_Float16*>(ph);
+    const size_t total_h = (size_t)E * K * MT * KB * 512;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_h;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e8 = idx & 7;
+        const int l = (idx >> 3) & 63;
+        size_t blk = idx >> 9;
+        const int kb = blk % KB; blk /= KB;
+        const int mt = blk % MT; blk /= MT;
+        const int k = blk % K;
+        const int e = blk / K;
+        const int f = mt * 16 + (l & 15);
+        const int g = kb * 32 + (l >> 4) * 8 + e8;
+        float v = 0.f;
+        if (f < F && g < G) v = h[(((size_t)f * E + e) * K + k) * G + g] * scale;
+        const _Float16 hi = (_Float16)v;
+        const size_t item = (idx >> 9) * 2;
+        out[(item * 64 + l) * 8 + e8] = hi;
+        out[((item + 1) * 64 + l) * 8 + e8] = (_Float16)(v - (float)hi);
+    }
 }
 
-// One shift: z_cur[r,:] = sum_m S[m, n(r)] * z_prev[m,:]   (node n gathers COLUMN n of S).
-// ONE HALF-WAVE PER NODE, two nodes in flight per wavefront.  The 32 lanes of a half scan 32
-// candidate neighbours m at a time (lane <-> m reads S[m,n]); the ballot of the non-zeros is the
-// column's sparsity pattern (exact: structural zeros contribute nothing).  Each lane then walks its
-// half's mask four neighbours at a time -- index by ffs on the mask, weight S[m,n] and the
-// neighbour's feature row (4 features per lane, one ds_read_b128) straight from LDS, so eight row
-// reads are in flight per wave and no scalar readlane chain sits between them.  fmaf in ascending m.
+// In-place fp32 -> split-f16 conversion of the valid rows of a z buffer (G = 128): a half-wave
+// owns a row, reads all of it (16 bytes per lane), then writes the hi halves to the first 256 bytes
+// of the row and the lo halves to the second 256 bytes.
+__device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs, int wave, int nwaves,
+                                           int lane) {
+    typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+    const int half = lane >> 5, hl = lane & 31;
+    for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {
+        const int r = rb + half;
+        const bool ok = r < R;
+        float* row = z + (ok ? r : rb) * zs;
+        const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
+        __builtin_amdgcn_wave_barrier();                 // all reads of a row precede its writes
+        v4h h, l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            h[c] = (_Float16)v[c];
+            l[c] = (_Float16)(v[c] - (float)h[c]);
+        }
+        if (ok) {
+            *reinterpret_cast<v2f*>(row + 2 * hl) = __builtin_bit_cast(v2f, h);
+            *reinterpret_cast<v2f*>(row + 64 + 2 * hl) = __builtin_bit_cast(v2f, l);
+        }
+    }
+}
+
 __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
                                             const float* __restrict__ zprev,
                                             float* __restrict__ zcur, int R, int wave, int nwaves,
@@ -197,7 +266,10 @@ __device__ __forceinline__ void stage_s(const LsigfArgs& p, float* __restrict__ 
 // RTW  = 16-row MFMA tiles per wave;  NGT = compile-time number of 16-wide input-feature groups
 //        (8 for G = 128: the whole tap's A fragments live in registers and the next tap's are
 //        prefetched during the shift; 0 = run-time NG, fragments loaded inside the loop).
-template <int RTW, int NW, int NGT>
+// H2 (G = 128 only): the contraction runs on the f16 matrix pipe with both operands split in
+//        hi + lo halves (3 MFMAs of K = 32 instead of 8 of K = 4, see encoder_kernel_h2.hip); the
+//        shifts stay exact fp32.  z_k is converted in place once shift k+1 has read it.
+template <int RTW, int NW, int NGT, bool H2>
 __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     constexpr int NT = NW * 64;
@@ -228,10 +300,12 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     // Packed block (e,k,mt,gg): 64 lanes x 4 floats = the A fragments of four MFMA k-steps.
     const int ntaps = p.E * p.K;
     const size_t tap_stride = (size_t)p.MT * NG * 256;
+    // fp32: NGA fragments of 4 k-steps; H2: 4 blocks x (hi, lo) fragments = the same 8 x 16 bytes
     v4f Acur[NGA], Anxt[NGA];
     auto load_tap = [&](v4f (&A)[NGA], int tap) {
         if (NGT && has_mfma) {
-            const float* wt = p.wpk + tap * tap_stride + ((size_t)mt * NGA * 64 + lane) * 4;
+            const float* wt = (H2 ? p.wpk_h : p.wpk) + tap * tap_stride +
+                              ((size_t)mt * NGA * 64 + lane) * 4;
 #pragma unroll
             for (int gg = 0; gg < NGA; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
         }
@@ -255,21 +329,63 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         if (ns && !(p.ablate & 4)) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
     }
 
-    v4f acc[RTW];
+    v4f acc[RTW], acc2[H2 ? RTW : 1];                    // H2: cross terms accumulate separately
 #pragma unroll
     for (int t = 0; t < RTW; ++t) acc[t] = vzero();
+#pragma unroll
+    for (int t = 0; t < (H2 ? RTW : 1); ++t) acc2[t] = vzero();
 
     int tap = 0;
     for (int e = 0; e < p.E; ++e) {
-        if (e > 0 && p.K > 1) {
+        if (e > 0 && (p.K > 1 || H2)) {
             __syncthreads();                           // previous e is done with Sl and the z's
-            stage_s(p, Sl, g0, ng, e, tid, NT);
-            // z_{e,0} = x: the ping-pong overwrote it when K > 2, so edge features e > 0 re-stage
-            // it (E > 1 is outside the planner's configs: simple and correct beats fast here).
-            if (p.K > 2) stage_x(p, zbuf0, g0, ng, tid, NT, true);
+            if (p.K > 1) stage_s(p, Sl, g0, ng, e, tid, NT);
+            // z_{e,0} = x: the ping-pong overwrote it when K > 2 (H2: converted it in place), so edge
+            // features e > 0 re-stage it (E > 1 is outside the planner's configs: simple and
+            // correct beats fast here).
+            if (p.K > 2 || H2) stage_x(p, zbuf0, g0, ng, tid, NT, true);
         }
         __syncthreads();                               // z_0 (and Sl) visible
 
+        if (H2) {
+            // order per tap: shift z_k -> z_{k+1} | convert z_k in place | contract z_k
+            for (int k = 0; k < p.K; ++k, ++tap) {
+                float* zcur = (k & 1) ? zbuf1 : zbuf0;
+                float* znxt = (k & 1) ? zbuf0 : zbuf1;
+                if (k + 1 < p.K && !(p.ablate & 1)) gather_rows(p, Sl, zcur, znxt, R, wave, NW, lane);
+                if (p.zs) {                              // training: keep z_{e,k} (fp32)
+                    float* zd = p.zs + ((size_t)tap * p.B + g0) * N * p.G;
+                    for (int i = tid; i < R * p.G; i += NT) {
+                        const int r = i / p.G, c = i - r * p.G;
+                        zd[i] = zcur[r * zs + c];
+                    }
+                }
+                __syncthreads();                         // every reader of the fp32 z_k is done
+                split_rows(zcur, R, zs, wave, NW, lane);
+                __syncthreads();
+                if (has_mfma && !(p.ablate & 2)) {
+                    const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const v8h Ah = __builtin_bit_cast(v8h, Acur[2 * kb]);
+                        const v8h Al = __builtin_bit_cast(v8h, Acur[2 * kb + 1]);
+#pragma unroll
+                        for (int t = 0; t < RTW; ++t) {   // one row tile's B pair at a time: 8 VGPRs
+                            const v8h Bh = __builtin_bit_cast(
+                                v8h, *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + kb * 16));
+                            const v8h Bl = __builtin_bit_cast(
+                                v8h, *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + 64 + kb * 16));
+                            acc2[t] = mfma16h(Ah, Bl, acc2[t]);
+                            acc[t] = mfma16h(Ah, Bh, acc[t]);
+                            acc2[t] = mfma16h(Al, Bh, acc2[t]);
+                        }
+                    }
+                }
+                // the next tap's fragments fly during the next shift (no second register set)
+                if (tap + 1 < ntaps) load_tap(Acur, tap + 1);
+                if (k + 1 < p.K) __syncthreads();         // z_k's buffer is the target of the next shift
+            }
+        } else
         for (int k = 0; k < p.K; ++k, ++tap) {
             float* zcur = (k & 1) ? zbuf1 : zbuf0;
             if (tap + 1 < ntaps) load_tap(Anxt, tap + 1);       // in flight during the shift
@@ -331,6 +447,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         for (int i = tid; i < 5 * p.F; i += NT) actw[i] = p.act_w[i];
     if (has_mfma) {
         const int f0 = mt * 16 + q * 4;
+        const float h2_inv = H2 ? p.wpk_h[filter_packed_h2_floats(p.G, p.F, p.K, p.E) + 1] : 1.f;
         v4f bv = vzero();
         if (p.bias) {
 #pragma unroll
@@ -339,7 +456,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
 #pragma unroll
         for (int t = 0; t < RTW; ++t) {
             if (rt0 + t < p.rt_total) {
-                v4f v = acc[t] + bv;
+                v4f v = H2 ? (acc[t] + acc2[t]) * h2_inv + bv : acc[t] + bv;
                 if (p.relu) v = vrelu(v);
                 *reinterpret_cast<v4f*>(ybuf + ((rt0 + t) * 16 + a) * zs + f0) = v;
             }
@@ -426,22 +543,25 @@ int g_filter_gpw = 0;               // 0: heuristic below; > 0: forced graphs pe
 int g_filter_waves = 0;             // 0: heuristic; 8 or 16: forced waves per workgroup (tuning)
 int g_filter_ablate = 0;            // measurement-only phase ablation mask (see LsigfArgs::ablate)
 
-template <int RTW, int NW, int NGT>
+template <int RTW, int NW, int NGT, bool H2>
 static hipError_t launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RTW, NW, NGT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RTW, NW, NGT, H2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lsigf_kernel<RTW, NW, NGT>), dim3(grid), dim3(NW * 64), smem, st, a);
+    hipLaunchKernelGGL((lsigf_kernel<RTW, NW, NGT, H2>), dim3(grid), dim3(NW * 64), smem, st, a);
     return hipGetLastError();
 }
 
+int g_filter_f16 = 1;               // split-f16 contraction when G == 128 (GNNPP_TUNE_FILTER_F16)
+
 template <int RTW, int NW>
 static hipError_t launch_ng(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
-    return a.NG == 8 ? launch_one<RTW, NW, 8>(a, grid, smem, st)
-                     : launch_one<RTW, NW, 0>(a, grid, smem, st);
+    if (a.NG != 8) return launch_one<RTW, NW, 0, false>(a, grid, smem, st);
+    return (a.G == 128 && g_filter_f16) ? launch_one<RTW, NW, 8, true>(a, grid, smem, st)
+                                        : launch_one<RTW, NW, 8, false>(a, grid, smem, st);
 }
 
 template <int NW>
@@ -469,6 +589,7 @@ int lsigf_launch(LsigfArgs a, hipStream_t st) {
     a.NG = (a.G + 15) / 16;
     a.MT = (a.F + 15) / 16;
     a.ablate = g_filter_ablate;
+    a.wpk_h = a.wpk + filter_packed_f32_floats(a.G, a.F, a.K, a.E);
     if (a.MT > 8) return -2;                          // F > 128: the caller splits F
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;
@@ -508,6 +629,9 @@ int lsigf_launch(LsigfArgs a, hipStream_t st) {
 
 int filter_pack_launch(const float* h, float* packed, int G, int F, int K, int E, hipStream_t st) {
     const size_t total = filter_packed_floats(G, F, K, E);
+    float* scale = packed + filter_packed_f32_floats(G, F, K, E) + filter_packed_h2_floats(G, F, K, E);
+    hipLaunchKernelGGL(filter_scale_kernel, dim3(1), dim3(256), 256 * sizeof(float), st, h, scale,
+                       (size_t)F * E * K * G);
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(pack_filter_kernel, dim3(grid), dim3(256), 0, st, h, packed, G, F, K, E);
     return hipGetLastError() == hipSuccess ? 0 : -3;

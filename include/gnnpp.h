@@ -55,6 +55,9 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_FILTER_ABLATE   3  /* MEASUREMENT ONLY, results become wrong: bit mask of filter
                                          phases to skip (1 shifts, 2 contraction, 4 GSO staging,
                                          8 epilogue); 0 (default) = the real kernel               */
+#define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
+                                         on the f16 matrix pipe with hi+lo split operands (shifts
+                                         stay exact fp32); 0: fp32 MFMA contraction              */
 #define GNNPP_TUNE_ENCODER_STOP     4  /* MEASUREMENT ONLY (schedule 7): return after phase 1 staging,
                                          2 L0, 3 L1, 4 L2, 5 L3, 6 L4; 0 (default) = whole encoder */
 int         gnnpp_set_tuning(int key, int value);

@@ -94,6 +94,8 @@ void sync_block() {
     }
 }
 
+void wave_sync() { wave_barrier(); }
+
 unsigned long long ballot(int pred) {
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];

@@ -52,6 +52,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void sync_block();
 unsigned long long ballot(int pred);
 int readlane(int v, int src_lane);
+void wave_sync();                 // lockstep point: every lane of the wave reaches it before any leaves
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
@@ -74,6 +75,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_wave_barrier() gnnpp_emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(x) (x)          // only used on wave-uniform values
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
