@@ -37,7 +37,7 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert lib.gnnpp_version() >= 100
     assert b'not supported' in lib.gnnpp_error_string(-2)
     assert lib.gnnpp_filter_packed_floats(128, 128, 3, 1) == 2 * (3 * 8 * 8 * 256) + 4   # fp32 + split-f16 fragments + scale
-    assert lib.gnnpp_filter_packed_floats(5, 3, 2, 1) == 2 * 256
+    assert lib.gnnpp_filter_packed_floats(5, 3, 2, 1) == 2 * 256 + 2 * 512 + 4
     assert lib.gnnpp_encoder_packed_floats() > 555000 // 4
     # argument validation happens before any HIP call, so it is checkable without a GPU
     assert lib.gnnpp_encoder_fwd(None, None, None, 16, None) == -1
