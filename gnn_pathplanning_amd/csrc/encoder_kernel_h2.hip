@@ -381,9 +381,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d[pp][e] = base[aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
         };
-        load_window(dcur, wave);
-        for (int win = wave; win < 25; win += kWaves) {
-            if (win + kWaves < 25) load_window(dnxt, win + kWaves);
+        auto window = [&](const unsigned (&d)[4][8], int win) {
             v4f acc[4][2];
             v8h Bh[4], Bl[4];
 #pragma unroll
@@ -391,9 +389,9 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 typedef unsigned v4u __attribute__((ext_vector_type(4)));
                 v4u h, l;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    h[w] = (dcur[pp][2 * w] & 0xffffu) | (dcur[pp][2 * w + 1] << 16);
-                    l[w] = (dcur[pp][2 * w] >> 16) | (dcur[pp][2 * w + 1] & 0xffff0000u);
+                for (int w = 0; w < 4; ++w) {            // one v_perm_b32 each: low halves / high halves
+                    h[w] = __builtin_amdgcn_perm(d[pp][2 * w + 1], d[pp][2 * w], 0x05040100u);
+                    l[w] = __builtin_amdgcn_perm(d[pp][2 * w + 1], d[pp][2 * w], 0x07060302u);
                 }
                 Bh[pp] = __builtin_bit_cast(v8h, h);
                 Bl[pp] = __builtin_bit_cast(v8h, l);
@@ -419,10 +417,16 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             split8(r[0], r[1], hi, lo);
             X4[(win * 2 + 0) * 64 + lane] = hi;
             X4[(win * 2 + 1) * 64 + lane] = lo;
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dcur[pp][e] = dnxt[pp][e];
+        };
+        // two windows per trip, operands of the next one in flight (no register copies)
+        load_window(dcur, wave);
+        for (int win = wave; win < 25; win += 2 * kWaves) {
+            if (win + kWaves < 25) load_window(dnxt, win + kWaves);
+            window(dcur, win);
+            if (win + kWaves < 25) {
+                if (win + 2 * kWaves < 25) load_window(dcur, win + 2 * kWaves);
+                window(dnxt, win + kWaves);
+            }
         }
     }
     __syncthreads();

@@ -80,6 +80,13 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 
+// v_perm_b32: byte k of the result is byte sel[k] of the 8-byte value {hi (bytes 4..7), lo (bytes 0..3)}
+inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) r |= (unsigned)((v >> (8 * ((sel >> (8 * k)) & 7))) & 0xff) << (8 * k);
+    return r;
+}
 inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 inline int __float_as_int(float f) { int v; std::memcpy(&v, &f, 4); return v; }
 using std::min;
