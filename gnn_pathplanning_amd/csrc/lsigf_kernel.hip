@@ -45,6 +45,9 @@ struct LsigfArgs {
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
+    const int* wait_flags; // optional: x is produced by encoder tiles of 16 agents; wait until
+    int wait_epoch;        //   wait_flags[t] == wait_epoch for every tile t this workgroup reads
+    int* wait_timeouts;    //   bumped if the bounded spin gives up (never expected; tests read it)
     int ablate;            // MEASUREMENT ONLY (tools/ab_bench.py): bit 0 skip the shifts, bit 1 skip
                            // the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
@@ -311,6 +314,27 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         }
     };
     load_tap(Acur, 0);
+
+    if (p.wait_flags) {
+        // x rows [g0*N, (g0+ng)*N) come from encoder tiles of 16 agents that may still be running
+        // (the encoder was launched first; its workgroups are all resident or ahead of us in the
+        // dispatch order, so they make progress while we poll).  Bounded spin: never hangs.
+        if (wave == 0) {
+            const int t_lo = (g0 * N) >> 4, t_hi = ((g0 + ng) * N - 1) >> 4;
+            for (int t = t_lo + lane; t <= t_hi; t += 64) {
+                int spins = 0;
+                while (__hip_atomic_load(p.wait_flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) !=
+                       p.wait_epoch) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1 << 21)) {
+                        __hip_atomic_fetch_add(p.wait_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- zero the pad rows of both z buffers (pad columns are never read when G % 16 == 0) -----
     {
@@ -583,9 +607,11 @@ static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
     return (size_t)2 * rt * 16 * a.zstride * 4 + (size_t)gpw * a.N * a.Ns * 4;
 }
 
-// Chooses graphs-per-workgroup and waves-per-workgroup, checks the LDS budget and launches.
-// Returns a GNNPP_* code.
-int lsigf_launch(LsigfArgs a, hipStream_t st) {
+// Chooses graphs-per-workgroup and waves-per-workgroup and checks the LDS budget.
+// Returns a GNNPP_* code; on success `a` is complete and plan holds the launch geometry.
+struct LsigfPlan { int grid, nw, rtw; size_t smem; };
+
+int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     a.NG = (a.G + 15) / 16;
     a.MT = (a.F + 15) / 16;
     a.ablate = g_filter_ablate;
@@ -613,18 +639,28 @@ int lsigf_launch(LsigfArgs a, hipStream_t st) {
         best = g_filter_gpw;
     a.gpw = best;
     a.rt_total = (a.gpw * a.N + 15) / 16;
-    const size_t smem = lsigf_smem(a, a.gpw);
-    if (smem > (size_t)kLdsBytes) return -2;
-    const int grid = (a.B + a.gpw - 1) / a.gpw;
+    plan.smem = lsigf_smem(a, a.gpw);
+    if (plan.smem > (size_t)kLdsBytes) return -2;
+    plan.grid = (a.B + a.gpw - 1) / a.gpw;
     // waves per workgroup: 16 when there are enough rows / row tiles to feed them
     const int mtp = a.MT > 4 ? 8 : 4;
-    int nw = (a.gpw * a.N > 24) ? 16 : 8;
-    if (g_filter_waves == 8 || g_filter_waves == 16) nw = g_filter_waves;
-    const int chunks = nw / mtp;
-    const int rtw = (a.rt_total + chunks - 1) / chunks;
-    const hipError_t err = nw == 16 ? launch_rtw<16>(rtw, a, grid, smem, st)
-                                    : launch_rtw<8>(rtw, a, grid, smem, st);
+    plan.nw = (a.gpw * a.N > 24) ? 16 : 8;
+    if (g_filter_waves == 8 || g_filter_waves == 16) plan.nw = g_filter_waves;
+    const int chunks = plan.nw / mtp;
+    plan.rtw = (a.rt_total + chunks - 1) / chunks;
+    return 0;
+}
+
+int lsigf_dispatch(const LsigfArgs& a, const LsigfPlan& plan, hipStream_t st) {
+    const hipError_t err = plan.nw == 16 ? launch_rtw<16>(plan.rtw, a, plan.grid, plan.smem, st)
+                                         : launch_rtw<8>(plan.rtw, a, plan.grid, plan.smem, st);
     return err == hipSuccess ? 0 : -3;
+}
+
+int lsigf_launch(LsigfArgs a, hipStream_t st) {
+    LsigfPlan plan;
+    const int rc = lsigf_plan(a, plan);
+    return rc ? rc : lsigf_dispatch(a, plan, st);
 }
 
 int filter_pack_launch(const float* h, float* packed, int G, int F, int K, int E, hipStream_t st) {

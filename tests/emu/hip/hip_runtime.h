@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -40,6 +41,23 @@ constexpr hipError_t hipSuccess = 0;
 constexpr hipError_t hipErrorInvalidValue = 1;
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// host API used by the overlapped policy step: in the emulator launches are synchronous and in order
+typedef void* hipEvent_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0 };
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+constexpr int hipMemcpyDeviceToHost = 2;
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
 namespace gnnpp_emu {
@@ -79,6 +97,11 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __builtin_amdgcn_readfirstlane(x) (x)          // only used on wave-uniform values
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
+#define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
+#define __hip_atomic_fetch_add(ptr, val, order, scope) (*(ptr) += (val))
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+inline void __threadfence() {}
 
 // v_perm_b32: byte k of the result is byte sel[k] of the 8-byte value {hi (bytes 4..7), lo (bytes 0..3)}
 inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {
