@@ -90,6 +90,10 @@ def main():
                     help='extra measurement: independent batches in flight on this many HIP streams '
                          '(reported under "pipelined", never as "value"); 0 disables')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--prewarm-seconds', type=float, default=0.25,
+                    help='untimed device pre-warm before the W warmup steps: the same step in a loop '
+                         'until the clocks / host caches have settled (the first few hundred steps '
+                         'after start-up run ~8 %% slower, profiles/r01_warmup_sweep.jsonl); 0 disables')
     ap.add_argument('--dist-backend', default='nccl',
                     help='nccl (= RCCL, default); gloo only to exercise the multi-rank code path '
                          'on a box with fewer GPUs than ranks (with GNNPP_BENCH_DEVICE=0)')
@@ -139,6 +143,11 @@ def main():
         return net(obs)
 
     with torch.no_grad():
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_seconds:     # set-up, not part of W or K
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             out = step()
         torch.cuda.synchronize()
@@ -197,7 +206,7 @@ def main():
         'metric': 'agent-steps/sec (policy fwd)', 'value': value, 'unit': 'agent-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'prewarm_s': args.prewarm_seconds,
         'config': {'workload': 'policy forward (addGSO+forward), %d agents, %dx%d map GSO, K=%d, '
                                'batch=%d per GPU, eval mode, fp32 GSO resident in HBM'
                                % (N, W, W, K, B),
