@@ -339,16 +339,25 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
+            // (agent, channel, y, x) of the first of four consecutive floats by division, the other
+            // three by carry: the index arithmetic was most of this phase's VALU work
             const int e0 = (tid + k * kThreads) * 4;
+            int ag = e0 / kObsFloats;
+            const int rem = e0 - ag * kObsFloats;
+            int ch = rem / 121;
+            const int r2 = rem - ch * 121;
+            int y = r2 / 11, x = r2 - y * 11;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int e = e0 + c;
-                if (e < valid) {
-                    const int ag = e / kObsFloats, rem = e - ag * kObsFloats;
-                    const int ch = rem / 121, r2 = rem - ch * 121;
-                    const int y = r2 / 11, x = r2 - y * 11;
+                if (e0 + c < valid)
                     bufObs[ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1] =
                         split_word(v[k][c]);
+                if (++x == 11) {
+                    x = 0;
+                    if (++y == 11) {
+                        y = 0;
+                        if (++ch == 3) { ch = 0; ++ag; }
+                    }
                 }
             }
         }
