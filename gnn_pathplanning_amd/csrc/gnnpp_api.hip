@@ -273,4 +273,14 @@ int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream) {
     return rollout_move_launch(*r, static_cast<hipStream_t>(stream));
 }
 
+int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream) {
+    if (!rollout_common_ok(r) || !r->grid || !r->goal || !r->obs || !r->radius || !r->S ||
+        (!r->logits && !r->actions) || !r->reached || !r->start_step || !r->end_step || !r->maxstep ||
+        !r->flags || !r->stats || r->H <= 0 || r->W <= 0)
+        return GNNPP_ERR_ARG;
+    if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
+    if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
+    return rollout_step_launch(*r, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

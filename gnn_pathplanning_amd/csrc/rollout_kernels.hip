@@ -44,24 +44,19 @@ __device__ __forceinline__ void projected_goal(int dx, int dy, int& px, int& py)
 
 constexpr int kObsAgentsPerWg = 16;
 
-// grid = (ceil(N / 16), B): a workgroup builds the episode's occupancy grid in LDS and writes the
-// observations of 16 agents.
-__global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    unsigned char* occ = reinterpret_cast<unsigned char*>(gnnpp_smem);     // [H*W] agents present
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int n0 = blockIdx.x * kObsAgentsPerWg;
-    const int n1 = min(p.N, n0 + kObsAgentsPerWg);
+// Observations of agents [n0, n1) of episode b by `nt` threads; `pos` may live in LDS (fused step)
+// or in global memory; occ = [H*W] bytes of LDS.
+__device__ __forceinline__ void observe_body(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
+                                             unsigned char* occ, int tid, int nt) {
     const int HW = p.H * p.W;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * HW : 0);
-    const int* pos = p.pos + (size_t)b * p.N * 2;
     const int* goal = p.goal + (size_t)b * p.N * 2;
-    for (int i = tid; i < HW; i += 256) occ[i] = 0;
+    for (int i = tid; i < HW; i += nt) occ[i] = 0;
     __syncthreads();
-    for (int n = tid; n < p.N; n += 256) occ[pos[2 * n] * p.W + pos[2 * n + 1]] = 1;
+    for (int n = tid; n < p.N; n += nt) occ[pos[2 * n] * p.W + pos[2 * n + 1]] = 1;
     __syncthreads();
     float* out = p.obs + ((size_t)b * p.N + n0) * 363;
-    for (int e = tid; e < (n1 - n0) * 363; e += 256) {
+    for (int e = tid; e < (n1 - n0) * 363; e += nt) {
         const int n = n0 + e / 363, r = e - (e / 363) * 363;
         const int ch = r / 121, r2 = r - ch * 121;
         const int i = r2 / 11, j = r2 - i * 11;
@@ -83,6 +78,16 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
     }
 }
 
+// grid = (ceil(N / 16), B): a workgroup builds the episode's occupancy grid in LDS and writes the
+// observations of 16 agents.
+__global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * kObsAgentsPerWg;
+    observe_body(p, b, p.pos + (size_t)b * p.N * 2, n0, min(p.N, n0 + kObsAgentsPerWg),
+                 reinterpret_cast<unsigned char*>(gnnpp_smem), threadIdx.x, 256);
+}
+
 // ---- communication GSO ---------------------------------------------------------------------------
 // A = (pdist < R) with zero diagonal; at step 0 R is divided by 1.1 once and multiplied by 1.1
 // until the graph is connected; S = D^-1/2 A D^-1/2 in fp64 (isolated nodes -> 0), rounded to fp32
@@ -98,30 +103,31 @@ __device__ __forceinline__ long long dist2_threshold(double R) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    unsigned long long* adj = reinterpret_cast<unsigned long long*>(gnnpp_smem);   // [N][2]
+constexpr int kGsoSmemBytes = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;
+
+__device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int* pos, bool grow,
+                                         char* smem, int tid, int nt) {
+    unsigned long long* adj = reinterpret_cast<unsigned long long*>(smem);          // [N][2]
     double* inv = reinterpret_cast<double*>(adj + 2 * kMaxAgents);                  // [N]
     double* shared_r = inv + kMaxAgents;                                            // [1]
     long long* shared_t = reinterpret_cast<long long*>(shared_r + 1);               // [1]
     int* shared_flag = reinterpret_cast<int*>(shared_t + 1);                        // [1]
-    const int b = blockIdx.x, tid = threadIdx.x, N = p.N;
-    const int* pos = p.pos + (size_t)b * N * 2;
+    const int N = p.N;
     if (tid == 0) {
         double r = p.radius[b];
-        if (p.grow) r = r / 1.1;
+        if (grow) r = r / 1.1;
         *shared_r = r;
         *shared_flag = 0;
     }
     __syncthreads();
     for (;;) {
         if (tid == 0) {
-            if (p.grow) *shared_r = *shared_r * 1.1;
+            if (grow) *shared_r = *shared_r * 1.1;
             *shared_t = dist2_threshold(*shared_r);
         }
         __syncthreads();
         const long long T = *shared_t;
-        for (int i = tid; i < N; i += 256) {
+        for (int i = tid; i < N; i += nt) {
             unsigned long long w0 = 0, w1 = 0;
             const int xi = pos[2 * i], yi = pos[2 * i + 1];
             for (int j = 0; j < N; ++j) {
@@ -146,16 +152,16 @@ __global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
             *shared_flag = (cnt == N);
         }
         __syncthreads();
-        if (*shared_flag || !p.grow) break;
+        if (*shared_flag || !grow) break;
         __syncthreads();
     }
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += nt) {
         const int deg = __popcll(adj[2 * i]) + __popcll(adj[2 * i + 1]);
         inv[i] = deg ? sqrt(1.0 / (double)deg) : 0.0;
     }
     __syncthreads();
     float* S = p.S + (size_t)b * N * N;
-    for (int i = tid / 16; i < N; i += 16) {                    // 16 rows in flight, 16 lanes per row
+    for (int i = tid / 16; i < N; i += nt / 16) {               // nt/16 rows in flight, 16 lanes per row
         const unsigned long long w0 = adj[2 * i], w1 = adj[2 * i + 1];
         const double ii = inv[i];
         for (int j = tid & 15; j < N; j += 16) {
@@ -167,6 +173,12 @@ __global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
         p.radius[b] = *shared_r;
         if (p.connected) p.connected[b] = *shared_flag;
     }
+}
+
+__global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    const int b = blockIdx.x;
+    gso_body(p, b, p.pos + (size_t)b * p.N * 2, p.grow != 0, gnnpp_smem, threadIdx.x, 256);
 }
 
 // ---- move + collision shielding -------------------------------------------------------------------
@@ -290,10 +302,11 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
     return collision;
 }
 
-__global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    int* red = reinterpret_cast<int*>(gnnpp_smem);              // [3][kMaxAgents] for the statistics
-    const int b = blockIdx.x, lane = threadIdx.x, N = p.N;
+// One episode's move by ONE wavefront (lane = threadIdx.x & 63; no workgroup barrier inside, so it can
+// run as wave 0 of a larger workgroup).  red = [2][kMaxAgents] ints of LDS; spos (optional) receives
+// the positions after the move ([N][2], LDS) for the fused step kernel.
+__device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos) {
+    const int N = p.N;
     int* pos = p.pos + (size_t)b * N * 2;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * p.H * p.W : 0);
     const int* goal = p.goal + (size_t)b * N * 2;
@@ -366,6 +379,7 @@ __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
             if (live[h]) {
                 const int n = lane + 64 * h;
                 pos[2 * n] = r.nxtx[h]; pos[2 * n + 1] = r.nxty[h];
+                r.curx[h] = r.nxtx[h]; r.cury[h] = r.nxty[h];
                 if (r.nxtx[h] == goal[2 * n] && r.nxty[h] == goal[2 * n + 1] && !rch[h]) {
                     rch[h] = 1;
                     est[h] = step;
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
                 red[kMaxAgents + n] = sst[h] < 0 ? 0 : sst[h];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                 // one wave: its LDS writes precede lane 0's reads
         if (lane == 0) {
             int flow = 0, emax = -(1 << 30), smin = 1 << 30;
             for (int n = 0; n < N; ++n) {
@@ -408,6 +422,37 @@ __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
         p.flags[3 * b + 2] = predict_collision;
         if (p.choice_count) p.choice_count[b] = calls;
     }
+    if (spos) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (live[h]) {
+                spos[2 * (lane + 64 * h)] = r.curx[h];
+                spos[2 * (lane + 64 * h) + 1] = r.cury[h];
+            }
+    }
+}
+
+__global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    move_body(p, blockIdx.x, threadIdx.x, reinterpret_cast<int*>(gnnpp_smem), nullptr);
+}
+
+// Fused simulator step between two policy forwards: move (wave 0) -> communication GSO ->
+// observations of the NEW positions, one workgroup per episode, positions handed over in LDS.
+// Same results as the three kernels in sequence (gso never grows the radius here: that only
+// happens at step 0, which runs the separate kernels).
+__global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    int* spos = reinterpret_cast<int*>(gnnpp_smem);                        // [N][2]
+    int* red = spos + 2 * kMaxAgents;                                      // [2][kMaxAgents]
+    char* gso_smem = reinterpret_cast<char*>(red + 2 * kMaxAgents);
+    unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (tid < 64) move_body(p, b, tid, red, spos);
+    __syncthreads();
+    gso_body(p, b, spos, false, gso_smem, tid, nt);
+    __syncthreads();
+    observe_body(p, b, spos, 0, p.N, occ, tid, nt);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -421,13 +466,22 @@ int rollout_observe_launch(const RolloutArgs& a, hipStream_t st) {
 }
 
 int rollout_gso_launch(const RolloutArgs& a, hipStream_t st) {
-    const size_t smem = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;
+    const size_t smem = kGsoSmemBytes;
     hipLaunchKernelGGL(rollout_gso_kernel, dim3(a.B), dim3(256), smem, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int rollout_move_launch(const RolloutArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(rollout_move_kernel, dim3(a.B), dim3(64), 2 * kMaxAgents * sizeof(int), st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int rollout_step_launch(const RolloutArgs& a, hipStream_t st) {
+    const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
+    if (occ > 64 * 1024) return -2;
+    const size_t smem = 4 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ;
+    const int nt = a.N > 32 ? 1024 : 256;               // enough threads for N * 363 observation cells
+    hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B), dim3(nt), smem, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

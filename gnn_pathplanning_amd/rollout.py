@@ -8,7 +8,8 @@ driving utils/multirobotsim_dcenlocal.py), with the episode state resident in HB
     model.addGSO / model() -> DecentralPlannerNet.forward_logits
     sim.move(actionVec, t) -> BatchedRollout.move(...)   move + interRobotCollision (:462-723)
 
-A step is four kernel launches and no host synchronisation; `run()` only reads back a "finished"
+A step is three kernel launches (encoder, filter + head, and one fused move -> gso -> observe
+kernel) and no host synchronisation; `run()` only reads back a "finished"
 flag every few steps.  The reference's random.choice tie-break among colliding agents (:489) is
 replaced by a deterministic rule (`tie_mode`): 'lowest' index, 'hashed' counter-based RNG, or
 'replay' of recorded choices (parity tests).  Positions are (row, col) integers.
@@ -61,6 +62,7 @@ class BatchedRollout:
         self.tie_mode = _TIE[tie_mode]
         self.seed = int(seed) & 0xffffffff
         self.t = 0                                            # steps taken so far
+        self._state_step = -1                                 # step whose positions obs / S describe
         r = _native.RolloutStruct()
         r.grid, r.grid_batched, r.goal, r.pos = _p(self.grid), self.grid_batched, _p(self.goal), _p(self.pos)
         r.B, r.N, r.H, r.W = B, N, self.H, self.W
@@ -91,6 +93,11 @@ class BatchedRollout:
         """Apply one joint action.  logits [N,B,5] (DecentralPlannerNet.forward_logits) or action
         ids [B,N] int32; `choices` [B,C] int16 only for tie_mode='replay'.  Returns flags [B,3]
         (allReachGoal at entry, moveCollision, predictCollision) -- a device tensor."""
+        self._prepare_move(logits, actions, choices, currentstep)
+        self._call(_native.lib().gnnpp_rollout_move, 'gnnpp_rollout_move')
+        return self.flags
+
+    def _prepare_move(self, logits, actions, choices, currentstep):
         r = self._r
         keep = []
         if logits is not None:
@@ -109,16 +116,30 @@ class BatchedRollout:
             r.choices, r.max_choices = _p(ch), int(ch.shape[1])
         self.t += 1
         r.currentstep = self.t if currentstep is None else int(currentstep)
-        self._call(_native.lib().gnnpp_rollout_move, 'gnnpp_rollout_move')
-        return self.flags
+        self._keep = keep                                   # alive until the launch has been enqueued
 
     # -- whole episodes ------------------------------------------------------------------------------
+    def move_and_observe(self, logits=None, actions=None, choices=None, currentstep=None):
+        """move(), then the next step's gso() and observe(), as ONE kernel launch
+        (gnnpp_rollout_step).  Same results as the three calls in sequence."""
+        self._prepare_move(logits, actions, choices, currentstep)
+        self._r.grow = 0
+        self._call(_native.lib().gnnpp_rollout_step, 'gnnpp_rollout_step')
+        self._state_step = self.t                          # obs / S describe the positions after step t
+        return self.flags
+
     def step(self, model):
-        """One rollout step of all episodes: observe -> gso -> policy forward -> move."""
-        obs = self.observe()
-        S = self.gso()
-        model.addGSO(S)
-        return self.move(logits=model.forward_logits(obs))
+        """One rollout step of all episodes: observe -> gso -> policy forward -> move.  From the
+        second step on the observation and the GSO were already produced by the previous step's
+        fused move kernel."""
+        if self._state_step != self.t or self.t == 0:        # step 0 may grow the radius
+            self.observe()
+            self.gso()
+        model.addGSO(self.S)
+        logits = model.forward_logits(self.obs)
+        # one workgroup per episode pays off while an episode's observations are small; large teams
+        # keep the three launches (16 agents per observation workgroup)
+        return self.move_and_observe(logits=logits) if self.N <= 32 else self.move(logits=logits)
 
     def run(self, model, max_steps=None, check_every=8):
         """Step until every episode has finished (all agents at their goals, or maxstep reached).

@@ -214,6 +214,11 @@ typedef struct gnnpp_rollout {
 int gnnpp_rollout_observe(const gnnpp_rollout* r, void* stream);
 int gnnpp_rollout_gso(const gnnpp_rollout* r, void* stream);
 int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream);
+/* move -> gso (grow = 0) -> observe of the new positions in ONE launch: the simulator work between
+ * two policy forwards of a rollout (the loop agents/decentralplannerlocal.py:560-599 runs move,
+ * then getCurrentState + getGSO of the next iteration).  Same results as the three calls in
+ * sequence; fields as for those calls. */
+int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists('/opt/rocm/lib/llvm/bin/clang
                                 reason='host clang++ from ROCm not present')
 
 
-def replay_case(lib, Struct, z, ci, m):
+def replay_case(lib, Struct, z, ci, m, fused=False):
     N, W, T = m['N'], m['W'], m['T']
     grid = np.ascontiguousarray(z['t%d_grid' % ci].astype(np.uint8))
     goal = np.ascontiguousarray(z['t%d_goal' % ci].astype(np.int32))[None]
@@ -42,10 +42,12 @@ def replay_case(lib, Struct, z, ci, m):
     r.tie_mode, r.choice_count = 2, ccount.ctypes.data
     for t in range(T):
         assert (pos[0] == pos_all[t]).all(), (ci, t)
-        assert lib.gnnpp_rollout_observe(ctypes.byref(r), None) == 0
+        if not fused or t == 0:     # fused: the previous gnnpp_rollout_step already produced obs and S
+            assert lib.gnnpp_rollout_observe(ctypes.byref(r), None) == 0
         assert (obs[0] == z['t%d_obs' % ci][t].astype(np.float32)).all(), (ci, t)
         r.grow = int(t == 0)
-        assert lib.gnnpp_rollout_gso(ctypes.byref(r), None) == 0
+        if not fused or t == 0:
+            assert lib.gnnpp_rollout_gso(ctypes.byref(r), None) == 0
         assert radius[0] == z['t%d_radius' % ci][t], (ci, t)
         assert (S[0] == z['t%d_gso' % ci][t].astype(np.float32)).all(), (ci, t)
         assert conn[0] in (0, 1)
@@ -57,7 +59,8 @@ def replay_case(lib, Struct, z, ci, m):
         used += nch
         r.logits, r.actions, r.currentstep = logits.ctypes.data, None, t + 1
         r.choices, r.max_choices = ch.ctypes.data, ch.shape[1]
-        assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == 0
+        r.grow = 0
+        assert (lib.gnnpp_rollout_step if fused else lib.gnnpp_rollout_move)(ctypes.byref(r), None) == 0
         assert ccount[0] == nch, (ci, t, ccount[0], nch)
         assert list(flags[0]) == [int(v) for v in z['t%d_flags' % ci][t]], (ci, t)
         assert (reached[0] == z['t%d_reached' % ci][t]).all(), (ci, t)
@@ -73,6 +76,16 @@ def test_emu_rollout_traces(rollout_golden):
     z, meta = rollout_golden
     for ci, m in enumerate(meta):
         replay_case(lib, RolloutStruct, z, ci, m)
+
+
+def test_emu_rollout_traces_fused_step(rollout_golden):
+    """gnnpp_rollout_step (move -> gso -> observe in one launch) replays the same traces."""
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    lib = emu_lib.load()
+    z, meta = rollout_golden
+    for ci, m in enumerate(meta):
+        replay_case(lib, RolloutStruct, z, ci, m, fused=True)
 
 
 def test_emu_rollout_argument_checks():

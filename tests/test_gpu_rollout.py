@@ -90,6 +90,28 @@ def test_batched_steps_vs_oracle_random_actions(dev, B, N, W, dens):
         assert res['flowtime'][b].item() == eps[b].flowtime
 
 
+@pytest.mark.parametrize('B,N,W,dens', [(64, 10, 20, 0.1), (16, 40, 24, 0.05), (8, 100, 40, 0.05)])
+def test_fused_step_equals_separate_kernels(dev, B, N, W, dens):
+    """move_and_observe (gnnpp_rollout_step: move -> gso -> observe in one launch) against the three
+    separate launches on a twin environment: every state tensor identical after every step."""
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    rng = np.random.default_rng(7 * B + N)
+    grids, starts, goals = random_episodes(rng, B, N, W, dens)
+    maxstep = 10
+    a = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode='hashed', seed=3)
+    b = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode='hashed', seed=3)
+    a.observe(); a.gso(0)
+    b.observe(); b.gso(0)
+    for t in range(maxstep + 2):
+        acts = torch.from_numpy(rng.integers(0, 5, size=(B, N))).to(dev)
+        fa = a.move_and_observe(actions=acts).clone()
+        fb = b.move(actions=acts).clone()
+        b.observe(); b.gso()
+        for name in ('pos', 'obs', 'S', 'radius', 'reached', 'start_step', 'end_step', 'stats', 'choice_count'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (t, name)
+        assert torch.equal(fa, fb), t
+
+
 def test_closed_loop_rollout_with_policy(dev):
     """observe -> gso -> forward -> move on the GPU; every stage checked against the CPU oracles
     fed with the GPU's own state, so a near-tie in the logits cannot make the trajectories drift."""
