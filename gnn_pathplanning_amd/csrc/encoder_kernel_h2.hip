@@ -188,6 +188,19 @@ struct Pos2x2H {
 
 // One (kb, tap) step IT of NMT channel tiles over a compile-time position set: B fragments of the
 // positions the tap reaches (from LDS, or from the preloaded registers Pin), 3 MFMAs per pair.
+// true iff step IT is the first (kb, tap) step, in stream order, whose tap reaches output slot j:
+// its first MFMA then starts from a literal zero instead of a zero-initialised accumulator
+template <int H, int W, class PosFn>
+__device__ __forceinline__ bool first_step_of_slot(int it, int j) {
+    int y = 0, x = 0;
+    if (!PosFn::get(j, y, x)) return false;
+    for (int s = 0; s < it; ++s) {
+        const int tap = s % 9, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        if (y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W) return false;
+    }
+    return true;
+}
+
 template <int IT, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD, int CH = NSLOT>
 __device__ __forceinline__ void tap_mfma(const v4f* in, const v4f* Pin, const v8h (&Ah)[NMT],
                                          const v8h (&Al)[NMT], v4f (&acc)[NSLOT][NMT], int lane) {
@@ -217,10 +230,11 @@ __device__ __forceinline__ void tap_mfma(const v4f* in, const v4f* Pin, const v8
                 const bool used = j < NSLOT && PosFn::get(j, y, x);
                 const int iy = y + dy, ix = x + dx;
                 if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const bool fresh = term == 0 && first_step_of_slot<H, W, PosFn>(IT, j);
 #pragma unroll
                     for (int m = 0; m < NMT; ++m)
                         acc[j][m] = mfma16h(term == 1 ? Al[m] : Ah[m], term == 0 ? Bl[jj] : Bh[jj],
-                                            acc[j][m]);
+                                            fresh ? vzero() : acc[j][m]);
                 }
             }
         }
@@ -452,9 +466,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
     {
         v4f sc[2], sh[2];
-        v4f acc[7][2];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
+        v4f acc[7][2];                                    // first touched by a zero-source MFMA (tap_mfma)
         stream_steps<kh_L1, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
             constexpr int IT = decltype(itc)::value;
             switch (wave) {
@@ -485,9 +497,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
     {
         const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
-        v4f acc[8][2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
+        v4f acc[8][2];                                    // first touched by a zero-source MFMA (tap_mfma)
         stream_steps<kh_L2, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
             constexpr int IT = decltype(itc)::value;
             if (pair == 0) tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<0>, false, 4>(X4, nullptr, Ah, Al, acc, lane);
@@ -519,9 +529,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
     {
         const int mt = wave;
-        v4f acc[4][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j][0] = vzero();
+        v4f acc[4][1];                                    // first touched by a zero-source MFMA (tap_mfma)
         conv_h2<kh_L3, 2, 2, 2, 1, 4, Pos2x2H, true>(ws, ring, Y4, acc, lane);
         v4f sc, sh;
         load_ss(sstab + EncLayout::kHssL3, 64, mt, q, sc, sh);
@@ -541,9 +549,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
-        v4f acc[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j][0] = vzero(); acc[j][1] = vzero(); }
+        v4f acc[4][2];                                    // first touched by a zero-source MFMA (tap_mfma)
         conv_h2<kh_L4, 2, 2, 2, 2, 4, Pos2x2H, true>(ws, ring, X4, acc, lane);
         v4f sc[2], sh[2];
         load_ss(sstab + EncLayout::kHssL4, 128, 2 * wave, q, sc[0], sh[0]);
