@@ -7,8 +7,9 @@
 //
 // Three v_mfma_f32_16x16x32_f16 (K = 32 channels, ~17 cycles each) replace eight
 // v_mfma_f32_16x16x4_f32 (K = 4, 32 cycles each): ~5x less matrix-pipe time per MAC, with the
-// operands still carrying 22 mantissa bits.  Measured against the fp32 oracle the logits move by
-// ~1e-6 (tolerance 1e-4); the exact-fp32 schedules stay selectable (gnnpp_set_tuning).
+// operands still carrying 22 mantissa bits.  Measured against the fp32 oracle: |dlogit| <= 9e-8 on
+// the BASELINE configs (tolerance 1e-4), i.e. the summation-order noise of the fp32 schedules, which
+// stay selectable (gnnpp_set_tuning).
 // Domain: |activation| < 65504 (f16 range; a larger value becomes inf and is not silent).
 // Weights are pre-scaled per layer by a power of two so that their lo halves are normal numbers;
 // f16 subnormals (small lo halves of activations) are kept by the cvt and by the MFMA
@@ -26,8 +27,9 @@
 //     (L1: 7/6/6/6 positions, L2: two pool windows each, 61/60 valid taps -- balanced).
 //   * L3/L4/FC (2x2 and 1x1 images): a wave reads its whole input (64 VGPRs) once and streams
 //     weights only; these layers are bound by the weight stream out of L2 (0.5 MB per tile).
-//   * weights go through the same ordered register ring as v2/v3 (16 x 16 bytes here), packed in
-//     each wave's consumption order so the stream is linear.
+//   * weights are packed in each wave's consumption order and stream through a 16-deep ring of
+//     16-byte loads kept in registers the compiler does not see (h2_ring_load / h2_ring_take below).
+//   * L0 (K = 27) is one 32-slot block on observations staged as (hi, lo) half pairs.
 #include <utility>
 
 #include "gnnpp_common.h"
