@@ -507,8 +507,7 @@ int g_encoder_variant = kDefaultEncoderVariant;   // 7: split-f16 (encoder_kerne
 int encoder_launch_v2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
                       int wino_l0, int late_y);
-int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
-                      int* done_flags, int epoch);
+int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 
 template <bool INPLACE>
 static int encoder_launch_t(const float* obs, const float* packed, float* feat, int M,
@@ -527,7 +526,7 @@ static int encoder_launch_t(const float* obs, const float* packed, float* feat, 
 }
 
 int encoder_launch(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
-    if (g_encoder_variant == 7) return encoder_launch_h2(obs, packed, feat, M, st, nullptr, 0);
+    if (g_encoder_variant == 7) return encoder_launch_h2(obs, packed, feat, M, st);
     if (g_encoder_variant == 3) return encoder_launch_v3(obs, packed, feat, M, st, 1, 1);
     if (g_encoder_variant == 4) return encoder_launch_v3(obs, packed, feat, M, st, 0, 1);
     if (g_encoder_variant == 5) return encoder_launch_v3(obs, packed, feat, M, st, 1, 0);

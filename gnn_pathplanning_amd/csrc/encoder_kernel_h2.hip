@@ -292,11 +292,7 @@ __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH],
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M,
-                                                                 int stop, int* __restrict__ done_flags,
-                                                                 int epoch) {
-    // done_flags (optional): done_flags[tile] = epoch once this tile's features are in memory, so the
-    // filter's workgroups (launched on a second stream, gnnpp_policy_fwd) start as soon as the tiles
-    // of THEIR graphs are finished instead of after the whole grid.
+                                                                 int stop) {
     // `stop` (measurement only, gnnpp_set_tuning): return after phase 1 = staging, 2 = L0, 3 = L1,
     // 4 = L2, 5 = L3, 6 = L4; 0 = the whole encoder
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
@@ -610,18 +606,11 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
-    if (done_flags) {                                    // kernel-uniform
-        __threadfence();                                 // this thread's feature stores are visible
-        __syncthreads();                                 // ... and so are everybody else's
-        if (tid == 0)
-            __hip_atomic_store(done_flags + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 int g_encoder_stop = 0;              // measurement only (GNNPP_TUNE_ENCODER_STOP)
 
-int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
-                      int* done_flags, int epoch) {
+int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
     if (!attr_set) {
@@ -631,7 +620,7 @@ int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M,
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
     hipLaunchKernelGGL(encoder_kernel_h2, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
-                       g_encoder_stop, done_flags, epoch);
+                       g_encoder_stop);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

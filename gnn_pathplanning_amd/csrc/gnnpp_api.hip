@@ -98,66 +98,6 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
     return encoder_launch(obs, packed, feat, M, static_cast<hipStream_t>(stream));
 }
 
-// ---- encoder-tail / filter overlap (gnnpp_policy_fwd) ---------------------------------------------
-// One per device: second stream, fork/join events, per-tile completion flags (+1 timeout counter).
-struct Overlap {
-    hipStream_t s2;
-    hipEvent_t fork, join;
-    int* flags;
-    int cap;            // tiles the flag array holds
-    int epoch;
-    bool ready, failed;
-};
-int g_overlap = 0;                    // GNNPP_TUNE_OVERLAP (off: measured no gain)
-static Overlap g_ov[16] = {};
-
-// Returns the device's overlap state when this call may use it, nullptr for the plain two-launch path.
-// Conditions: split-f16 encoder (the schedule that signals tiles), the filter grid leaves at least
-// half of the CUs to the encoder (so polling workgroups can never starve it), not inside a stream
-// capture (the epoch is a launch-time constant), resources available.
-static Overlap* overlap_for(hipStream_t st, int tiles, int filter_grid) {
-    if (!g_overlap || g_encoder_variant != 7 || g_encoder_stop || filter_grid > 128) return nullptr;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    Overlap& o = g_ov[dev];
-    if (o.failed) return nullptr;
-    if (!o.ready || o.cap < tiles) {
-        if (o.ready) {                 // grow: everything queued on both streams must be finished
-            (void)hipStreamSynchronize(o.s2);
-            (void)hipStreamSynchronize(st);
-            (void)hipFree(o.flags);
-            o.flags = nullptr;
-        } else if (hipStreamCreateWithFlags(&o.s2, hipStreamNonBlocking) != hipSuccess ||
-                   hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) != hipSuccess ||
-                   hipEventCreateWithFlags(&o.join, hipEventDisableTiming) != hipSuccess) {
-            o.failed = true;
-            return nullptr;
-        }
-        int cap = 4096;
-        while (cap < tiles) cap *= 2;
-        if (hipMalloc(reinterpret_cast<void**>(&o.flags), (size_t)(cap + 1) * sizeof(int)) != hipSuccess ||
-            hipMemsetAsync(o.flags, 0, (size_t)(cap + 1) * sizeof(int), st) != hipSuccess) {
-            o.failed = true;
-            return nullptr;
-        }
-        o.cap = cap;
-        o.epoch = 0;
-        o.ready = true;
-    }
-    return &o;
-}
-
-// number of flag waits that gave up (0 unless something is badly wrong); synchronises the device
-static int overlap_timeouts() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_ov[dev].ready) return 0;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&n, g_ov[dev].flags + g_ov[dev].cap, sizeof(int), hipMemcpyDeviceToHost);
-    return n;
-}
-
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
                      const float* filt_packed, const float* gf_bias, const float* act_w,
                      const float* act_b, float* feat_ws, float* logits, int B, int N, int K,
@@ -176,23 +116,8 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
     LsigfPlan plan;
     int rc = lsigf_plan(a, plan);
     if (rc) return rc;
-    Overlap* ov = overlap_for(st, (B * N + kTileAgents - 1) / kTileAgents, plan.grid);
-    if (!ov) {
-        rc = encoder_launch(obs, enc_packed, feat_ws, B * N, st);
-        return rc ? rc : lsigf_dispatch(a, plan, st);
-    }
-    // Overlapped step: the filter's workgroups start on a second stream while the encoder's tail is
-    // still running and wait per 16-agent tile (completion flags stamped with this call's epoch).
-    const int epoch = ++ov->epoch;
-    if (hipEventRecord(ov->fork, st) != hipSuccess || hipStreamWaitEvent(ov->s2, ov->fork, 0) != hipSuccess)
-        return GNNPP_ERR_LAUNCH;
-    rc = encoder_launch_h2(obs, enc_packed, feat_ws, B * N, st, ov->flags, epoch);
-    if (rc) return rc;
-    a.wait_flags = ov->flags; a.wait_epoch = epoch; a.wait_timeouts = ov->flags + ov->cap;
-    rc = lsigf_dispatch(a, plan, ov->s2);
-    if (hipEventRecord(ov->join, ov->s2) != hipSuccess || hipStreamWaitEvent(st, ov->join, 0) != hipSuccess)
-        return GNNPP_ERR_LAUNCH;
-    return rc;
+    rc = encoder_launch(obs, enc_packed, feat_ws, B * N, st);
+    return rc ? rc : lsigf_dispatch(a, plan, st);
 }
 
 int gnnpp_get_tuning(int key) {
@@ -203,8 +128,6 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate;
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop;
         case GNNPP_TUNE_FILTER_F16: return g_filter_f16;
-        case GNNPP_TUNE_OVERLAP: return g_overlap;
-        case GNNPP_STAT_OVERLAP_TIMEOUTS: return overlap_timeouts();
         default: return GNNPP_ERR_ARG;
     }
 }
@@ -222,10 +145,6 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_ENCODER_STOP:
             if (value < 0 || value > 6) return GNNPP_ERR_ARG;
             g_encoder_stop = value;
-            return GNNPP_OK;
-        case GNNPP_TUNE_OVERLAP:
-            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
-            g_overlap = value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_F16:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;

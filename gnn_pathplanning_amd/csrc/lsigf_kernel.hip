@@ -45,9 +45,6 @@ struct LsigfArgs {
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
-    const int* wait_flags; // optional: x is produced by encoder tiles of 16 agents; wait until
-    int wait_epoch;        //   wait_flags[t] == wait_epoch for every tile t this workgroup reads
-    int* wait_timeouts;    //   bumped if the bounded spin gives up (never expected; tests read it)
     int ablate;            // MEASUREMENT ONLY (tools/ab_bench.py): bit 0 skip the shifts, bit 1 skip
                            // the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
@@ -315,27 +312,6 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     };
     load_tap(Acur, 0);
 
-    if (p.wait_flags) {
-        // x rows [g0*N, (g0+ng)*N) come from encoder tiles of 16 agents that may still be running
-        // (the encoder was launched first; its workgroups are all resident or ahead of us in the
-        // dispatch order, so they make progress while we poll).  Bounded spin: never hangs.
-        if (wave == 0) {
-            const int t_lo = (g0 * N) >> 4, t_hi = ((g0 + ng) * N - 1) >> 4;
-            for (int t = t_lo + lane; t <= t_hi; t += 64) {
-                int spins = 0;
-                while (__hip_atomic_load(p.wait_flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) !=
-                       p.wait_epoch) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1 << 21)) {
-                        __hip_atomic_fetch_add(p.wait_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
     // ---- zero the pad rows of both z buffers (pad columns are never read when G % 16 == 0) -----
     {
         const bool all = (p.G & 15) != 0 || (p.F & 15) != 0 || p.Nin < N;
@@ -349,8 +325,8 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     // x and S(e=0) are staged by disjoint thread ranges so their load latencies overlap
     {
         const int ns = (p.K > 1) ? (NT / 4) : 0;       // last quarter of the threads stage S
-        stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
         if (ns && !(p.ablate & 4)) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
+        stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
     }
 
     v4f acc[RTW], acc2[H2 ? RTW : 1];                    // H2: cross terms accumulate separately

@@ -58,13 +58,6 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
                                          on the f16 matrix pipe with hi+lo split operands (shifts
                                          stay exact fp32); 0: fp32 MFMA contraction              */
-#define GNNPP_TUNE_OVERLAP          6  /* 0 (default): encoder and filter launch in order on the
-                                         caller's stream; 1 (experimental, results identical):
-                                         gnnpp_policy_fwd runs the filter on an internal second
-                                         stream, its workgroups waiting per encoder tile -- measured
-                                         no gain (polling workgroups hold LDS the encoder needs)   */
-#define GNNPP_STAT_OVERLAP_TIMEOUTS 7  /* gnnpp_get_tuning only: flag waits that gave up (must be 0);
-                                         synchronises the device                                  */
 #define GNNPP_TUNE_ENCODER_STOP     4  /* MEASUREMENT ONLY (schedule 7): return after phase 1 staging,
                                          2 L0, 3 L1, 4 L2, 5 L3, 6 L4; 0 (default) = whole encoder */
 int         gnnpp_set_tuning(int key, int value);

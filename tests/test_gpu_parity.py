@@ -187,36 +187,6 @@ def test_non_binary_observations(dev, enc_variant):
     assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize('B,N,K,W', [(512, 10, 3, 20), (128, 100, 3, 100), (3, 10, 3, 20), (2048, 10, 3, 20)])
-def test_overlapped_step_equals_sequential_step(dev, B, N, K, W):
-    """gnnpp_policy_fwd can overlap the filter with the encoder's tail (second stream + per-tile
-    flags, off by default); the result must be bit-identical to the two-launch path, repeatedly, and no flag wait may time
-    out.  (2048 x 10 agents: the filter grid is too large for the overlap, the plain path runs.)"""
-    from gnn_pathplanning_amd import _native
-    L = _native.lib()
-    sd = orc.init_state_dict(K, seed=21)
-    net = _net(N, K, dev, sd)
-    S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=3)).float().to(dev)
-    net.addGSO(S)
-    outs = {}
-    try:
-        for mode in (1, 0, 1):
-            assert L.gnnpp_set_tuning(6, mode) == 0
-            for rep in range(4):                        # back-to-back steps: epochs advance, no stale flags
-                obs = orc.synth_obs(B, N, seed=100 + rep).to(dev)
-                got = torch.stack(net(obs), 1)
-                key = (rep,)
-                if key in outs:
-                    assert torch.equal(outs[key], got), (mode, rep)
-                outs[key] = got.clone()
-        assert L.gnnpp_get_tuning(7) == 0                # no flag wait gave up
-    finally:
-        L.gnnpp_set_tuning(6, 0)                         # the default
-    want = orc.policy_forward(sd, S.cpu(), orc.synth_obs(B, N, seed=103))
-    err = max((g.cpu() - w).abs().max().item() for g, w in zip(outs[(3,)].unbind(1), want))
-    assert err <= TOL
-
-
 def test_encoder_dynamic_range(dev, enc_variant):
     """Weights and activations spread over several decades (the split-f16 schedule rescales the
     weights per layer and keeps subnormal lo halves): the relative error must stay at fp32 level."""

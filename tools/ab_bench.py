@@ -59,37 +59,7 @@ def encoder_phases():
     L.gnnpp_set_tuning(0, -1)
 
 
-def overlap_ab():
-    """Whole policy step (addGSO + forward) with the filter overlapped with the encoder's tail (second
-    stream + per-tile flags) vs the plain two-launch path; same session, interleaved."""
-    import time
-    for (N, B, K, W) in ((10, 512, 3, 20), (50, 256, 3, 50), (100, 128, 3, 100), (10, 64, 3, 20)):
-        net = DecentralPlannerNet(Cfg(N, K)).to(dev).eval()
-        net.load_state_dict(orc.init_state_dict(K))
-        obs = orc.synth_obs(B, N, seed=1).to(dev)
-        S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=1)).float().to(dev)
-        row = {'kernel': 'policy_step', 'N': N, 'B': B}
-        for rep in range(3):
-            for mode in (1, 0):
-                L.gnnpp_set_tuning(6, mode)
-                for _ in range(20):
-                    net.addGSO(S); net(obs)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(200):
-                    net.addGSO(S); net(obs)
-                torch.cuda.synchronize()
-                us = (time.perf_counter() - t0) / 200 * 1e6
-                k = 'overlap_us' if mode else 'sequential_us'
-                row[k] = min(round(us, 2), row.get(k, 1e9))
-        L.gnnpp_set_tuning(6, 0)
-        row['timeouts'] = L.gnnpp_get_tuning(7)
-        print(json.dumps(row), flush=True)
-
-
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == 'overlap':
-        return overlap_ab()
     if len(sys.argv) > 1 and sys.argv[1] == 'encoder_phases':
         return encoder_phases()
     sd = orc.init_state_dict(3)

@@ -21,3 +21,22 @@ extern "C" int probe_valu_burn(float* out, int blocks, int iters, void* stream) 
                        1.0f);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// One wave that waits `us` microseconds: mode 0 = s_sleep only, 1 = s_sleep + relaxed atomic load
+// of *flag per iteration, 2 = busy loop reading the clock (no sleep).
+__global__ void spin_kernel(const unsigned long long* flag, int us, int mode, unsigned long long* sink) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();                           // 100 MHz
+    unsigned long long acc = 0;
+    while (wall_clock64() - t0 < (long long)us * 100) {
+        if (mode != 2) __builtin_amdgcn_s_sleep(32);
+        if (mode == 1) acc += __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *sink = acc;
+}
+
+extern "C" int probe_spin(const void* flag, int us, int mode, void* sink, void* stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       (const unsigned long long*)flag, us, mode, (unsigned long long*)sink);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
