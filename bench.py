@@ -281,7 +281,45 @@ def main():
             }
         result['encoder_schedule'] = variant
         if variant == 7:
-            result['dtype'] = 'f32 operands as f16 hi+lo pairs on the f16 MFMA pipe (encoder), f32 MFMA (filter, head); f32 accumulate'
+            result['dtype'] = ('f32 operands as f16 hi+lo pairs on the f16 MFMA pipe (encoder, filter contraction), '
+                               'f32 MFMA (graph shifts, head); f32 accumulate')
+        # Is the step ONE kernel?  (gnnpp_policy_fwd's rule: N <= 16, K = 3, B <= 512 or N >= 13.)  Then the
+        # dominant kernel of the step is the fused policy kernel -- encoder + this graph's filter + head in
+        # one workgroup per graph -- and the roofline describes THAT launch; the encoder-only figures
+        # above move to `encoder_kernel_alone`.
+        fused = (variant == 7 and L.gnnpp_get_tuning(6) == 1 and L.gnnpp_get_tuning(5) == 1 and N <= 16
+                 and K == 3 and (B <= 512 or N >= 13))
+        if fused:
+            act = net.actionsMLP[0]
+            aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
+            gbias = net.GFL[0].bias.detach().reshape(-1).contiguous()
+            lg = torch.empty(N, B, 5, device=dev)
+            taps = net.GFL[0].packed_taps()
+            t_pol = time_kernel(lambda: L.gnnpp_policy_fwd(vp(obs), vp(S), vp(enc), vp(taps), vp(gbias), vp(aw),
+                                                           vp(ab), vp(feat), vp(lg), B, N, K, 0, st), reps=200)
+            pflops = policy_flops_per_agent(K, mean_deg) * M
+            pmc_pol = os.path.join(ROOT, 'profiles', 'pmc_policy_%s.json' % args.config)
+            ptraffic = args.traffic_bytes
+            if ptraffic is None and os.path.exists(pmc_pol):
+                pp = json.load(open(pmc_pol))
+                ptraffic = (2.0 * pp['FETCH_SIZE_KB_per_dispatch'] + pp['WRITE_SIZE_KB_per_dispatch']) * 1024.0
+            enc_alone = result['roofline']
+            exe = (4314 + 288) * 16384.0 * B          # f16 MFMAs per graph tile: encoder 4314 + filter 288
+            result['encoder_kernel_alone'] = enc_alone
+            result['roofline'] = {
+                'kernel': 'gnnpp::encoder_kernel_h2<true> (fused policy kernel: encoder + graph filter + '
+                          'action head, one workgroup per graph)', 'bound': 'mfma',
+                'dtype': enc_alone['dtype'], 'achieved': pflops / t_pol / 1e12, 'peak': enc_alone['peak'],
+                'unit': 'TFLOP/s', 'frac': pflops / t_pol / 1e12 / enc_alone['peak'],
+                'peak_note': enc_alone['peak_note'] + '; a graph of %d agents occupies a 16-lane tile, so at '
+                             'most %d/16 of the pipe does algorithmic work' % (N, N),
+                'vs_fp32_mfma_peak': pflops / t_pol / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                'traffic': ptraffic,
+                'algorithmic_bytes': M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (156288 + 3 * 128 * 128 + 768) * 4.0,
+                'avg_launch_us': t_pol * 1e6, 'flops_per_launch': pflops,
+                'executed_f16_flops_per_launch': exe,
+                'f16_pipe_busy_frac': exe / t_pol / 1e12 / F16_MFMA_PEAK_TFLOPS,
+            }
         # secondary: the graph-filter kernel alone (node-major features in, ReLU'd features out)
         gf = net.GFL[0]
         y = torch.empty(M, 128, device=dev)
@@ -295,8 +333,10 @@ def main():
             'algorithmic_GBps': gf_bytes / t_gf / 1e9, 'hbm_frac_of_8TBps': gf_bytes / t_gf / 8e12,
             'mfma_TFLOPs': 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * M / t_gf / 1e12,
         }
-        result['step_breakdown_us'] = {'encoder': t_enc * 1e6, 'filter+head': t_gf * 1e6,
+        result['step_breakdown_us'] = {'encoder_kernel_alone': t_enc * 1e6, 'filter_kernel_alone': t_gf * 1e6,
                                        'whole_step_wall': 1e6 * elapsed / args.steps}
+        if fused:
+            result['step_breakdown_us']['fused_policy_kernel'] = t_pol * 1e6
         result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value / world / 1e12
 
         # secondary: one whole rollout step on the device (observation builder + communication GSO

@@ -37,12 +37,16 @@
 namespace gnnpp {
 
 constexpr int kRingH = 16;
+constexpr int kZs = 136;               // fused policy tail: row stride of the z / y rows in LDS (floats)
 // per-wave item stream: L1 (36) | L2 (36) | L3 (36) | L4 (72) | FC (16); one item = one 16-byte
 // hi or lo fragment of one (kb, tap, mt)
 constexpr int kh_L1 = 0, kh_L2 = 36, kh_L3 = 72, kh_L4 = 108, kh_FC = 180, kh_END = 196;
+// fused policy kernel (one graph per workgroup): the graph filter's split-f16 taps follow,
+// [tap 3][kb 4][mt_local 2][hi/lo] = 48 items, read in place from gnnpp_filter_pack's buffer
+constexpr int kh_FILT = kh_END, kh_END_POLICY = kh_FILT + 48;
 
 struct WStreamH {                 // per-wave segment bases (wave-uniform: SGPRs) + this lane's offset
-    const float* seg[5];
+    const float* seg[6];
     int lane_bytes;               // lane * 16: the lane's 16 bytes inside every 1 KiB fragment
 };
 
@@ -51,7 +55,11 @@ __device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx)
     if (idx < kh_L3) return ws.seg[1] + (idx - kh_L2) * EncLayout::kHItem;
     if (idx < kh_L4) return ws.seg[2] + (idx - kh_L3) * EncLayout::kHItem;
     if (idx < kh_FC) return ws.seg[3] + (idx - kh_L4) * EncLayout::kHItem;
-    return ws.seg[4] + (idx - kh_FC) * EncLayout::kHItem;
+    if (idx < kh_FILT) return ws.seg[4] + (idx - kh_FC) * EncLayout::kHItem;
+    // filter block (tap, mt, kb) of gnnpp_filter_pack: ((tap * 8 + mt) * 4 + kb) * 512 floats, lo at +256;
+    // seg[5] already points at this wave's first channel tile
+    const int j = idx - kh_FILT, hl = j & 1, ml = (j >> 1) & 1, kb = (j >> 2) & 3, tap = j >> 4;
+    return ws.seg[5] + tap * (8 * 4 * 512) + ml * (4 * 512) + kb * 512 + hl * 256;
 }
 
 // The weight stream is what bounds this kernel (tools/probe/wstream_probe.hip: a CU pulls ~70 GB/s
@@ -74,8 +82,9 @@ __device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx)
     X(12, 240, 241, 242, 243) X(13, 244, 245, 246, 247) X(14, 248, 249, 250, 251)             \
     X(15, 252, 253, 254, 255)
 
+template <int END>
 __device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRingH], int idx) {
-    if (idx < kh_END) {
+    if (idx < END) {
         const float* p = h2_item_ptr(ws, idx);             // wave-uniform (scalar) fragment base
 #if defined(__HIP_DEVICE_COMPILE__)
         (void)ring;
@@ -96,10 +105,11 @@ __device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRi
 }
 
 // the fragment of item idx, once it has landed
+template <int END>
 __device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)ring;
-    const int younger = kh_END - 1 - idx < kRingH - 1 ? kh_END - 1 - idx : kRingH - 1;
+    const int younger = END - 1 - idx < kRingH - 1 ? END - 1 - idx : kRingH - 1;
     switch (younger) {
 #define GNNPP_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ") ; RINGWAIT" ::: "memory"); break;
         GNNPP_W(0) GNNPP_W(1) GNNPP_W(2) GNNPP_W(3) GNNPP_W(4) GNNPP_W(5) GNNPP_W(6) GNNPP_W(7)
@@ -248,7 +258,7 @@ __device__ __forceinline__ void tap_mfma(const v4f* in, const v4f* Pin, const v8
 // traffic is issued from this wave-uniform, branch-free code; per-wave specialisation (which
 // positions a wave owns) lives inside `body`, so every path through the kernel performs the same
 // ring sequence (tools/check_ring_isa.py relies on that).
-template <int START, int NMT, class Body, int... IT>
+template <int END, int START, int NMT, class Body, int... IT>
 __device__ __forceinline__ void stream_steps(const WStreamH& ws, v4f (&ring)[kRingH], Body&& body,
                                              std::integer_sequence<int, IT...>) {
     auto step = [&](auto itc) {
@@ -258,10 +268,10 @@ __device__ __forceinline__ void stream_steps(const WStreamH& ws, v4f (&ring)[kRi
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
             const int idx = START + (it * NMT + m) * 2;
-            Ah[m] = h2_ring_take(ring, idx);
-            h2_ring_load(ws, ring, idx + kRingH);
-            Al[m] = h2_ring_take(ring, idx + 1);
-            h2_ring_load(ws, ring, idx + 1 + kRingH);
+            Ah[m] = h2_ring_take<END>(ring, idx);
+            h2_ring_load<END>(ws, ring, idx + kRingH);
+            Al[m] = h2_ring_take<END>(ring, idx + 1);
+            h2_ring_load<END>(ws, ring, idx + 1 + kRingH);
         }
         body(itc, Ah, Al);
     };
@@ -269,7 +279,7 @@ __device__ __forceinline__ void stream_steps(const WStreamH& ws, v4f (&ring)[kRi
 }
 
 // a whole layer for one position set (no per-wave specialisation)
-template <int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD>
+template <int END, int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD>
 __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH], const v4f* in,
                                         v4f (&acc)[NSLOT][NMT], int lane) {
     v4f Pin[PRELOAD ? H * W * NKB * 2 : 1];
@@ -277,7 +287,7 @@ __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH],
 #pragma unroll
         for (int i = 0; i < H * W * NKB * 2; ++i) Pin[i] = in[i * 64 + lane];
     }
-    stream_steps<START, NMT>(ws, ring, [&](auto itc, const v8h (&Ah)[NMT], const v8h (&Al)[NMT]) {
+    stream_steps<END, START, NMT>(ws, ring, [&](auto itc, const v8h (&Ah)[NMT], const v8h (&Al)[NMT]) {
         tap_mfma<decltype(itc)::value, NKB, H, W, NMT, NSLOT, PosFn, PRELOAD>(in, Pin, Ah, Al, acc, lane);
     }, std::make_integer_sequence<int, 9 * NKB>{});
 }
@@ -289,10 +299,26 @@ __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH],
 #else
 #define GNNPP_H2_VGPR_BUDGET
 #endif
+// What the fused policy kernel needs after the encoder (FUSED = true): one workgroup = one graph of
+// N <= 16 agents, so the graph filter (K = 3 taps, 128 -> 128) and the action head run right here on the
+// features, which never leave the chip: no feature round trip through HBM, no second launch, and no
+// filter kernel whose cost is one workgroup's latency.
+struct PolicyTail {
+    const void* S;            // [B,N,N] fp32 or fp64
+    const float* filt_h2;     // split-f16 taps of gnnpp_filter_pack (+ {2^k, 2^-k} behind them)
+    const float* gf_bias;     // [128] or nullptr
+    const float* act_w;       // [5,128]
+    const float* act_b;       // [5]
+    float* logits;            // [N,B,5]
+    int B, N, s_is_f64;
+};
+
+template <bool FUSED>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M,
-                                                                 int stop) {
+                                                                 int stop, const PolicyTail pt) {
+    constexpr int END = FUSED ? kh_END_POLICY : kh_END;
     // `stop` (measurement only, gnnpp_set_tuning): return after phase 1 = staging, 2 = L0, 3 = L1,
     // 4 = L2, 5 = L3, 6 = L4; 0 = the whole encoder
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
@@ -306,7 +332,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: real branches per wave
     const int a = lane & 15;
     const int q = lane >> 4;
-    const int agent0 = blockIdx.x * kTileAgents;
+    const int agent0 = blockIdx.x * (FUSED ? pt.N : kTileAgents);   // FUSED: the tile is graph blockIdx.x
 
     WStreamH ws;
     ws.seg[0] = pk + EncLayout::kH1;
@@ -314,6 +340,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     ws.seg[2] = pk + EncLayout::kH3 + wave * (36 * EncLayout::kHItem);
     ws.seg[3] = pk + EncLayout::kH4 + wave * (72 * EncLayout::kHItem);
     ws.seg[4] = pk + EncLayout::kHfc + wave * (16 * EncLayout::kHItem);
+    ws.seg[5] = FUSED ? pt.filt_h2 + wave * (2 * 4 * 512) : pk;     // channel tiles 2w, 2w+1
     ws.lane_bytes = lane * 16;
     // BatchNorm scale/shift of L1..L4: fetched now, parked in LDS after L0 (behind Y's live part), so
     // that no compiler-issued global load (whose wait would drain the ring) sits between the layers
@@ -322,19 +349,32 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     for (int i = 0; i < 3; ++i)
         ssv[i] = pk[EncLayout::kHss + min(tid + i * kThreads, EncLayout::kHssFloats - 1)];
     float* const sstab = bufObs + 16 * 256;                          // Y holds <= 16 fragments
+    float* const Ssm = sstab + EncLayout::kHssFloats;                // FUSED: GSO, [16][17], zero padded
+    float* const actw = Ssm + 16 * 17;                               // FUSED: action head weights [5][128]
+    float sval = 0.f, awv[3] = {0.f, 0.f, 0.f};
+    if (FUSED) {
+        const int m = tid >> 4, n = tid & 15;                        // one GSO entry per thread
+        if (m < pt.N && n < pt.N) {
+            const size_t i = ((size_t)blockIdx.x * pt.N + m) * pt.N + n;
+            sval = pt.s_is_f64 ? (float)reinterpret_cast<const double*>(pt.S)[i]
+                               : reinterpret_cast<const float*>(pt.S)[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) awv[i] = pt.act_w[min(tid + i * kThreads, 5 * 128 - 1)];
+    }
     v4f ring[kRingH];
 #pragma unroll
-    for (int i = 0; i < kRingH; ++i) h2_ring_load(ws, ring, i);
+    for (int i = 0; i < kRingH; ++i) h2_ring_load<END>(ws, ring, i);
 
     // ---- observations: all loads first, zero-fill while they fly, then scatter (as v2/v3) -------
     {
         constexpr int NV4 = kTileAgents * kObsFloats / 4;
         constexpr int PER = (NV4 + kThreads - 1) / kThreads;
-        const int n_agents = min(kTileAgents, M - agent0);
+        const int n_agents = FUSED ? pt.N : min(kTileAgents, M - agent0);
         const int valid = n_agents * kObsFloats;
         const float* src = obs + (size_t)agent0 * kObsFloats;
         v4f v[PER];
-        if (n_agents == kTileAgents) {
+        if (!FUSED && n_agents == kTileAgents) {         // (a graph's rows are only 8-byte aligned)
 #pragma unroll
             for (int k = 0; k < PER; ++k)
                 v[k] = *reinterpret_cast<const v4f*>(src + 4 * min(tid + k * kThreads, NV4 - 1));
@@ -460,12 +500,18 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     for (int i = 0; i < 3; ++i)
         if (tid + i * kThreads < EncLayout::kHssFloats) sstab[tid + i * kThreads] = ssv[i];
     // (first read after L1's mid-layer barrier)
+    if (FUSED) {
+        Ssm[(tid >> 4) * 17 + (tid & 15)] = sval;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (tid + i * kThreads < 5 * 128) actw[tid + i * kThreads] = awv[i];
+    }
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
     {
         v4f sc[2], sh[2];
         v4f acc[7][2];                                    // first touched by a zero-source MFMA (tap_mfma)
-        stream_steps<kh_L1, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
+        stream_steps<END, kh_L1, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
             constexpr int IT = decltype(itc)::value;
             switch (wave) {
                 case 0: tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<0>, false>(X4, nullptr, Ah, Al, acc, lane); break;
@@ -496,7 +542,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     {
         const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
         v4f acc[8][2];                                    // first touched by a zero-source MFMA (tap_mfma)
-        stream_steps<kh_L2, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
+        stream_steps<END, kh_L2, 2>(ws, ring, [&](auto itc, const v8h (&Ah)[2], const v8h (&Al)[2]) {
             constexpr int IT = decltype(itc)::value;
             if (pair == 0) tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<0>, false, 4>(X4, nullptr, Ah, Al, acc, lane);
             else           tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<1>, false, 4>(X4, nullptr, Ah, Al, acc, lane);
@@ -528,7 +574,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     {
         const int mt = wave;
         v4f acc[4][1];                                    // first touched by a zero-source MFMA (tap_mfma)
-        conv_h2<kh_L3, 2, 2, 2, 1, 4, Pos2x2H, true>(ws, ring, Y4, acc, lane);
+        conv_h2<END, kh_L3, 2, 2, 2, 1, 4, Pos2x2H, true>(ws, ring, Y4, acc, lane);
         v4f sc, sh;
         load_ss(sstab + EncLayout::kHssL3, 64, mt, q, sc, sh);
         v2f* const X2 = reinterpret_cast<v2f*>(X);
@@ -548,7 +594,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
         v4f acc[4][2];                                    // first touched by a zero-source MFMA (tap_mfma)
-        conv_h2<kh_L4, 2, 2, 2, 2, 4, Pos2x2H, true>(ws, ring, X4, acc, lane);
+        conv_h2<END, kh_L4, 2, 2, 2, 2, 4, Pos2x2H, true>(ws, ring, X4, acc, lane);
         v4f sc[2], sh[2];
         load_ss(sstab + EncLayout::kHssL4, 128, 2 * wave, q, sc[0], sh[0]);
         load_ss(sstab + EncLayout::kHssL4, 128, 2 * wave + 1, q, sc[1], sh[1]);
@@ -583,10 +629,10 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int idx = kh_FC + (kb * 2 + m) * 2;
-                Ah[m] = h2_ring_take(ring, idx);
-                h2_ring_load(ws, ring, idx + kRingH);
-                Al[m] = h2_ring_take(ring, idx + 1);
-                h2_ring_load(ws, ring, idx + 1 + kRingH);
+                Ah[m] = h2_ring_take<END>(ring, idx);
+                h2_ring_load<END>(ws, ring, idx + kRingH);
+                Al[m] = h2_ring_take<END>(ring, idx + 1);
+                h2_ring_load<END>(ws, ring, idx + 1 + kRingH);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -595,7 +641,18 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 acc[m][0] = mfma16h(Ah[m], Bh[kb], acc[m][0]);
             }
         }
-        if (agent0 + a < M) {
+        if (FUSED) {
+            // features of the graph's agents: rows of z_0 in LDS (fp32, row stride 136), lane (q, a)
+            // holds channels 16 mt + 4 q .. + 3 of agent a
+            const float inv = pk[EncLayout::kHinv + 4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int mt = 2 * wave + m;
+                const v4f b = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt * 16 + q * 4);
+                *reinterpret_cast<v4f*>(X + a * kZs + mt * 16 + q * 4) =
+                    vrelu((acc[m][0] + acc[m][1]) * inv + b);
+            }
+        } else if (agent0 + a < M) {
             const float inv = pk[EncLayout::kHinv + 4];
             float* dst = feat + (size_t)(agent0 + a) * 128 + q * 4;
 #pragma unroll
@@ -603,6 +660,109 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 const int mt = 2 * wave + m;
                 const v4f b = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt * 16 + q * 4);
                 *reinterpret_cast<v4f*>(dst + mt * 16) = vrelu((acc[m][0] + acc[m][1]) * inv + b);
+            }
+        }
+    }
+    if (!FUSED) return;
+
+    // ==== graph filter + action head of this graph (K = 3, G = F = 128) ===========================
+    // z_k = z_{k-1} S as a dense product on the fp32 MFMA, all m in ascending order: bit-identical to
+    // lsigf_kernel's sparse gather (fmaf(0, z, acc) == acc).  Rows >= N hold the features of the
+    // zero-observation padding lanes; S is zero there, so they never reach a real node.
+    float* const z0 = X;
+    __syncthreads();                                     // z_0 complete
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        const float* zp = z0 + (k - 1) * (16 * kZs);
+        float* zn = z0 + k * (16 * kZs);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ft = 2 * wave + t;
+            v4f d = vzero();
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int m = 4 * st + q;
+                d = mfma16(zp[m * kZs + 16 * ft + a], Ssm[m * 17 + a], d);   // A[i = feature][k = m], B[k = m][j = node]
+            }
+            *reinterpret_cast<v4f*>(zn + a * kZs + 16 * ft + 4 * q) = d;    // node a, features 16 ft + 4 q ..
+        }
+        __syncthreads();
+    }
+    // z_0..z_2 -> (hi, lo) half rows in place: 48 rows, a half-wave per row (as lsigf_kernel's split_rows)
+    {
+        typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+        const int half = lane >> 5, hl = lane & 31;
+        for (int rb = 2 * wave; rb < 48; rb += 2 * kWaves) {
+            float* row = z0 + (rb + half) * kZs;
+            const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
+            __builtin_amdgcn_wave_barrier();             // all reads of a row precede its writes
+            v4h h, l;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                h[c] = (_Float16)v[c];
+                l[c] = (_Float16)(v[c] - (float)h[c]);
+            }
+            *reinterpret_cast<v2f*>(row + 2 * hl) = __builtin_bit_cast(v2f, h);
+            *reinterpret_cast<v2f*>(row + 64 + 2 * hl) = __builtin_bit_cast(v2f, l);
+        }
+    }
+    __syncthreads();
+    // contraction on the f16 pipe: channel tiles 2w, 2w+1; same term order as lsigf_kernel
+    v4f fa[2] = {vzero(), vzero()}, fc[2] = {vzero(), vzero()};
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const float* zr = z0 + (tap * 16 + a) * kZs + 4 * q;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            __builtin_amdgcn_sched_barrier(kSchedItemMask);
+            v8h Ah[2], Al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int idx = kh_FILT + ((tap * 4 + kb) * 2 + m) * 2;
+                Ah[m] = h2_ring_take<END>(ring, idx);
+                h2_ring_load<END>(ws, ring, idx + kRingH);
+                Al[m] = h2_ring_take<END>(ring, idx + 1);
+                h2_ring_load<END>(ws, ring, idx + 1 + kRingH);
+            }
+            const v8h Bh = as_h8(*reinterpret_cast<const v4f*>(zr + 16 * kb));
+            const v8h Bl = as_h8(*reinterpret_cast<const v4f*>(zr + 64 + 16 * kb));
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                fc[m] = mfma16h(Ah[m], Bl, fc[m]);
+                fa[m] = mfma16h(Ah[m], Bh, fa[m]);
+                fc[m] = mfma16h(Al[m], Bh, fc[m]);
+            }
+        }
+    }
+    // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA
+    float* const yb = z0 + 3 * (16 * kZs);
+    {
+        const float finv = pt.filt_h2[filter_packed_h2_floats(128, 128, 3, 1) + 1];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int f0 = (2 * wave + m) * 16 + 4 * q;
+            v4f bv = vzero();
+            if (pt.gf_bias) bv = *reinterpret_cast<const v4f*>(pt.gf_bias + f0);
+            *reinterpret_cast<v4f*>(yb + a * kZs + f0) = vrelu((fa[m] + fc[m]) * finv + bv);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        v4f d = vzero();
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) {
+            const int f0 = gg * 16 + 4 * q;
+            v4f A = vzero();
+            if (a < 5) A = *reinterpret_cast<const v4f*>(actw + a * 128 + f0);
+            d = mfma16x4(A, *reinterpret_cast<const v4f*>(yb + a * kZs + f0), d);
+        }
+        if (a < pt.N && q < 2) {                          // lane holds node a, outputs 4 q + reg
+            float* dst = pt.logits + ((size_t)a * pt.B + blockIdx.x) * 5;
+            if (q == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dst[t] = d[t] + pt.act_b[t];
+            } else {
+                dst[4] = d[0] + pt.act_b[4];
             }
         }
     }
@@ -614,13 +774,27 @@ int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M,
     static bool attr_set = false;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_h2),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_h2<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL(encoder_kernel_h2, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
-                       g_encoder_stop);
+    hipLaunchKernelGGL(encoder_kernel_h2<false>, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
+                       g_encoder_stop, PolicyTail{});
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// whole policy step of B graphs with N <= 16 agents, K = 3: one workgroup per graph
+int policy_launch_fused(const float* obs, const float* packed, const PolicyTail& pt, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_h2<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(encoder_kernel_h2<true>, dim3(pt.B), dim3(kThreads), smem, st, obs, packed,
+                       static_cast<float*>(nullptr), pt.B * pt.N, 0, pt);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -98,6 +98,8 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
     return encoder_launch(obs, packed, feat, M, static_cast<hipStream_t>(stream));
 }
 
+int g_fused_policy = 1;               // GNNPP_TUNE_FUSED_POLICY
+
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
                      const float* filt_packed, const float* gf_bias, const float* act_w,
                      const float* act_b, float* feat_ws, float* logits, int B, int N, int K,
@@ -116,6 +118,18 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
     LsigfPlan plan;
     int rc = lsigf_plan(a, plan);
     if (rc) return rc;
+    // Fused path: a 16-lane tile per graph wastes (16 - N) / 16 of the encoder's lanes, which is free
+    // while the graphs fit the chip in one round (2 workgroups per CU) -- measured -8 % at B = 512,
+    // -17 % at B <= 64 (N = 10), but +40 % at B = 2048 -- or when N nearly fills the tile.
+    const bool fused_pays = B <= 2 * 256 || N >= 13;
+    if (g_fused_policy && fused_pays && g_encoder_variant == 7 && g_filter_f16 && !g_filter_ablate &&
+        !g_encoder_stop && N <= kTileAgents && K == 3) {
+        // one launch: a workgroup encodes one graph's agents and runs its filter + action head
+        PolicyTail pt;
+        pt.S = S; pt.filt_h2 = a.wpk_h; pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b;
+        pt.logits = logits; pt.B = B; pt.N = N; pt.s_is_f64 = s_is_f64;
+        return policy_launch_fused(obs, enc_packed, pt, st);
+    }
     rc = encoder_launch(obs, enc_packed, feat_ws, B * N, st);
     return rc ? rc : lsigf_dispatch(a, plan, st);
 }
@@ -128,6 +142,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate;
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop;
         case GNNPP_TUNE_FILTER_F16: return g_filter_f16;
+        case GNNPP_TUNE_FUSED_POLICY: return g_fused_policy;
         default: return GNNPP_ERR_ARG;
     }
 }
@@ -145,6 +160,10 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_ENCODER_STOP:
             if (value < 0 || value > 6) return GNNPP_ERR_ARG;
             g_encoder_stop = value;
+            return GNNPP_OK;
+        case GNNPP_TUNE_FUSED_POLICY:
+            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            g_fused_policy = value;
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_F16:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;

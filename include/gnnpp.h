@@ -58,6 +58,12 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
                                          on the f16 matrix pipe with hi+lo split operands (shifts
                                          stay exact fp32); 0: fp32 MFMA contraction              */
+#define GNNPP_TUNE_FUSED_POLICY     6  /* 1 (default): for teams of N <= 16 agents and K = 3 taps (with
+                                         encoder schedule 7 and FILTER_F16 = 1), when B <= 512 graphs
+                                         or N >= 13, gnnpp_policy_fwd is ONE kernel -- a workgroup
+                                         encodes one graph's agents, then runs that graph's filter and
+                                         action head on chip (identical logits); 0: always the encoder
+                                         kernel followed by the filter kernel                        */
 #define GNNPP_TUNE_ENCODER_STOP     4  /* MEASUREMENT ONLY (schedule 7): return after phase 1 staging,
                                          2 L0, 3 L1, 4 L2, 5 L3, 6 L4; 0 (default) = whole encoder */
 int         gnnpp_set_tuning(int key, int value);

@@ -94,6 +94,42 @@ def test_emu_policy_golden(emu, policy_golden, variant):
         assert (acts == want.argmax(-1)).all()
 
 
+def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden):
+    """GNNPP_TUNE_FUSED_POLICY: one workgroup per graph (encoder + dense-MFMA shifts + split-f16
+    contraction + head) must give the very same logits as the encoder kernel followed by the filter
+    kernel: same arithmetic in the same order (the dense shift adds exact zeros)."""
+    el, lib = emu
+    z, meta = policy_golden
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
+    enc = el.pack_encoder(lib, sd)
+    filt = el.pack_filter(lib, z['sd/GFL.0.weight'])
+    gb = el.f32(sd['GFL.0.bias'].reshape(-1))
+    aw, ab = el.f32(sd['actionsMLP.0.weight']), el.f32(sd['actionsMLP.0.bias'])
+    ran = 0
+    try:
+        for i, m in enumerate(meta):
+            if m['K'] != 3 or m['N'] > 16:
+                continue
+            B, N = m['B'], m['N']
+            obs = el.f32(z['p%d_obs' % i])
+            S = np.ascontiguousarray(z['p%d_S' % i])
+            outs = []
+            for mode in (1, 0):
+                assert lib.gnnpp_set_tuning(6, mode) == 0
+                logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+                ws = np.zeros((B * N, 128), dtype=np.float32)
+                assert lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb),
+                                            el.ptr(aw), el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, 3,
+                                            int(S.dtype == np.float64), None) == 0
+                outs.append(logits)
+            assert np.array_equal(outs[0], outs[1]), (i, m, np.abs(outs[0] - outs[1]).max())
+            assert np.abs(outs[0].transpose(1, 0, 2) - z['p%d_logits' % i]).max() <= TOL
+            ran += 1
+    finally:
+        lib.gnnpp_set_tuning(6, 1)
+    assert ran >= 2
+
+
 def test_emu_filter_forced_gpw(emu, lsigf_golden):
     """The graphs-per-workgroup choice only changes the schedule, never the result."""
     el, lib = emu

@@ -187,6 +187,32 @@ def test_non_binary_observations(dev, enc_variant):
     assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('B,N,W', [(512, 10, 20), (33, 16, 24), (5, 1, 8), (64, 7, 12), (600, 14, 20), (2048, 10, 20)])
+def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W):
+    """For N <= 16 and K = 3 the policy step is ONE kernel (a workgroup per graph: encoder, dense-MFMA
+    shifts, split-f16 contraction, head).  It performs the same arithmetic in the same order as the
+    encoder kernel + filter kernel, so the logits must be identical; fp64 and fp32 GSOs both."""
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    sd = orc.init_state_dict(3, seed=31)
+    net = _net(N, 3, dev, sd)
+    obs = orc.synth_obs(B, N, seed=B + 3 * N).to(dev)
+    S64 = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=N))
+    try:
+        for S in (S64.to(dev), S64.float().to(dev)):
+            net.addGSO(S)
+            outs = []
+            for mode in (1, 0, 1):
+                assert L.gnnpp_set_tuning(6, mode) == 0
+                outs.append(net.forward_logits(obs).clone())
+            assert torch.equal(outs[0], outs[2])
+            assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+    finally:
+        L.gnnpp_set_tuning(6, 1)
+    want = torch.stack(orc.policy_forward(sd, S64.float(), obs.cpu()), 0)
+    assert (outs[0].cpu() - want).abs().max().item() <= TOL
+
+
 def test_encoder_dynamic_range(dev, enc_variant):
     """Weights and activations spread over several decades (the split-f16 schedule rescales the
     weights per layer and keeps subnormal lo halves): the relative error must stay at fp32 level."""

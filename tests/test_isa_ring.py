@@ -21,17 +21,19 @@ def test_ring_registers_are_private_to_the_asm(tmp_path):
     subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
                            '-Wno-unused-result', '-w',
                            os.path.join(ROOT, 'gnn_pathplanning_amd', 'csrc', 'gnnpp_api.hip'), '-o', out])
-    errors, stats, meta = check_ring_isa.check(out)
-    assert not errors, errors[:10]
-    assert stats['loads'] == 196 and stats['takes'] == 196          # every stream item, exactly once
-    assert meta == {'NumVgprs': 256, 'ScratchSize': 0, 'Occupancy': 2}
+    # encoder only (196 stream items) and fused policy kernel (+ 48 filter-tap fragments)
+    for kern, items in (('encoder_kernel_h2ILb0', 196), ('encoder_kernel_h2ILb1', 244)):
+        errors, stats, meta = check_ring_isa.check(out, kern)
+        assert not errors, (kern, errors[:10])
+        assert stats['loads'] == items and stats['takes'] == items, (kern, stats)   # each item exactly once
+        assert meta == {'NumVgprs': 256, 'ScratchSize': 0, 'Occupancy': 2}, (kern, meta)
 
 
 def test_checker_catches_violations(tmp_path):
     """The checker itself: a compiler-looking instruction that touches a ring register, a take
     with too weak a wait, and a reload of a pending slot must all be reported."""
     import check_ring_isa
-    good = '''_ZN5gnnpp17encoder_kernel_h2EPKfS1_Pfii:
+    good = '''_ZN5gnnpp17encoder_kernel_h2ILb0EEEvPKfS2_Pfii:
 \tglobal_load_dwordx4 v[192:195], v1, s[0:1] ; RINGLOAD 0
 \tglobal_load_dwordx4 v[196:199], v1, s[0:1] ; RINGLOAD 1
 \ts_waitcnt vmcnt(1) ; RINGWAIT

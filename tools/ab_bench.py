@@ -59,7 +59,35 @@ def encoder_phases():
     L.gnnpp_set_tuning(0, -1)
 
 
+def fused_ab():
+    """Whole policy step (addGSO + forward): fused one-kernel path vs encoder kernel + filter kernel."""
+    import time
+    for (N, B, K, W) in ((10, 512, 3, 20), (10, 64, 3, 20), (10, 1, 3, 20), (16, 320, 3, 24), (10, 2048, 3, 20)):
+        net = DecentralPlannerNet(Cfg(N, K)).to(dev).eval()
+        net.load_state_dict(orc.init_state_dict(K))
+        obs = orc.synth_obs(B, N, seed=1).to(dev)
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=1)).float().to(dev)
+        row = {'kernel': 'policy_step', 'N': N, 'B': B}
+        for rep in range(3):
+            for mode in (1, 0):
+                L.gnnpp_set_tuning(6, mode)
+                for _ in range(30):
+                    net.addGSO(S); net(obs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(300):
+                    net.addGSO(S); net(obs)
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) / 300 * 1e6
+                k = 'fused_us' if mode else 'two_kernels_us'
+                row[k] = min(round(us, 2), row.get(k, 1e9))
+        L.gnnpp_set_tuning(6, 1)
+        print(json.dumps(row), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'fused':
+        return fused_ab()
     if len(sys.argv) > 1 and sys.argv[1] == 'encoder_phases':
         return encoder_phases()
     sd = orc.init_state_dict(3)

@@ -30,6 +30,7 @@ def regs_of(text):
 
 
 def kernel_text(path, name):
+    """name: a substring of the mangled kernel symbol, e.g. 'encoder_kernel_h2ILb0' (first match)."""
     lines, on, meta = [], False, {}
     for ln in open(path):
         if not on and re.match(r'^_Z\w*%s\w*:' % re.escape(name), ln):
@@ -46,7 +47,7 @@ def kernel_text(path, name):
     return lines, meta
 
 
-def check(path, name='encoder_kernel_h2'):
+def check(path, name='encoder_kernel_h2ILb0'):
     lines, meta = kernel_text(path, name)
     if not lines:
         raise SystemExit('kernel %s not found in %s' % (name, path))
@@ -163,8 +164,12 @@ def check(path, name='encoder_kernel_h2'):
 
 
 if __name__ == '__main__':
-    errs, st, meta = check(sys.argv[1], *(sys.argv[2:3]))
-    print('ring loads: %d, fragments taken: %d, %r, violations: %d' % (st['loads'], st['takes'], meta, len(errs)))
-    for e in errs[:40]:
-        print('  ' + e)
-    sys.exit(1 if errs else 0)
+    bad = 0
+    for kern in (sys.argv[2:3] or ['encoder_kernel_h2ILb0', 'encoder_kernel_h2ILb1']):
+        errs, st, meta = check(sys.argv[1], kern)
+        print('%s: ring loads: %d, fragments taken: %d, %r, violations: %d'
+              % (kern, st['loads'], st['takes'], meta, len(errs)))
+        for e in errs[:40]:
+            print('  ' + e)
+        bad += len(errs)
+    sys.exit(1 if bad else 0)

@@ -19,6 +19,8 @@ if has bench; then stamp "bench c2"
   timeout 300 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
 if has abenc; then stamp "ab_bench encoder"
   timeout 400 python tools/ab_bench.py encoder 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_encoder.jsonl; fi
+if has fusedab; then stamp "fused policy kernel A/B"
+  timeout 300 python tools/ab_bench.py fused 2>&1 | grep -v amdgpu.ids | tee $OUT/fused_ab.jsonl; fi
 if has encphases; then stamp "encoder phases"
   timeout 300 python tools/ab_bench.py encoder_phases 2>&1 | grep -v amdgpu.ids | tee $OUT/encoder_phases.jsonl; fi
 if has ab; then stamp "ab_bench"
