@@ -30,6 +30,10 @@
 //   * weights are packed in each wave's consumption order and stream through a 16-deep ring of
 //     16-byte loads kept in registers the compiler does not see (h2_ring_load / h2_ring_take below).
 //   * L0 (K = 27) is one 32-slot block on observations staged as (hi, lo) half pairs.
+//
+// Two instantiations: <false> = the encoder (16-agent tiles, features to HBM); <true> = the fused
+// policy kernel for teams of N <= 16 agents: one workgroup per graph, which after the FC runs that
+// graph's K = 3 graph filter and the action head on the features in LDS (PolicyTail below).
 #include <utility>
 
 #include "gnnpp_common.h"

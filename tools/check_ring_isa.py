@@ -10,7 +10,10 @@ This script verifies on the ISA hipcc produced that
      a slot is never reloaded before it was taken,
   3. the kernel allocates 256 VGPRs, spills nothing and keeps two waves per SIMD.
 
-    python tools/check_ring_isa.py file.s        (exit status 1 on any violation)
+Both instantiations are checked: encoder_kernel_h2<false> (196 stream items) and the fused policy
+kernel encoder_kernel_h2<true> (244: + the graph filter's taps).
+
+    python tools/check_ring_isa.py file.s [mangled-name-substring]   (exit status 1 on any violation)
 """
 import re
 import sys
