@@ -21,7 +21,7 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
-           'gnnpp_rollout_move', 'gnnpp_rollout_step')
+           'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step')
 
 
 class GnnppError(RuntimeError):
@@ -105,6 +105,8 @@ def lib():
     for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move', 'gnnpp_rollout_step'):
         getattr(L, f).argtypes = [ctypes.POINTER(RolloutStruct), vp]
         getattr(L, f).restype = ci
+    L.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, vp]
+    L.gnnpp_rollout_policy_step.restype = ci
     for f in ('gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_encoder_pack', 'gnnpp_encoder_fwd',
               'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move'):

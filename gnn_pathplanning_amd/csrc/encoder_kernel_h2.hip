@@ -315,7 +315,13 @@ struct PolicyTail {
     const float* act_b;       // [5]
     float* logits;            // [N,B,5]
     int B, N, s_is_f64;
+    int with_sim;             // 1: continue with the simulator step of this episode (gnnpp_rollout_policy_step):
+    gnnpp_rollout sim;        //    move on these logits -> gso -> observations of the new positions
 };
+// LDS left behind the filter's z / y rows for the simulator step: positions, move scratch, GSO scratch
+// and the episode's occupancy grid
+constexpr size_t kPolicySimOccBytes =
+    (kBufFloats - 4 * 16 * 136) * sizeof(float) - 4 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
 
 template <bool FUSED>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
@@ -770,6 +776,26 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
+    if (!pt.with_sim) return;
+
+    // ==== simulator step of this episode (same code as rollout_step_kernel) ===========================
+    // The logits go through memory (this workgroup wrote them, its own L2 serves them back); wave 0
+    // moves, then everybody builds the GSO and the observations of the new positions -- into the very
+    // obs / S rows this workgroup consumed at its start, which nobody else reads.
+    __threadfence_block();
+    __syncthreads();
+    {
+        int* spos = reinterpret_cast<int*>(z0 + 4 * (16 * kZs));
+        int* red = spos + 2 * kMaxAgents;
+        char* gso_smem = reinterpret_cast<char*>(red + 2 * kMaxAgents);
+        unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
+        const int b = blockIdx.x;
+        if (tid < 64) move_body(pt.sim, b, tid, red, spos);
+        __syncthreads();
+        gso_body(pt.sim, b, spos, false, gso_smem, tid, kThreads);
+        __syncthreads();
+        observe_body(pt.sim, b, spos, 0, pt.sim.N, occ, tid, kThreads);
+    }
 }
 
 int g_encoder_stop = 0;              // measurement only (GNNPP_TUNE_ENCODER_STOP)
@@ -784,7 +810,7 @@ int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M,
     }
     const int grid = (M + kTileAgents - 1) / kTileAgents;
     hipLaunchKernelGGL(encoder_kernel_h2<false>, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
-                       g_encoder_stop, PolicyTail{});
+                       g_encoder_stop, PolicyTail{});   // (zero-initialised: unused by <false>)
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

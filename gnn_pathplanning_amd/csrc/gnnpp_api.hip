@@ -5,9 +5,9 @@
 #include "encoder_kernel.hip"
 #include "encoder_kernel_v2.hip"
 #include "encoder_kernel_v3.hip"
+#include "rollout_kernels.hip"       // before the fused policy kernel, which can run the simulator step too
 #include "encoder_kernel_h2.hip"
 #include "lsigf_kernel.hip"
-#include "rollout_kernels.hip"
 
 using namespace gnnpp;
 
@@ -128,6 +128,7 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
         PolicyTail pt;
         pt.S = S; pt.filt_h2 = a.wpk_h; pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b;
         pt.logits = logits; pt.B = B; pt.N = N; pt.s_is_f64 = s_is_f64;
+        pt.with_sim = 0;
         return policy_launch_fused(obs, enc_packed, pt, st);
     }
     rc = encoder_launch(obs, enc_packed, feat_ws, B * N, st);
@@ -219,6 +220,31 @@ int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream) {
     if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
     if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
     return rollout_step_launch(*r, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
+                              const float* gf_bias, const float* act_w, const float* act_b, int K,
+                              void* stream) {
+    if (!rollout_common_ok(r) || !r->grid || !r->goal || !r->obs || !r->radius || !r->S || !r->logits ||
+        !r->reached || !r->start_step || !r->end_step || !r->maxstep || !r->flags || !r->stats ||
+        r->H <= 0 || r->W <= 0 || !enc_packed || !filt_packed || !act_w || !act_b)
+        return GNNPP_ERR_ARG;
+    if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
+    if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
+    // same conditions as the fused policy kernel of gnnpp_policy_fwd, plus room for the occupancy grid
+    const bool fused_pays = r->B <= 2 * 256 || r->N >= 13;
+    if (!(g_fused_policy && fused_pays && g_encoder_variant == 7 && g_filter_f16 && !g_filter_ablate &&
+          !g_encoder_stop && r->N <= kTileAgents && K == 3 && (size_t)r->H * r->W <= kPolicySimOccBytes))
+        return GNNPP_ERR_UNSUPPORTED;
+    PolicyTail pt;
+    pt.S = r->S; pt.filt_h2 = filt_packed + filter_packed_f32_floats(GNNPP_FEAT, GNNPP_FEAT, K, 1);
+    pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b; pt.logits = const_cast<float*>(r->logits);
+    pt.B = r->B; pt.N = r->N; pt.s_is_f64 = 0;
+    pt.with_sim = 1;
+    pt.sim = *r;
+    pt.sim.grow = 0;
+    pt.sim.actions = nullptr;
+    return policy_launch_fused(r->obs, enc_packed, pt, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

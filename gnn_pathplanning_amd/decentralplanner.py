@@ -185,6 +185,19 @@ class DecentralPlannerNet(nn.Module):
         aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
         return (gb.data_ptr() if gb is not None else None, aw.data_ptr(), ab.data_ptr(), (gb, aw, ab))
 
+    def policy_pointers(self):
+        """(encoder pack, filter taps, GFL bias, head weight, head bias) raw pointers + K for the
+        C entry points that run the policy inside a larger kernel (BatchedRollout's one-launch step).
+        The tensors behind them are cached on the module and stay alive with it."""
+        assert self.L == 1 and self.E == 1
+        enc = self.packed_encoder()                        # (also refreshes self._mods)
+        gf, act = self._mods
+        taps = gf.packed_taps()
+        gb_p, aw_p, ab_p, _keep = self._head_cache.get(
+            (gf.bias, act.weight, act.bias) if gf.bias is not None else (act.weight, act.bias),
+            lambda: self._head_pointers(gf, act))
+        return enc.data_ptr(), taps.data_ptr(), gb_p, aw_p, ab_p, gf.K
+
     def forward_logits(self, inputTensor):
         """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
         contiguous [B,5] block) -- what forward() unbinds into the reference's list."""

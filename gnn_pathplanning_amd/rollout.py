@@ -8,8 +8,9 @@ driving utils/multirobotsim_dcenlocal.py), with the episode state resident in HB
     model.addGSO / model() -> DecentralPlannerNet.forward_logits
     sim.move(actionVec, t) -> BatchedRollout.move(...)   move + interRobotCollision (:462-723)
 
-A step is three kernel launches (encoder, filter + head, and one fused move -> gso -> observe
-kernel) and no host synchronisation; `run()` only reads back a "finished"
+A step is ONE kernel launch for teams of up to 16 agents (policy forward, move, next GSO and
+observations in the same workgroup per episode), otherwise encoder, filter + head and the simulator
+kernels, and never a host synchronisation; `run()` only reads back a "finished"
 flag every few steps.  The reference's random.choice tie-break among colliding agents (:489) is
 replaced by a deterministic rule (`tie_mode`): 'lowest' index, 'hashed' counter-based RNG, or
 'replay' of recorded choices (parity tests).  Positions are (row, col) integers.
@@ -63,6 +64,7 @@ class BatchedRollout:
         self.seed = int(seed) & 0xffffffff
         self.t = 0                                            # steps taken so far
         self._state_step = -1                                 # step whose positions obs / S describe
+        self._logits = None                                   # [N,B,5] of the one-launch step
         r = _native.RolloutStruct()
         r.grid, r.grid_batched, r.goal, r.pos = _p(self.grid), self.grid_batched, _p(self.goal), _p(self.pos)
         r.B, r.N, r.H, r.W = B, N, self.H, self.W
@@ -128,6 +130,30 @@ class BatchedRollout:
         self._state_step = self.t                          # obs / S describe the positions after step t
         return self.flags
 
+    def _policy_step(self, model):
+        """gnnpp_rollout_policy_step: policy forward + move + next gso/observe in ONE kernel, when the
+        model and the team qualify (eval mode, N = model.numAgents <= 16, K = 3, not 'replay')."""
+        if (self.N > 16 or self.tie_mode == 2 or getattr(model, 'training', True)
+                or getattr(model, 'numAgents', -1) != self.N or not hasattr(model, 'policy_pointers')):
+            return False
+        enc, taps, gb, aw, ab, K = model.policy_pointers()
+        if K != 3:
+            return False
+        if self._logits is None:
+            self._logits = torch.empty(self.N, self.B, 5, dtype=torch.float32, device=self.device)
+        r = self._r
+        r.logits, r.actions, r.grow = _p(self._logits), None, 0
+        r.currentstep = self.t + 1
+        with _native.device_guard(self.device):
+            rc = _native.lib().gnnpp_rollout_policy_step(ctypes.byref(r), enc, taps, gb, aw, ab, K,
+                                                         _native.stream_ptr(self.device))
+        if rc == -2:                                         # shape not supported by the fused kernel
+            return False
+        _native.check(rc, 'gnnpp_rollout_policy_step')
+        self.t += 1
+        self._state_step = self.t
+        return True
+
     def step(self, model):
         """One rollout step of all episodes: observe -> gso -> policy forward -> move.  From the
         second step on the observation and the GSO were already produced by the previous step's
@@ -135,6 +161,8 @@ class BatchedRollout:
         if self._state_step != self.t or self.t == 0:        # step 0 may grow the radius
             self.observe()
             self.gso()
+        if self._policy_step(model):                         # small teams: the whole step is one launch
+            return self.flags
         model.addGSO(self.S)
         logits = model.forward_logits(self.obs)
         # one workgroup per episode pays off while an episode's observations are small; large teams

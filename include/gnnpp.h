@@ -218,6 +218,14 @@ int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream);
  * then getCurrentState + getGSO of the next iteration).  Same results as the three calls in
  * sequence; fields as for those calls. */
 int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream);
+/* A WHOLE rollout step in one launch for teams of N <= 16 agents (K = 3): policy forward on r->obs /
+ * r->S (fp32) with the packed encoder / filter weights, logits to r->logits [N,B,5], then move ->
+ * gso -> observe as gnnpp_rollout_step; r->obs and r->S are overwritten with the next step's.
+ * GNNPP_ERR_UNSUPPORTED (nothing enqueued) when the shape does not qualify (see GNNPP_TUNE_FUSED_POLICY;
+ * H*W must fit the kernel's spare LDS): use gnnpp_policy_fwd + gnnpp_rollout_step then. */
+int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
+                              const float* gf_bias, const float* act_w, const float* act_b, int K,
+                              void* stream);
 
 #ifdef __cplusplus
 }

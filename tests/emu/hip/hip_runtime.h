@@ -103,6 +103,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(n) ((void)0)
 inline void __threadfence() {}
+inline void __threadfence_block() {}
 
 // v_perm_b32: byte k of the result is byte sel[k] of the 8-byte value {hi (bytes 4..7), lo (bytes 0..3)}
 inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {

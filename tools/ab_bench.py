@@ -175,6 +175,7 @@ def rollout_bench():
         row = {'kernel': 'rollout_step', 'N': N, 'B': B}
         row['observe_us'] = round(timeit(env.observe, reps=20), 2)
         row['gso_us'] = round(timeit(lambda: env.gso(5), reps=20), 2)
+        net.addGSO(env.S)
         lg = net.forward_logits(env.obs)
         row['move_us'] = round(timeit(lambda: env.move(logits=lg), reps=20), 2)
         t = timeit(lambda: env.step(net), reps=20)

@@ -50,13 +50,17 @@ def kernel_text(path, name):
     return lines, meta
 
 
-def check(path, name='encoder_kernel_h2ILb0'):
+def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
+    """max_scratch: bytes of scratch per lane tolerated.  Scratch traffic cannot break the ring (loads
+    return in order, so `vmcnt <= younger ring loads` can only hold once the awaited load is back,
+    whatever stores are outstanding); it is a performance guard: 0 for the encoder, a few bytes for the
+    fused policy kernel whose simulator tail keeps small indexed arrays."""
     lines, meta = kernel_text(path, name)
     if not lines:
         raise SystemExit('kernel %s not found in %s' % (name, path))
     errors = []
-    if meta.get('NumVgprs') != 256 or meta.get('ScratchSize') != 0 or meta.get('Occupancy') != 2:
-        errors.append('resource usage %r (want NumVgprs 256, ScratchSize 0, Occupancy 2)' % meta)
+    if meta.get('NumVgprs') != 256 or meta.get('ScratchSize', 1 << 30) > max_scratch or meta.get('Occupancy') != 2:
+        errors.append('resource usage %r (want NumVgprs 256, ScratchSize <= %d, Occupancy 2)' % (meta, max_scratch))
     blocks, cur, label_of = [], {'label': None, 'ins': []}, {}
     for ln in lines:
         t = ln.strip()
@@ -169,7 +173,7 @@ def check(path, name='encoder_kernel_h2ILb0'):
 if __name__ == '__main__':
     bad = 0
     for kern in (sys.argv[2:3] or ['encoder_kernel_h2ILb0', 'encoder_kernel_h2ILb1']):
-        errs, st, meta = check(sys.argv[1], kern)
+        errs, st, meta = check(sys.argv[1], kern, 0 if kern.endswith('ILb0') else 32)
         print('%s: ring loads: %d, fragments taken: %d, %r, violations: %d'
               % (kern, st['loads'], st['takes'], meta, len(errs)))
         for e in errs[:40]:
