@@ -102,6 +102,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+inline long long wall_clock64() { return 0; }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
