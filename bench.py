@@ -9,18 +9,34 @@ input resident in HBM: BASELINE.json configs[1] = 10 agents, K=3, B=512 GSO+obse
 (seed 1337).  With N GPUs every rank runs its own replica on its own batch
 (independent rollout shards, no data-path collective): weak scaling, value = total agent-steps/s.
 
+Timing: W warm-up steps, then `--repeats` timed regions of EXACTLY K steps each, every region
+bracketed by barrier + torch.cuda.synchronize() on both sides, max over ranks per region; the
+reported region is the MEDIAN one (all of them are listed under `regions_ms`).  HIP events recorded
+on the launch stream around the same regions give the device-side time the roofline uses, so the
+kernel time can never exceed the step time it is part of.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel (the fused encoder): algorithmic fp32 FLOPs / measured launch time
-                vs the matrix-pipe peak of /opt/skills/guides/MI355X_MICROARCH.md for the arithmetic
-                the kernel runs (split-f16 schedule: 2500 / 3 TFLOP/s; fp32 schedules: 157.3)
+  roofline      dominant kernel: algorithmic fp32 FLOPs per launch / launch time measured in the timed
+                region itself (one-kernel step) or in an identical back-to-back loop (two-kernel step),
+                against the matrix-pipe peak of /opt/skills/guides/MI355X_MICROARCH.md for the
+                arithmetic the kernel runs; `traffic` = HBM bytes per launch from rocprofv3 --pmc
+                passes run by THIS process (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction),
+                or null when rocprofv3 is not usable
   cpu_baseline  the CPU oracle (op-for-op restatement of the reference's PyTorch path, pinned to
-                golden vectors) timed on this box's host cores on a bounded sample of the workload
-  parity        max |dlogit| and action-id agreement GPU vs oracle on the bench batch
+                golden vectors) timed on this box's host cores: C2 batch at the fastest thread count
+                (headline), at 1 thread, and the reference's own B = 1 rollout step (C1)
+  parity        max |dlogit| and action-id agreement GPU vs oracle on the bench batch, near-tie rows listed
+  secondary     exact-fp32 schedule, argmax-D2H-inclusive rate, batch sweep, filter-only HBM fraction
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -36,7 +52,9 @@ CONFIGS = {
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, chip-level parameters
 F16_MFMA_PEAK_TFLOPS = 2500.0           # dense f16/bf16 MFMA peak (~2.5 PF), same table
+HBM_PEAK_TBPS = 8.0
 ENC_MACS_PER_AGENT = 1238112 + 16384    # CNN + compress MLP
+ENC_WEIGHT_FLOATS = 156288              # conv + BN-folded scale/shift + FC, read once per launch
 
 
 def usable_cores():
@@ -75,8 +93,88 @@ def pick_cpu_threads(orc, sd, N, K, budget_s=6.0):
     return best_t
 
 
+def time_cpu(orc, sd, S_cpu, obs_cpu, seconds, max_reps=200):
+    """Median wall time of oracle.policy_forward (>= 3 warm repetitions, bounded by `seconds`)."""
+    with torch.no_grad():
+        orc.policy_forward(sd, S_cpu, obs_cpu)
+        times = []
+        t_start = time.perf_counter()
+        while (time.perf_counter() - t_start < seconds or len(times) < 3) and len(times) < max_reps:
+            t1 = time.perf_counter()
+            orc.policy_forward(sd, S_cpu, obs_cpu)
+            times.append(time.perf_counter() - t1)
+    times.sort()
+    return times[len(times) // 2], len(times), sum(times)
+
+
 def policy_flops_per_agent(K, mean_deg):
     return 2.0 * (1238112 + 16384 + K * 128 * 128 + (K - 1) * mean_deg * 128 + 640)
+
+
+def build_case(orc, name, dev, seed):
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    N, W, K, B = CONFIGS[name]
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, K, dev
+    sd = orc.init_state_dict(K, seed=1337)
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(sd)
+    obs_cpu = orc.synth_obs(B, N, seed=seed)
+    S64 = orc.synth_gso_geometric(B, N, W, seed=seed)
+    S_cpu = torch.from_numpy(S64).float()
+    return net, sd, Cfg, obs_cpu, S_cpu, float((S64 != 0).sum() / (B * N))
+
+
+def pmc_target(args):
+    """Hidden mode run UNDER rocprofv3 --pmc by measure_traffic(): a handful of policy steps."""
+    from oracle import policy_oracle as orc           # synthetic inputs only
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    net, _, _, obs_cpu, S_cpu, _ = build_case(orc, args.config, dev, 1337)
+    obs, S = obs_cpu.to(dev), S_cpu.to(dev)
+    with torch.no_grad():
+        for _ in range(12):
+            net.addGSO(S)
+            net(obs)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(config, kernel_substr, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel: two rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass on gfx950) over `bench.py --pmc-target`, mean counter value per
+    dispatch of the kernel, combined as the microarch guide prescribes for gfx950:
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE counts half of wide coalesced reads;
+    both counters are in KB).  Returns (bytes | None, detail dict)."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, {'note': 'rocprofv3 not found'}
+    vals, detail = {}, {}
+    env = dict(os.environ, TMPDIR='/tmp')
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='gnnpp_pmc_', dir='/tmp')
+        try:
+            cmd = [exe, '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
+                   sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-target', '--config', config]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT)
+            tot, n = 0.0, 0
+            for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get('Counter_Name') == ctr and kernel_substr in row.get('Kernel_Name', ''):
+                        tot += float(row.get('Counter_Value', 0) or 0)
+                        n += 1
+            if n == 0:
+                return None, {'note': '%s pass produced no rows for %s (rc=%d)' % (ctr, kernel_substr, r.returncode)}
+            vals[ctr] = tot / n
+            detail[ctr + '_KB_per_dispatch'] = tot / n
+            detail[ctr + '_dispatches'] = n
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, {'note': '%s pass failed: %s' % (ctr, type(e).__name__)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    detail['formula'] = '(2*FETCH_SIZE + WRITE_SIZE) * 1024 B (gfx950 correction, MI355X_MICROARCH.md HBM section)'
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, detail
 
 
 def main():
@@ -85,11 +183,14 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--repeats', type=int, default=7,
+                    help='timed regions of exactly --steps steps each; the median one is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip sweeps / rollout / exact-fp32 extras')
     ap.add_argument('--pipeline-streams', type=int, default=3,
                     help='extra measurement: independent batches in flight on this many HIP streams '
                          '(reported under "pipelined", never as "value"); 0 disables')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-seconds', type=float, default=10.0)
     ap.add_argument('--prewarm-seconds', type=float, default=0.25,
                     help='untimed device pre-warm before the W warmup steps: the same step in a loop '
                          'until the clocks / host caches have settled (the first few hundred steps '
@@ -97,15 +198,18 @@ def main():
     ap.add_argument('--dist-backend', default='nccl',
                     help='nccl (= RCCL, default); gloo only to exercise the multi-rank code path '
                          'on a box with fewer GPUs than ranks (with GNNPP_BENCH_DEVICE=0)')
-    ap.add_argument('--traffic-bytes', type=float, default=None,
-                    help='HBM bytes per encoder launch from a separate rocprofv3 --pmc pass')
+    ap.add_argument('--pmc', default='auto', choices=('auto', 'off'),
+                    help='auto: rank 0 at N=1 measures roofline.traffic with two rocprofv3 --pmc passes')
+    ap.add_argument('--pmc-target', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X'
+    if args.pmc_target:
+        return pmc_target(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
-    assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     dev_index = int(os.environ.get('GNNPP_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -120,28 +224,48 @@ def main():
 
     from gnn_pathplanning_amd import _native
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
-    from oracle import policy_oracle as orc           # checker + cpu_baseline leg only
-    _native.lib()
+    from gnn_pathplanning_amd.sharding import aggregate_throughput
+    from oracle import policy_oracle as orc           # checker + cpu_baseline leg + synthetic inputs only
+    L = _native.lib()
 
     N, W, K, B = CONFIGS[args.config]
-
-    class Cfg:
-        num_agents, nGraphFilterTaps, device = N, K, dev
-
-    sd = orc.init_state_dict(K, seed=1337)
-    net = DecentralPlannerNet(Cfg()).to(dev).eval()
-    net.load_state_dict(sd)
     seed = 1337 + rank
-    obs_cpu = orc.synth_obs(B, N, seed=seed)
-    S64 = orc.synth_gso_geometric(B, N, W, seed=seed)
-    mean_deg = float((S64 != 0).sum() / (B * N))
-    S_cpu = torch.from_numpy(S64).float()
+    net, sd, Cfg, obs_cpu, S_cpu, mean_deg = build_case(orc, args.config, dev, seed)
     obs, S = obs_cpu.to(dev), S_cpu.to(dev)
+    M = B * N
 
     def step():
         net.addGSO(S)
         return net(obs)
 
+    def timed_regions(fn, steps, repeats, collective=True):
+        """`repeats` regions of exactly `steps` calls; per region (wall seconds max over ranks,
+        device seconds from HIP events on the launch stream).  collective=False: rank-local (the
+        secondary measurements run on rank 0 only)."""
+        dist = dist_all if collective else None
+        out = []
+        for _ in range(repeats):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            if dist is not None:
+                _, _, wall = aggregate_throughput(1, wall, device=dev)    # max over ranks
+            out.append((wall, e0.elapsed_time(e1) * 1e-3))
+        return out
+
+    dist_all = dist
     with torch.no_grad():
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.prewarm_seconds:     # set-up, not part of W or K
@@ -150,26 +274,17 @@ def main():
             torch.cuda.synchronize()
         for _ in range(args.warmup):
             out = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    from gnn_pathplanning_amd.sharding import aggregate_throughput
-    value, _, elapsed = aggregate_throughput(B * N * args.steps, elapsed, device=dev)
+        regions = timed_regions(step, args.steps, max(1, args.repeats))
+    dist_all = None                              # everything below is rank-local
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, dev_elapsed = regions[order[len(order) // 2]]              # the median region
+    value = world * B * N * args.steps / elapsed
 
     # Secondary: the same K steps with `pipeline_streams` independent rollout batches in flight
     # (batch i on stream i % S).  Sequentially dependent steps of ONE batch cannot overlap, so this
     # is reported separately; it is what a rollout driver holding S episode batches per GPU gets.
     pipelined = None
-    if args.pipeline_streams > 1:
+    if args.pipeline_streams > 1 and not args.no_secondary:
         S_n = args.pipeline_streams
         nets, ins, streams = [net], [(obs, S)], [torch.cuda.Stream() for _ in range(S_n)]
         for i in range(1, S_n):
@@ -207,156 +322,192 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'prewarm_s': args.prewarm_seconds,
+        'regions_ms': [round(1e3 * r[0], 4) for r in regions],
+        'timing': 'median of %d timed regions of exactly %d steps each (barrier + synchronize on both '
+                  'sides of every region, max over ranks)' % (len(regions), args.steps),
         'config': {'workload': 'policy forward (addGSO+forward), %d agents, %dx%d map GSO, K=%d, '
-                               'batch=%d per GPU, eval mode, fp32 GSO resident in HBM'
+                               'batch=%d per GPU, eval mode, fp32 GSO resident in HBM; the SAME resident '
+                               'batch every step (inputs are L2 / Infinity-Cache warm by construction)'
                                % (N, W, W, K, B),
                    'name': args.config, 'agents': N, 'taps': K, 'batch_per_gpu': B,
                    'mean_degree': round(mean_deg, 3), 'parallelism': 'replicas x%d' % world},
     }
-
     if pipelined is not None:
         result['pipelined'] = pipelined
+
     if rank == 0:
-        L = _native.lib()
-        M = B * N
+        import ctypes
         enc = net.packed_encoder()
         feat = torch.empty(M, 128, device=dev)
         st = _native.stream_ptr(dev)
-        import ctypes
-        vp = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None       # noqa: E731
+        gf, act = net.GFL[0], net.actionsMLP[0]
+        aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
+        gbias = gf.bias.detach().reshape(-1).contiguous()
+        taps = gf.packed_taps()
+        lg = torch.empty(N, B, 5, device=dev)
 
-        def time_kernel(fn, reps=50):
-            for _ in range(5):
+        def time_kernel(fn, reps=None):
+            """Back-to-back launches of ONE C entry point, timed like the main regions (median of 5)."""
+            reps = reps or max(50, args.steps)
+            for _ in range(10):
                 fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()                                     # events on the stream the kernels use
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e-3 / reps
+            return sorted(r[1] for r in timed_regions(fn, reps, 5))[2] / reps
 
-        traffic = args.traffic_bytes
-        pmc_file = os.path.join(ROOT, 'profiles', 'pmc_encoder_%s.json' % args.config)
-        if traffic is None and os.path.exists(pmc_file):
-            # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command,
-            # gfx950 correction of the microarch guide: FETCH_SIZE counts half of wide reads
-            pmc = json.load(open(pmc_file))
-            traffic = (2.0 * pmc['FETCH_SIZE_KB_per_dispatch'] + pmc['WRITE_SIZE_KB_per_dispatch']) * 1024.0
-        t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
-        flops = 2.0 * ENC_MACS_PER_AGENT * M
-        achieved = flops / t_enc / 1e12
-        tiles = (M + 15) // 16
         variant = L.gnnpp_get_tuning(0)
-        if variant == 7:
-            # split-f16 schedule: every fp32 MAC is three f16 MACs on the f16 matrix pipe, so the
-            # bound for ALGORITHMIC fp32 FLOPs is the dense f16 MFMA peak / 3.  Executed work per
-            # 16-agent tile: 4314 v_mfma_f32_16x16x32_f16 of 16384 FLOP (taps that fall on the
-            # zero padding and pooled-away positions are never issued).
-            peak = F16_MFMA_PEAK_TFLOPS / 3.0
-            exe = 4314 * 16384.0 * tiles
-            result['roofline'] = {
-                'kernel': 'gnnpp::encoder_kernel_h2', 'bound': 'mfma',
-                'dtype': 'f16 hi/lo split of fp32 operands (3 f16 MFMAs per fp32 product), fp32 accumulate',
-                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'peak_note': 'dense f16 MFMA peak %.1f / 3 products; the exact-fp32 MFMA pipe peaks at '
-                             '%.1f TFLOP/s' % (F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS),
-                'vs_fp32_mfma_peak': achieved / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': traffic, 'algorithmic_bytes': M * (363 + 128) * 4.0 + 156288 * 4.0,
-                'avg_launch_us': t_enc * 1e6, 'flops_per_launch': flops,
-                'executed_f16_flops_per_launch': exe,
-                'f16_pipe_busy_frac': exe / t_enc / 1e12 / F16_MFMA_PEAK_TFLOPS,
-            }
+        split_f16 = variant == 7
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split_f16 else FP32_MFMA_PEAK_TFLOPS
+        dtype_note = ('f16 hi/lo split of fp32 operands (3 f16 MFMAs per fp32 product), fp32 accumulate'
+                      if split_f16 else 'fp32 MFMA')
+        peak_note = ('dense f16 MFMA peak %.1f / 3 products; the exact-fp32 MFMA pipe peaks at %.1f TFLOP/s'
+                     % (F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)) if split_f16 else \
+            'fp32 MFMA peak (MI355X_MICROARCH.md)'
+        tiles = (M + 15) // 16
+        # Is the step ONE kernel?  (gnnpp_policy_fwd's rule: N <= 16, K = 3, B <= 512 or N >= 13, split-f16
+        # schedules.)  Then the dominant kernel IS the step and its launch time is measured in the timed
+        # region itself.
+        fused = (split_f16 and L.gnnpp_get_tuning(6) == 1 and L.gnnpp_get_tuning(5) == 1 and N <= 16
+                 and K == 3 and (B <= 512 or N >= 13))
+        t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st))
+        y = torch.empty(M, 128, device=dev)
+        t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(y), B, N, N,
+                                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, None, st))
+        enc_flops = 2.0 * ENC_MACS_PER_AGENT * M
+        pol_flops = policy_flops_per_agent(K, mean_deg) * M
+        if fused:
+            kernel = ('gnnpp::encoder_kernel_h2<true> (fused policy kernel: encoder + graph filter + action '
+                      'head, one workgroup per graph)')
+            kname = 'encoder_kernel_h2<true>'
+            t_dom = dev_elapsed / args.steps                   # HIP events around the reported region
+            how = ('HIP events on the launch stream around the reported timed region / its %d launches '
+                   '(the step is this one kernel; includes the inter-launch gap)' % args.steps)
+            flops = pol_flops
+            alg_bytes = M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (ENC_WEIGHT_FLOATS + K * 128 * 128 + 768) * 4.0
+            exe = (4314 + 288) * 16384.0 * B                   # f16 MFMAs per graph tile: encoder 4314 + filter 288
+            lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
+                    'algorithmic work' % (N, N)
         else:
-            result['roofline'] = {
-                'kernel': 'gnnpp::encoder_kernel', 'bound': 'mfma', 'achieved': achieved,
-                'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': traffic, 'algorithmic_bytes': M * (363 + 128) * 4.0 + 156288 * 4.0,
-                'avg_launch_us': t_enc * 1e6,
-                # the kernel skips zero-padding taps and pooled-away positions: MFMA work it executes
-                # (v3: 8876 MFMAs of 2048 FLOP per 16-agent tile; v2: 11300; nominal: 12544)
-                'executed_flops_per_launch': 8876 * 2048.0 * tiles,
-                'executed_frac': 8876 * 2048.0 * tiles / t_enc / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                'flops_per_launch': flops,
-            }
+            kernel = 'gnnpp::encoder_kernel_h2<false>' if split_f16 else 'gnnpp::encoder_kernel_f32'
+            kname = 'encoder_kernel_h2<false>' if split_f16 else 'encoder_kernel_f32'
+            t_dom = t_enc
+            how = ('HIP events around back-to-back launches of the kernel (median of 5 regions); the step is '
+                   'this kernel followed by gnnpp::lsigf_kernel')
+            flops = enc_flops
+            alg_bytes = M * (363 + 128) * 4.0 + ENC_WEIGHT_FLOATS * 4.0
+            exe = (4314 * 16384.0 if split_f16 else 8876 * 2048.0) * tiles   # MFMAs per 16-agent tile x FLOP each
+            lanes = ''
+        traffic, traffic_detail = None, {'note': 'not measured (--pmc off, N > 1, or not rank 0)'}
+        if args.pmc == 'auto' and world == 1:
+            try:
+                traffic, traffic_detail = measure_traffic(args.config, kname)
+            except Exception as e:                              # never let the profiler break the bench line
+                traffic, traffic_detail = None, {'note': 'pmc pass raised %s' % type(e).__name__}
+        result['roofline'] = {
+            'kernel': kernel, 'bound': 'mfma', 'dtype': dtype_note,
+            'achieved': flops / t_dom / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': flops / t_dom / 1e12 / peak, 'peak_note': peak_note + lanes,
+            'vs_fp32_mfma_peak': flops / t_dom / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            'traffic': traffic, 'traffic_detail': traffic_detail, 'algorithmic_bytes': alg_bytes,
+            'avg_launch_us': t_dom * 1e6, 'avg_launch_how': how, 'flops_per_launch': flops,
+            'executed_mfma_flops_per_launch': exe,
+            'pipe_busy_frac': exe / t_dom / 1e12 / (F16_MFMA_PEAK_TFLOPS if split_f16 else FP32_MFMA_PEAK_TFLOPS),
+        }
         result['encoder_schedule'] = variant
-        if variant == 7:
+        if split_f16:
             result['dtype'] = ('f32 operands as f16 hi+lo pairs on the f16 MFMA pipe (encoder, filter contraction), '
                                'f32 MFMA (graph shifts, head); f32 accumulate')
-        # Is the step ONE kernel?  (gnnpp_policy_fwd's rule: N <= 16, K = 3, B <= 512 or N >= 13.)  Then the
-        # dominant kernel of the step is the fused policy kernel -- encoder + this graph's filter + head in
-        # one workgroup per graph -- and the roofline describes THAT launch; the encoder-only figures
-        # above move to `encoder_kernel_alone`.
-        fused = (variant == 7 and L.gnnpp_get_tuning(6) == 1 and L.gnnpp_get_tuning(5) == 1 and N <= 16
-                 and K == 3 and (B <= 512 or N >= 13))
-        if fused:
-            act = net.actionsMLP[0]
-            aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
-            gbias = net.GFL[0].bias.detach().reshape(-1).contiguous()
-            lg = torch.empty(N, B, 5, device=dev)
-            taps = net.GFL[0].packed_taps()
-            t_pol = time_kernel(lambda: L.gnnpp_policy_fwd(vp(obs), vp(S), vp(enc), vp(taps), vp(gbias), vp(aw),
-                                                           vp(ab), vp(feat), vp(lg), B, N, K, 0, st), reps=200)
-            pflops = policy_flops_per_agent(K, mean_deg) * M
-            pmc_pol = os.path.join(ROOT, 'profiles', 'pmc_policy_%s.json' % args.config)
-            ptraffic = args.traffic_bytes
-            if ptraffic is None and os.path.exists(pmc_pol):
-                pp = json.load(open(pmc_pol))
-                ptraffic = (2.0 * pp['FETCH_SIZE_KB_per_dispatch'] + pp['WRITE_SIZE_KB_per_dispatch']) * 1024.0
-            enc_alone = result['roofline']
-            exe = (4314 + 288) * 16384.0 * B          # f16 MFMAs per graph tile: encoder 4314 + filter 288
-            result['encoder_kernel_alone'] = enc_alone
-            result['roofline'] = {
-                'kernel': 'gnnpp::encoder_kernel_h2<true> (fused policy kernel: encoder + graph filter + '
-                          'action head, one workgroup per graph)', 'bound': 'mfma',
-                'dtype': enc_alone['dtype'], 'achieved': pflops / t_pol / 1e12, 'peak': enc_alone['peak'],
-                'unit': 'TFLOP/s', 'frac': pflops / t_pol / 1e12 / enc_alone['peak'],
-                'peak_note': enc_alone['peak_note'] + '; a graph of %d agents occupies a 16-lane tile, so at '
-                             'most %d/16 of the pipe does algorithmic work' % (N, N),
-                'vs_fp32_mfma_peak': pflops / t_pol / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': ptraffic,
-                'algorithmic_bytes': M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (156288 + 3 * 128 * 128 + 768) * 4.0,
-                'avg_launch_us': t_pol * 1e6, 'flops_per_launch': pflops,
-                'executed_f16_flops_per_launch': exe,
-                'f16_pipe_busy_frac': exe / t_pol / 1e12 / F16_MFMA_PEAK_TFLOPS,
-            }
-        # secondary: the graph-filter kernel alone (node-major features in, ReLU'd features out)
-        gf = net.GFL[0]
-        y = torch.empty(M, 128, device=dev)
-        gb = gf.bias.detach().reshape(-1)
-        t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(gf.packed_taps()), vp(gb),
-                                                     vp(y), B, N, N, 128, 128, K, 1, 0, 1, 1, 1, 1, st))
         gf_bytes = M * (1024 + 4 * N) + 196608.0 * K / 3
+        result['step_breakdown_us'] = {
+            'whole_step_wall': 1e6 * elapsed / args.steps, 'whole_step_device': 1e6 * dev_elapsed / args.steps,
+            'encoder_kernel_alone': t_enc * 1e6, 'filter_kernel_alone': t_gf * 1e6,
+            'one_kernel_step': bool(fused)}
         result['filter_kernel'] = {
-            'kernel': 'gnnpp::lsigf_kernel', 'avg_launch_us': t_gf * 1e6,
-            'agent_steps_per_s': M / t_gf,
-            'algorithmic_GBps': gf_bytes / t_gf / 1e9, 'hbm_frac_of_8TBps': gf_bytes / t_gf / 8e12,
+            'kernel': 'gnnpp::lsigf_kernel (node-major features in, bias + ReLU fused)', 'avg_launch_us': t_gf * 1e6,
+            'agent_steps_per_s': M / t_gf, 'algorithmic_GBps': gf_bytes / t_gf / 1e9,
+            'hbm_frac_of_8TBps': gf_bytes / t_gf / (HBM_PEAK_TBPS * 1e12),
             'mfma_TFLOPs': 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * M / t_gf / 1e12,
-        }
-        result['step_breakdown_us'] = {'encoder_kernel_alone': t_enc * 1e6, 'filter_kernel_alone': t_gf * 1e6,
-                                       'whole_step_wall': 1e6 * elapsed / args.steps}
-        if fused:
-            result['step_breakdown_us']['fused_policy_kernel'] = t_pol * 1e6
+            'regime': 'one launch over a %.1f MB working set: launch-latency bound, not HBM bound' % (gf_bytes / 1e6)}
         result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value / world / 1e12
 
-        # secondary: one whole rollout step on the device (observation builder + communication GSO
-        # + this forward + action decode / collision shielding), B episodes on random maps
-        import numpy as np
-        from gnn_pathplanning_amd.rollout import BatchedRollout
-        rng = np.random.default_rng(1337)
-        grids = (rng.random((B, W, W)) < 0.08).astype(np.uint8)
-        starts = np.zeros((B, N, 2), np.int64)
-        goals = np.zeros((B, N, 2), np.int64)
-        for b_i in range(B):
-            free = np.argwhere(grids[b_i] == 0)
-            pick = rng.choice(len(free), size=2 * N, replace=False)
-            starts[b_i], goals[b_i] = free[pick[:N]], free[pick[N:]]
-        env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed', seed=1337)
-        with torch.no_grad():
-            t_roll = time_kernel(lambda: env.step(net), reps=30)
-        result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
-                                  'what': 'observe + gso + policy forward + move (collision shielding), '
-                                          'all on the device, %d episodes' % B}
+        if not args.no_secondary:
+            sec = {}
+            with torch.no_grad():
+                # (1) what the rollout loop needs on the host: forward + argmax decode + D2H of the ids
+                def step_d2h():
+                    net.addGSO(S)
+                    return net.decode_actions(net.forward_logits(obs)).cpu()
+                for _ in range(10):
+                    step_d2h()
+                r = sorted(x[0] for x in timed_regions(step_d2h, max(20, args.steps // 4), 5))[2]
+                sec['with_argmax_d2h'] = {'agent_steps_per_s': M * max(20, args.steps // 4) / r,
+                                          'ms_per_step': 1e3 * r / max(20, args.steps // 4),
+                                          'what': 'addGSO + forward + decode_actions kernel + .cpu() of the [B,N] int32 '
+                                                  'ids, synchronous every step (multirobotsim_dcenlocal.py:589-599)'}
+                # (2) the exact-fp32 schedules (no f16 pipe anywhere): same step
+                L.gnnpp_set_tuning(0, 5)
+                L.gnnpp_set_tuning(5, 0)
+                try:
+                    for _ in range(10):
+                        out32 = step()
+                    r = sorted(x[0] for x in timed_regions(step, max(20, args.steps // 2), 5))[2]
+                    t32 = r / max(20, args.steps // 2)
+                    t_enc32 = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st), 50)
+                finally:
+                    L.gnnpp_set_tuning(0, -1)
+                    L.gnnpp_set_tuning(5, 1)
+                sec['exact_fp32_schedule'] = {
+                    'agent_steps_per_s': M / t32, 'ms_per_step': 1e3 * t32,
+                    'encoder_kernel_us': t_enc32 * 1e6,
+                    'encoder_frac_of_fp32_mfma_peak': enc_flops / t_enc32 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    'max_abs_dlogit_vs_default': max((a - b).abs().max().item() for a, b in zip(out, out32)),
+                    'what': 'GNNPP_TUNE_ENCODER_VARIANT=5, GNNPP_TUNE_FILTER_F16=0: every MFMA is v_mfma_f32_16x16x4_f32'}
+                # (3) batch sweep: many graphs per launch (throughput regime) -- policy step and filter alone
+                sweep, fsweep = [], []
+                for Bs in (B, 4 * B, 16 * B, 64 * B):
+                    o = orc.synth_obs(min(Bs, 2048), N, seed=7).to(dev)
+                    o = o.repeat((Bs + o.shape[0] - 1) // o.shape[0], 1, 1, 1, 1)[:Bs].contiguous()
+                    Ss = S.repeat((Bs + B - 1) // B, 1, 1)[:Bs].contiguous()
+
+                    def sstep():
+                        net.addGSO(Ss)
+                        return net(o)
+                    for _ in range(3):
+                        sstep()
+                    reps = max(5, min(args.steps, int(2e6 / (Bs * N)) + 1))
+                    r = sorted(x[0] for x in timed_regions(sstep, reps, 3))[1]
+                    sweep.append({'batch': Bs, 'agent_steps_per_s': Bs * N * reps / r, 'ms_per_step': 1e3 * r / reps})
+                    xf = torch.relu(torch.randn(Bs * N, 128, device=dev))
+                    yf = torch.empty_like(xf)
+                    tf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(xf), vp(Ss), vp(taps), vp(gbias), vp(yf), Bs, N, N,
+                                                               128, 128, K, 1, 0, 1, 1, 1, 1, 0, None, st), reps)
+                    fb = Bs * N * (1024 + 4 * N) + 196608.0 * K / 3
+                    fsweep.append({'batch': Bs, 'us': tf * 1e6, 'agent_steps_per_s': Bs * N / tf,
+                                   'algorithmic_GBps': fb / tf / 1e9, 'hbm_frac_of_8TBps': fb / tf / (HBM_PEAK_TBPS * 1e12)})
+                    del o, Ss, xf, yf
+                sec['batch_sweep_policy'] = sweep
+                sec['batch_sweep_filter_only'] = fsweep
+                sec['batch_sweep_note'] = ('larger batches amortise launch latency and the per-launch weight stream; '
+                                           'the filter-only rows are the HBM-fraction figure of SURVEY.md section 8d')
+            result['secondary'] = sec
+
+            # one whole rollout step on the device (observation builder + communication GSO + this
+            # forward + action decode / collision shielding), B episodes on random maps
+            import numpy as np
+            from gnn_pathplanning_amd.rollout import BatchedRollout
+            rng = np.random.default_rng(1337)
+            grids = (rng.random((B, W, W)) < 0.08).astype(np.uint8)
+            starts = np.zeros((B, N, 2), np.int64)
+            goals = np.zeros((B, N, 2), np.int64)
+            for b_i in range(B):
+                free = np.argwhere(grids[b_i] == 0)
+                pick = rng.choice(len(free), size=2 * N, replace=False)
+                starts[b_i], goals[b_i] = free[pick[:N]], free[pick[N:]]
+            env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed', seed=1337)
+            with torch.no_grad():
+                t_roll = time_kernel(lambda: env.step(net), reps=40)
+            result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
+                                      'what': 'observe + gso + policy forward + move (collision shielding), '
+                                              'all on the device, %d episodes' % B}
 
         # parity gate on the bench batch + CPU baseline (bounded sample of the same workload)
         threads = pick_cpu_threads(orc, sd, N, K)
@@ -368,27 +519,47 @@ def main():
         ids_w = orc.decode_actions(want)
         ids_g = torch.stack([g.argmax(-1) for g in got], 1)
         clear = margin > 1e-5
+        near = [{'graph': int(b_), 'agent': int(n_), 'margin': float(margin[b_, n_]),
+                 'same_action': bool(ids_g[b_, n_] == ids_w[b_, n_])}
+                for b_, n_ in (~clear).nonzero().tolist()][:16]
+        net.check_range()
         result['parity'] = {'max_abs_dlogit': err, 'tolerance': 1e-4,
                             'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear])),
-                            'near_tie_rows': int((~clear).sum()), 'rows': int(clear.numel())}
+                            'near_tie_rows': int((~clear).sum()), 'near_tie_list': near,
+                            'rows': int(clear.numel()), 'range_flag': 0}
         if not args.no_cpu_baseline:
+            med, reps, spent = time_cpu(orc, sd, S_cpu, obs_cpu, args.cpu_seconds)
+            cb = {'value': B * N / med, 'unit': 'agent-steps/s', 'cores': threads, 'usable_cores': usable_cores(),
+                  'kind': 'port',
+                  'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
+                            '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'
+                            % (reps, args.config, torch.__version__, spent),
+                  'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value / world / (B * N / med)}
+            # the reference's own rollout step: B = 1 (BASELINE.json configs[0]), same thread count
+            o1, S1 = obs_cpu[:1].contiguous(), S_cpu[:1].contiguous()
+            med1, reps1, _ = time_cpu(orc, sd, S1, o1, min(3.0, args.cpu_seconds))
+            net1 = DecentralPlannerNet(Cfg()).to(dev).eval()
+            net1.load_state_dict(sd)
+            o1d, S1d = o1.to(dev), S1.to(dev)
+
+            def step1():
+                net1.addGSO(S1d)
+                return net1(o1d)
             with torch.no_grad():
-                orc.policy_forward(sd, S_cpu, obs_cpu)
-                times = []
-                t_start = time.perf_counter()
-                while time.perf_counter() - t_start < args.cpu_seconds and len(times) < 200:
-                    t1 = time.perf_counter()
-                    orc.policy_forward(sd, S_cpu, obs_cpu)
-                    times.append(time.perf_counter() - t1)
-            times.sort()
-            med = times[len(times) // 2]
-            result['cpu_baseline'] = {
-                'value': B * N / med, 'unit': 'agent-steps/s', 'cores': threads, 'usable_cores': usable_cores(),
-                'kind': 'port',
-                'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
-                          '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'
-                          % (len(times), args.config, torch.__version__, sum(times)),
-                'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value / world / (B * N / med)}
+                for _ in range(20):
+                    step1()
+                g1 = sorted(x[0] for x in timed_regions(step1, 100, 5))[2] / 100
+            cb['c1_b1'] = {'cpu_agent_steps_per_s': N / med1, 'cpu_ms_per_step': med1 * 1e3, 'cores': threads,
+                           'gpu_agent_steps_per_s': N / g1, 'gpu_ms_per_step': g1 * 1e3,
+                           'speedup_gpu_over_cpu': med1 / g1, 'repetitions': reps1,
+                           'what': 'one 10-agent case per step (the rollout loop of agents/decentralplannerlocal.py:560-599)'}
+            torch.set_num_threads(1)
+            medt, repst, _ = time_cpu(orc, sd, S_cpu, obs_cpu, min(6.0, args.cpu_seconds), max_reps=20)
+            medt1, _, _ = time_cpu(orc, sd, S1, o1, 2.0)
+            torch.set_num_threads(threads)
+            cb['one_thread'] = {'agent_steps_per_s': B * N / medt, 'ms_per_step': medt * 1e3, 'repetitions': repst,
+                                'c1_b1_agent_steps_per_s': N / medt1}
+            result['cpu_baseline'] = cb
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

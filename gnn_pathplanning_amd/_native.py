@@ -14,13 +14,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libgnnpp.so')
+MEASURE_LIB_PATH = os.path.join(_HERE, 'libgnnpp_measure.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'gnnpp.h')
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
                '-Wno-unused-result']
 
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
-           'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
+           'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step')
 
 
@@ -32,19 +33,59 @@ def _sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [HEADER]
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 csrc/gnnpp_api.hip -> libgnnpp.so (cross-compiles without a GPU)."""
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in _sources())):
-        return LIB_PATH
+def build(force=False, verbose=False, measure=False):
+    """hipcc --offload-arch=gfx950 csrc/gnnpp_api.hip -> libgnnpp.so (cross-compiles without a GPU).
+
+    The device ISA of the very same compilation (-save-temps) then goes through
+    tools/check_ring_isa.py: the split-f16 encoder keeps a weight ring in registers the compiler
+    must never touch, which only a look at the generated code can guarantee -- a toolchain that
+    breaks the scheme fails the BUILD, not a test.  measure=True builds libgnnpp_measure.so with
+    -DGNNPP_MEASURE (phase-ablation knobs for tools/ab_bench.py; never loaded by the package)."""
+    out = MEASURE_LIB_PATH if measure else LIB_PATH
+    if (not force and os.path.exists(out)
+            and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in _sources())):
+        return out
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise GnnppError('hipcc not found: libgnnpp.so cannot be built on this machine')
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, 'gnnpp_api.hip'), '-o', LIB_PATH]
+    tmp = os.path.join(_HERE, 'build', 'measure' if measure else 'product')
+    os.makedirs(tmp, exist_ok=True)
+    tmp_lib = os.path.join(tmp, 'libgnnpp.so')
+    cmd = [hipcc] + HIPCC_FLAGS + (['-DGNNPP_MEASURE'] if measure else []) + \
+          ['-save-temps', os.path.join(CSRC, 'gnnpp_api.hip'), '-o', tmp_lib]
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+    subprocess.check_call(cmd, cwd=tmp)
+    isa = os.path.join(tmp, 'gnnpp_api-hip-amdgcn-amd-amdhsa-gfx950.s')
+    check_ring_isa(isa, verbose=verbose)
+    for f in os.listdir(tmp):                                # keep the ISA, drop the bulky temporaries
+        if f != os.path.basename(isa) and f != 'libgnnpp.so':
+            os.remove(os.path.join(tmp, f))
+    os.replace(tmp_lib, out)
+    return out
+
+
+RING_KERNELS = (('encoder_kernel_h2ILb0', 196, 0), ('encoder_kernel_h2ILb1', 244, 32))
+
+
+def check_ring_isa(isa_path, verbose=False):
+    """tools/check_ring_isa.py on both instantiations of the split-f16 encoder kernel: ring
+    registers private to the asm, load -> wait -> take discipline on every path, every stream item
+    loaded and taken exactly once, 256 VGPRs, occupancy 2, no (encoder) / tiny (policy) scratch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'gnnpp_check_ring_isa', os.path.join(os.path.dirname(_HERE), 'tools', 'check_ring_isa.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for kern, items, scratch in RING_KERNELS:
+        errors, stats, meta = mod.check(isa_path, kern, scratch)
+        ok = (not errors and stats['loads'] == items and stats['takes'] == items
+              and meta.get('NumVgprs') == 256 and meta.get('Occupancy') == 2)
+        if verbose or not ok:
+            print('ring ISA check %s: %s %s, %d violation(s)' % (kern, stats, meta, len(errors)))
+        if not ok:
+            raise GnnppError('generated ISA of %s violates the weight-ring discipline (%s): this '
+                             'toolchain cannot build the split-f16 encoder safely' % (kern, errors[:3]))
 
 
 class EncoderParams(ctypes.Structure):
@@ -64,24 +105,18 @@ class RolloutStruct(ctypes.Structure):
                 ('grow', ctypes.c_int), ('logits', ctypes.c_void_p), ('actions', ctypes.c_void_p),
                 ('reached', ctypes.c_void_p), ('start_step', ctypes.c_void_p),
                 ('end_step', ctypes.c_void_p), ('maxstep', ctypes.c_void_p),
-                ('flags', ctypes.c_void_p), ('stats', ctypes.c_void_p), ('currentstep', ctypes.c_int),
+                ('done', ctypes.c_void_p), ('flags', ctypes.c_void_p), ('stats', ctypes.c_void_p), ('currentstep', ctypes.c_int),
                 ('tie_mode', ctypes.c_int), ('seed', ctypes.c_uint), ('choices', ctypes.c_void_p),
-                ('choice_count', ctypes.c_void_p), ('max_choices', ctypes.c_int)]
+                ('choice_count', ctypes.c_void_p), ('max_choices', ctypes.c_int),
+                ('range_flag', ctypes.c_void_p)]
 
 
 _lib = None
+_measure_lib = None
 
 
-def lib():
-    """The loaded library; raises loudly when it has not been built (no fallback exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise GnnppError(
-            'libgnnpp.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; '
-            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+def _bind(path):
+    L = ctypes.CDLL(path)
     vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     L.gnnpp_version.restype = ci
     L.gnnpp_error_string.restype = ctypes.c_char_p
@@ -93,14 +128,16 @@ def lib():
     L.gnnpp_filter_packed_floats.restype = cs
     L.gnnpp_filter_packed_floats.argtypes = [ci] * 4
     L.gnnpp_filter_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp]
-    L.gnnpp_lsigf_fwd.argtypes = [vp] * 5 + [ci] * 12 + [vp]
-    L.gnnpp_lsigf_fwd_save.argtypes = [vp] * 6 + [ci] * 13 + [vp]
+    L.gnnpp_lsigf_fwd.argtypes = [vp] * 5 + [ci] * 13 + [vp, vp]
+    L.gnnpp_lsigf_fwd_save.argtypes = [vp] * 6 + [ci] * 14 + [vp, vp]
     L.gnnpp_lsigf_fwd_save.restype = ci
     L.gnnpp_encoder_packed_floats.restype = cs
     L.gnnpp_encoder_packed_floats.argtypes = []
     L.gnnpp_encoder_pack.argtypes = [ctypes.POINTER(EncoderParams), vp, vp]
-    L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, vp]
-    L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 4 + [vp]
+    L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, vp, vp]
+    L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 5 + [vp, vp]
+    L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 7 + [vp, vp]
+    L.gnnpp_filter_head_fwd.restype = ci
     L.gnnpp_decode_actions.argtypes = [vp, vp, ci, ci, vp]
     for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move', 'gnnpp_rollout_step'):
         getattr(L, f).argtypes = [ctypes.POINTER(RolloutStruct), vp]
@@ -111,8 +148,30 @@ def lib():
               'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move'):
         getattr(L, f).restype = ci
-    _lib = L
     return L
+
+
+def lib():
+    """The loaded library; raises loudly when it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnnppError(
+            'libgnnpp.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def measure_lib():
+    """libgnnpp_measure.so (-DGNNPP_MEASURE: phase-ablation / early-exit knobs of csrc/gnnpp_measure.h).
+    Profiling tools only -- results under those knobs are wrong by construction; the package's
+    modules never load it."""
+    global _measure_lib
+    if _measure_lib is None:
+        _measure_lib = _bind(build(measure=True))
+    return _measure_lib
 
 
 def check(rc, what):
@@ -160,9 +219,21 @@ class device_guard:
         return False
 
 
+_pack_generation = 0
+
+
+def invalidate_packs():
+    """Force every PackCache to rebuild on its next use.  Needed after parameter updates that
+    torch's version counters do not see: a HIP-graph replay of an optimizer step
+    (training.GraphedTrainStep calls this), or in-place edits through `.data`."""
+    global _pack_generation
+    _pack_generation += 1
+
+
 class PackCache:
     """Packed (MFMA-fragment-ordered) copy of some parameters, rebuilt when any of them changes
-    (load_state_dict / optimizer step / .to()): keyed on (data_ptr, _version) of each tensor."""
+    (load_state_dict / optimizer step / .to()): keyed on (_version, id) of each tensor plus the
+    process-wide generation counter of invalidate_packs()."""
 
     def __init__(self):
         self.key = None
@@ -172,7 +243,7 @@ class PackCache:
         # _version changes on every in-place update; id() changes when .to()/.cuda() replaces the
         # tensor objects' storage holders.  (data_ptr() per tensor is 3x slower than this.)
         key = tuple([t._version for t in tensors] + [id(t) for t in tensors] +
-                    [tensors[0].data_ptr(), tensors[-1].data_ptr()])   # .to(device) swaps storage
+                    [tensors[0].data_ptr(), tensors[-1].data_ptr(), _pack_generation])
         if key != self.key:
             self.buf = pack_fn()
             self.key = key

@@ -1,4 +1,5 @@
-// Encoder kernel, schedule v3: v2 (encoder_kernel_v2.hip) with Winograd F(2x2,3x3) for the two
+// Encoder kernel, exact-fp32 schedule (tuning value 5): fp32 MFMA 16x16x4 with the weight-fragment
+// register ring of encoder_ring_f32.hip and Winograd F(2x2,3x3) for the two
 // layers whose 2x2 output tiles coincide with a MaxPool window, L0 (3 -> 32 @ 11x11) and
 // L2 (32 -> 64 @ 5x5).  The encoder is bound by the fp32 matrix pipe for the MFMAs it issues, so the
 // remaining lever is to issue fewer:
@@ -76,22 +77,17 @@ __device__ __forceinline__ void winograd_output(const v4f (&m)[16], v4f (&y)[4])
     y[3] = r1[1] - r1[2] - r1[3];
 }
 
-// WINO_L0 = false keeps v2's direct L0 (28 ds_read_b32 + 56 MFMAs per pool window) and uses
-// Winograd for L2 only; selectable through gnnpp_set_tuning for A/B measurements.
-// LATE_Y = true: L2/L3/L4 outputs ping-pong X <-> Y (the dead observation buffer);
-// LATE_Y = false: they stay in X, in place, held in registers across a barrier (as v2).
-template <bool WINO_L0, bool LATE_Y>
-__global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __restrict__ obs,
+__global__ __launch_bounds__(kThreads, 2) void encoder_kernel_f32(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* const X = reinterpret_cast<float*>(gnnpp_smem);          // activations, in place
     float* const bufObs = X + kBufFloats;                            // padded observations
     v4f* const X4 = reinterpret_cast<v4f*>(X);
-    // The observation buffer is dead after L0 and big enough (27.7 KB) for the pooled L2 / L3 / L4
-    // outputs (<= 16 KB): the late layers ping-pong X <-> Y instead of running in place, which
-    // drops three barriers and the registers that held a layer's outputs across them.
-    v4f* const Y4 = LATE_Y ? reinterpret_cast<v4f*>(bufObs) : X4;
+    // late layers run in place: a wave holds its outputs in registers across a barrier (measured
+    // faster than ping-ponging through the dead observation buffer, profiles/r01_ab_encoder_variants.jsonl)
+    constexpr bool LATE_Y = false;
+    v4f* const Y4 = X4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -153,59 +149,6 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     }
     __syncthreads();
 
-    if (!WINO_L0) {
-        // ---- L0 direct (as v2): 3 -> 32 @ 11x11 (10x10 used), BN, ReLU, pool ------------------------
-        float A0[2][7];
-        int offB[7];
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            A0[0][s] = pk[EncLayout::kW0 + (0 * 7 + s) * 64 + lane];
-            A0[1][s] = pk[EncLayout::kW0 + (1 * 7 + s) * 64 + lane];
-            int k = 4 * s + q;
-            if (k >= 27) k = 0;
-            const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
-            offB[s] = a * kAgentStride + c * (kPadHW * kPadHW) + ky * kPadHW + kx;
-        }
-        v4f sc[2], sh[2];
-        load_ss(pk + EncLayout::kSS0, 32, 0, q, sc[0], sh[0]);
-        load_ss(pk + EncLayout::kSS0, 32, 1, q, sc[1], sh[1]);
-        float Bc[28], Bn[28];
-        auto load_window = [&](float (&B)[28], int win) {
-            const int wy = win / 5, wx = win - wy * 5;
-            const float* base = bufObs + (2 * wy) * kPadHW + 2 * wx;
-#pragma unroll
-            for (int s = 0; s < 7; ++s)
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp)
-                    B[s * 4 + pp] = base[offB[s] + (pp >> 1) * kPadHW + (pp & 1)];
-        };
-        load_window(Bc, wave);
-        for (int win = wave; win < 25; win += kWaves) {
-            if (win + kWaves < 25) load_window(Bn, win + kWaves);
-            v4f acc[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) acc[i][pp] = vzero();
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    acc[0][pp] = mfma16(A0[0][s], Bc[s * 4 + pp], acc[0][pp]);
-                    acc[1][pp] = mfma16(A0[1][s], Bc[s * 4 + pp], acc[1][pp]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                v4f m = vrelu(vfma(acc[i][0], sc[i], sh[i]));
-#pragma unroll
-                for (int pp = 1; pp < 4; ++pp) m = vmax(m, vfma(acc[i][pp], sc[i], sh[i]));
-                X4[(win * 2 + i) * 64 + lane] = m;
-            }
-#pragma unroll
-            for (int i = 0; i < 28; ++i) Bc[i] = Bn[i];
-        }
-    } else
     // ---- L0 (Winograd): one 4x4 input patch per pool window, 16 MFMAs per channel tile ------------
     {
         float U0[2][16];
@@ -390,28 +333,14 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_kernel_v3(const float* __
     }
 }
 
-template <bool WINO_L0, bool LATE_Y>
-static int encoder_launch_v3_t(const float* obs, const float* packed, float* feat, int M,
-                               hipStream_t st) {
-    static bool attr_set = false;
+int encoder_launch_f32(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    static LdsAttrOnce once;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_v3<WINO_L0, LATE_Y>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_f32), (int)smem);
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL((encoder_kernel_v3<WINO_L0, LATE_Y>), dim3(grid), dim3(kThreads), smem, st, obs, packed,
+    hipLaunchKernelGGL((encoder_kernel_f32), dim3(grid), dim3(kThreads), smem, st, obs, packed,
                        feat, M);
     return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-int encoder_launch_v3(const float* obs, const float* packed, float* feat, int M, hipStream_t st,
-                      int wino_l0, int late_y) {
-    if (wino_l0) return late_y ? encoder_launch_v3_t<true, true>(obs, packed, feat, M, st)
-                               : encoder_launch_v3_t<true, false>(obs, packed, feat, M, st);
-    return late_y ? encoder_launch_v3_t<false, true>(obs, packed, feat, M, st)
-                  : encoder_launch_v3_t<false, false>(obs, packed, feat, M, st);
 }
 
 }  // namespace gnnpp

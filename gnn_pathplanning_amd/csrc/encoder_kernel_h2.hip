@@ -1,5 +1,5 @@
 // Encoder kernel, split-f16 schedule ("h2").  Same layers, same 16-agent tile and the same LDS
-// budget as v3 (encoder_kernel_v3.hip); every layer runs on the f16 matrix pipe with each fp32
+// budget as the exact-fp32 schedule (encoder_kernel_f32.hip); every layer runs on the f16 matrix pipe with each fp32
 // operand split in two halves:
 //
 //      x = xh + xl,  xh = f16(x),  xl = f16(x - xh)          (x - xh is exact in fp32)
@@ -96,7 +96,7 @@ __device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRi
 #define GNNPP_X(s, a, b, c, d)                                                                 \
     case s:                                                                                    \
         asm volatile("global_load_dwordx4 v[" #a ":" #d "], %0, %1 ; RINGLOAD " #s             \
-                     :: "v"(ws.lane_bytes), "s"(p) : "v" #a, "v" #b, "v" #c, "v" #d);          \
+                     :: "v"(ws.lane_bytes), "s"(p));                                            \
         break;
             GNNPP_RING_SLOTS(GNNPP_X)
 #undef GNNPP_X
@@ -142,8 +142,22 @@ __device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
 __device__ __forceinline__ v8h as_h8(v4f v) { return __builtin_bit_cast(v8h, v); }
 __device__ __forceinline__ v4f as_f4(v8h v) { return __builtin_bit_cast(v4f, v); }
 
+// Range guard of the split-f16 schedules: every value that is about to be split is folded into a
+// per-lane running maximum (one v_max3 per two values); at the end of the kernel a lane that saw
+// |x| >= 65504 (the f16 range: the hi half would be inf and hi + lo no longer x) raises the caller's
+// range flag.  Post-ReLU activations are >= 0, so only the observations and the filter's z rows
+// need the absolute value.
+constexpr float kF16Max = 65504.f;
+__device__ __forceinline__ float max4(float m, v4f a) {
+    return fmaxf(fmaxf(fmaxf(m, a[0]), fmaxf(a[1], a[2])), a[3]);
+}
+__device__ __forceinline__ float max4abs(float m, v4f a) {
+    return fmaxf(fmaxf(fmaxf(m, fabsf(a[0])), fmaxf(fabsf(a[1]), fabsf(a[2]))), fabsf(a[3]));
+}
+
 // eight fp32 values (two D tiles) -> hi and lo f16 fragments
-__device__ __forceinline__ void split8(v4f a, v4f b, v4f& hi, v4f& lo) {
+__device__ __forceinline__ void split8(v4f a, v4f b, v4f& hi, v4f& lo, float& amax) {
+    amax = max4(max4(amax, a), b);
     v8h h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -164,7 +178,8 @@ __device__ __forceinline__ float split_word(float x) {
     return __builtin_bit_cast(float, p);
 }
 // four fp32 values (one D tile) -> the 8-byte half of a hi and of a lo fragment
-__device__ __forceinline__ void split4(v4f a, v2f& hi, v2f& lo) {
+__device__ __forceinline__ void split4(v4f a, v2f& hi, v2f& lo, float& amax) {
+    amax = max4(amax, a);
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     v4h h, l;
 #pragma unroll
@@ -314,6 +329,7 @@ struct PolicyTail {
     const float* act_w;       // [5,128]
     const float* act_b;       // [5]
     float* logits;            // [N,B,5]
+    int* range_flag;          // optional: set to 1 when a value left the f16 range
     int B, N, s_is_f64;
     int with_sim;             // 1: continue with the simulator step of this episode (gnnpp_rollout_policy_step):
     gnnpp_rollout sim;        //    move on these logits -> gso -> observations of the new positions
@@ -327,9 +343,10 @@ template <bool FUSED>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M,
-                                                                 int stop, const PolicyTail pt) {
+                                                                 int stop, int* __restrict__ range_flag,
+                                                                 const PolicyTail pt) {
     constexpr int END = FUSED ? kh_END_POLICY : kh_END;
-    // `stop` (measurement only, gnnpp_set_tuning): return after phase 1 = staging, 2 = L0, 3 = L1,
+    // `stop` (GNNPP_MEASURE builds only, gnnpp_set_tuning): return after phase 1 = staging, 2 = L0, 3 = L1,
     // 4 = L2, 5 = L3, 6 = L4; 0 = the whole encoder
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* const X = reinterpret_cast<float*>(gnnpp_smem);          // activations
@@ -343,6 +360,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     const int a = lane & 15;
     const int q = lane >> 4;
     const int agent0 = blockIdx.x * (FUSED ? pt.N : kTileAgents);   // FUSED: the tile is graph blockIdx.x
+    float amax = 0.f;                                               // range guard (see max4 above)
 
     WStreamH ws;
     ws.seg[0] = pk + EncLayout::kH1;
@@ -373,6 +391,12 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         for (int i = 0; i < 3; ++i) awv[i] = pt.act_w[min(tid + i * kThreads, 5 * 128 - 1)];
     }
     v4f ring[kRingH];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The ONE statement that names a ring register to the compiler: it makes the kernel allocate all
+    // 256 VGPRs (v[192:255] are beyond the compiler's own budget, so hipcc warns that this clobber
+    // "may not be preserved" -- which is the point: nothing but the ring asm may use them).
+    asm volatile("; weight ring lives in v[192:255]" ::: "v255");
+#endif
 #pragma unroll
     for (int i = 0; i < kRingH; ++i) h2_ring_load<END>(ws, ring, i);
 
@@ -409,6 +433,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             int ch = rem / 121;
             const int r2 = rem - ch * 121;
             int y = r2 / 11, x = r2 - y * 11;
+            amax = max4abs(amax, v[k]);               // (slots past `valid` hold clamped copies of real values)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (e0 + c < valid)
@@ -425,7 +450,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         }
     }
     __syncthreads();
-    if (stop == 1) return;
+    if (GNNPP_STOP_AT(stop, 1)) return;
 
     // ---- L0: 3 -> 32 @ 11x11 (the 10x10 the pool reads), direct, K = 27 in ONE 32-slot block -------
     // A pixel sits in LDS as the word (lo half << 16 | hi half).  Lane (q, agent) owns k-slots
@@ -489,7 +514,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 for (int pp = 1; pp < 4; ++pp) r[i] = vmax(r[i], vfma(acc[pp][i], sc[i], sh[i]));
             }
             v4f hi, lo;
-            split8(r[0], r[1], hi, lo);
+            split8(r[0], r[1], hi, lo, amax);
             X4[(win * 2 + 0) * 64 + lane] = hi;
             X4[(win * 2 + 1) * 64 + lane] = lo;
         };
@@ -505,7 +530,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         }
     }
     __syncthreads();
-    if (stop == 2) return;
+    if (GNNPP_STOP_AT(stop, 2)) return;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         if (tid + i * kThreads < EncLayout::kHssFloats) sstab[tid + i * kThreads] = ssv[i];
@@ -539,14 +564,14 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             if (p < 25) {
                 v4f hi, lo;
                 split8(vrelu(vfma(acc[j][0], sc[0], sh[0])), vrelu(vfma(acc[j][1], sc[1], sh[1])),
-                       hi, lo);
+                       hi, lo, amax);
                 X4[(p * 2 + 0) * 64 + lane] = hi;
                 X4[(p * 2 + 1) * 64 + lane] = lo;
             }
         }
     }
     __syncthreads();
-    if (stop == 3) return;
+    if (GNNPP_STOP_AT(stop, 3)) return;
 
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
     {
@@ -572,13 +597,13 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                     r[m] = vmax(r[m], vfma(acc[4 * wi + pp][m], sc[m], sh[m]));
             }
             v4f hi, lo;
-            split8(r[0], r[1], hi, lo);
+            split8(r[0], r[1], hi, lo, amax);
             Y4[((t * 2 + mp) * 2 + 0) * 64 + lane] = hi;
             Y4[((t * 2 + mp) * 2 + 1) * 64 + lane] = lo;
         }
     }
     __syncthreads();
-    if (stop == 4) return;
+    if (GNNPP_STOP_AT(stop, 4)) return;
 
     // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
     {
@@ -591,7 +616,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v2f hi, lo;
-            split4(vrelu(vfma(acc[j][0], sc, sh)), hi, lo);
+            split4(vrelu(vfma(acc[j][0], sc, sh)), hi, lo, amax);
             // fragment (pos j, block mt >> 1): this tile is its e = 4 (mt & 1) .. +3 half
             const int o = (j * 2 + (mt >> 1)) * 2;
             X2[((o + 0) * 64 + lane) * 2 + (mt & 1)] = hi;
@@ -599,7 +624,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         }
     }
     __syncthreads();
-    if (stop == 5) return;
+    if (GNNPP_STOP_AT(stop, 5)) return;
 
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
@@ -616,12 +641,12 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             for (int j = 1; j < 4; ++j) r[m] = vmax(r[m], vfma(acc[j][m], sc[m], sh[m]));
         }
         v4f hi, lo;
-        split8(r[0], r[1], hi, lo);
+        split8(r[0], r[1], hi, lo, amax);
         Y4[(wave * 2 + 0) * 64 + lane] = hi;
         Y4[(wave * 2 + 1) * 64 + lane] = lo;
     }
     __syncthreads();
-    if (stop == 6) return;
+    if (GNNPP_STOP_AT(stop, 6)) return;
 
     // ---- FC 128 -> 128 + ReLU -> feat[agent][128]; tiles 2w, 2w+1 per wave ------------------------
     {
@@ -673,7 +698,10 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
-    if (!FUSED) return;
+    if (!FUSED) {
+        if (range_flag && amax >= kF16Max) *range_flag = 1;
+        return;
+    }
 
     // ==== graph filter + action head of this graph (K = 3, G = F = 128) ===========================
     // z_k = z_{k-1} S as a dense product on the fp32 MFMA, all m in ascending order: bit-identical to
@@ -706,6 +734,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             float* row = z0 + (rb + half) * kZs;
             const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
             __builtin_amdgcn_wave_barrier();             // all reads of a row precede its writes
+            amax = max4abs(amax, v);
             v4h h, l;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -744,6 +773,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
+    if (range_flag && amax >= kF16Max) *range_flag = 1;   // (every split of this kernel is behind us)
     // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA
     float* const yb = z0 + 3 * (16 * kZs);
     {
@@ -798,33 +828,31 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
 }
 
-int g_encoder_stop = 0;              // measurement only (GNNPP_TUNE_ENCODER_STOP)
+#ifdef GNNPP_MEASURE
+std::atomic<int> g_encoder_stop{0};  // measurement only (GNNPP_TUNE_ENCODER_STOP)
+#define GNNPP_ENCODER_STOP_VALUE g_encoder_stop.load(std::memory_order_relaxed)
+#else
+#define GNNPP_ENCODER_STOP_VALUE 0
+#endif
 
-int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
-    static bool attr_set = false;
+int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, int* range_flag,
+                      hipStream_t st) {
+    static LdsAttrOnce once;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_h2<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_h2<false>), (int)smem);
     const int grid = (M + kTileAgents - 1) / kTileAgents;
     hipLaunchKernelGGL(encoder_kernel_h2<false>, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
-                       g_encoder_stop, PolicyTail{});   // (zero-initialised: unused by <false>)
+                       GNNPP_ENCODER_STOP_VALUE, range_flag, PolicyTail{});   // (zero-initialised: unused by <false>)
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // whole policy step of B graphs with N <= 16 agents, K = 3: one workgroup per graph
 int policy_launch_fused(const float* obs, const float* packed, const PolicyTail& pt, hipStream_t st) {
-    static bool attr_set = false;
+    static LdsAttrOnce once;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_kernel_h2<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_h2<true>), (int)smem);
     hipLaunchKernelGGL(encoder_kernel_h2<true>, dim3(pt.B), dim3(kThreads), smem, st, obs, packed,
-                       static_cast<float*>(nullptr), pt.B * pt.N, 0, pt);
+                       static_cast<float*>(nullptr), pt.B * pt.N, 0, pt.range_flag, pt);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -1,10 +1,13 @@
 // extern "C" surface of libgnnpp.so -- see include/gnnpp.h for the contract of every entry point.
 // Single translation unit: the kernels are included so hipcc builds one code object.
 #include "../../include/gnnpp.h"
+#ifdef GNNPP_MEASURE
+#include "gnnpp_measure.h"
+#endif
 
-#include "encoder_kernel.hip"
-#include "encoder_kernel_v2.hip"
-#include "encoder_kernel_v3.hip"
+#include "encoder_pack.hip"
+#include "encoder_ring_f32.hip"
+#include "encoder_kernel_f32.hip"
 #include "rollout_kernels.hip"       // before the fused policy kernel, which can run the simulator step too
 #include "encoder_kernel_h2.hip"
 #include "lsigf_kernel.hip"
@@ -15,13 +18,14 @@ static_assert(GNNPP_OK == 0 && GNNPP_ERR_UNSUPPORTED == -2 && GNNPP_ERR_LAUNCH =
 
 extern "C" {
 
-int gnnpp_version(void) { return 100; }
+int gnnpp_version(void) { return 200; }
 
 const char* gnnpp_error_string(int code) {
     switch (code) {
         case GNNPP_OK: return "ok";
         case GNNPP_ERR_ARG: return "invalid argument (null pointer, non-positive size or inconsistent flags)";
-        case GNNPP_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels (N > 100 or LDS budget exceeded)";
+        case GNNPP_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels (more than 112 nodes, or the graph's rows exceed the 160 KB LDS budget: N <= 100 is guaranteed at G, F <= 128)";
+        case GNNPP_ERR_RANGE: return "an activation left the f16 range (|x| >= 65504) of the split-f16 schedule; results of this call are not finite -- select the exact-fp32 schedule (GNNPP_TUNE_ENCODER_VARIANT = 5, GNNPP_TUNE_FILTER_F16 = 0)";
         case GNNPP_ERR_LAUNCH: return "HIP kernel launch failed";
         default: return "unknown gnnpp error code";
     }
@@ -37,42 +41,43 @@ int gnnpp_filter_pack(const float* h, float* packed, int G, int F, int K, int E,
     return filter_pack_launch(h, packed, G, F, K, E, static_cast<hipStream_t>(stream));
 }
 
-// One launch covers F <= 128 output features; wider filters are split over output-feature
-// chunks (each chunk recomputes the cheap shifts).  Packed taps are [e][k][mt][gg] so a chunk's
-// tiles are not contiguous: a chunk launch gets the full buffer plus its first tile index.
+// One launch covers F <= 128 output features; wider filters run as several launches over
+// output-feature chunks inside lsigf_launch (each chunk recomputes the cheap shifts).
 int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const float* bias,
                     float* y, int B, int N, int Nin, int G, int F, int K, int E, int s_is_f64,
-                    int s_batched, int x_node_major, int y_node_major, int relu, void* stream) {
+                    int s_batched, int x_node_major, int y_node_major, int relu, int bias_per_node,
+                    int* range_flag, void* stream) {
     if (!x || !packed || !y || B <= 0 || N <= 0 || Nin <= 0 || Nin > N || G <= 0 || F <= 0 ||
         K <= 0 || E <= 0)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
     if ((x_node_major || y_node_major) && Nin != N) return GNNPP_ERR_ARG;
-    if (N > GNNPP_MAX_NODES + 12) return GNNPP_ERR_UNSUPPORTED;
-    if (F > 128) return GNNPP_ERR_UNSUPPORTED;      // TODO(round 2): chunk the output features
+    if (N > GNNPP_MAX_ROWS) return GNNPP_ERR_UNSUPPORTED;
     LsigfArgs a = {};
     a.x = x; a.S = S; a.wpk = packed; a.bias = bias; a.y = y;
     a.B = B; a.N = N; a.Nin = Nin; a.G = G; a.F = F; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = s_batched;
     a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
+    a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
                          float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
                          int s_is_f64, int s_batched, int s_transposed, int x_node_major,
-                         int y_node_major, int relu, void* stream) {
+                         int y_node_major, int relu, int bias_per_node, int* range_flag, void* stream) {
     if (!x || !packed || !y || B <= 0 || N <= 0 || Nin <= 0 || Nin > N || G <= 0 || F <= 0 ||
         K <= 0 || E <= 0)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
     if ((x_node_major || y_node_major) && Nin != N) return GNNPP_ERR_ARG;
-    if (N > GNNPP_MAX_NODES + 12 || F > 128) return GNNPP_ERR_UNSUPPORTED;
+    if (N > GNNPP_MAX_ROWS) return GNNPP_ERR_UNSUPPORTED;
     LsigfArgs a = {};
     a.x = x; a.S = S; a.wpk = packed; a.bias = bias; a.y = y; a.zs = zs;
     a.B = B; a.N = N; a.Nin = Nin; a.G = G; a.F = F; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = s_batched; a.s_transposed = s_transposed;
     a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
+    a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
@@ -93,57 +98,90 @@ int gnnpp_encoder_pack(const gnnpp_encoder_params* p, float* packed, void* strea
     return encoder_pack_launch(rp, packed, static_cast<hipStream_t>(stream));
 }
 
-int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, void* stream) {
+int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, int* range_flag,
+                      void* stream) {
     if (!obs || !packed || !feat || M <= 0) return GNNPP_ERR_ARG;
-    return encoder_launch(obs, packed, feat, M, static_cast<hipStream_t>(stream));
+    return encoder_launch(obs, packed, feat, M, range_flag, static_cast<hipStream_t>(stream));
 }
 
-int g_fused_policy = 1;               // GNNPP_TUNE_FUSED_POLICY
+std::atomic<int> g_fused_policy{1};   // GNNPP_TUNE_FUSED_POLICY
+
+// Does the one-launch policy kernel apply?  (split-f16 schedules selected, N <= 16, K = 3, and a
+// batch for which one workgroup per graph pays: measured -8 % at B = 512, -17 % at B <= 64 (N = 10),
+// but +40 % at B = 2048 -- or N nearly fills the 16-lane tile.)
+static bool fused_policy_applies(int B, int N, int K) {
+#ifdef GNNPP_MEASURE
+    if (g_filter_ablate.load(std::memory_order_relaxed) || g_encoder_stop.load(std::memory_order_relaxed))
+        return false;
+#endif
+    const bool fused_pays = B <= 2 * 256 || N >= 13;
+    return g_fused_policy.load(std::memory_order_relaxed) && fused_pays &&
+           g_encoder_variant.load(std::memory_order_relaxed) == 7 &&
+           g_filter_f16.load(std::memory_order_relaxed) && N <= kTileAgents && K == 3;
+}
 
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
                      const float* filt_packed, const float* gf_bias, const float* act_w,
-                     const float* act_b, float* feat_ws, float* logits, int B, int N, int K,
-                     int s_is_f64, void* stream) {
+                     const float* act_b, float* feat_ws, float* logits, int B, int N, int K, int E,
+                     int s_is_f64, int* range_flag, void* stream) {
     if (!obs || !enc_packed || !filt_packed || !act_w || !act_b || !feat_ws || !logits || B <= 0 ||
-        N <= 0 || K <= 0)
+        N <= 0 || K <= 0 || E <= 0)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
-    if (N > GNNPP_MAX_NODES + 12) return GNNPP_ERR_UNSUPPORTED;
+    if (N > GNNPP_MAX_ROWS) return GNNPP_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     LsigfArgs a = {};
     a.x = feat_ws; a.S = S; a.wpk = filt_packed; a.bias = gf_bias; a.y = nullptr;
     a.act_w = act_w; a.act_b = act_b; a.logits = logits;
-    a.B = B; a.N = N; a.Nin = N; a.G = GNNPP_FEAT; a.F = GNNPP_FEAT; a.K = K; a.E = 1;
+    a.B = B; a.N = N; a.Nin = N; a.G = GNNPP_FEAT; a.F = GNNPP_FEAT; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1;
+    a.range_flag = range_flag;
     LsigfPlan plan;
     int rc = lsigf_plan(a, plan);
     if (rc) return rc;
     // Fused path: a 16-lane tile per graph wastes (16 - N) / 16 of the encoder's lanes, which is free
-    // while the graphs fit the chip in one round (2 workgroups per CU) -- measured -8 % at B = 512,
-    // -17 % at B <= 64 (N = 10), but +40 % at B = 2048 -- or when N nearly fills the tile.
-    const bool fused_pays = B <= 2 * 256 || N >= 13;
-    if (g_fused_policy && fused_pays && g_encoder_variant == 7 && g_filter_f16 && !g_filter_ablate &&
-        !g_encoder_stop && N <= kTileAgents && K == 3) {
+    // while the graphs fit the chip in one round (2 workgroups per CU).
+    if (E == 1 && fused_policy_applies(B, N, K)) {
         // one launch: a workgroup encodes one graph's agents and runs its filter + action head
         PolicyTail pt;
         pt.S = S; pt.filt_h2 = a.wpk_h; pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b;
         pt.logits = logits; pt.B = B; pt.N = N; pt.s_is_f64 = s_is_f64;
+        pt.range_flag = range_flag;
         pt.with_sim = 0;
         return policy_launch_fused(obs, enc_packed, pt, st);
     }
-    rc = encoder_launch(obs, enc_packed, feat_ws, B * N, st);
+    rc = encoder_launch(obs, enc_packed, feat_ws, B * N, range_flag, st);
     return rc ? rc : lsigf_dispatch(a, plan, st);
+}
+
+int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, const float* bias,
+                          const float* act_w, const float* act_b, float* logits, int B, int N, int G,
+                          int F, int K, int E, int s_is_f64, int* range_flag, void* stream) {
+    if (!x || !packed || !act_w || !act_b || !logits || B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 ||
+        E <= 0)
+        return GNNPP_ERR_ARG;
+    if (K > 1 && !S) return GNNPP_ERR_ARG;
+    if (N > GNNPP_MAX_ROWS || F > 128) return GNNPP_ERR_UNSUPPORTED;   // the head needs all features at once
+    LsigfArgs a = {};
+    a.x = x; a.S = S; a.wpk = packed; a.bias = bias; a.y = nullptr;
+    a.act_w = act_w; a.act_b = act_b; a.logits = logits;
+    a.B = B; a.N = N; a.Nin = N; a.G = G; a.F = F; a.K = K; a.E = E;
+    a.s_is_f64 = s_is_f64; a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1;
+    a.range_flag = range_flag;
+    return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_get_tuning(int key) {
     switch (key) {
-        case GNNPP_TUNE_ENCODER_VARIANT: return g_encoder_variant;
-        case GNNPP_TUNE_FILTER_GPW: return g_filter_gpw;
-        case GNNPP_TUNE_FILTER_WAVES: return g_filter_waves;
-        case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate;
-        case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop;
-        case GNNPP_TUNE_FILTER_F16: return g_filter_f16;
-        case GNNPP_TUNE_FUSED_POLICY: return g_fused_policy;
+        case GNNPP_TUNE_ENCODER_VARIANT: return g_encoder_variant.load();
+        case GNNPP_TUNE_FILTER_GPW: return g_filter_gpw.load();
+        case GNNPP_TUNE_FILTER_WAVES: return g_filter_waves.load();
+        case GNNPP_TUNE_FILTER_F16: return g_filter_f16.load();
+        case GNNPP_TUNE_FUSED_POLICY: return g_fused_policy.load();
+#ifdef GNNPP_MEASURE
+        case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
+        case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
+#endif
         default: return GNNPP_ERR_ARG;
     }
 }
@@ -151,32 +189,34 @@ int gnnpp_get_tuning(int key) {
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT:
-            if (value < -1 || value > 7) return GNNPP_ERR_ARG;
-            g_encoder_variant = value < 0 ? kDefaultEncoderVariant : value;
+            if (value != -1 && value != 5 && value != 7) return GNNPP_ERR_ARG;
+            g_encoder_variant.store(value < 0 ? kDefaultEncoderVariant : value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_GPW:
             if (value < 0) return GNNPP_ERR_ARG;
-            g_filter_gpw = value;
-            return GNNPP_OK;
-        case GNNPP_TUNE_ENCODER_STOP:
-            if (value < 0 || value > 6) return GNNPP_ERR_ARG;
-            g_encoder_stop = value;
+            g_filter_gpw.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FUSED_POLICY:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;
-            g_fused_policy = value;
+            g_fused_policy.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_F16:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;
-            g_filter_f16 = value;
-            return GNNPP_OK;
-        case GNNPP_TUNE_FILTER_ABLATE:
-            g_filter_ablate = value;
+            g_filter_f16.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_WAVES:
             if (value != 0 && value != 8 && value != 16) return GNNPP_ERR_ARG;
-            g_filter_waves = value;
+            g_filter_waves.store(value);
             return GNNPP_OK;
+#ifdef GNNPP_MEASURE
+        case GNNPP_TUNE_ENCODER_STOP:
+            if (value < 0 || value > 6) return GNNPP_ERR_ARG;
+            g_encoder_stop.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_ABLATE:
+            g_filter_ablate.store(value);
+            return GNNPP_OK;
+#endif
         default:
             return GNNPP_ERR_ARG;
     }
@@ -232,14 +272,13 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
     if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
     if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
     // same conditions as the fused policy kernel of gnnpp_policy_fwd, plus room for the occupancy grid
-    const bool fused_pays = r->B <= 2 * 256 || r->N >= 13;
-    if (!(g_fused_policy && fused_pays && g_encoder_variant == 7 && g_filter_f16 && !g_filter_ablate &&
-          !g_encoder_stop && r->N <= kTileAgents && K == 3 && (size_t)r->H * r->W <= kPolicySimOccBytes))
+    if (!(fused_policy_applies(r->B, r->N, K) && (size_t)r->H * r->W <= kPolicySimOccBytes))
         return GNNPP_ERR_UNSUPPORTED;
     PolicyTail pt;
     pt.S = r->S; pt.filt_h2 = filt_packed + filter_packed_f32_floats(GNNPP_FEAT, GNNPP_FEAT, K, 1);
     pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b; pt.logits = const_cast<float*>(r->logits);
     pt.B = r->B; pt.N = r->N; pt.s_is_f64 = 0;
+    pt.range_flag = r->range_flag;
     pt.with_sim = 1;
     pt.sim = *r;
     pt.sim.grow = 0;

@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace gnnpp {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -28,6 +30,32 @@ constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kThreads = 256;        // 4 waves per workgroup, one per SIMD
 constexpr int kWaves = kThreads / kWave;
 constexpr int kLdsBytes = 160 * 1024;
+
+// Phase ablation / early exit for profiling exist only in -DGNNPP_MEASURE builds (tools/ab_bench.py
+// builds its own libgnnpp_measure.so); the product library has no knob that changes results.
+#ifdef GNNPP_MEASURE
+#define GNNPP_ABLATE(p, bits) ((p).ablate & (bits))
+#define GNNPP_STOP_AT(stop, phase) ((stop) == (phase))
+#else
+#define GNNPP_ABLATE(p, bits) 0
+#define GNNPP_STOP_AT(stop, phase) false
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), thread-safe: one
+// LdsAttrOnce per kernel instantiation (a function-local static at the launch site), one bit per
+// device ordinal.  A process that drives several GPUs sets the attribute on each of them.
+struct LdsAttrOnce {
+    std::atomic<unsigned long long> mask[4] = {};
+};
+inline void set_lds_attr_once(LdsAttrOnce& once, const void* kernel, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::atomic<unsigned long long>& m = once.mask[(dev >> 6) & 3];
+    if (m.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    m.fetch_or(bit, std::memory_order_release);
+}
 
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

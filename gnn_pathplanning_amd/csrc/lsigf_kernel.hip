@@ -38,15 +38,21 @@ struct LsigfArgs {
     float* logits;         // [N,B,5]
     int B, N, Nin, G, F, K, E;
     int NG, MT;            // ceil(G/16), ceil(F/16)   (F <= 128 per launch -> MT <= 8)
+    // A filter wider than 128 output features runs as several launches over output-feature chunks:
+    // this launch computes features [f0, f0 + F) of F_all (each chunk recomputes the cheap shifts).
+    // The packed taps, the bias and y are the FULL tensors; mt0 = f0 / 16 is the chunk's first tile.
+    int F_all, f0, mt0, MT_all;
     int zstride;           // LDS row stride in floats = 16*max(NG,MT) + 8
     int gpw;               // graphs per workgroup
     int rt_total;          // 16-row MFMA tiles per workgroup = ceil(gpw*N / 16)
     int Ns;                // LDS row stride of an S slab (odd)
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
+    int bias_per_node;     // bias is [F_all, N] (one value per feature AND node, graphML.py:2300-2302)
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
-    int ablate;            // MEASUREMENT ONLY (tools/ab_bench.py): bit 0 skip the shifts, bit 1 skip
-                           // the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
+    int* range_flag;       // optional device int: set to 1 when the split-f16 contraction saw |z| >= 65504
+    int ablate;            // GNNPP_MEASURE builds only (tools/ab_bench.py): bit 0 skip the shifts, bit 1
+                           // skip the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
 
 // Re-order h[F,E,K,G] into MFMA A fragments: block (e,k,mt,gg) holds, for lane l = q*16 + i and
@@ -61,8 +67,12 @@ __global__ void filter_scale_kernel(const float* __restrict__ h, float* __restri
     for (size_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(h[i]));
     red[threadIdx.x] = m;
     __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {          // tree reduction (blockDim.x = 2^k)
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)blockDim.x; ++i) m = fmaxf(m, red[i]);
+        m = red[0];
         int k = 0;
         if (m > 0.f && m < 3.0e38f) {
             int e;
@@ -125,7 +135,7 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
 // owns a row, reads all of it (16 bytes per lane), then writes the hi halves to the first 256 bytes
 // of the row and the lo halves to the second 256 bytes.
 __device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs, int wave, int nwaves,
-                                           int lane) {
+                                           int lane, float& amax) {
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     const int half = lane >> 5, hl = lane & 31;
     for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {
@@ -134,6 +144,8 @@ __device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs,
         float* row = z + (ok ? r : rb) * zs;
         const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
         __builtin_amdgcn_wave_barrier();                 // all reads of a row precede its writes
+        // range guard: |z| >= 65504 does not fit the hi half (rows >= R are copies of valid rows)
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
         v4h h, l;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -299,13 +311,13 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     // Tap weights of the first tap: issued first so their L2 latency hides behind the staging.
     // Packed block (e,k,mt,gg): 64 lanes x 4 floats = the A fragments of four MFMA k-steps.
     const int ntaps = p.E * p.K;
-    const size_t tap_stride = (size_t)p.MT * NG * 256;
+    const size_t tap_stride = (size_t)p.MT_all * NG * 256;
     // fp32: NGA fragments of 4 k-steps; H2: 4 blocks x (hi, lo) fragments = the same 8 x 16 bytes
     v4f Acur[NGA], Anxt[NGA];
     auto load_tap = [&](v4f (&A)[NGA], int tap) {
         if (NGT && has_mfma) {
             const float* wt = (H2 ? p.wpk_h : p.wpk) + tap * tap_stride +
-                              ((size_t)mt * NGA * 64 + lane) * 4;
+                              ((size_t)(p.mt0 + mt) * NGA * 64 + lane) * 4;
 #pragma unroll
             for (int gg = 0; gg < NGA; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
         }
@@ -325,10 +337,11 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     // x and S(e=0) are staged by disjoint thread ranges so their load latencies overlap
     {
         const int ns = (p.K > 1) ? (NT / 4) : 0;       // last quarter of the threads stage S
-        if (ns && !(p.ablate & 4)) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
+        if (ns && !GNNPP_ABLATE(p, 4)) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
         stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
     }
 
+    float amax = 0.f;                                    // H2: largest |z| handed to the f16 pipe
     v4f acc[RTW], acc2[H2 ? RTW : 1];                    // H2: cross terms accumulate separately
 #pragma unroll
     for (int t = 0; t < RTW; ++t) acc[t] = vzero();
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             for (int k = 0; k < p.K; ++k, ++tap) {
                 float* zcur = (k & 1) ? zbuf1 : zbuf0;
                 float* znxt = (k & 1) ? zbuf0 : zbuf1;
-                if (k + 1 < p.K && !(p.ablate & 1)) gather_rows(p, Sl, zcur, znxt, R, wave, NW, lane);
+                if (k + 1 < p.K && !GNNPP_ABLATE(p, 1)) gather_rows(p, Sl, zcur, znxt, R, wave, NW, lane);
                 if (p.zs) {                              // training: keep z_{e,k} (fp32)
                     float* zd = p.zs + ((size_t)tap * p.B + g0) * N * p.G;
                     for (int i = tid; i < R * p.G; i += NT) {
@@ -361,9 +374,9 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                     }
                 }
                 __syncthreads();                         // every reader of the fp32 z_k is done
-                split_rows(zcur, R, zs, wave, NW, lane);
+                split_rows(zcur, R, zs, wave, NW, lane, amax);
                 __syncthreads();
-                if (has_mfma && !(p.ablate & 2)) {
+                if (has_mfma && !GNNPP_ABLATE(p, 2)) {
                     const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             float* zcur = (k & 1) ? zbuf1 : zbuf0;
             if (tap + 1 < ntaps) load_tap(Anxt, tap + 1);       // in flight during the shift
             if (k > 0) {
-                if (!(p.ablate & 1))
+                if (!GNNPP_ABLATE(p, 1))
                     gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, NW, lane);
                 __syncthreads();
             }
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                 }
             }
             // ---- contraction of tap (e,k) on MFMA: D[f, row] += W[f, g] z[row, g] --------------
-            if (has_mfma && !(p.ablate & 2)) {
+            if (has_mfma && !GNNPP_ABLATE(p, 2)) {
                 const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
                 if (NGT) {
 #pragma unroll
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
 #pragma unroll
                     for (int gg = 0; gg < NGA; ++gg) Acur[gg] = Anxt[gg];
                 } else {
-                    const float* wt = p.wpk + tap * tap_stride + ((size_t)mt * NG * 64 + lane) * 4;
+                    const float* wt = p.wpk + tap * tap_stride + ((size_t)(p.mt0 + mt) * NG * 64 + lane) * 4;
                     for (int gg = 0; gg < NG; ++gg) {
                         const v4f A = *reinterpret_cast<const v4f*>(wt + gg * 256);
                         v4f Bf[RTW];
@@ -439,7 +452,8 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     }
 
     // ---- epilogue: bias (+ReLU) -> LDS [row][f] -> coalesced store / fused action head --------
-    if (p.ablate & 8) return;
+    if (GNNPP_ABLATE(p, 8)) return;
+    if (H2 && p.range_flag && amax >= 65504.f) *p.range_flag = 1;
     __syncthreads();                                   // every wave is done reading z
     float* ybuf = zbuf0;
     float* actw = zbuf1;                               // act_w staged here: [5][F]
@@ -447,15 +461,22 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         for (int i = tid; i < 5 * p.F; i += NT) actw[i] = p.act_w[i];
     if (has_mfma) {
         const int f0 = mt * 16 + q * 4;
-        const float h2_inv = H2 ? p.wpk_h[filter_packed_h2_floats(p.G, p.F, p.K, p.E) + 1] : 1.f;
+        const float h2_inv = H2 ? p.wpk_h[filter_packed_h2_floats(p.G, p.F_all, p.K, p.E) + 1] : 1.f;
         v4f bv = vzero();
-        if (p.bias) {
+        if (p.bias && !p.bias_per_node) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (f0 + r < p.F) ? p.bias[f0 + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bv[r] = (f0 + r < p.F) ? p.bias[p.f0 + f0 + r] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < RTW; ++t) {
             if (rt0 + t < p.rt_total) {
+                if (p.bias_per_node) {                       // b[f, n]: this lane's row is node n
+                    const int row = (rt0 + t) * 16 + a;
+                    const int n = row % N;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        bv[r] = (f0 + r < p.F && row < R) ? p.bias[(size_t)(p.f0 + f0 + r) * N + n] : 0.f;
+                }
                 v4f v = H2 ? (acc[t] + acc2[t]) * h2_inv + bv : acc[t] + bv;
                 if (p.relu) v = vrelu(v);
                 *reinterpret_cast<v4f*>(ybuf + ((rt0 + t) * 16 + a) * zs + f0) = v;
@@ -466,24 +487,24 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
 
     if (p.y) {
         if (p.y_node_major) {
-            float* yd = p.y + (size_t)g0 * N * p.F;
-            if ((p.F & 3) == 0) {
+            float* yd = p.y + (size_t)g0 * N * p.F_all + p.f0;
+            if ((p.F & 3) == 0 && (p.F_all & 3) == 0) {
                 const int F4 = p.F >> 2;
                 for (int i = tid; i < R * F4; i += NT) {
                     const int r = i / F4, c = i - r * F4;
-                    *reinterpret_cast<v4f*>(yd + (size_t)r * p.F + 4 * c) =
+                    *reinterpret_cast<v4f*>(yd + (size_t)r * p.F_all + 4 * c) =
                         *reinterpret_cast<const v4f*>(ybuf + r * zs + 4 * c);
                 }
             } else {
                 for (int i = tid; i < R * p.F; i += NT) {
                     const int r = i / p.F, c = i - r * p.F;
-                    yd[(size_t)r * p.F + c] = ybuf[r * zs + c];
+                    yd[(size_t)r * p.F_all + c] = ybuf[r * zs + c];
                 }
             }
         } else {
             const int slab = p.F * p.Nin;
             for (int j = 0; j < ng; ++j) {
-                float* yd = p.y + (size_t)(g0 + j) * slab;
+                float* yd = p.y + ((size_t)(g0 + j) * p.F_all + p.f0) * p.Nin;
                 for (int i = tid; i < slab; i += NT) {
                     const int f = i / p.Nin, n = i - f * p.Nin;
                     yd[i] = ybuf[(j * N + n) * zs + f];
@@ -539,29 +560,32 @@ __global__ void decode_actions_kernel(const float* __restrict__ logits, int* __r
 }
 
 // ---- host-side launcher -----------------------------------------------------------------------
-int g_filter_gpw = 0;               // 0: heuristic below; > 0: forced graphs per workgroup (tuning)
-int g_filter_waves = 0;             // 0: heuristic; 8 or 16: forced waves per workgroup (tuning)
-int g_filter_ablate = 0;            // measurement-only phase ablation mask (see LsigfArgs::ablate)
+// Tuning state: read on every dispatch, written by gnnpp_set_tuning (relaxed atomics: a concurrent
+// dispatch sees the old or the new value, never a torn one; every value computes the same function).
+std::atomic<int> g_filter_gpw{0};     // 0: heuristic below; > 0: forced graphs per workgroup
+std::atomic<int> g_filter_waves{0};   // 0: heuristic; 8 or 16: forced waves per workgroup
+#ifdef GNNPP_MEASURE
+std::atomic<int> g_filter_ablate{0};  // measurement-only phase ablation mask (see LsigfArgs::ablate)
+#endif
 
 template <int RTW, int NW, int NGT, bool H2>
 static hipError_t launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lsigf_kernel<RTW, NW, NGT, H2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = true;
-    }
+    static LdsAttrOnce once;
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_kernel<RTW, NW, NGT, H2>), kLdsBytes);
     hipLaunchKernelGGL((lsigf_kernel<RTW, NW, NGT, H2>), dim3(grid), dim3(NW * 64), smem, st, a);
     return hipGetLastError();
 }
 
-int g_filter_f16 = 1;               // split-f16 contraction when G == 128 (GNNPP_TUNE_FILTER_F16)
+std::atomic<int> g_filter_f16{1};     // split-f16 contraction when G == 128 (GNNPP_TUNE_FILTER_F16)
 
 template <int RTW, int NW>
 static hipError_t launch_ng(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
     if (a.NG != 8) return launch_one<RTW, NW, 0, false>(a, grid, smem, st);
-    return (a.G == 128 && g_filter_f16) ? launch_one<RTW, NW, 8, true>(a, grid, smem, st)
-                                        : launch_one<RTW, NW, 8, false>(a, grid, smem, st);
+    // The input-gradient launch (s_transposed: x := dy) keeps the fp32 MFMA: cotangents of 1e-4 .. 1e-7
+    // sit in the f16 subnormal range, where the unscaled hi/lo split of the B operand loses them.
+    return (a.G == 128 && g_filter_f16.load(std::memory_order_relaxed) && !a.s_transposed)
+               ? launch_one<RTW, NW, 8, true>(a, grid, smem, st)
+               : launch_one<RTW, NW, 8, false>(a, grid, smem, st);
 }
 
 template <int NW>
@@ -586,22 +610,28 @@ static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
 // Chooses graphs-per-workgroup and waves-per-workgroup and checks the LDS budget.
 // Returns a GNNPP_* code; on success `a` is complete and plan holds the launch geometry.
 struct LsigfPlan { int grid, nw, rtw; size_t smem; };
+constexpr int kMaxRows = 112;       // rows (graphs x nodes) one workgroup keeps in LDS = 7 MFMA row tiles
 
 int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     a.NG = (a.G + 15) / 16;
     a.MT = (a.F + 15) / 16;
-    a.ablate = g_filter_ablate;
-    a.wpk_h = a.wpk + filter_packed_f32_floats(a.G, a.F, a.K, a.E);
-    if (a.MT > 8) return -2;                          // F > 128: the caller splits F
+#ifdef GNNPP_MEASURE
+    a.ablate = g_filter_ablate.load(std::memory_order_relaxed);
+#endif
+    if (a.F_all <= 0) { a.F_all = a.F; a.f0 = 0; }    // single launch covering every output feature
+    a.mt0 = a.f0 / 16;
+    a.MT_all = (a.F_all + 15) / 16;
+    a.wpk_h = a.wpk + filter_packed_f32_floats(a.G, a.F_all, a.K, a.E);
+    if (a.MT > 8) return -2;                          // F > 128 per launch: lsigf_launch splits F
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;
     a.Ns = a.N | 1;
-    if (a.N > 112) return -2;
+    if (a.N > kMaxRows) return -2;
     // graphs per workgroup: fill the 16-row MFMA tiles, but keep the 256 CUs busy.  Cost model:
     // rounds over the chip x (fixed staging/latency cost + MFMA work per row tile).
     int best = 1;
     double best_cost = 1e30;
-    const int max_gpw = 112 / a.N;
+    const int max_gpw = kMaxRows / a.N;
     for (int g = 1; g <= max_gpw && g <= a.B; ++g) {
         if (lsigf_smem(a, g) > (size_t)kLdsBytes) break;
         const int rt = (g * a.N + 15) / 16;
@@ -610,9 +640,10 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
         const double cost = rounds * (1.0 + rt);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = g; }
     }
-    if (g_filter_gpw > 0 && g_filter_gpw <= max_gpw && g_filter_gpw <= a.B &&
-        lsigf_smem(a, g_filter_gpw) <= (size_t)kLdsBytes)
-        best = g_filter_gpw;
+    const int forced_gpw = g_filter_gpw.load(std::memory_order_relaxed);
+    if (forced_gpw > 0 && forced_gpw <= max_gpw && forced_gpw <= a.B &&
+        lsigf_smem(a, forced_gpw) <= (size_t)kLdsBytes)
+        best = forced_gpw;
     a.gpw = best;
     a.rt_total = (a.gpw * a.N + 15) / 16;
     plan.smem = lsigf_smem(a, a.gpw);
@@ -621,7 +652,8 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     // waves per workgroup: 16 when there are enough rows / row tiles to feed them
     const int mtp = a.MT > 4 ? 8 : 4;
     plan.nw = (a.gpw * a.N > 24) ? 16 : 8;
-    if (g_filter_waves == 8 || g_filter_waves == 16) plan.nw = g_filter_waves;
+    const int forced_nw = g_filter_waves.load(std::memory_order_relaxed);
+    if (forced_nw == 8 || forced_nw == 16) plan.nw = forced_nw;
     const int chunks = plan.nw / mtp;
     plan.rtw = (a.rt_total + chunks - 1) / chunks;
     return 0;
@@ -633,16 +665,36 @@ int lsigf_dispatch(const LsigfArgs& a, const LsigfPlan& plan, hipStream_t st) {
     return err == hipSuccess ? 0 : -3;
 }
 
+// Any F: output features in chunks of 128 (the accumulators of one launch); all chunks are planned
+// before the first one is enqueued, so a failing call has enqueued nothing.
 int lsigf_launch(LsigfArgs a, hipStream_t st) {
-    LsigfPlan plan;
-    const int rc = lsigf_plan(a, plan);
-    return rc ? rc : lsigf_dispatch(a, plan, st);
+    constexpr int kChunk = 128, kMaxChunks = 64;
+    const int F_all = a.F;
+    const int nchunks = (F_all + kChunk - 1) / kChunk;
+    if (nchunks > kMaxChunks) return -2;
+    if (nchunks > 1 && a.act_w) return -2;            // the fused action head needs all features at once
+    LsigfArgs args[kMaxChunks];
+    LsigfPlan plans[kMaxChunks];
+    for (int c = 0; c < nchunks; ++c) {
+        args[c] = a;
+        args[c].F_all = F_all;
+        args[c].f0 = c * kChunk;
+        args[c].F = F_all - c * kChunk < kChunk ? F_all - c * kChunk : kChunk;
+        if (c > 0) args[c].zs = nullptr;              // the tap signals do not depend on the chunk
+        const int rc = lsigf_plan(args[c], plans[c]);
+        if (rc) return rc;
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const int rc = lsigf_dispatch(args[c], plans[c], st);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int filter_pack_launch(const float* h, float* packed, int G, int F, int K, int E, hipStream_t st) {
     const size_t total = filter_packed_floats(G, F, K, E);
     float* scale = packed + filter_packed_f32_floats(G, F, K, E) + filter_packed_h2_floats(G, F, K, E);
-    hipLaunchKernelGGL(filter_scale_kernel, dim3(1), dim3(256), 256 * sizeof(float), st, h, scale,
+    hipLaunchKernelGGL(filter_scale_kernel, dim3(1), dim3(1024), 1024 * sizeof(float), st, h, scale,
                        (size_t)F * E * K * G);
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(pack_filter_kernel, dim3(grid), dim3(256), 0, st, h, packed, G, F, K, E);

@@ -22,7 +22,9 @@ typedef ::gnnpp_rollout RolloutArgs;      // the C-ABI struct itself (include/gn
 // Border cell standing for a goal outside the 9x9 field of view (statetransformer.py:47-66).  The
 // reference decides with atan2 against +-pi/4, +-3pi/4 and np.round (half to even); for integer
 // offsets that is exactly: "vertical" branch iff |dy| >= |dx| and dy != 0, and round-half-even of
-// 5*dx/|dy| (verified exhaustively for |dx|,|dy| <= 150 in tests/test_rollout_oracle.py).
+// 5*dx/|dy| (tests/test_rollout_oracle.py::test_integer_projected_goal_rule_exhaustive compares the
+// two rules on every offset with |dx|, |dy| <= 150; this kernel itself is checked on full grids of
+// offsets by tests/test_rollout_oracle.py and tests/test_gpu_rollout.py).
 __device__ __forceinline__ int round_half_even_div(int num, int den) {      // den > 0
     int q = num / den, rem = num - q * den;
     if (rem < 0) { rem += den; q -= 1; }                                     // floor division
@@ -345,6 +347,27 @@ __device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane,
     const bool all_reached = !(not_reached.lo | not_reached.hi);
     bool predict_collision = false, move_collision = false;
     int calls = 0;
+    // The reference never calls move() again for a case whose loop has ended
+    // (agents/decentralplannerlocal.py:560-605: `for step in range(maxstep)`, break after the call
+    // that saw allReachGoal).  In a batch the other episodes go on, so such an episode is frozen:
+    // nothing of its state changes, its flags read (allReachGoal, 0, 0).
+    if ((p.done && p.done[b] != 0) || step > maxstep) {
+        if (lane == 0) {
+            p.flags[3 * b] = all_reached;
+            p.flags[3 * b + 1] = 0;
+            p.flags[3 * b + 2] = 0;
+            if (p.choice_count) p.choice_count[b] = 0;
+        }
+        if (spos) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (live[h]) {
+                    spos[2 * (lane + 64 * h)] = r.curx[h];
+                    spos[2 * (lane + 64 * h) + 1] = r.cury[h];
+                }
+        }
+        return;
+    }
     if (!all_reached || step < maxstep) {
         bool bumped[2] = {false, false};
 #pragma unroll
@@ -421,6 +444,7 @@ __device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane,
         p.flags[3 * b + 1] = move_collision;
         p.flags[3 * b + 2] = predict_collision;
         if (p.choice_count) p.choice_count[b] = calls;
+        if (p.done && (all_reached || step >= maxstep)) p.done[b] = 1;   // the reference's loop breaks here
     }
     if (spos) {
 #pragma unroll

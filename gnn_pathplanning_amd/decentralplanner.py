@@ -57,8 +57,15 @@ class DecentralPlannerNet(nn.Module):
         numCompressFeatures = [2 ** 7]
         nMaxPoolFilterTaps = 2
         numMaxPoolStride = 2
-        dimNodeSignals = [2 ** 7]
-        nGraphFilterTaps = [self.config.nGraphFilterTaps]
+        # The reference fixes one graph-filter layer in its source (decentralplanner.py:130-131:
+        # dimNodeSignals = [2**7], nGraphFilterTaps = [config.nGraphFilterTaps], E = 1 at :208) but builds
+        # and runs L layers / E edge features generically (:205-224, :266-276, :293-298).  The same
+        # generality is reachable here without editing source: optional config fields
+        # `dimNodeSignals` (list), a LIST in `nGraphFilterTaps`, `numEdgeFeatures`.
+        taps = self.config.nGraphFilterTaps
+        nGraphFilterTaps = list(taps) if isinstance(taps, (list, tuple)) else [taps]
+        dimNodeSignals = list(getattr(self.config, 'dimNodeSignals', None) or [2 ** 7] * len(nGraphFilterTaps))
+        assert len(dimNodeSignals) == len(nGraphFilterTaps)
         numActionFeatures = [numAction]
 
         # ---- CNN (parameter container; layout fixed by the fused kernel) ----
@@ -89,7 +96,7 @@ class DecentralPlannerNet(nn.Module):
         self.L = len(nGraphFilterTaps)
         self.F = [numCompressFeatures[-1]] + dimNodeSignals
         self.K = nGraphFilterTaps
-        self.E = 1
+        self.E = int(getattr(self.config, 'numEdgeFeatures', 1))
         self.bias = True
         gfl = []
         for l in range(self.L):
@@ -105,6 +112,12 @@ class DecentralPlannerNet(nn.Module):
         self._enc_cache = _native.PackCache()
         self._head_cache = _native.PackCache()
         self._ws = None
+        # Range guard of the split-f16 schedules (include/gnnpp.h): a device int the kernels raise when
+        # an activation leaves the f16 range.  'flag' (default): no synchronisation, the caller (or
+        # BatchedRollout.run) polls check_range(); 'strict': every forward reads the flag back and
+        # transparently re-runs an out-of-range call under the exact-fp32 schedules.
+        self.range_policy = getattr(self.config, 'range_policy', 'flag')
+        self._range_flag = None
 
     # ------------------------------------------------------------------------------------
     def addGSO(self, S):
@@ -119,31 +132,60 @@ class DecentralPlannerNet(nn.Module):
 
     def _encoder_tensors(self):
         """The 32 tensors the packed encoder depends on.  Walking nn.Sequential / __getattr__ costs
-        ~40 us per call, so the list is memoised; _apply() (.to/.cuda/.float), load_state_dict()
-        and a periodic refresh invalidate it (replacing a Parameter OBJECT by hand is caught at the
-        latest after 256 forwards -- call invalidate_packed() to force it)."""
+        ~40 us per call, so the list is memoised; _apply() (.to/.cuda/.float), load_state_dict(),
+        train()/eval() transitions and invalidate_packed() drop it; a periodic refresh catches a
+        Parameter OBJECT replaced by hand after at most 64 forwards."""
         self._calls = getattr(self, '_calls', 0) + 1
         t = getattr(self, '_enc_tensors', None)
-        if t is None or (self._calls & 255) == 0:
+        if t is None or (self._calls & 63) == 0:
             t = []
             for ci, bi in zip(_CONV_IDX, _BN_IDX):
                 conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
                 t += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
             t += [self.compressMLP[0].weight, self.compressMLP[0].bias]
             self._enc_tensors = t
-            self._mods = (self.GFL[0], self.actionsMLP[0])
+            self._mods = (tuple(self.GFL[2 * l] for l in range(self.L)), self.actionsMLP[0])
         return t
 
     def invalidate_packed(self):
+        """Rebuild every packed / BN-folded weight copy on the next forward.  Call it after updating
+        parameters in a way torch's version counters cannot see (`p.data.mul_()`, writes through
+        raw pointers, a captured-graph replay -- training.GraphedTrainStep does it for you)."""
         self._enc_tensors = None
+        _native.invalidate_packs()
+
+    def train(self, mode=True):
+        if mode != self.training:                 # weights usually changed in between: repack once
+            self._enc_tensors = None
+            _native.invalidate_packs()
+        return super().train(mode)
 
     def _apply(self, fn, *args, **kwargs):
         self._enc_tensors = None
+        self._range_flag = None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self._enc_tensors = None
         return super().load_state_dict(*args, **kwargs)
+
+    # ---- range guard -----------------------------------------------------------------------------
+    def _flag(self, dev):
+        if self._range_flag is None or self._range_flag.device != dev:
+            self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._range_flag
+
+    def range_exceeded(self):
+        """True iff some forward since the last reset handed |activation| >= 65504 to the split-f16
+        schedules (synchronises the device)."""
+        return self._range_flag is not None and bool(self._range_flag.item())
+
+    def check_range(self, reset=True):
+        """Raise GnnppError if a forward left the f16 range of the default schedules."""
+        if self.range_exceeded():
+            if reset:
+                self._range_flag.zero_()
+            raise _native.GnnppError(_native.lib().gnnpp_error_string(-4).decode())
 
     def _pack_encoder(self):
         L = _native.lib()
@@ -175,23 +217,27 @@ class DecentralPlannerNet(nn.Module):
         feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)
         with _native.device_guard(dev):
             _native.check(_native.lib().gnnpp_encoder_fwd(
-                _ptr(obs), _ptr(self.packed_encoder()), _ptr(feat), B * N,
+                _ptr(obs), _ptr(self.packed_encoder()), _ptr(feat), B * N, _ptr(self._flag(dev)),
                 _native.stream_ptr(dev)), 'gnnpp_encoder_fwd')
         return feat
 
     @staticmethod
     def _head_pointers(gf, act):
-        gb = gf.bias.detach().reshape(-1).contiguous() if gf.bias is not None else None
-        aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
+        # fp32 kernels read these through raw pointers: cast (a no-op for fp32 modules) and keep
+        # the casted tensors alive in the cache entry
+        gb = gf.bias.detach().reshape(-1).contiguous().float() if gf.bias is not None else None
+        aw, ab = act.weight.detach().contiguous().float(), act.bias.detach().contiguous().float()
         return (gb.data_ptr() if gb is not None else None, aw.data_ptr(), ab.data_ptr(), (gb, aw, ab))
 
     def policy_pointers(self):
         """(encoder pack, filter taps, GFL bias, head weight, head bias) raw pointers + K for the
         C entry points that run the policy inside a larger kernel (BatchedRollout's one-launch step).
-        The tensors behind them are cached on the module and stay alive with it."""
-        assert self.L == 1 and self.E == 1
+        The tensors behind them are cached on the module and stay alive with it.  None when the
+        model is not the single-layer, single-edge-feature planner those kernels implement."""
+        if self.L != 1 or self.E != 1 or self.F[-1] != 128:
+            return None
         enc = self.packed_encoder()                        # (also refreshes self._mods)
-        gf, act = self._mods
+        (gf,), act = self._mods
         taps = gf.packed_taps()
         gb_p, aw_p, ab_p, _keep = self._head_cache.get(
             (gf.bias, act.weight, act.bias) if gf.bias is not None else (act.weight, act.bias),
@@ -205,7 +251,22 @@ class DecentralPlannerNet(nn.Module):
             return torch.stack(self._forward_train(inputTensor), 0)
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
-        assert self.L == 1 and self.E == 1
+        logits = self._forward_eval(inputTensor)
+        if self.range_policy == 'strict' and self.range_exceeded():
+            # an activation left the f16 range: this call again under the exact-fp32 schedules
+            L = _native.lib()
+            self._range_flag.zero_()
+            old = (L.gnnpp_get_tuning(0), L.gnnpp_get_tuning(5))
+            L.gnnpp_set_tuning(0, 5)
+            L.gnnpp_set_tuning(5, 0)
+            try:
+                logits = self._forward_eval(inputTensor)
+            finally:
+                L.gnnpp_set_tuning(0, old[0])
+                L.gnnpp_set_tuning(5, old[1])
+        return logits
+
+    def _forward_eval(self, inputTensor):
         B = inputTensor.shape[0]
         N = self.numAgents
         assert inputTensor.shape[1] >= N
@@ -214,7 +275,7 @@ class DecentralPlannerNet(nn.Module):
             obs = obs[:, :N]                      # the reference only visits the first numAgents
         if obs.dtype is not torch.float32 or not obs.is_contiguous():
             obs = obs.contiguous().float()
-        S = self.S.detach()
+        S = self.S.detach()                       # [B,E,N,N]
         assert S.shape[0] == B
         Ns = S.shape[2]
         assert Ns >= N                            # Nin <= N zero padding (graphML.py:2464-2469)
@@ -223,38 +284,57 @@ class DecentralPlannerNet(nn.Module):
         if S.dtype not in (torch.float32, torch.float64):
             S = S.float()
         enc = self.packed_encoder()
-        gf, act = self._mods
-        dev = _native.require_gpu(obs, S, gf.weight, act.weight)
+        gfs, act = self._mods
+        dev = _native.require_gpu(obs, S, gfs[0].weight, act.weight)
         if Ns > gml.MAX_NODES:
-            raise _native.GnnppError('graphs with N=%d > %d nodes are not supported yet'
+            raise _native.GnnppError('graphs with N=%d > %d nodes are not supported'
                                      % (Ns, gml.MAX_NODES))
         L = _native.lib()
-        taps = gf.packed_taps()
-        # raw pointers of the small head tensors, refreshed only when one of them changes
+        s64 = int(S.dtype is torch.float64)
+        flag = self._flag(dev).data_ptr()
+        gl = gfs[-1]                               # last graph-filter layer: fused with the head
         gb_p, aw_p, ab_p, _keep = self._head_cache.get(
-            (gf.bias, act.weight, act.bias) if gf.bias is not None else (act.weight, act.bias),
-            lambda: self._head_pointers(gf, act))
-        gbias = _keep[0]
+            (gl.bias, act.weight, act.bias) if gl.bias is not None else (act.weight, act.bias),
+            lambda: self._head_pointers(gl, act))
         with _native.device_guard(dev):
             st = _native.stream_ptr(dev)
-            if Ns == N:
-                # the feature workspace is internal (one model instance per stream)
+            if self.L == 1 and Ns == N and gl.F == 128:
+                # the planner of the reference's configs: ONE C call (one or two kernels)
                 if self._ws is None or self._ws.shape[0] != B * N or self._ws.device != dev:
                     self._ws = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
                 logits = torch.empty(N, B, 5, dtype=torch.float32, device=dev)
-                rc = L.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc.data_ptr(), taps.data_ptr(),
-                                        gb_p, aw_p, ab_p, self._ws.data_ptr(), logits.data_ptr(),
-                                        B, N, gf.K, int(S.dtype is torch.float64), st)
+                rc = L.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc.data_ptr(),
+                                        gl.packed_taps().data_ptr(), gb_p, aw_p, ab_p,
+                                        self._ws.data_ptr(), logits.data_ptr(), B, N, gl.K, self.E,
+                                        s64, flag, st)
                 _native.check(rc, 'gnnpp_policy_fwd')
                 return logits
-            # GSO larger than numAgents: missing nodes carry zero features, extra outputs dropped
-            feat = torch.zeros(B, Ns, 128, dtype=torch.float32, device=dev)
-            feat[:, :N] = self.encode(obs)
-            y = torch.empty(B, Ns, 128, dtype=torch.float32, device=dev)
-            rc = L.gnnpp_lsigf_fwd(_ptr(feat), _ptr(S), _ptr(taps), _ptr(gbias), _ptr(y), B, Ns, Ns,
-                                   128, 128, gf.K, 1, int(S.dtype == torch.float64), 1, 1, 1, 1, st)
-            _native.check(rc, 'gnnpp_lsigf_fwd')
-        out = torch.nn.functional.linear(y[:, :N], act.weight.detach(), act.bias.detach())
+            # general form: encoder kernel, then one filter kernel per layer (node-major in / out, bias
+            # + ReLU fused), the last one with the action head.  A GSO larger than numAgents carries
+            # zero features on the extra nodes, whose outputs are dropped.
+            x = torch.zeros(B, Ns, 128, dtype=torch.float32, device=dev) if Ns != N else None
+            feat = self.encode(obs)
+            if x is not None:
+                x[:, :N] = feat
+            else:
+                x = feat
+            for l, gf in enumerate(gfs):
+                last = l == self.L - 1
+                bias = gf.bias.detach().reshape(-1).contiguous().float() if gf.bias is not None else None
+                if last and gf.F <= 128:
+                    logits = torch.empty(Ns, B, 5, dtype=torch.float32, device=dev)
+                    rc = L.gnnpp_filter_head_fwd(_ptr(x), _ptr(S), _ptr(gf.packed_taps()), _ptr(bias),
+                                                 aw_p, ab_p, _ptr(logits), B, Ns, gf.G, gf.F, gf.K,
+                                                 self.E, s64, flag, st)
+                    _native.check(rc, 'gnnpp_filter_head_fwd')
+                    return logits[:N] if Ns != N else logits
+                y = torch.empty(B, Ns, gf.F, dtype=torch.float32, device=dev)
+                rc = L.gnnpp_lsigf_fwd(_ptr(x), _ptr(S), _ptr(gf.packed_taps()), _ptr(bias), _ptr(y),
+                                       B, Ns, Ns, gf.G, gf.F, gf.K, self.E, s64, 1, 1, 1, 1, 0, flag, st)
+                _native.check(rc, 'gnnpp_lsigf_fwd')
+                x = y
+        # last layer wider than 128 features: the 5-row head is one small library GEMM
+        out = torch.nn.functional.linear(x[:, :N], act.weight.detach().float(), act.bias.detach().float())
         return out.permute(1, 0, 2).contiguous()
 
     def _forward_train(self, inputTensor):

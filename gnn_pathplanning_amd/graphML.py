@@ -55,27 +55,28 @@ def pack_filter_taps(h):
     return packed
 
 
+def _bias_arg(b, F_out, N):
+    """The reference's bias is F x 1 (one value per feature) or F x N (per feature and node,
+    graphML.py:2300-2302); both are applied in the kernel's epilogue."""
+    if b is None:
+        return None, 0
+    if b.numel() == F_out:
+        return b.detach().contiguous().float().reshape(-1), 0
+    assert b.shape[0] == F_out and b.shape[-1] == N, 'bias must be [F,1] or [F,N]'
+    return b.detach().contiguous().float(), 1
+
+
 def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
                   save_taps=False):
     """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
-    (and, with save_taps, zs [E*K, B*N, G])."""
-    if transposed or save_taps:
-        return _lsigf_device_ex(h, S, x, b, batched, Nin, packed, transposed, save_taps)
+    (and, with save_taps, zs [E*K, B*N, G]).  Any F: the C entry point splits wide filters."""
     dev = _native.require_gpu(h, S, x, b)
     L = _native.lib()
     F_out, E, K, G = h.shape
     N = S.shape[-1]
     B = x.shape[0]
     if N > MAX_NODES:
-        raise _native.GnnppError('graphs with N=%d > %d nodes are not supported yet' % (N, MAX_NODES))
-    if F_out > _MAX_F_PER_LAUNCH:
-        # wide filters: split the output features (each chunk recomputes the cheap shifts)
-        outs = []
-        for f0 in range(0, F_out, _MAX_F_PER_LAUNCH):
-            f1 = min(F_out, f0 + _MAX_F_PER_LAUNCH)
-            bb = None if b is None else b[f0:f1]
-            outs.append(_lsigf_device(h[f0:f1], S, x, bb, batched, Nin, None, relu))
-        return torch.cat(outs, dim=1)
+        raise _native.GnnppError('graphs with N=%d > %d nodes are not supported' % (N, MAX_NODES))
     xc = x.detach().contiguous()
     if xc.dtype != torch.float32:
         xc = xc.float()
@@ -84,49 +85,35 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
         Sc = Sc.float()
     if packed is None:
         packed = pack_filter_taps(h)
-    fused_bias = None
-    if b is not None and b.numel() == F_out:
-        fused_bias = b.detach().contiguous().float().reshape(-1)
-    y = torch.empty(B, F_out, Nin, dtype=torch.float32, device=dev)
-    with _native.device_guard(dev):
-        rc = L.gnnpp_lsigf_fwd(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(fused_bias), _ptr(y),
-                               B, N, Nin, G, F_out, K, E, int(Sc.dtype == torch.float64),
-                               int(batched), 0, 0, int(relu and (b is None or fused_bias is not None)),
-                               _native.stream_ptr(dev))
-    _native.check(rc, 'gnnpp_lsigf_fwd')
-    if b is not None and fused_bias is None:      # per-node bias [F,N]: not fused
-        y = y + b.detach()[:, :Nin]
-        if relu:
-            y = torch.relu_(y)
-    return y
-
-
-def _lsigf_device_ex(h, S, x, b, batched, Nin, packed, transposed, save_taps):
-    """gnnpp_lsigf_fwd_save: optional S^T and tap dump (training path).  F <= 128 per call."""
-    dev = _native.require_gpu(h, S, x, b)
-    L = _native.lib()
-    F_out, E, K, G = h.shape
-    N, B = S.shape[-1], x.shape[0]
-    if N > MAX_NODES or F_out > _MAX_F_PER_LAUNCH:
-        raise _native.GnnppError('training path supports N <= %d and F <= %d' % (MAX_NODES, _MAX_F_PER_LAUNCH))
-    xc = x.detach().contiguous().float()
-    Sc = S.detach().contiguous()
-    if Sc.dtype not in (torch.float32, torch.float64):
-        Sc = Sc.float()
-    if packed is None:
-        packed = pack_filter_taps(h)
-    bias = None
-    if b is not None:
-        assert b.numel() == F_out, 'per-node bias is not supported on the training path'
-        bias = b.detach().contiguous().float().reshape(-1)
+    bias, per_node = _bias_arg(b, F_out, N)
     y = torch.empty(B, F_out, Nin, dtype=torch.float32, device=dev)
     zs = torch.empty(E * K, B * N, G, dtype=torch.float32, device=dev) if save_taps else None
+    s64 = int(Sc.dtype == torch.float64)
     with _native.device_guard(dev):
-        rc = L.gnnpp_lsigf_fwd_save(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y), _ptr(zs),
-                                    B, N, Nin, G, F_out, K, E, int(Sc.dtype == torch.float64),
-                                    int(batched), int(transposed), 0, 0, 0, _native.stream_ptr(dev))
-    _native.check(rc, 'gnnpp_lsigf_fwd_save')
+        if transposed or save_taps:
+            rc = L.gnnpp_lsigf_fwd_save(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y), _ptr(zs),
+                                        B, N, Nin, G, F_out, K, E, s64, int(batched), int(transposed),
+                                        0, 0, int(relu), per_node, None, _native.stream_ptr(dev))
+        else:
+            rc = L.gnnpp_lsigf_fwd(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y),
+                                   B, N, Nin, G, F_out, K, E, s64, int(batched), 0, 0, int(relu),
+                                   per_node, None, _native.stream_ptr(dev))
+    _native.check(rc, 'gnnpp_lsigf_fwd')
     return (y, zs) if save_taps else y
+
+
+_transposed_packs = {}
+
+
+def _packed_transposed_taps(h):
+    """Packed h.permute(3,1,2,0) (the taps of the input-gradient filter), cached per weight version:
+    a training step needs it once, however many backward calls share the weight."""
+    key = (id(h), h._version, h.data_ptr(), _native._pack_generation)
+    hit = _transposed_packs.get('k') == key
+    if not hit:
+        _transposed_packs['k'] = key
+        _transposed_packs['v'] = pack_filter_taps(h.detach().permute(3, 1, 2, 0).contiguous())
+    return _transposed_packs['v']
 
 
 class _LSIGFFunction(torch.autograd.Function):
@@ -135,9 +122,10 @@ class _LSIGFFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, S, x, b, batched, packed):
         Nin = x.shape[2]
-        y, zs = _lsigf_device_ex(h, S, x, b, batched, Nin, packed, False, True)
+        y, zs = _lsigf_device(h, S, x, b, batched, Nin, packed, save_taps=True)
         ctx.save_for_backward(h, S, zs)
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
+        ctx.bias_shape = None if b is None else tuple(b.shape)
         return y
 
     @staticmethod
@@ -149,15 +137,19 @@ class _LSIGFFunction(torch.autograd.Function):
         dy = dy.contiguous().float()
         dh = dx = db = None
         if ctx.needs_input_grad[2]:
-            hT = h.detach().permute(3, 1, 2, 0).contiguous()             # [G,E,K,F]
-            dx = _lsigf_device_ex(hT, S, dy, None, ctx.batched, ctx.Nin, None, True, False)
+            hT = h.detach().permute(3, 1, 2, 0)                          # [G,E,K,F] (shape only)
+            dx = _lsigf_device(hT, S, dy, None, ctx.batched, ctx.Nin, _packed_transposed_taps(h),
+                               transposed=True)
         if ctx.needs_input_grad[0]:
             dyp = dy if ctx.Nin == N else torch.nn.functional.pad(dy, (0, N - ctx.Nin))
             dy2 = dyp.permute(1, 0, 2).reshape(F_out, B * N)             # [F, B*N]
             dh = torch.matmul(dy2.unsqueeze(0), zs)                      # [E*K, F, G]
             dh = dh.reshape(E, K, F_out, G).permute(2, 0, 1, 3).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = dy.sum(dim=(0, 2)).reshape(F_out, 1)
+            if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
+                db = dy.sum(dim=(0, 2)).reshape(ctx.bias_shape)
+            else:                                                         # per-node bias [F,N]
+                db = torch.nn.functional.pad(dy.sum(dim=0), (0, N - ctx.Nin)).reshape(ctx.bias_shape)
         return dh, None, dx, db, None, None
 
 
@@ -224,6 +216,7 @@ class _GraphFilterBase(nn.Module):
         self.weight.data.uniform_(-stdv, stdv)
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
+        _native.invalidate_packs()              # `.data` writes are invisible to the version counters
 
     def packed_taps(self):
         """Fragment-ordered taps, repacked only when `weight` changed."""
@@ -285,21 +278,22 @@ class GraphFilterBatch(_GraphFilterBase):
 
 def matrixPowersBatch(S, K):
     """S^k for k = 0..K-1 per batch element (graphML.py:2063-2113).  S [B,N,N] -> [B,K,N,N];
-    S [B,E,N,N] -> [B,E,K,N,N].  A chain of batched library GEMMs, run once per addGSO."""
-    if len(S.shape) == 3:
-        B, N = S.shape[0], S.shape[1]
-        assert S.shape[2] == N
-        E, S, scalar = 1, S.unsqueeze(1), True
-    else:
-        assert len(S.shape) == 4
-        B, E, N = S.shape[0], S.shape[1], S.shape[2]
-        assert S.shape[3] == N
-        scalar = False
-    cur = torch.eye(N, device=S.device).repeat([B, E, 1, 1])
-    SK = cur.unsqueeze(2)
-    for _ in range(1, K):
-        cur = torch.matmul(cur, S)
-        SK = torch.cat((SK, cur.unsqueeze(2)), dim=2)
+    S [B,E,N,N] -> [B,E,K,N,N].  The result tensor is allocated once and power k is written in place
+    by one batched library GEMM from power k-1 (K-2 GEMMs, no concatenation copies); the return value
+    is a [B,E,K,N,N] view of that power-major buffer."""
+    assert S.dim() in (3, 4)
+    scalar = S.dim() == 3
+    S4 = S.unsqueeze(1) if scalar else S
+    B, E, N = S4.shape[0], S4.shape[1], S4.shape[2]
+    assert S4.shape[3] == N
+    flat = S4.reshape(B * E, N, N)
+    P = flat.new_zeros(max(K, 1), B * E, N, N)             # power-major: every P[k] is contiguous
+    P[0].diagonal(dim1=-2, dim2=-1).fill_(1)
+    if K > 1:
+        P[1] = flat
+    for k in range(2, K):
+        torch.bmm(P[k - 1], flat, out=P[k])
+    SK = P.reshape(max(K, 1), B, E, N, N).permute(1, 2, 0, 3, 4)
     return SK.squeeze(1) if scalar else SK
 
 

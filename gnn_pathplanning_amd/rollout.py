@@ -58,6 +58,7 @@ class BatchedRollout:
         self.start_step = torch.full((B, N), -1, dtype=torch.int32, device=dev)
         self.end_step = torch.full((B, N), -1, dtype=torch.int32, device=dev)
         self.flags = torch.zeros(B, 3, dtype=torch.int32, device=dev)
+        self.done = torch.zeros(B, dtype=torch.int32, device=dev)   # the case's loop has ended: frozen
         self.stats = torch.zeros(B, 2, dtype=torch.int32, device=dev)
         self.choice_count = torch.zeros(B, dtype=torch.int32, device=dev)
         self.tie_mode = _TIE[tie_mode]
@@ -71,6 +72,7 @@ class BatchedRollout:
         r.obs, r.radius, r.S, r.connected = _p(self.obs), _p(self.radius), _p(self.S), _p(self.connected)
         r.reached, r.start_step, r.end_step = _p(self.reached), _p(self.start_step), _p(self.end_step)
         r.maxstep, r.flags, r.stats = _p(self.maxstep), _p(self.flags), _p(self.stats)
+        r.done = _p(self.done)
         r.tie_mode, r.seed, r.choice_count = self.tie_mode, self.seed, _p(self.choice_count)
         self._r = r
 
@@ -136,13 +138,15 @@ class BatchedRollout:
         if (self.N > 16 or self.tie_mode == 2 or getattr(model, 'training', True)
                 or getattr(model, 'numAgents', -1) != self.N or not hasattr(model, 'policy_pointers')):
             return False
-        enc, taps, gb, aw, ab, K = model.policy_pointers()
-        if K != 3:
+        ptrs = model.policy_pointers()
+        if ptrs is None or ptrs[5] != 3:
             return False
+        enc, taps, gb, aw, ab, K = ptrs
         if self._logits is None:
             self._logits = torch.empty(self.N, self.B, 5, dtype=torch.float32, device=self.device)
         r = self._r
         r.logits, r.actions, r.grow = _p(self._logits), None, 0
+        r.range_flag = _p(model._flag(self.device))          # range guard of the split-f16 policy
         r.currentstep = self.t + 1
         with _native.device_guard(self.device):
             rc = _native.lib().gnnpp_rollout_policy_step(ctypes.byref(r), enc, taps, gb, aw, ab, K,
@@ -170,16 +174,23 @@ class BatchedRollout:
         return self.move_and_observe(logits=logits) if self.N <= 32 else self.move(logits=logits)
 
     def run(self, model, max_steps=None, check_every=8):
-        """Step until every episode has finished (all agents at their goals, or maxstep reached).
-        Like the reference loop (agents/decentralplannerlocal.py:560-599) an episode needs one more
-        move() after its last agent arrives for its statistics to be written."""
+        """Step until every episode's loop has ended: the call after its last agent arrived (that call
+        writes its statistics, like the reference loop agents/decentralplannerlocal.py:560-605), or
+        the call at its OWN maxstep.  An ended episode is frozen by the move kernel (`done`), so mixed
+        per-episode limits (maxstep = rate * makespan[b]) report exactly what the reference reports
+        case by case."""
         limit = int(self.maxstep.max().item()) if max_steps is None else int(max_steps)
         steps = 0
         while steps < limit:
             self.step(model)
             steps += 1
-            if steps % check_every == 0 and bool((self.flags[:, 0] == 1).all().item()):
-                break
+            if steps % check_every == 0:
+                if hasattr(model, 'check_range'):
+                    model.check_range()                      # an activation left the f16 range: error
+                if bool((self.done != 0).all().item()):
+                    break
+        if hasattr(model, 'check_range'):
+            model.check_range()
         return self.results()
 
     def results(self):
@@ -188,4 +199,4 @@ class BatchedRollout:
         return {'steps': self.t, 'reached': reached.cpu(), 'success': reached.all(dim=1).cpu(),
                 'makespan': self.stats[:, 0].cpu(), 'flowtime': self.stats[:, 1].cpu(),
                 'end_step': self.end_step.cpu(), 'start_step': self.start_step.cpu(),
-                'positions': self.pos.cpu(), 'radius': self.radius.cpu()}
+                'positions': self.pos.cpu(), 'radius': self.radius.cpu(), 'done': self.done.bool().cpu()}

@@ -14,6 +14,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as tF
 
+from . import _native
+
 
 def policy_loss(predict, batch_target):
     """predict: list of N tensors [B,5]; batch_target [B,N,5] one-hot expert actions.
@@ -70,6 +72,9 @@ class GraphedTrainStep:
         self.tgt.copy_(batch_target)
         self.gso.copy_(batch_GSO)
         self.graph.replay()
+        # the replayed optimizer step changed the parameters behind torch's version counters: every
+        # packed / BN-folded copy (eval forward, rollouts) must be rebuilt before its next use
+        _native.invalidate_packs()
         return self.loss
 
 

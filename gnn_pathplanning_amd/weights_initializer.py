@@ -4,6 +4,8 @@ weight ~ N(1, 0.02) and bias 0.  Dispatch is by class name exactly like the refe
 GraphFilter* modules (own reset_parameters) are untouched."""
 import torch
 
+from . import _native
+
 
 def weights_init(m):
     name = type(m).__name__
@@ -15,3 +17,4 @@ def weights_init(m):
     elif 'Linear' in name:
         torch.nn.init.xavier_normal_(m.weight)
         m.bias.data.fill_(0.0)
+    _native.invalidate_packs()                  # `.data` writes are invisible to the version counters

@@ -29,32 +29,29 @@ extern "C" {
 #define GNNPP_ERR_ARG         (-1)   /* null pointer / non-positive size / inconsistent flags   */
 #define GNNPP_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels cover (see each call)     */
 #define GNNPP_ERR_LAUNCH      (-3)   /* HIP launch error                                         */
+#define GNNPP_ERR_RANGE       (-4)   /* gnnpp_check_finite: an activation overflowed the f16 range */
 
 #define GNNPP_OBS_C        3         /* observation channels      (decentralplanner.py:89)       */
 #define GNNPP_OBS_HW       11        /* observation height=width  (decentralplanner.py:22-23)    */
 #define GNNPP_FEAT         128       /* numFeatures2Share         (decentralplanner.py:93,197)   */
 #define GNNPP_ACTIONS      5         /* numAction                 (decentralplanner.py:27)       */
-#define GNNPP_MAX_NODES    100       /* largest N one workgroup holds in LDS with G=F=128        */
+#define GNNPP_MAX_NODES    100       /* N <= 100 nodes per graph always fits (G, F <= 128)       */
+#define GNNPP_MAX_ROWS     112       /* hard limit: a workgroup keeps <= 112 node rows in LDS; N in
+                                        101..112 works when the 160 KB LDS budget allows (narrower
+                                        G / F), else GNNPP_ERR_UNSUPPORTED                          */
 
 int         gnnpp_version(void);
 const char* gnnpp_error_string(int code);
 
-/* Process-wide tuning knobs for A/B measurements (bench.py); defaults are the fast settings.
- * Every setting computes the same function; the fp32 schedules (0..6) agree to summation order,
- * the split-f16 schedule (7) to ~2^-22 per operand (measured: |dfeature| <= 2e-7, as the others). */
-#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 7: split-f16 MFMA for L1..FC (encoder_kernel_h2.hip);
-                                         -1: restore the built-in default;
-                                         5: v3 = v2 + Winograd F(2x2,3x3) in L0 and L2,
-                                         late layers in place; 3: v3 with the late layers through
-                                         the observation buffer; 4 / 6: Winograd in L2 only;
-                                         2: schedule v2 (weight-fragment register ring, up-front
-                                         observation loads); 1: v1, in-place layers, 79 KB LDS;
-                                         0: v1, ping-pong buffers, 100 KB LDS                      */
+/* Process-wide tuning knobs (atomic; a concurrent call sees the old or the new value).  EVERY
+ * setting computes the same function: the exact-fp32 schedules agree with the split-f16 defaults to
+ * ~2^-22 per operand (measured: |dlogit| <= 2e-7).  Knobs that skip kernel phases for profiling are
+ * not part of this ABI (csrc/gnnpp_measure.h, -DGNNPP_MEASURE builds only). */
+#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 7 (default): split-f16 MFMA schedule (encoder_kernel_h2.hip);
+                                         5: exact-fp32 MFMA schedule (encoder_kernel_f32.hip);
+                                         -1: restore the default                                    */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
 #define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
-#define GNNPP_TUNE_FILTER_ABLATE   3  /* MEASUREMENT ONLY, results become wrong: bit mask of filter
-                                         phases to skip (1 shifts, 2 contraction, 4 GSO staging,
-                                         8 epilogue); 0 (default) = the real kernel               */
 #define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
                                          on the f16 matrix pipe with hi+lo split operands (shifts
                                          stay exact fp32); 0: fp32 MFMA contraction              */
@@ -64,8 +61,6 @@ const char* gnnpp_error_string(int code);
                                          encodes one graph's agents, then runs that graph's filter and
                                          action head on chip (identical logits); 0: always the encoder
                                          kernel followed by the filter kernel                        */
-#define GNNPP_TUNE_ENCODER_STOP     4  /* MEASUREMENT ONLY (schedule 7): return after phase 1 staging,
-                                         2 L0, 3 L1, 4 L2, 5 L3, 6 L4; 0 (default) = whole encoder */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 
@@ -88,17 +83,29 @@ int gnnpp_filter_pack(const float* h, float* packed, int G, int F, int K, int E,
  *          [B,N,G]   node-major when x_node_major == 1 (requires Nin == N);
  * S        [B,E,N,N] when s_batched == 1 (BatchLSIGF), [E,N,N] when 0 (LSIGF, shared by the batch);
  *          element type double when s_is_f64 != 0, else float;
- * packed   from gnnpp_filter_pack;  bias [F] or NULL (graphML.py:139-140 / :2365-2366);
+ * packed   from gnnpp_filter_pack;  bias [F] (bias_per_node == 0), [F,N] one value per feature and
+ *          node (bias_per_node != 0; the reference's `b` is F x N or F x 1, graphML.py:2300-2302,
+ *          :2365-2366), or NULL;
  * y        [B,F,Nin] when y_node_major == 0, [B,N,F] when 1;
  * Nin <= N: nodes Nin..N-1 of x are zero and the corresponding outputs are dropped
  *          (zero padding + index_select of graphML.py:1206-1218 / :2464-2476);
  * relu     apply max(.,0) to y (GFL[1], decentralplanner.py:221).
- * Limits:  1 <= N <= GNNPP_MAX_NODES at G,F <= 128 (LDS footprint); K >= 1.
+ * Limits:  1 <= N <= GNNPP_MAX_NODES at G,F <= 128 (LDS footprint); K >= 1; any F
+ *          (more than 128 output features run as ceil(F/128) launches inside the call).
+ * range_flag  optional DEVICE int (NULL = no check), see "Range guard" below.
  */
 int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const float* bias,
                     float* y, int B, int N, int Nin, int G, int F, int K, int E,
                     int s_is_f64, int s_batched, int x_node_major, int y_node_major, int relu,
-                    void* stream);
+                    int bias_per_node, int* range_flag, void* stream);
+
+/* Range guard.  The default schedules feed the f16 matrix pipe with fp32 operands split in hi + lo
+ * halves (22 mantissa bits), which is exact to ~2^-22 as long as every activation
+ * satisfies |x| < 65504.  A call that hands a larger value to that pipe stores 1 to *range_flag
+ * (never cleared by the library; plain store, no synchronisation added): the results of that call
+ * are then NOT trustworthy -- re-run it under the exact-fp32 schedules (GNNPP_TUNE_ENCODER_VARIANT
+ * = 5, GNNPP_TUNE_FILTER_F16 = 0), which have no range limit and never write the flag.
+ * gnnpp_error_string(GNNPP_ERR_RANGE) is the message the Python layer raises. */
 
 /*
  * Training variant of gnnpp_lsigf_fwd (loss.backward() at agents/decentralplannerlocal.py:314):
@@ -106,12 +113,13 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
  *                 dW[f,e,k,g] = sum_{b,n} dy[b,f,n] z_{e,k}[b,n,g] is one library GEMM per tap;
  *   s_transposed  use S^T.  The input gradient of the filter is itself a filter,
  *                 dx = sum_k W_k^T . dy . (S^T)^k, i.e. this call with x := dy, taps packed from
- *                 h.permute(3,1,2,0) and s_transposed = 1.
+ *                 h.permute(3,1,2,0) and s_transposed = 1.  This form always contracts on the exact
+ *                 fp32 MFMA (cotangents are far below the f16 normal range).
  */
 int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
                          float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
                          int s_is_f64, int s_batched, int s_transposed, int x_node_major,
-                         int y_node_major, int relu, void* stream);
+                         int y_node_major, int relu, int bias_per_node, int* range_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-agent encoder: 5 x (conv3x3 pad 1 -> BatchNorm(eval) -> ReLU [-> MaxPool 2]) -> flatten ->
@@ -140,16 +148,18 @@ int gnnpp_encoder_pack(const gnnpp_encoder_params* params, float* packed, void* 
 
 /* obs [M,3,11,11] (M = B*N agents, agent index b*N+n as in inputTensor[B,N,3,11,11]) ->
  * feat [M,128] node-major.  Any M >= 1. */
-int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, void* stream);
+int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, int* range_flag,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole policy step: DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318):
  * encoder -> GraphFilterBatch(128,128,K,E=1) -> ReLU -> actionsMLP Linear(128,5).
  * ------------------------------------------------------------------------------------------ */
 /*
- * obs      [B,N,3,11,11];  S [B,N,N] float or double (s_is_f64);
- * enc_packed / filt_packed from the two pack calls; gf_bias [128] (GFL.0.bias), act_w [5,128],
- * act_b [5] (actionsMLP.0.*);
+ * obs      [B,N,3,11,11];  S [B,E,N,N] float or double (s_is_f64); E = 1 in the reference's
+ *          configuration (decentralplanner.py:208; addGSO :266-276 handles E > 1);
+ * enc_packed / filt_packed from the two pack calls (taps h[128,E,K,128]); gf_bias [128] (GFL.0.bias),
+ * act_w [5,128], act_b [5] (actionsMLP.0.*);
  * feat_ws  workspace [B*N,128] (receives the encoder output, i.e. extractFeatureMap in
  *          node-major order);
  * logits   [N,B,5]: logits + n*B*5 is the contiguous [B,5] tensor of agent n, the n-th element
@@ -157,8 +167,17 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
  */
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
                      const float* filt_packed, const float* gf_bias, const float* act_w,
-                     const float* act_b, float* feat_ws, float* logits, int B, int N, int K,
-                     int s_is_f64, void* stream);
+                     const float* act_b, float* feat_ws, float* logits, int B, int N, int K, int E,
+                     int s_is_f64, int* range_flag, void* stream);
+
+/* Last graph-filter layer + ReLU + action head of a planner with SEVERAL graph-filter layers
+ * (decentralplanner.py:205-224 builds L layers, :293-315 runs them and the head): the earlier layers
+ * are gnnpp_lsigf_fwd calls (node-major in/out, relu = 1); this call runs layer L on
+ * x [B,N,G] node-major with taps h[F,E,K,G] (F <= 128), bias [F] or NULL, then Linear(F,5):
+ * logits [N,B,5] as gnnpp_policy_fwd. */
+int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, const float* bias,
+                          const float* act_w, const float* act_b, float* logits, int B, int N, int G,
+                          int F, int K, int E, int s_is_f64, int* range_flag, void* stream);
 
 /* Action decode used by the rollout loop (utils/multirobotsim_dcenlocal.py:589-591: LogSoftmax
  * then argmax == argmax of the logits, first maximum wins like torch.max).
@@ -199,7 +218,13 @@ typedef struct gnnpp_rollout {
     int*         reached;       /* [B,N] 0/1                 (count_reachgoal)                   */
     int*         start_step;    /* [B,N], -1 = None          (startStep_action_predict)          */
     int*         end_step;      /* [B,N], -1 = None          (endStep_action_predict)            */
-    const int*   maxstep;       /* [B]                                                           */
+    const int*   maxstep;       /* [B] per-episode step limit (rate_maxstep * makespanTarget)    */
+    int*         done;          /* [B] in/out, or NULL.  The reference's loop stops calling move() for
+                                   a case after the call that saw allReachGoal at entry, or ran with
+                                   currentstep >= maxstep (agents/decentralplannerlocal.py:560-605).
+                                   That call sets done[b] = 1; an episode with done[b] != 0 -- or, with
+                                   or without this array, one called with currentstep > maxstep[b] -- is
+                                   FROZEN: nothing of its state (pos, reached, steps, stats) changes  */
     int*         flags;         /* out [B,3]: allReachGoal at entry, moveCollision, predictCollision */
     int*         stats;         /* out [B,2]: makespan, flowtime (written when the episode ends) */
     int          currentstep;   /* 1-based step index, as the agent passes it (:588)            */
@@ -208,6 +233,7 @@ typedef struct gnnpp_rollout {
     const short* choices;       /* [B,max_choices] recorded outcomes for GNNPP_TIE_REPLAY       */
     int*         choice_count;  /* out [B] tie-breaks consumed in this call, or NULL            */
     int          max_choices;
+    int*         range_flag;    /* gnnpp_rollout_policy_step only: range guard of the policy, or NULL */
 } gnnpp_rollout;
 
 int gnnpp_rollout_observe(const gnnpp_rollout* r, void* stream);

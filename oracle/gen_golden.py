@@ -10,6 +10,9 @@ Outputs
   tests/golden/lsigf_cases.npz    LSIGF / BatchLSIGF / GraphFilter / GraphFilterBatch I/O
   tests/golden/policy_model.npz   DecentralPlannerNet parameters (reference init + randomised BN
                                   running stats) and forward I/O for several (N, K, B)
+  tests/golden/policy_multilayer.npz  planners with L = 2 graph-filter layers and / or E = 2
+  tests/golden/training_grads.npz train-mode forward/backward, standalone filter gradients
+Every random draw is seeded (module constructors included): re-running reproduces the files bit for bit.
 """
 import json
 import os
@@ -90,9 +93,23 @@ def gen_lsigf(gml):
             with torch.no_grad():
                 add('BatchLSIGF', h, Sb, x, b, gml.BatchLSIGF(h, Sb, x, b))
 
+    # per-node bias b[F,N] (graphML.py:2300-2302) and filters wider than one 128-feature launch ------
+    for (G, F_out, K, N, E, wide) in ((16, 24, 3, 10, 1, False), (128, 128, 3, 10, 1, False),
+                                      (20, 150, 3, 7, 2, True), (128, 256, 2, 10, 1, True)):
+        B = 2
+        h = rnd(F_out, E, K, G) / (G * K) ** 0.5
+        x = torch.relu(rnd(B, G, N))
+        b = rnd(F_out, 1) * 0.1 if wide else rnd(F_out, N) * 0.1
+        S1 = synth_gso_sparse(E, N, 3.5, seed=G * 3 + F_out)
+        Sb = synth_gso_sparse(B * E, N, 3.5, seed=G * 5 + F_out).reshape(B, E, N, N)
+        with torch.no_grad():
+            add('LSIGF', h, S1, x, b, gml.LSIGF(h, S1, x, b), {'bias_per_node': not wide})
+            add('BatchLSIGF', h, Sb, x, b, gml.BatchLSIGF(h, Sb, x, b), {'bias_per_node': not wide})
+
     # module forms incl. the Nin < N zero-padding path --------------------------------------
     for (G, F_out, K, N, Nin) in ((8, 12, 3, 10, 7), (128, 128, 3, 10, 10), (5, 3, 2, 6, 6)):
         B = 3
+        torch.manual_seed(G * 1000 + F_out)            # the modules draw their taps from the global RNG
         gf = gml.GraphFilter(G, F_out, K, 1, True)
         gfb = gml.GraphFilterBatch(G, F_out, K, 1, True)
         x = torch.relu(rnd(B, G, Nin))
@@ -159,6 +176,58 @@ def gen_policy(DecentralPlannerNet):
     print('policy_model: %d cases' % len(meta))
 
 
+def gen_multilayer(DecentralPlannerNet, gml):
+    """Planners with SEVERAL graph-filter layers and E > 1 edge features -> policy_multilayer.npz.
+    The reference builds / runs L layers and E features generically (decentralplanner.py:205-224,
+    266-276, 293-315) but fixes L = 1, E = 1 in its source (:130-131, :208); here the reference
+    object is re-wired after construction exactly as editing those lines would (its own
+    GraphFilterBatch modules, its own addGSO / forward)."""
+    from oracle.policy_oracle import synth_gso_geometric, synth_gso_sparse, synth_obs
+    z = np.load(os.path.join(OUT, 'policy_model.npz'))
+    sd_enc = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith('sd/')}
+    store, meta = {}, []
+    for ci, (N, B, dims, taps, E, gso) in enumerate(((10, 3, [64, 128], [3, 2], 1, 'geo64'),
+                                                     (10, 2, [128], [3], 2, 'sparse32'),
+                                                     (5, 2, [32, 48], [2, 3], 2, 'sparse32'),
+                                                     (50, 2, [128, 128], [3, 3], 1, 'geo64'))):
+        torch.manual_seed(8000 + ci)
+        net = DecentralPlannerNet(Cfg(N, 3))
+        net.load_state_dict(sd_enc)                    # encoder (and the soon replaced GFL / head)
+        F = [128] + dims
+        layers = []
+        for l in range(len(dims)):
+            layers += [gml.GraphFilterBatch(F[l], F[l + 1], taps[l], E, True), torch.nn.ReLU(inplace=True)]
+        net.GFL = torch.nn.Sequential(*layers)
+        net.L, net.F, net.K, net.E = len(dims), F, taps, E
+        head = torch.nn.Linear(F[-1], 5)
+        torch.nn.init.xavier_normal_(head.weight)
+        with torch.no_grad():
+            head.bias.copy_(0.05 * torch.randn(5))
+        net.actionsMLP = torch.nn.Sequential(head)
+        net.eval()
+        obs = synth_obs(B, N, seed=300 + ci)
+        if gso == 'geo64':
+            S = torch.from_numpy(synth_gso_geometric(B * E, N, 20, seed=310 + ci)).reshape(B, E, N, N)
+        else:
+            S = synth_gso_sparse(B * E, N, 3.0, seed=310 + ci).reshape(B, E, N, N)
+        with torch.no_grad():
+            net.addGSO(S.squeeze(1) if E == 1 else S)
+            out = net(obs)
+        k = 'm%d_' % ci
+        for l in range(len(dims)):
+            store[k + 'GFL.%d.weight' % (2 * l)] = net.GFL[2 * l].weight.detach().numpy()
+            store[k + 'GFL.%d.bias' % (2 * l)] = net.GFL[2 * l].bias.detach().numpy()
+        store[k + 'actionsMLP.0.weight'] = head.weight.detach().numpy()
+        store[k + 'actionsMLP.0.bias'] = head.bias.detach().numpy()
+        store[k + 'obs'] = obs.numpy().astype(np.uint8)
+        store[k + 'S'] = S.numpy()
+        store[k + 'logits'] = torch.stack(out, dim=1).numpy()                  # [B,N,5]
+        meta.append({'N': N, 'B': B, 'dims': dims, 'taps': taps, 'E': E, 'gso': gso})
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'policy_multilayer.npz'), **store)
+    print('policy_multilayer: %d cases' % len(meta))
+
+
 def gen_training(DecentralPlannerNet, gml):
     """Train-mode forward + backward of the reference (agents/decentralplannerlocal.py:283-317) and
     standalone graph-filter gradients -> tests/golden/training_grads.npz."""
@@ -211,6 +280,7 @@ def gen_training(DecentralPlannerNet, gml):
     for ci, (cls, G, F_out, K, E, N, Nin, B) in enumerate((('GraphFilterBatch', 16, 24, 3, 2, 7, 5, 3),
                                                           ('GraphFilter', 128, 128, 3, 1, 10, 10, 2),
                                                           ('GraphFilterBatch', 128, 128, 4, 1, 10, 10, 2))):
+        torch.manual_seed(6000 + ci)                   # module taps come from the global RNG
         mod = getattr(gml, cls)(G, F_out, K, E, True)
         x = torch.randn(B, G, Nin, generator=g, requires_grad=True)
         if cls == 'GraphFilter':
@@ -235,6 +305,7 @@ def gen_training(DecentralPlannerNet, gml):
     # pre-powered GSO family: matrixPowersBatch / batchLSIGF / GraphFilterBatchGSO
     for ci, (G, F_out, K, E, N, B) in enumerate(((12, 20, 3, 1, 9, 3), (128, 128, 3, 1, 10, 2),
                                                  (8, 8, 4, 2, 6, 2))):
+        torch.manual_seed(7000 + ci)
         mod = gml.GraphFilterBatchGSO(G, F_out, K, E, True)
         S = synth_gso_sparse(B * E, N, 3.0, seed=70 + ci).reshape(B, E, N, N)
         if E == 1 and ci == 0:
@@ -265,4 +336,5 @@ if __name__ == '__main__':
         sys.exit(0)
     gen_lsigf(gml)
     gen_policy(Net)
+    gen_multilayer(Net, gml)
     gen_training(Net, gml)

@@ -165,16 +165,22 @@ def encoder_one_agent(sd, obs_agent, training=False):
 def policy_forward(sd, S, obs, training=False):
     """DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318); eval mode by default.
 
-    sd: state_dict (CPU tensors), S: [B,N,N] (fp32 or fp64), obs: [B,N,3,11,11] fp32.
+    sd: state_dict (CPU tensors), S: [B,N,N] (E = 1, :271-272) or [B,E,N,N] (:274-276), fp32 or fp64,
+    obs: [B,N,3,11,11] fp32.  The graph-filter layers are the `GFL.{2l}` entries of sd -- one in the
+    reference's own configuration, L of them when :130-131 list several (:293-301 runs them all).
     Returns a list of N tensors [B,5] exactly like the reference.
     """
-    assert S.dim() == 3
+    assert S.dim() in (3, 4)
     B, N = obs.shape[0], obs.shape[1]
-    S4 = S.unsqueeze(1)
+    S4 = S.unsqueeze(1) if S.dim() == 3 else S
     feat = torch.zeros(B, 128, N)
     for n in range(N):
         feat[:, :, n] = encoder_one_agent(sd, obs[:, n], training)
-    shared = tF.relu(graph_filter_batch(sd['GFL.0.weight'], sd['GFL.0.bias'], S4, feat))
+    shared, l = feat, 0
+    while 'GFL.%d.weight' % (2 * l) in sd:
+        shared = tF.relu(graph_filter_batch(sd['GFL.%d.weight' % (2 * l)], sd.get('GFL.%d.bias' % (2 * l)),
+                                            S4, shared))
+        l += 1
     out = []
     for n in range(N):
         out.append(tF.linear(shared[:, :, n].reshape(B, -1),

@@ -131,6 +131,7 @@ class EpisodeState:
         self.last_action = [STOP] * self.N
         self.makespan = self.maxstep
         self.flowtime = self.maxstep * self.N
+        self.done = False          # the case loop of the agent has ended (loop_step below)
 
 
 def _inter_robot_collision(ep, choose):
@@ -212,3 +213,18 @@ def move_step(ep, action_ids, currentstep, choose):
         ep.flowtime = sum(ep.end_step[i] - ep.start_step[i] for i in range(ep.N))
         ep.makespan = max(ep.end_step) - min(ep.start_step)
     return all_reached, move_collision, predict_collision
+
+
+def loop_step(ep, action_ids, currentstep, choose):
+    """One iteration of the agent's per-case loop around move()
+    (agents/decentralplannerlocal.py:560-605): `for step in range(maxstep)` with currentStep =
+    step + 1, `break` after the call that returned allReachGoal or ran at currentStep >= maxstep.
+    Once the loop has ended the simulator is never called again, so a batch that keeps stepping its
+    other episodes must leave this one untouched: returns (allReachGoal, False, False) and changes
+    nothing."""
+    if ep.done or currentstep > ep.maxstep:
+        return all(ep.reached), False, False
+    out = move_step(ep, action_ids, currentstep, choose)
+    if out[0] or currentstep >= ep.maxstep:
+        ep.done = True
+    return out

@@ -47,3 +47,19 @@ def rollout_golden():
 @pytest.fixture(scope='session')
 def training_golden():
     return _load('training_grads.npz')
+
+
+@pytest.fixture(scope='session')
+def multilayer_golden():
+    return _load('policy_multilayer.npz')
+
+
+def multilayer_state_dict(zp, zm, ci):
+    """Encoder parameters of policy_model.npz + the graph-filter layers / head of multilayer case ci."""
+    import torch
+    sd = {k: v for k, v in golden_state_dict(zp, 3).items() if not k.startswith(('GFL.', 'actionsMLP.'))}
+    pre = 'm%d_' % ci
+    for k in zm.files:
+        if k.startswith(pre + 'GFL.') or k.startswith(pre + 'actionsMLP.'):
+            sd[k[len(pre):]] = torch.from_numpy(np.array(zm[k]))
+    return sd

@@ -97,3 +97,54 @@ def test_emu_rollout_argument_checks():
     assert lib.gnnpp_rollout_gso(None, None) == -1
     r.B, r.N = 1, 200
     assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == -1
+
+
+def test_emu_mixed_maxstep_freezes_finished_episodes():
+    """Batch with different per-episode limits through the emulated move kernel vs the oracle's case
+    loop (oracle.rollout_oracle.loop_step): an episode past its own maxstep, or whose loop broke
+    after allReachGoal, is left untouched (success/makespan were inflated)."""
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    from oracle import rollout_oracle as ro
+    lib = emu_lib.load()
+    rng = np.random.default_rng(3)
+    B, N, W = 6, 5, 7
+    grids = (rng.random((B, W, W)) < 0.05).astype(np.uint8)
+    starts = np.zeros((B, N, 2), np.int32); goals = np.zeros((B, N, 2), np.int32)
+    for b in range(B):
+        free = np.argwhere(grids[b] == 0)
+        pick = rng.choice(len(free), 2 * N, replace=False)
+        starts[b], goals[b] = free[pick[:N]], free[pick[N:]]
+    grids[0] = 0                              # episode 0: every agent one step (action 3) from its goal
+    starts[0] = [[i, 0] for i in range(N)]
+    goals[0] = [[i, 1] for i in range(N)]
+    limits = np.array([6, 2, 3, 8, 1, 5], np.int32)
+    pos = np.ascontiguousarray(starts.copy())
+    reached = np.zeros((B, N), np.int32)
+    start = np.full((B, N), -1, np.int32); end = np.full((B, N), -1, np.int32)
+    flags = np.zeros((B, 3), np.int32); stats = np.zeros((B, 2), np.int32)
+    done = np.zeros(B, np.int32)
+    r = RolloutStruct()
+    r.grid, r.grid_batched, r.goal, r.pos = grids.ctypes.data, 1, goals.ctypes.data, pos.ctypes.data
+    r.B, r.N, r.H, r.W = B, N, W, W
+    r.reached, r.start_step, r.end_step = reached.ctypes.data, start.ctypes.data, end.ctypes.data
+    r.maxstep, r.flags, r.stats, r.done = limits.ctypes.data, flags.ctypes.data, stats.ctypes.data, done.ctypes.data
+    r.tie_mode = 0
+    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], limits[b]) for b in range(B)]
+    for t in range(10):
+        acts = np.ascontiguousarray(rng.integers(0, 5, size=(B, N)).astype(np.int32))
+        if t == 0:
+            acts[0] = 3                        # all arrive at call 1; call 2 sees allReachGoal and ends the loop
+        r.logits, r.actions, r.currentstep = None, acts.ctypes.data, t + 1
+        assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == 0
+        for b in range(B):
+            f = ro.loop_step(eps[b], acts[b], t + 1, lambda c: c[0])
+            assert [int(v) for v in f] == list(flags[b]), (t, b)
+            assert (pos[b] == eps[b].cur).all(), (t, b)
+            assert bool(done[b]) == eps[b].done, (t, b)
+    for b in range(B):
+        assert eps[b].done and done[b] == 1
+        assert list(stats[b]) == [eps[b].makespan, eps[b].flowtime], b
+        assert list(reached[b]) == [int(v) for v in eps[b].reached]
+        assert list(end[b]) == eps[b].end_step
+    assert list(stats[0]) == [1, N] and limits[0] == 6   # ended by allReachGoal, long before its maxstep

@@ -297,3 +297,122 @@ def test_error_conventions(dev):
     with pytest.raises(RuntimeError):
         gml.LSIGF(torch.zeros(4, 1, 2, 4, device=dev), torch.zeros(1, 5, 5, device=dev).double(),
                   torch.zeros(1, 4, 5, device=dev))
+
+
+def test_multilayer_and_edge_feature_planners(dev, policy_golden, multilayer_golden, enc_variant):
+    """L = 2 graph-filter layers / E = 2 edge features (the generality decentralplanner.py:205-224,
+    266-276, 293-315 has; reference re-wired to produce tests/golden/policy_multilayer.npz) through
+    DecentralPlannerNet's optional config fields."""
+    from conftest import multilayer_state_dict
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    zp, _ = policy_golden
+    zm, meta = multilayer_golden
+    for ci, m in enumerate(meta):
+        class C:
+            num_agents, nGraphFilterTaps, device = m['N'], list(m['taps']), dev
+            dimNodeSignals, numEdgeFeatures = list(m['dims']), m['E']
+        net = DecentralPlannerNet(C()).to(dev).eval()
+        assert net.L == len(m['dims']) and net.E == m['E'] and net.F == [128] + m['dims']
+        sd = multilayer_state_dict(zp, zm, ci)
+        net.load_state_dict(sd)                                   # strict: same key set as the re-wired reference
+        obs = torch.from_numpy(zm['m%d_obs' % ci]).float().to(dev)
+        S = torch.from_numpy(zm['m%d_S' % ci]).to(dev)
+        net.addGSO(S.squeeze(1) if m['E'] == 1 else S)
+        got = torch.stack(net(obs), 1).cpu().numpy()
+        want = zm['m%d_logits' % ci]
+        assert np.abs(got - want).max() <= TOL, (ci, m, np.abs(got - want).max())
+        assert (got.argmax(-1) == want.argmax(-1)).all()
+        # train mode runs the same layers differentiably
+        net.train()
+        net.addGSO(S.squeeze(1) if m['E'] == 1 else S)
+        out = net(obs)
+        assert len(out) == m['N'] and out[0].requires_grad
+        net.eval()
+
+
+def test_filter_split_f16_wide_dynamic_range(dev):
+    """The FILTER's split-f16 contraction (G = 128) with trained-scale taps spread over several decades
+    and features from 1e-3 to 1e3: relative error stays at fp32 level against the float64 statement."""
+    import gnn_pathplanning_amd.graphML as gml
+    g = torch.Generator().manual_seed(17)
+    B, N, K = 64, 10, 3
+    for tap_scale, feat_scale in ((1.0, 1.0), (60.0, 300.0), (0.003, 1e-3), (25.0, 2e-2)):
+        h = torch.randn(128, 1, K, 128, generator=g) * tap_scale / (128 * K) ** 0.5
+        h[:, :, 1] *= 0.01                                         # taps of very different magnitude
+        h[:7] *= 40.0                                              # and a few dominant output features
+        b = torch.randn(128, 1, generator=g) * tap_scale * 0.1
+        x = torch.relu(torch.randn(B, 128, N, generator=g)) * feat_scale
+        x[:, ::5] *= 1e-3
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=3)).unsqueeze(1)
+        ref = orc.lsigf_f64(h.numpy(), S.numpy(), x.numpy(), b.numpy())
+        y = gml.BatchLSIGF(h.to(dev), S.to(dev), x.to(dev), b.to(dev)).cpu().numpy()
+        scale = np.abs(ref).max()
+        assert np.isfinite(y).all() and np.abs(y - ref).max() <= 2e-5 * scale, (tap_scale, feat_scale,
+                                                                               np.abs(y - ref).max() / scale)
+
+
+def test_range_guard_and_exact_fallback(dev):
+    """|activation| >= 65504 cannot go through the split-f16 schedules: the kernels raise the range
+    flag (check_range -> GnnppError), nothing is raised for in-range inputs, and range_policy =
+    'strict' re-runs the call under the exact-fp32 schedules and matches the oracle."""
+    from gnn_pathplanning_amd import _native
+    sd = orc.init_state_dict(3, seed=12)
+    B, N = 9, 10
+    obs = orc.synth_obs(B, N, seed=4)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=4))
+    net = _net(N, 3, dev, sd)
+    net.addGSO(S.to(dev))
+    net(obs.to(dev))
+    net.check_range()                                              # in range: no error
+    big = obs.clone()
+    big[3, 2, 0, 5, 5] = 2.0e5                                      # one huge observation value
+    net(big.to(dev))
+    with pytest.raises(_native.GnnppError, match='f16 range'):
+        net.check_range()
+    net.check_range()                                              # the flag was reset by the raise
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2['ConvLayers.0.weight'] *= 3.0e4                             # activations of L0 beyond 65504
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd2, S, obs), 0)
+    assert torch.isfinite(want).all()
+    net2 = _net(N, 3, dev, sd2)
+    net2.range_policy = 'strict'
+    net2.addGSO(S.to(dev))
+    got = net2.forward_logits(obs.to(dev)).cpu()
+    assert not net2.range_exceeded()                               # consumed by the fallback
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    # the fallback restored the default schedules
+    L = _native.lib()
+    assert L.gnnpp_get_tuning(0) == 7 and L.gnnpp_get_tuning(5) == 1
+
+
+def test_unseen_parameter_updates_and_invalidate_packed(dev):
+    """`p.data` edits do not bump torch's version counters: invalidate_packed() (or a train()/eval()
+    transition) makes the next forward repack."""
+    sd = orc.init_state_dict(3, seed=2)
+    net = _net(5, 3, dev, sd)
+    obs = orc.synth_obs(2, 5, seed=1).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(2, 5, 12, seed=1)).to(dev)
+    net.addGSO(S)
+    a = net.forward_logits(obs).clone()
+    net.actionsMLP[0].weight.data.mul_(3.0)
+    net.GFL[0].weight.data.mul_(0.5)
+    net.ConvLayers[0].weight.data.mul_(1.5)
+    net.invalidate_packed()
+    b = net.forward_logits(obs).clone()
+    sd2 = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd2, S.cpu(), obs.cpu()), 0)
+    assert (b.cpu() - want).abs().max().item() <= TOL and (a - b).abs().max().item() > 1e-3
+    net.GFL[0].weight.data.mul_(2.0)
+    net.train(); net.eval()                                        # the transition repacks as well
+    c = net.forward_logits(obs)
+    sd3 = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want3 = torch.stack(orc.policy_forward(sd3, S.cpu(), obs.cpu()), 0)
+    assert (c.cpu() - want3).abs().max().item() <= TOL
+    # a module moved to another dtype is read through casted copies, not misread
+    net64 = _net(5, 3, dev, sd).double()
+    net64.addGSO(S)
+    d = net64.forward_logits(obs)
+    assert (d - a).abs().max().item() <= 1e-6

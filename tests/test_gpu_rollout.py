@@ -59,15 +59,19 @@ def test_replay_simulator_traces(dev, rollout_golden):
         assert res['start_step'][0].tolist() == m['start_step']
 
 
-@pytest.mark.parametrize('B,N,W,dens', [(64, 10, 20, 0.1), (16, 40, 24, 0.05), (8, 100, 40, 0.05)])
+@pytest.mark.parametrize('B,N,W,dens', [(64, 10, 20, 0.1), (16, 40, 24, 0.05), (8, 100, 40, 0.05),
+                                        (4, 100, 100, 0.02)])        # C5's map size: goal offsets up to 99
 def test_batched_steps_vs_oracle_random_actions(dev, B, N, W, dens):
     """Many episodes at once, random joint actions (lots of collisions), lowest-index tie-break."""
     from gnn_pathplanning_amd.rollout import BatchedRollout
     rng = np.random.default_rng(B + N)
     grids, starts, goals = random_episodes(rng, B, N, W, dens)
     maxstep = 12
-    env = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode='lowest')
-    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], maxstep) for b in range(B)]
+    # mixed per-episode limits (maxstep = rate * makespan[b] in the reference): an episode whose own
+    # loop has ended must stay frozen while the rest of the batch goes on
+    limits = [maxstep - (b % 4) * 3 for b in range(B)]
+    env = BatchedRollout(grids, starts, goals, limits, dev, tie_mode='lowest')
+    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], limits[b]) for b in range(B)]
     radius = [6.0] * B
     lowest = lambda c: c[0]                                              # noqa: E731
     for t in range(maxstep + 1):
@@ -81,13 +85,44 @@ def test_batched_steps_vs_oracle_random_actions(dev, B, N, W, dens):
             assert (obs[b] == ro.build_observations(grids[b], goals[b], eps[b].cur)).all(), (t, b)
             Sb, radius[b], _ = ro.communication_gso(eps[b].cur, radius[b], grow=(t == 0))
             assert radius[b] == rad[b] and (S[b] == Sb.astype(np.float32)).all(), (t, b)
-            f = ro.move_step(eps[b], acts[b], t + 1, lowest)
+            f = ro.loop_step(eps[b], acts[b], t + 1, lowest)
             assert [int(v) for v in f] == flags[b].tolist(), (t, b)
             assert (pos[b] == eps[b].cur).all(), (t, b)
     res = env.results()
     for b in range(B):
         assert res['makespan'][b].item() == eps[b].makespan
         assert res['flowtime'][b].item() == eps[b].flowtime
+        assert bool(res['done'][b]) == eps[b].done and eps[b].done
+        assert res['reached'][b].tolist() == eps[b].reached
+        assert res['end_step'][b].tolist() == eps[b].end_step
+
+
+def test_run_respects_per_episode_maxstep(dev):
+    """BatchedRollout.run() with mixed limits == the reference's case loop run episode by episode
+    (agents/decentralplannerlocal.py:560-605): an episode that hits its own maxstep reports failure
+    and makespan = maxstep even though the batch keeps stepping."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    B, N, W = 12, 10, 20
+    rng = np.random.default_rng(77)
+    grids, starts, goals = random_episodes(rng, B, N, W, 0.08)
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(orc.init_state_dict(3, seed=4))
+    limits = [2 + 3 * (b % 5) for b in range(B)]
+    out = BatchedRollout(grids, starts, goals, limits, dev, tie_mode='lowest').run(net, check_every=3)
+    assert out['done'].all()
+    # episode by episode, alone, with the same limit: identical metrics
+    for b in range(B):
+        solo = BatchedRollout(grids[b:b + 1], starts[b:b + 1], goals[b:b + 1], limits[b], dev,
+                              tie_mode='lowest').run(net, check_every=1)
+        assert solo['steps'] <= limits[b]
+        for k in ('makespan', 'flowtime', 'reached', 'end_step', 'start_step', 'positions'):
+            assert torch.equal(solo[k][0], out[k][b]), (b, k)
+        if not bool(out['success'][b]):
+            assert out['makespan'][b].item() <= limits[b] and out['end_step'][b].max().item() == limits[b]
 
 
 @pytest.mark.parametrize('B,N,W,dens', [(64, 10, 20, 0.1), (16, 40, 24, 0.05), (8, 100, 40, 0.05)])
@@ -174,7 +209,7 @@ def test_closed_loop_rollout_with_policy(dev):
         env.move(logits=logits)
         pos = env.pos.cpu().numpy()
         for b in range(B):
-            ro.move_step(eps[b], acts[b], t + 1, lambda c: c[0])
+            ro.loop_step(eps[b], acts[b], t + 1, lambda c: c[0])
             assert (pos[b] == eps[b].cur).all(), (t, b)
     out = BatchedRollout(grids, starts, goals, 24, dev).run(net, check_every=4)
     assert out['steps'] <= 24 and out['reached'].shape == (B, N)
@@ -200,3 +235,26 @@ def test_rollout_from_reference_case_files(dev, rollout_golden):
     obs = env.observe().cpu().numpy()
     assert (obs[0] == z['t2_obs'][0]).all() and (obs[1] == z['t2_obs'][0]).all()
     assert (env.gso(0)[1].cpu().numpy() == z['t2_gso'][0].astype(np.float32)).all()
+
+
+def test_observe_kernel_projected_goals_full_grid(dev):
+    """Every goal offset with |dx|, |dy| <= 120 around a common goal on a 241x241 map through the REAL
+    observation kernel: channel 1 is the oracle's one-hot cell (atan2 / np.round rule of
+    dataloader/statetransformer.py:47-66 vs the kernel's integer rule)."""
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    W, c, N = 241, 120, 128
+    cells = [(x, y) for x in range(W) for y in range(W) if (x, y) != (c, c)]
+    B = (len(cells) + N - 1) // N
+    cells += cells[:B * N - len(cells)]
+    pos = np.array(cells, np.int64).reshape(B, N, 2)
+    goal = np.full((B, N, 2), c, np.int64)
+    env = BatchedRollout(np.zeros((W, W), np.uint8), pos, goal, 4, dev)
+    ch1 = env.observe()[:, :, 1].cpu().numpy()
+    assert (ch1.sum(axis=(2, 3)) == 1).all()
+    want = np.zeros((B, N, 2), np.int64)
+    for b in range(B):
+        for n in range(N):
+            dx, dy = c - pos[b, n, 0], c - pos[b, n, 1]
+            want[b, n] = (dx + 5, dy + 5) if (abs(dx) <= 4 and abs(dy) <= 4) else ro.projected_goal(dx, dy)
+    bi, ni = np.meshgrid(np.arange(B), np.arange(N), indexing='ij')
+    assert (ch1[bi, ni, want[..., 0], want[..., 1]] == 1.0).all()

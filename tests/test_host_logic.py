@@ -40,7 +40,7 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert lib.gnnpp_filter_packed_floats(5, 3, 2, 1) == 2 * 256 + 2 * 512 + 4
     assert lib.gnnpp_encoder_packed_floats() > 555000 // 4
     # argument validation happens before any HIP call, so it is checkable without a GPU
-    assert lib.gnnpp_encoder_fwd(None, None, None, 16, None) == -1
+    assert lib.gnnpp_encoder_fwd(None, None, None, 16, None, None) == -1
     assert lib.gnnpp_decode_actions(None, None, 1, 1, None) == -1
 
 

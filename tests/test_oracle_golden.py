@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import policy_oracle as orc
-from conftest import golden_state_dict
+from conftest import golden_state_dict, multilayer_state_dict
 
 TOL = 5e-6
 
@@ -85,3 +85,27 @@ def test_synth_gso_properties():
     assert 2.0 < deg.mean() < 6.0              # ~3.4 under the reference rule at (10, 20x20)
     A = orc.synth_gso_sparse(4, 50, 6.6, seed=1)
     assert not torch.allclose(A, A.transpose(1, 2))
+
+
+def test_multilayer_policy_matches_reference(policy_golden, multilayer_golden):
+    """L = 2 graph-filter layers and / or E = 2 edge features (reference re-wired as editing
+    decentralplanner.py:130-131 / :208 would): the oracle's layer loop against the reference's."""
+    zp, _ = policy_golden
+    zm, meta = multilayer_golden
+    seen = set()
+    for ci, m in enumerate(meta):
+        sd = multilayer_state_dict(zp, zm, ci)
+        obs = torch.from_numpy(zm['m%d_obs' % ci]).float()
+        S = torch.from_numpy(zm['m%d_S' % ci])
+        with torch.no_grad():
+            out = orc.policy_forward(sd, S.squeeze(1) if m['E'] == 1 else S, obs)
+        logits = torch.stack(out, dim=1).numpy()
+        assert np.abs(logits - zm['m%d_logits' % ci]).max() <= TOL, (ci, m)
+        seen.add((len(m['dims']), m['E']))
+    assert {(2, 1), (1, 2), (2, 2)} <= seen
+
+
+def test_bias_per_node_and_wide_cases_present(lsigf_golden):
+    _, meta = lsigf_golden
+    assert sum(1 for m in meta if m.get('bias_per_node')) >= 4
+    assert sum(1 for m in meta if m['F'] > 128) >= 4

@@ -14,6 +14,9 @@ from oracle import policy_oracle as orc                       # noqa: E402  (inp
 
 dev = torch.device('cuda:0')
 L = _native.lib()
+# phase ablation / early exit exist only in the -DGNNPP_MEASURE build (csrc/gnnpp_measure.h)
+if len(sys.argv) > 1 and sys.argv[1] in ('encoder_phases', 'filter_ablation'):
+    L = _native.measure_lib()
 vp = lambda t: ctypes.c_void_p(t.data_ptr())                  # noqa: E731
 st = _native.stream_ptr(dev)
 
@@ -52,7 +55,7 @@ def encoder_phases():
         for rep in range(2):
             for stop in (1, 2, 3, 4, 5, 6, 0):
                 L.gnnpp_set_tuning(4, stop)
-                t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
+                t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st))
                 row[names[stop]] = min(round(t, 2), row.get(names[stop], 1e9))
         L.gnnpp_set_tuning(4, 0)
         print(json.dumps(row), flush=True)
@@ -100,14 +103,14 @@ def main():
         feat = torch.empty(M, 128, device=dev)
         row = {'kernel': 'encoder', 'M': M}
         L.gnnpp_set_tuning(0, 5)
-        L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st)
+        L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st)
         ref = feat.clone()
         L.gnnpp_set_tuning(0, 7)
-        L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st)
+        L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st)
         row['max_abs_diff_v7_vs_v5'] = float((feat - ref).abs().max())
         for v in (7, 5, 7, 5):
             L.gnnpp_set_tuning(0, v)
-            t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, st))
+            t = timeit(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st))
             row['v%d_us' % v] = min(round(t, 2), row.get('v%d_us' % v, 1e9))
         L.gnnpp_set_tuning(0, -1)
         print(json.dumps(row), flush=True)
@@ -129,7 +132,7 @@ def main():
                     continue
                 L.gnnpp_set_tuning(1, gpw)
                 t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(x), vp(S), vp(taps), vp(gb), vp(y), B, N, N,
-                                                     128, 128, K, 1, 0, 1, 1, 1, 1, st))
+                                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, None, st))
                 row['w%d_gpw%d_us' % (waves, gpw)] = round(t, 2)
         L.gnnpp_set_tuning(1, 0)
         L.gnnpp_set_tuning(2, 0)
@@ -138,7 +141,7 @@ def main():
         yf = torch.empty(B, 128, N, device=dev)
         S4 = S.unsqueeze(1).contiguous()
         t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(xf), vp(S4), vp(taps), vp(gb), vp(yf), B, N, N, 128, 128,
-                                             K, 1, 0, 1, 0, 0, 0, st))
+                                             K, 1, 0, 1, 0, 0, 0, 0, None, st))
         row['feature_major_us'] = round(t, 2)
         print(json.dumps(row), flush=True)
     # ---- whole policy step (python call included in the stream time) ----
@@ -198,7 +201,7 @@ def filter_ablation():
                            ('no_shift_no_mfma', 3), ('staging_only', 15), ('no_shift_mfma_S', 7)):
             L.gnnpp_set_tuning(3, mask)
             t = timeit(lambda: L.gnnpp_lsigf_fwd(vp(x), vp(S), vp(taps), vp(gb), vp(y), B, N, N, 128,
-                                                 128, K, 1, 0, 1, 1, 1, 1, st))
+                                                 128, K, 1, 0, 1, 1, 1, 1, 0, None, st))
             row[name] = round(t, 2)
         L.gnnpp_set_tuning(3, 0)
         print(json.dumps(row), flush=True)

@@ -46,7 +46,7 @@ def run(M, blocks, iters, mode, reps=20):
             ea0.record()
             if mode in ('mfma', 'both'):
                 for _ in range(reps):
-                    L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, ctypes.c_void_p(sA.cuda_stream))
+                    L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, ctypes.c_void_p(sA.cuda_stream))
             ea1.record()
         with torch.cuda.stream(sB):
             eb0.record()

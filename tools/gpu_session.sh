@@ -12,11 +12,13 @@ has() { [[ " $STEPS " == *" $1 "* ]]; }
 T0=$(date +%s)
 stamp() { echo "== [$(( $(date +%s) - T0 ))s] $1"; }
 if has test; then stamp "pytest -m gpu"
-  timeout 600 python -m pytest tests -q -m gpu --maxfail=6 2>&1 | tail -40 | tee $OUT/pytest_gpu.log; fi
+  timeout 900 python -m pytest tests -q -m gpu --maxfail=8 2>&1 | tail -60 | tee $OUT/pytest_gpu.log; fi
 if has smoke; then stamp smoke
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log; fi
 if has bench; then stamp "bench c2"
-  timeout 300 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
+  timeout 400 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
+if has benchdrv; then stamp "bench c2 with the driver's flags"
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 | tee $OUT/bench_c2_driverflags.json; fi
 if has abenc; then stamp "ab_bench encoder"
   timeout 400 python tools/ab_bench.py encoder 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_encoder.jsonl; fi
 if has fusedab; then stamp "fused policy kernel A/B"
@@ -43,17 +45,17 @@ if has pipelined; then stamp "pipelined steps"
 if has dualpipe; then stamp "dual-pipe probe"
   timeout 300 python tools/dualpipe_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/dualpipe_probe.jsonl; fi
 if has bench35; then for c in c3 c5; do stamp "bench $c"
-  timeout 300 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 5 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
+  timeout 400 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 4 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then stamp "rocprofv3 kernel trace"
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --pipeline-streams 0 > $OUT/prof_run.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --pipeline-streams 0 --pmc off > $OUT/prof_run.log 2>&1
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -12 "$f" | tee $OUT/kernel_stats_head.csv
   find $OUT/prof -name "*kernel_trace.csv" -size +6M -delete; fi
 if has pmc; then stamp "rocprofv3 pmc passes"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-    timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --pipeline-streams 0 > $OUT/pmc_$name.log 2>&1
+    timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --pmc-target > $OUT/pmc_$name.log 2>&1
     python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt
     find $OUT/pmc_$name -name "*.csv" -size +2M -delete
   done; fi

@@ -33,7 +33,7 @@ flag = torch.zeros(2, dtype=torch.int64, device=dev)
 sink = torch.zeros(2, dtype=torch.int64, device=dev)
 sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
 for _ in range(20):
-    L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, ctypes.c_void_p(sA.cuda_stream))
+    L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, ctypes.c_void_p(sA.cuda_stream))
 torch.cuda.synchronize()
 row = {'probe': 'encoder next to one spinning wave', 'M': M}
 for name, mode in (('alone', None), ('s_sleep_only', 0), ('s_sleep_and_poll', 1), ('busy_clock_loop', 2)):
@@ -45,7 +45,7 @@ for name, mode in (('alone', None), ('s_sleep_only', 0), ('s_sleep_and_poll', 1)
         with torch.cuda.stream(sA):
             e0.record()
             for _ in range(5):
-                L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, ctypes.c_void_p(sA.cuda_stream))
+                L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, ctypes.c_void_p(sA.cuda_stream))
             e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / 5)
