@@ -142,12 +142,16 @@ __device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
 __device__ __forceinline__ v8h as_h8(v4f v) { return __builtin_bit_cast(v8h, v); }
 __device__ __forceinline__ v4f as_f4(v8h v) { return __builtin_bit_cast(v4f, v); }
 
-// Range guard of the split-f16 schedules: every value that is about to be split is folded into a
-// per-lane running maximum (one v_max3 per two values); at the end of the kernel a lane that saw
-// |x| >= 65504 (the f16 range: the hi half would be inf and hi + lo no longer x) raises the caller's
-// range flag.  Post-ReLU activations are >= 0, so only the observations and the filter's z rows
-// need the absolute value.
+// Range guard of the split-f16 schedules: the maximum of every group of values about to be split
+// (one v_max3 per two values) is compared against 65504 (the f16 range: the hi half would be inf and
+// hi + lo no longer x) and the wave-wide outcome is OR-ed into a scalar mask -- no vector register
+// stays live for it; at the end of the kernel a non-zero mask raises the caller's range flag.
+// Post-ReLU activations are >= 0, so only the observations and the filter's z rows need |x|.
 constexpr float kF16Max = 65504.f;
+typedef unsigned long long RangeMask;
+__device__ __forceinline__ void range_note(float group_max, RangeMask& bad) {
+    bad |= __ballot(group_max >= kF16Max);
+}
 __device__ __forceinline__ float max4(float m, v4f a) {
     return fmaxf(fmaxf(fmaxf(m, a[0]), fmaxf(a[1], a[2])), a[3]);
 }
@@ -156,8 +160,8 @@ __device__ __forceinline__ float max4abs(float m, v4f a) {
 }
 
 // eight fp32 values (two D tiles) -> hi and lo f16 fragments
-__device__ __forceinline__ void split8(v4f a, v4f b, v4f& hi, v4f& lo, float& amax) {
-    amax = max4(max4(amax, a), b);
+__device__ __forceinline__ void split8(v4f a, v4f b, v4f& hi, v4f& lo, RangeMask& bad) {
+    range_note(max4(max4(0.f, a), b), bad);
     v8h h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -178,8 +182,8 @@ __device__ __forceinline__ float split_word(float x) {
     return __builtin_bit_cast(float, p);
 }
 // four fp32 values (one D tile) -> the 8-byte half of a hi and of a lo fragment
-__device__ __forceinline__ void split4(v4f a, v2f& hi, v2f& lo, float& amax) {
-    amax = max4(amax, a);
+__device__ __forceinline__ void split4(v4f a, v2f& hi, v2f& lo, RangeMask& bad) {
+    range_note(max4(0.f, a), bad);
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     v4h h, l;
 #pragma unroll
@@ -360,7 +364,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     const int a = lane & 15;
     const int q = lane >> 4;
     const int agent0 = blockIdx.x * (FUSED ? pt.N : kTileAgents);   // FUSED: the tile is graph blockIdx.x
-    float amax = 0.f;                                               // range guard (see max4 above)
+    RangeMask bad = 0;                                              // range guard (see range_note above)
 
     WStreamH ws;
     ws.seg[0] = pk + EncLayout::kH1;
@@ -378,8 +382,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         ssv[i] = pk[EncLayout::kHss + min(tid + i * kThreads, EncLayout::kHssFloats - 1)];
     float* const sstab = bufObs + 16 * 256;                          // Y holds <= 16 fragments
     float* const Ssm = sstab + EncLayout::kHssFloats;                // FUSED: GSO, [16][17], zero padded
-    float* const actw = Ssm + 16 * 17;                               // FUSED: action head weights [5][128]
-    float sval = 0.f, awv[3] = {0.f, 0.f, 0.f};
+    float sval = 0.f;
     if (FUSED) {
         const int m = tid >> 4, n = tid & 15;                        // one GSO entry per thread
         if (m < pt.N && n < pt.N) {
@@ -387,8 +390,6 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             sval = pt.s_is_f64 ? (float)reinterpret_cast<const double*>(pt.S)[i]
                                : reinterpret_cast<const float*>(pt.S)[i];
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) awv[i] = pt.act_w[min(tid + i * kThreads, 5 * 128 - 1)];
     }
     v4f ring[kRingH];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -433,7 +434,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             int ch = rem / 121;
             const int r2 = rem - ch * 121;
             int y = r2 / 11, x = r2 - y * 11;
-            amax = max4abs(amax, v[k]);               // (slots past `valid` hold clamped copies of real values)
+            range_note(max4abs(0.f, v[k]), bad);      // (slots past `valid` hold clamped copies of real values)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (e0 + c < valid)
@@ -514,7 +515,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 for (int pp = 1; pp < 4; ++pp) r[i] = vmax(r[i], vfma(acc[pp][i], sc[i], sh[i]));
             }
             v4f hi, lo;
-            split8(r[0], r[1], hi, lo, amax);
+            split8(r[0], r[1], hi, lo, bad);
             X4[(win * 2 + 0) * 64 + lane] = hi;
             X4[(win * 2 + 1) * 64 + lane] = lo;
         };
@@ -537,9 +538,6 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // (first read after L1's mid-layer barrier)
     if (FUSED) {
         Ssm[(tid >> 4) * 17 + (tid & 15)] = sval;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (tid + i * kThreads < 5 * 128) actw[tid + i * kThreads] = awv[i];
     }
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
@@ -564,7 +562,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             if (p < 25) {
                 v4f hi, lo;
                 split8(vrelu(vfma(acc[j][0], sc[0], sh[0])), vrelu(vfma(acc[j][1], sc[1], sh[1])),
-                       hi, lo, amax);
+                       hi, lo, bad);
                 X4[(p * 2 + 0) * 64 + lane] = hi;
                 X4[(p * 2 + 1) * 64 + lane] = lo;
             }
@@ -597,7 +595,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                     r[m] = vmax(r[m], vfma(acc[4 * wi + pp][m], sc[m], sh[m]));
             }
             v4f hi, lo;
-            split8(r[0], r[1], hi, lo, amax);
+            split8(r[0], r[1], hi, lo, bad);
             Y4[((t * 2 + mp) * 2 + 0) * 64 + lane] = hi;
             Y4[((t * 2 + mp) * 2 + 1) * 64 + lane] = lo;
         }
@@ -616,7 +614,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v2f hi, lo;
-            split4(vrelu(vfma(acc[j][0], sc, sh)), hi, lo, amax);
+            split4(vrelu(vfma(acc[j][0], sc, sh)), hi, lo, bad);
             // fragment (pos j, block mt >> 1): this tile is its e = 4 (mt & 1) .. +3 half
             const int o = (j * 2 + (mt >> 1)) * 2;
             X2[((o + 0) * 64 + lane) * 2 + (mt & 1)] = hi;
@@ -641,7 +639,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             for (int j = 1; j < 4; ++j) r[m] = vmax(r[m], vfma(acc[j][m], sc[m], sh[m]));
         }
         v4f hi, lo;
-        split8(r[0], r[1], hi, lo, amax);
+        split8(r[0], r[1], hi, lo, bad);
         Y4[(wave * 2 + 0) * 64 + lane] = hi;
         Y4[(wave * 2 + 1) * 64 + lane] = lo;
     }
@@ -699,7 +697,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         }
     }
     if (!FUSED) {
-        if (range_flag && amax >= kF16Max) *range_flag = 1;
+        if (range_flag && bad) *range_flag = 1;
         return;
     }
 
@@ -734,7 +732,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             float* row = z0 + (rb + half) * kZs;
             const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
             __builtin_amdgcn_wave_barrier();             // all reads of a row precede its writes
-            amax = max4abs(amax, v);
+            range_note(max4abs(0.f, v), bad);
             v4h h, l;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -773,9 +771,17 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
-    if (range_flag && amax >= kF16Max) *range_flag = 1;   // (every split of this kernel is behind us)
-    // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA
+    if (range_flag && bad) *range_flag = 1;               // (every split of this kernel is behind us)
+    // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA.
+    // Wave 0 fetches its A fragments of actionsMLP.0.weight [5,128] now (the weight ring is empty, so a
+    // compiler-issued load no longer interferes); they land while the y rows are written.
     float* const yb = z0 + 3 * (16 * kZs);
+    v4f headA[8];
+    if (wave == 0) {
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg)
+            headA[gg] = a < 5 ? *reinterpret_cast<const v4f*>(pt.act_w + a * 128 + gg * 16 + 4 * q) : vzero();
+    }
     {
         const float finv = pt.filt_h2[filter_packed_h2_floats(128, 128, 3, 1) + 1];
 #pragma unroll
@@ -792,9 +798,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 #pragma unroll
         for (int gg = 0; gg < 8; ++gg) {
             const int f0 = gg * 16 + 4 * q;
-            v4f A = vzero();
-            if (a < 5) A = *reinterpret_cast<const v4f*>(actw + a * 128 + f0);
-            d = mfma16x4(A, *reinterpret_cast<const v4f*>(yb + a * kZs + f0), d);
+            d = mfma16x4(headA[gg], *reinterpret_cast<const v4f*>(yb + a * kZs + f0), d);
         }
         if (a < pt.N && q < 2) {                          // lane holds node a, outputs 4 q + reg
             float* dst = pt.logits + ((size_t)a * pt.B + blockIdx.x) * 5;

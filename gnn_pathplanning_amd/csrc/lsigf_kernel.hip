@@ -135,7 +135,7 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
 // owns a row, reads all of it (16 bytes per lane), then writes the hi halves to the first 256 bytes
 // of the row and the lo halves to the second 256 bytes.
 __device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs, int wave, int nwaves,
-                                           int lane, float& amax) {
+                                           int lane, unsigned long long& bad) {
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     const int half = lane >> 5, hl = lane & 31;
     for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {
@@ -145,7 +145,7 @@ __device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs,
         const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
         __builtin_amdgcn_wave_barrier();                 // all reads of a row precede its writes
         // range guard: |z| >= 65504 does not fit the hi half (rows >= R are copies of valid rows)
-        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+        bad |= __ballot(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= 65504.f);
         v4h h, l;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
     }
 
-    float amax = 0.f;                                    // H2: largest |z| handed to the f16 pipe
+    unsigned long long bad = 0;                          // H2: lanes that handed |z| >= 65504 to the f16 pipe
     v4f acc[RTW], acc2[H2 ? RTW : 1];                    // H2: cross terms accumulate separately
 #pragma unroll
     for (int t = 0; t < RTW; ++t) acc[t] = vzero();
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                     }
                 }
                 __syncthreads();                         // every reader of the fp32 z_k is done
-                split_rows(zcur, R, zs, wave, NW, lane, amax);
+                split_rows(zcur, R, zs, wave, NW, lane, bad);
                 __syncthreads();
                 if (has_mfma && !GNNPP_ABLATE(p, 2)) {
                     const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
 
     // ---- epilogue: bias (+ReLU) -> LDS [row][f] -> coalesced store / fused action head --------
     if (GNNPP_ABLATE(p, 8)) return;
-    if (H2 && p.range_flag && amax >= 65504.f) *p.range_flag = 1;
+    if (H2 && p.range_flag && bad) *p.range_flag = 1;
     __syncthreads();                                   // every wave is done reading z
     float* ybuf = zbuf0;
     float* actw = zbuf1;                               // act_w staged here: [5][F]
