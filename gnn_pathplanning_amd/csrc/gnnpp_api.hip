@@ -178,6 +178,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_WAVES: return g_filter_waves.load();
         case GNNPP_TUNE_FILTER_F16: return g_filter_f16.load();
         case GNNPP_TUNE_FUSED_POLICY: return g_fused_policy.load();
+        case GNNPP_TUNE_FILTER_SPLIT: return g_filter_split.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -207,6 +208,10 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_FILTER_WAVES:
             if (value != 0 && value != 8 && value != 16) return GNNPP_ERR_ARG;
             g_filter_waves.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_SPLIT:
+            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
+            g_filter_split.store(value);
             return GNNPP_OK;
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_ENCODER_STOP:

@@ -9,17 +9,26 @@
 //
 //   1. the feature rows x[b] are staged ONCE into LDS, node-major, row stride G+8 floats
 //      (coalesced 512-byte row reads; the +8 makes the MFMA B-fragment ds_read_b128 conflict free);
-//   2. the dense S slabs are staged into LDS (fp64 -> fp32 on the fly, like `S.float()`);
-//   3. shift k: one half-wavefront per node (two nodes in flight per wave).  Lane m reads S[m,n], a
-//      ballot compacts the column to its non-zeros (exact: structural zeros contribute nothing),
-//      and for each neighbour the half-wave reads that neighbour's 512-byte feature row from LDS
-//      (ds_read_b128 per lane) and accumulates 4 features per lane.  z ping-pongs between two
-//      LDS buffers;
-//   4. contraction of tap k right after its shift: D[f, row] += W_k[f, g] z_k[row, g] on fp32 MFMA
-//      16x16x4 with the accumulators living in registers across all taps; W_k fragments stream
-//      from L2 in a pre-packed order (one 16-byte load per lane per four MFMAs);
+//   2. the dense S slabs are staged into LDS (fp64 -> fp32 on the fly, like `S.float()`), and every
+//      column n is compacted ONCE into its neighbour list: a half-wavefront scans the column 32
+//      candidates at a time, a ballot + prefix popcount gives each non-zero its slot, and the row
+//      indices m (ascending) go to a byte array idx[n][.] with the degree in cnt[n] (exact: structural
+//      zeros contribute nothing).  All K-1 shifts reuse the lists;
+//   3. shift k: one half-wavefront per node (two nodes in flight per wave).  Four neighbours per trip:
+//      one 4-byte read of the index list, the four weights S[m,n] and four 512-byte feature rows from
+//      LDS (ds_read_b128 per lane), an fmaf chain in ascending m with 4 features per lane -- exact
+//      fp32, no ballots or bit scans left in the loop.  z ping-pongs between two LDS buffers;
+//   4. contraction of tap k right after its shift: D[f, row] += W_k[f, g] z_k[row, g] on the MFMA with
+//      the accumulators living in registers across all taps; W_k fragments stream from L2 in a
+//      pre-packed order (one 16-byte load per lane per four MFMAs);
 //   5. epilogue: + bias, optional ReLU, staged through LDS so the store is coalesced in either
 //      output layout; optionally the 128 -> 5 action head (decentralplanner.py:304-315) is fused.
+//
+// Large graphs on an under-filled chip (one graph per workgroup and at most 128 workgroups, e.g. 128
+// graphs of 100 agents): TWO workgroups per graph.  Both stage the whole graph and run the shifts
+// k < K-1 on all rows, but each runs the last shift, the contraction and the epilogue on its own half
+// of the 16-row tiles only; blocks b and b + 8 (same XCD under round-robin dispatch) share a graph so
+// the second reader of x / S hits that XCD's L2.
 //
 // HBM traffic per launch is the algorithmic minimum: x, S and y once (+ the packed taps, L2 hits).
 #include "gnnpp_common.h"
@@ -44,8 +53,10 @@ struct LsigfArgs {
     int F_all, f0, mt0, MT_all;
     int zstride;           // LDS row stride in floats = 16*max(NG,MT) + 8
     int gpw;               // graphs per workgroup
-    int rt_total;          // 16-row MFMA tiles per workgroup = ceil(gpw*N / 16)
+    int rt_total;          // 16-row MFMA tiles of a workgroup's graphs = ceil(gpw*N / 16)
     int Ns;                // LDS row stride of an S slab (odd)
+    int Nl;                // bytes per neighbour-index list = N rounded up to a multiple of 4
+    int nsplit;            // 1, or 2: two workgroups per graph share its row tiles (gpw == 1 only)
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int bias_per_node;     // bias is [F_all, N] (one value per feature AND node, graphML.py:2300-2302)
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
@@ -134,17 +145,17 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
 // In-place fp32 -> split-f16 conversion of the valid rows of a z buffer (G = 128): a half-wave
 // owns a row, reads all of it (16 bytes per lane), then writes the hi halves to the first 256 bytes
 // of the row and the lo halves to the second 256 bytes.
-__device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs, int wave, int nwaves,
-                                           int lane, unsigned long long& bad) {
+__device__ __forceinline__ void split_rows(float* __restrict__ z, int row_lo, int row_hi, int zs,
+                                           int wave, int nwaves, int lane, unsigned long long& bad) {
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     const int half = lane >> 5, hl = lane & 31;
-    for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {
+    for (int rb = row_lo + 2 * wave; rb < row_hi; rb += 2 * nwaves) {
         const int r = rb + half;
-        const bool ok = r < R;
+        const bool ok = r < row_hi;
         float* row = z + (ok ? r : rb) * zs;
         const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
         __builtin_amdgcn_wave_barrier();                 // all reads of a row precede its writes
-        // range guard: |z| >= 65504 does not fit the hi half (rows >= R are copies of valid rows)
+        // range guard: |z| >= 65504 does not fit the hi half (rows >= row_hi are copies of valid rows)
         bad |= __ballot(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= 65504.f);
         v4h h, l;
 #pragma unroll
@@ -159,51 +170,75 @@ __device__ __forceinline__ void split_rows(float* __restrict__ z, int R, int zs,
     }
 }
 
-__device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
-                                            const float* __restrict__ zprev,
-                                            float* __restrict__ zcur, int R, int wave, int nwaves,
+// Column n of every staged S slab -> ascending list of its non-zero row indices (bytes) + degree.
+__device__ __forceinline__ void build_lists(const LsigfArgs& p, const float* __restrict__ Sl,
+                                            unsigned char* __restrict__ idx,
+                                            unsigned char* __restrict__ cnt, int R, int wave, int nwaves,
                                             int lane) {
-    const int N = p.N, zs = p.zstride, GP = p.NG * 16;
+    const int N = p.N;
     const int half = lane >> 5, hl = lane & 31;
     for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {          // wave-uniform trip count
+        const int c = rb + half;
+        const bool cv = c < R;
+        const int cc = cv ? c : rb;
+        const int j = cc / N, n = cc - j * N;
+        const float* Sg = Sl + j * N * p.Ns + n;                 // column n of graph j's slab
+        unsigned char* il = idx + cc * p.Nl;
+        int base = 0;
+        for (int m0 = 0; m0 < N; m0 += 32) {
+            const int m = m0 + hl;
+            const bool nz = cv && m < N && Sg[m * p.Ns] != 0.f;
+            const unsigned long long bal = __ballot(nz);
+            const unsigned mine = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+            if (nz) il[base + __popc(mine & ((1u << hl) - 1u))] = (unsigned char)m;
+            base += __popc(mine);
+        }
+        if (cv && hl == 0) cnt[c] = (unsigned char)base;
+    }
+}
+
+// z_k[r,:] = sum over the neighbours m of node r (ascending) of S[m,n] * z_{k-1}[m,:] for the rows
+// r in [row_lo, row_hi); one half-wave per row, 4 features per lane, 4 neighbours per trip.
+__device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
+                                            const unsigned char* __restrict__ idx,
+                                            const unsigned char* __restrict__ cnt,
+                                            const float* __restrict__ zprev,
+                                            float* __restrict__ zcur, int row_lo, int row_hi, int wave,
+                                            int nwaves, int lane) {
+    const int N = p.N, zs = p.zstride, GP = p.NG * 16;
+    const int half = lane >> 5, hl = lane & 31;
+    for (int rb = row_lo + 2 * wave; rb < row_hi; rb += 2 * nwaves) {   // wave-uniform trip count
         const int r = rb + half;
-        const bool rv = r < R;
+        const bool rv = r < row_hi;
         const int rr = rv ? r : rb;
         const int j = rr / N, n = rr - j * N;
         const float* Sg = Sl + j * N * p.Ns + n;                 // column n of this graph's slab
         const float* zg = zprev + j * N * zs;
+        const unsigned char* il = idx + rr * p.Nl;
+        const int deg = rv ? (int)cnt[rr] : 0;
         for (int c0 = 0; c0 < GP; c0 += 128) {
             const int col = c0 + 4 * hl;
             const bool live = rv && col < GP;
             const int colc = col < GP ? col : 0;
             v4f acc = vzero();
-            for (int m0 = 0; m0 < N; m0 += 32) {
-                const int m = m0 + hl;
-                const float sv = (rv && m < N) ? Sg[m * p.Ns] : 0.f;
-                const unsigned long long bal = __ballot(sv != 0.f);
-                unsigned mine = half ? (unsigned)(bal >> 32) : (unsigned)bal;
-                while (__ballot(mine != 0u)) {                   // any half still has neighbours
-                    int src[4];
-                    float w[4];
+            for (int d = 0; __ballot(d < deg) != 0ull; d += 4) {  // until both halves are done
+                // four list entries at once; entries past the degree are stale bytes of an earlier,
+                // longer list (or the zero fill): valid row indices, weight forced to 0
+                const unsigned pk = *reinterpret_cast<const unsigned*>(il + d);
+                float w[4];
+                v4f zv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool ok = mine != 0u;
-                        const int mm = ok ? __ffs((int)mine) - 1 : 0;
-                        if (ok) mine &= mine - 1u;
-                        src[u] = m0 + mm;
-                        w[u] = ok ? Sg[src[u] * p.Ns] : 0.f;     // weight 0: harmless re-read
-                    }
-                    v4f zv[4];
+                for (int u = 0; u < 4; ++u) {
+                    const int m = (pk >> (8 * u)) & 255;
+                    w[u] = (d + u < deg) ? Sg[m * p.Ns] : 0.f;
+                    zv[u] = *reinterpret_cast<const v4f*>(zg + m * zs + colc);
+                }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        zv[u] = *reinterpret_cast<const v4f*>(zg + src[u] * zs + colc);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc[0] = fmaf(w[u], zv[u][0], acc[0]);
-                        acc[1] = fmaf(w[u], zv[u][1], acc[1]);
-                        acc[2] = fmaf(w[u], zv[u][2], acc[2]);
-                        acc[3] = fmaf(w[u], zv[u][3], acc[3]);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    acc[0] = fmaf(w[u], zv[u][0], acc[0]);
+                    acc[1] = fmaf(w[u], zv[u][1], acc[1]);
+                    acc[2] = fmaf(w[u], zv[u][2], acc[2]);
+                    acc[3] = fmaf(w[u], zv[u][3], acc[3]);
                 }
             }
             if (live) *reinterpret_cast<v4f*>(zcur + r * zs + col) = acc;
@@ -211,7 +246,8 @@ __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __r
     }
 }
 
-// x -> z_0 rows (node-major in LDS) by the threads [t0, t0+nt) of the workgroup.
+// x -> z_0 rows (node-major in LDS) by the threads [t0, t0+nt) of the workgroup.  Index pairs
+// (row, column) advance incrementally: no integer division in the loops.
 __device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ z0, int g0, int ng,
                                         int t0, int nt, bool rezero) {
     const int N = p.N, zs = p.zstride, R = ng * N;
@@ -220,30 +256,39 @@ __device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ 
         const float* xs = p.x + (size_t)g0 * N * p.G;
         if ((p.G & 3) == 0) {
             const int G4 = p.G >> 2;
-            for (int i = t0; i < R * G4; i += nt) {
-                const int r = i / G4, c = i - r * G4;
+            const int dr = nt / G4, dc = nt - dr * G4;
+            int r = t0 / G4, c = t0 - r * G4;
+            for (; r < R; ) {
                 *reinterpret_cast<v4f*>(z0 + r * zs + 4 * c) =
                     *reinterpret_cast<const v4f*>(xs + (size_t)r * p.G + 4 * c);
+                r += dr; c += dc;
+                if (c >= G4) { c -= G4; ++r; }
             }
         } else {
-            for (int i = t0; i < R * p.G; i += nt) {
-                const int r = i / p.G, c = i - r * p.G;
+            const int dr = nt / p.G, dc = nt - dr * p.G;
+            int r = t0 / p.G, c = t0 - r * p.G;
+            for (; r < R; ) {
                 z0[r * zs + c] = xs[(size_t)r * p.G + c];
+                r += dr; c += dc;
+                if (c >= p.G) { c -= p.G; ++r; }
             }
         }
     } else {
         // x[b][g][n], n < Nin; linear (coalesced) walk over each graph's G x Nin slab
         const int slab = p.G * p.Nin;
+        const int dg = nt / p.Nin, dn = nt - dg * p.Nin;
         for (int j = 0; j < ng; ++j) {
             const float* xs = p.x + (size_t)(g0 + j) * slab;
+            int g = t0 / p.Nin, n = t0 - g * p.Nin;
             for (int i = t0; i < slab; i += nt) {
-                const int g = i / p.Nin, n = i - g * p.Nin;
                 z0[(j * N + n) * zs + g] = xs[i];
+                g += dg; n += dn;
+                if (n >= p.Nin) { n -= p.Nin; ++g; }
             }
             if (rezero)                                 // rows n >= Nin must be zero again
                 for (int i = t0; i < (N - p.Nin) * p.G; i += nt) {
-                    const int n = p.Nin + i / p.G, g = i % p.G;
-                    z0[(j * N + n) * zs + g] = 0.f;
+                    const int nn = p.Nin + i / p.G, gg = i % p.G;
+                    z0[(j * N + nn) * zs + gg] = 0.f;
                 }
         }
     }
@@ -254,20 +299,24 @@ __device__ __forceinline__ void stage_s(const LsigfArgs& p, float* __restrict__ 
                                         int e, int t0, int nt) {
     const int N = p.N, NN = N * N;
     if (t0 < 0) return;
+    const int dm = nt / N, dn = nt - dm * N;
     for (int j = 0; j < ng; ++j) {
         const size_t sidx = ((size_t)(p.s_batched ? (g0 + j) * p.E : 0) + e) * NN;
         float* dst = Sl + j * N * p.Ns;
+        int m = t0 / N, n = t0 - m * N;
         if (p.s_is_f64) {
             const double* src = reinterpret_cast<const double*>(p.S) + sidx;
             for (int i = t0; i < NN; i += nt) {
-                const int m = i / N, n = i - m * N;
                 dst[p.s_transposed ? n * p.Ns + m : m * p.Ns + n] = (float)src[i];
+                m += dm; n += dn;
+                if (n >= N) { n -= N; ++m; }
             }
         } else {
             const float* src = reinterpret_cast<const float*>(p.S) + sidx;
             for (int i = t0; i < NN; i += nt) {
-                const int m = i / N, n = i - m * N;
                 dst[p.s_transposed ? n * p.Ns + m : m * p.Ns + n] = src[i];
+                m += dm; n += dn;
+                if (n >= N) { n -= N; ++m; }
             }
         }
     }
@@ -281,6 +330,9 @@ __device__ __forceinline__ void stage_s(const LsigfArgs& p, float* __restrict__ 
 // H2 (G = 128 only): the contraction runs on the f16 matrix pipe with both operands split in
 //        hi + lo halves (3 MFMAs of K = 32 instead of 8 of K = 4, see encoder_kernel_h2.hip); the
 //        shifts stay exact fp32.  z_k is converted in place once shift k+1 has read it.
+// LDS: z buffers hold exactly R = gpw*N rows (no pad rows): MFMA B-fragment reads of the last,
+//        partial row tile clamp their row to R-1 -- a D column only depends on its own B column, and
+//        the columns of rows >= R are never stored.
 template <int RTW, int NW, int NGT, bool H2>
 __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
@@ -291,22 +343,37 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     const int a = lane & 15;      // row inside a 16-row tile (MFMA j)
     const int q = lane >> 4;      // MFMA k slot
 
-    const int g0 = blockIdx.x * p.gpw;                 // first graph of this workgroup
+    // workgroup -> (first graph, part): with nsplit == 2 the blocks b and b + 8 of a group of 16
+    // carry the two halves of one graph (same XCD under round-robin dispatch)
+    int gblk = blockIdx.x, part = 0;
+    if (p.nsplit == 2) {
+        part = (gblk >> 3) & 1;
+        gblk = (gblk >> 4) * 8 + (gblk & 7);
+    }
+    const int g0 = gblk * p.gpw;                       // first graph of this workgroup
+    if (g0 >= p.B) return;                             // padding block of a split grid (uniform)
     const int ng = min(p.gpw, p.B - g0);               // graphs actually present
     const int N = p.N;
     const int R = ng * N;                              // valid rows
+    const int RA = p.gpw * N;                          // rows allocated per z buffer
     const int zs = p.zstride;
-    const int ROWS = p.rt_total * 16;
     const int NG = NGT ? NGT : p.NG;
     constexpr int NGA = NGT ? NGT : 1;
     const int mtp = p.MT > 4 ? 8 : 4;
     const int mt = wave & (mtp - 1);
-    const int rt0 = (wave / mtp) * RTW;                // first row tile of this wave
-    const bool has_mfma = mt < p.MT && rt0 < p.rt_total;
+    // this workgroup's row tiles [tile_lo, tile_hi) and rows [row_lo, row_hi)
+    const int rt_all = (R + 15) >> 4;
+    const int tile_lo = p.nsplit == 2 ? (part ? rt_all >> 1 : 0) : 0;
+    const int tile_hi = p.nsplit == 2 ? (part ? rt_all : rt_all >> 1) : rt_all;
+    const int row_lo = tile_lo * 16, row_hi = min(tile_hi * 16, R);
+    const int rt0 = tile_lo + (wave / mtp) * RTW;      // first row tile of this wave
+    const bool has_mfma = mt < p.MT && rt0 < tile_hi;
 
     float* zbuf0 = reinterpret_cast<float*>(gnnpp_smem);
-    float* zbuf1 = zbuf0 + ROWS * zs;
-    float* Sl = zbuf1 + ROWS * zs;                     // [gpw][N][Ns]
+    float* zbuf1 = zbuf0 + RA * zs;
+    float* Sl = zbuf1 + RA * zs;                       // [gpw][N][Ns]
+    unsigned char* idx = reinterpret_cast<unsigned char*>(Sl + RA * p.Ns);   // [gpw*N][Nl]
+    unsigned char* cnt = idx + RA * p.Nl;              // [gpw*N]
 
     // Tap weights of the first tap: issued first so their L2 latency hides behind the staging.
     // Packed block (e,k,mt,gg): 64 lanes x 4 floats = the A fragments of four MFMA k-steps.
@@ -324,14 +391,20 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     };
     load_tap(Acur, 0);
 
-    // ---- zero the pad rows of both z buffers (pad columns are never read when G % 16 == 0) -----
+    // ---- zero what the staging does not overwrite ---------------------------------------------------
     {
+        // pad columns / missing nodes must read as zero (pad columns are never read when G % 16 == 0)
         const bool all = (p.G & 15) != 0 || (p.F & 15) != 0 || p.Nin < N;
-        const int r_lo = all ? 0 : R;
-        const int n4 = ((ROWS - r_lo) * zs) >> 2;      // zs is a multiple of 8
-        v4f* z0 = reinterpret_cast<v4f*>(zbuf0 + r_lo * zs);
-        v4f* z1 = reinterpret_cast<v4f*>(zbuf1 + r_lo * zs);
-        for (int i = tid; i < n4; i += NT) { z0[i] = vzero(); z1[i] = vzero(); }
+        if (all) {
+            const int n4 = (RA * zs) >> 2;             // zs is a multiple of 8
+            v4f* z0 = reinterpret_cast<v4f*>(zbuf0);
+            v4f* z1 = reinterpret_cast<v4f*>(zbuf1);
+            for (int i = tid; i < n4; i += NT) { z0[i] = vzero(); z1[i] = vzero(); }
+        }
+        if (p.K > 1) {                                 // index lists: stale entries must be valid rows
+            unsigned* iz = reinterpret_cast<unsigned*>(idx);
+            for (int i = tid; i < (RA * p.Nl) >> 2; i += NT) iz[i] = 0u;
+        }
         if (all) __syncthreads();                      // the x staging below overwrites zeroed cells
     }
     // x and S(e=0) are staged by disjoint thread ranges so their load latencies overlap
@@ -348,6 +421,9 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
 #pragma unroll
     for (int t = 0; t < (H2 ? RTW : 1); ++t) acc2[t] = vzero();
 
+    // B-fragment row of this lane for the wave's t-th row tile, clamped into the allocated rows
+    auto brow = [&](int t) { return min((rt0 + t) * 16 + a, R - 1); };
+
     int tap = 0;
     for (int e = 0; e < p.E; ++e) {
         if (e > 0 && (p.K > 1 || H2)) {
@@ -359,35 +435,44 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             if (p.K > 2 || H2) stage_x(p, zbuf0, g0, ng, tid, NT, true);
         }
         __syncthreads();                               // z_0 (and Sl) visible
+        if (p.K > 1 && !GNNPP_ABLATE(p, 1)) {
+            build_lists(p, Sl, idx, cnt, R, wave, NW, lane);
+            __syncthreads();
+        }
 
         if (H2) {
             // order per tap: shift z_k -> z_{k+1} | convert z_k in place | contract z_k
             for (int k = 0; k < p.K; ++k, ++tap) {
                 float* zcur = (k & 1) ? zbuf1 : zbuf0;
                 float* znxt = (k & 1) ? zbuf0 : zbuf1;
-                if (k + 1 < p.K && !GNNPP_ABLATE(p, 1)) gather_rows(p, Sl, zcur, znxt, R, wave, NW, lane);
-                if (p.zs) {                              // training: keep z_{e,k} (fp32)
+                if (k + 1 < p.K && !GNNPP_ABLATE(p, 1)) {
+                    // only the LAST shift may be restricted to this workgroup's rows
+                    const bool last = k + 2 == p.K;
+                    gather_rows(p, Sl, idx, cnt, zcur, znxt, last ? row_lo : 0, last ? row_hi : R, wave,
+                                NW, lane);
+                }
+                if (p.zs) {                              // training: keep z_{e,k} (fp32), own rows
                     float* zd = p.zs + ((size_t)tap * p.B + g0) * N * p.G;
-                    for (int i = tid; i < R * p.G; i += NT) {
+                    for (int i = row_lo * p.G + tid; i < row_hi * p.G; i += NT) {
                         const int r = i / p.G, c = i - r * p.G;
                         zd[i] = zcur[r * zs + c];
                     }
                 }
                 __syncthreads();                         // every reader of the fp32 z_k is done
-                split_rows(zcur, R, zs, wave, NW, lane, bad);
+                split_rows(zcur, row_lo, row_hi, zs, wave, NW, lane, bad);
                 __syncthreads();
                 if (has_mfma && !GNNPP_ABLATE(p, 2)) {
-                    const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {
                         const v8h Ah = __builtin_bit_cast(v8h, Acur[2 * kb]);
                         const v8h Al = __builtin_bit_cast(v8h, Acur[2 * kb + 1]);
 #pragma unroll
                         for (int t = 0; t < RTW; ++t) {   // one row tile's B pair at a time: 8 VGPRs
+                            const float* zrow = zcur + brow(t) * zs + q * 4;
                             const v8h Bh = __builtin_bit_cast(
-                                v8h, *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + kb * 16));
+                                v8h, *reinterpret_cast<const v4f*>(zrow + kb * 16));
                             const v8h Bl = __builtin_bit_cast(
-                                v8h, *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + 64 + kb * 16));
+                                v8h, *reinterpret_cast<const v4f*>(zrow + 64 + kb * 16));
                             acc2[t] = mfma16h(Ah, Bl, acc2[t]);
                             acc[t] = mfma16h(Ah, Bh, acc[t]);
                             acc2[t] = mfma16h(Al, Bh, acc2[t]);
@@ -403,27 +488,29 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             float* zcur = (k & 1) ? zbuf1 : zbuf0;
             if (tap + 1 < ntaps) load_tap(Anxt, tap + 1);       // in flight during the shift
             if (k > 0) {
-                if (!GNNPP_ABLATE(p, 1))
-                    gather_rows(p, Sl, (k & 1) ? zbuf0 : zbuf1, zcur, R, wave, NW, lane);
+                if (!GNNPP_ABLATE(p, 1)) {
+                    const bool last = k + 1 == p.K;
+                    gather_rows(p, Sl, idx, cnt, (k & 1) ? zbuf0 : zbuf1, zcur, last ? row_lo : 0,
+                                last ? row_hi : R, wave, NW, lane);
+                }
                 __syncthreads();
             }
             if (p.zs) {                                  // training: keep z_{e,k} for dW = dy . z^T
                 float* zd = p.zs + ((size_t)tap * p.B + g0) * N * p.G;
-                for (int i = tid; i < R * p.G; i += NT) {
+                for (int i = row_lo * p.G + tid; i < row_hi * p.G; i += NT) {
                     const int r = i / p.G, c = i - r * p.G;
                     zd[i] = zcur[r * zs + c];
                 }
             }
             // ---- contraction of tap (e,k) on MFMA: D[f, row] += W[f, g] z[row, g] --------------
             if (has_mfma && !GNNPP_ABLATE(p, 2)) {
-                const float* zrow = zcur + (rt0 * 16 + a) * zs + q * 4;
                 if (NGT) {
 #pragma unroll
                     for (int gg = 0; gg < NGA; ++gg) {
                         v4f Bf[RTW];
 #pragma unroll
                         for (int t = 0; t < RTW; ++t)
-                            Bf[t] = *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + gg * 16);
+                            Bf[t] = *reinterpret_cast<const v4f*>(zcur + brow(t) * zs + q * 4 + gg * 16);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -439,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                         v4f Bf[RTW];
 #pragma unroll
                         for (int t = 0; t < RTW; ++t)
-                            Bf[t] = *reinterpret_cast<const v4f*>(zrow + t * 16 * zs + gg * 16);
+                            Bf[t] = *reinterpret_cast<const v4f*>(zcur + brow(t) * zs + q * 4 + gg * 16);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -469,39 +556,40 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         }
 #pragma unroll
         for (int t = 0; t < RTW; ++t) {
-            if (rt0 + t < p.rt_total) {
-                if (p.bias_per_node) {                       // b[f, n]: this lane's row is node n
-                    const int row = (rt0 + t) * 16 + a;
+            const int row = (rt0 + t) * 16 + a;
+            if (rt0 + t < tile_hi && row < R) {          // (rows >= R have no storage)
+                if (p.bias_per_node) {                   // b[f, n]: this lane's row is node n
                     const int n = row % N;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        bv[r] = (f0 + r < p.F && row < R) ? p.bias[(size_t)(p.f0 + f0 + r) * N + n] : 0.f;
+                        bv[r] = (f0 + r < p.F) ? p.bias[(size_t)(p.f0 + f0 + r) * N + n] : 0.f;
                 }
                 v4f v = H2 ? (acc[t] + acc2[t]) * h2_inv + bv : acc[t] + bv;
                 if (p.relu) v = vrelu(v);
-                *reinterpret_cast<v4f*>(ybuf + ((rt0 + t) * 16 + a) * zs + f0) = v;
+                *reinterpret_cast<v4f*>(ybuf + row * zs + f0) = v;
             }
         }
     }
     __syncthreads();
 
+    const int nrows = row_hi - row_lo;
     if (p.y) {
         if (p.y_node_major) {
             float* yd = p.y + (size_t)g0 * N * p.F_all + p.f0;
             if ((p.F & 3) == 0 && (p.F_all & 3) == 0) {
                 const int F4 = p.F >> 2;
-                for (int i = tid; i < R * F4; i += NT) {
-                    const int r = i / F4, c = i - r * F4;
+                for (int i = tid; i < nrows * F4; i += NT) {
+                    const int r = row_lo + i / F4, c = i % F4;
                     *reinterpret_cast<v4f*>(yd + (size_t)r * p.F_all + 4 * c) =
                         *reinterpret_cast<const v4f*>(ybuf + r * zs + 4 * c);
                 }
             } else {
-                for (int i = tid; i < R * p.F; i += NT) {
-                    const int r = i / p.F, c = i - r * p.F;
+                for (int i = tid; i < nrows * p.F; i += NT) {
+                    const int r = row_lo + i / p.F, c = i % p.F;
                     yd[(size_t)r * p.F_all + c] = ybuf[r * zs + c];
                 }
             }
-        } else {
+        } else if (p.nsplit == 1) {
             const int slab = p.F * p.Nin;
             for (int j = 0; j < ng; ++j) {
                 float* yd = p.y + ((size_t)(g0 + j) * p.F_all + p.f0) * p.Nin;
@@ -510,14 +598,24 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                     yd[i] = ybuf[(j * N + n) * zs + f];
                 }
             }
+        } else {
+            // one graph, this workgroup's nodes [row_lo, row_hi) that exist in the output (n < Nin)
+            const int n_lo = row_lo, n_hi = min(row_hi, p.Nin), nn = max(n_hi - n_lo, 0);
+            float* yd = p.y + ((size_t)g0 * p.F_all + p.f0) * p.Nin;
+            for (int i = tid; i < p.F * nn; i += NT) {
+                const int f = i / nn, n = n_lo + i - f * nn;
+                yd[(size_t)f * p.Nin + n] = ybuf[n * zs + f];
+            }
         }
     }
     if (p.act_w) {
         // Action head on MFMA: D[a5, row] = sum_f act_w[a5, f] * y[row, f]; A fragment from the
         // staged act_w (rows >= 5 are zero), B fragment from the staged y tile.
         const int i5 = lane & 15;
-        for (int rt = wave; rt < p.rt_total; rt += NW) {
+        for (int rt = tile_lo + wave; rt < tile_hi; rt += NW) {
             v4f d = vzero();
+            const int r = rt * 16 + a;                  // this lane's row; it holds a5 = 4*q + reg
+            const float* yrow = ybuf + min(r, R - 1) * zs;
             for (int gg = 0; gg < p.MT; ++gg) {
                 const int f0 = gg * 16 + q * 4;
                 v4f A = vzero();
@@ -526,10 +624,9 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                     for (int s = 0; s < 4; ++s)
                         if (f0 + s < p.F) A[s] = actw[i5 * p.F + f0 + s];
                 }
-                const v4f Bv = *reinterpret_cast<const v4f*>(ybuf + (rt * 16 + a) * zs + f0);
+                const v4f Bv = *reinterpret_cast<const v4f*>(yrow + f0);
                 d = mfma16x4(A, Bv, d);
             }
-            const int r = rt * 16 + a;                  // this lane's row; it holds a5 = 4*q + reg
             if (r < R && q < 2) {
                 const int j = r / N, n = r - j * N;
                 float* dst = p.logits + ((size_t)n * p.B + (g0 + j)) * 5;
@@ -564,6 +661,7 @@ __global__ void decode_actions_kernel(const float* __restrict__ logits, int* __r
 // dispatch sees the old or the new value, never a torn one; every value computes the same function).
 std::atomic<int> g_filter_gpw{0};     // 0: heuristic below; > 0: forced graphs per workgroup
 std::atomic<int> g_filter_waves{0};   // 0: heuristic; 8 or 16: forced waves per workgroup
+std::atomic<int> g_filter_split{0};   // 0: heuristic; 1: never, 2: always two workgroups per graph (gpw == 1)
 #ifdef GNNPP_MEASURE
 std::atomic<int> g_filter_ablate{0};  // measurement-only phase ablation mask (see LsigfArgs::ablate)
 #endif
@@ -603,8 +701,9 @@ static hipError_t launch_rtw(int rtw, const LsigfArgs& a, int grid, size_t smem,
 }
 
 static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
-    const int rt = (gpw * a.N + 15) / 16;
-    return (size_t)2 * rt * 16 * a.zstride * 4 + (size_t)gpw * a.N * a.Ns * 4;
+    const size_t rows = (size_t)gpw * a.N;            // z buffers hold exactly the graphs' rows
+    const size_t lists = a.K > 1 ? rows * a.Nl + ((rows + 15) & ~(size_t)15) : 0;
+    return 2 * rows * a.zstride * 4 + rows * a.Ns * 4 + lists;
 }
 
 // Chooses graphs-per-workgroup and waves-per-workgroup and checks the LDS budget.
@@ -626,9 +725,10 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;
     a.Ns = a.N | 1;
+    a.Nl = (a.N + 3) & ~3;
     if (a.N > kMaxRows) return -2;
     // graphs per workgroup: fill the 16-row MFMA tiles, but keep the 256 CUs busy.  Cost model:
-    // rounds over the chip x (fixed staging/latency cost + MFMA work per row tile).
+    // rounds over the chip x (fixed staging/latency cost + work per row tile).
     int best = 1;
     double best_cost = 1e30;
     const int max_gpw = kMaxRows / a.N;
@@ -649,13 +749,22 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     plan.smem = lsigf_smem(a, a.gpw);
     if (plan.smem > (size_t)kLdsBytes) return -2;
     plan.grid = (a.B + a.gpw - 1) / a.gpw;
+    // Two workgroups per graph when single-graph workgroups leave at least half of the 256 CUs idle
+    // and the graph has row tiles to share (see the header); GNNPP_TUNE_FILTER_SPLIT forces 1 / 2.
+    const int forced_split = g_filter_split.load(std::memory_order_relaxed);
+    a.nsplit = 1;
+    if (a.gpw == 1 && a.rt_total >= 2 && (forced_split == 2 || (forced_split == 0 && plan.grid <= 128 &&
+                                                                a.rt_total >= 4)))
+        a.nsplit = 2;
+    const int tiles_per_wg = a.nsplit == 2 ? a.rt_total - a.rt_total / 2 : a.rt_total;
+    if (a.nsplit == 2) plan.grid = ((plan.grid + 7) / 8) * 16;      // groups of 8 graphs x 2 parts
     // waves per workgroup: 16 when there are enough rows / row tiles to feed them
     const int mtp = a.MT > 4 ? 8 : 4;
     plan.nw = (a.gpw * a.N > 24) ? 16 : 8;
     const int forced_nw = g_filter_waves.load(std::memory_order_relaxed);
     if (forced_nw == 8 || forced_nw == 16) plan.nw = forced_nw;
     const int chunks = plan.nw / mtp;
-    plan.rtw = (a.rt_total + chunks - 1) / chunks;
+    plan.rtw = (tiles_per_wg + chunks - 1) / chunks;
     return 0;
 }
 

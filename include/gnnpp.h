@@ -52,6 +52,9 @@ const char* gnnpp_error_string(int code);
                                          -1: restore the default                                    */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
 #define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
+#define GNNPP_TUNE_FILTER_SPLIT    7  /* 0 = heuristic (two workgroups per graph when one-graph workgroups
+                                         fill at most half of the 256 CUs); 1 = never; 2 = whenever
+                                         a workgroup holds one graph with >= 2 row tiles            */
 #define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
                                          on the f16 matrix pipe with hi+lo split operands (shifts
                                          stay exact fp32); 0: fp32 MFMA contraction              */

@@ -89,6 +89,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __ffsll(x) __builtin_ffsll(x)
 #define __ffs(x) __builtin_ffs(x)
 #define __popcll(x) __builtin_popcountll(x)
+#define __popc(x) __builtin_popcount(x)
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16

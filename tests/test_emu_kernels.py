@@ -146,7 +146,7 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
     finally:
         lib.gnnpp_set_tuning(1, 0)
         lib.gnnpp_set_tuning(2, 0)
-    assert lib.gnnpp_set_tuning(7, 0) == -1 and lib.gnnpp_set_tuning(0, 9) == -1
+    assert lib.gnnpp_set_tuning(8, 0) == -1 and lib.gnnpp_set_tuning(0, 9) == -1
     # removed schedules and the measurement-only knobs (csrc/gnnpp_measure.h) are not part of the ABI
     assert lib.gnnpp_set_tuning(0, 3) == -1 and lib.gnnpp_set_tuning(3, 1) == -1 and lib.gnnpp_set_tuning(4, 1) == -1
     assert lib.gnnpp_set_tuning(0, -1) == 0 and lib.gnnpp_get_tuning(0) == 7
@@ -280,3 +280,51 @@ def test_emu_range_guard(emu):
 def el_ref(h, S, x):
     from oracle import policy_oracle as orc
     return orc.lsigf_f64(h, S, x).astype(np.float32)
+
+
+def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
+    """GNNPP_TUNE_FILTER_SPLIT = 2: two workgroups share a graph's row tiles (both run the early shifts
+    on all rows, each the last shift / contraction / epilogue on its half).  Same results as one
+    workgroup per graph, bit for bit, in both layouts, with Nin < N, E = 2 and the tap dump."""
+    el, lib = emu
+    z, meta = lsigf_golden
+    picked = 0
+    try:
+        for i, m in enumerate(meta):
+            N = z['c%d_S' % i].shape[-1]
+            if N < 17 or (m['G'] > 32 and N > 50) or m['kind'] == 'LSIGF':
+                continue
+            h, S, x = z['c%d_h' % i], z['c%d_S' % i], z['c%d_x' % i]
+            b = z['c%d_b' % i] if m['has_bias'] else None
+            batched = m['kind'] in ('BatchLSIGF', 'GraphFilterBatch')
+            outs = []
+            for split in (1, 2):
+                assert lib.gnnpp_set_tuning(7, split) == 0 and lib.gnnpp_set_tuning(1, 1) == 0
+                outs.append(el.lsigf(lib, h, S, x, b, batched, Nin=m.get('Nin')))
+            assert np.array_equal(outs[0], outs[1]), (i, m)
+            assert np.abs(outs[1] - z['c%d_y' % i]).max() <= TOL * max(1.0, np.abs(z['c%d_y' % i]).max())
+            picked += 1
+        # node-major + ReLU + tap dump (training entry point) on a 37-node graph, odd sizes
+        g = np.random.default_rng(11)
+        B, G, F_out, K, E, N = 3, 24, 20, 3, 2, 37
+        h = g.standard_normal((F_out, E, K, G)).astype(np.float32) / 6
+        x = g.standard_normal((B, N, G)).astype(np.float32)
+        S = (g.random((B, E, N, N)) < 0.15).astype(np.float32) * g.random((B, E, N, N)).astype(np.float32)
+        packed = el.pack_filter(lib, h)
+        res = []
+        for split in (1, 2):
+            assert lib.gnnpp_set_tuning(7, split) == 0
+            y = np.full((B, N, F_out), np.nan, np.float32)
+            zs = np.full((E * K, B * N, G), np.nan, np.float32)
+            rc = lib.gnnpp_lsigf_fwd_save(el.ptr(x), el.ptr(S), el.ptr(packed), None, el.ptr(y), el.ptr(zs),
+                                          B, N, N, G, F_out, K, E, 0, 1, 0, 1, 1, 1, 0, None, None)
+            assert rc == 0
+            res.append((y, zs))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        from oracle import policy_oracle as orc
+        ref = np.maximum(orc.lsigf_f64(h, S, x.transpose(0, 2, 1)), 0).transpose(0, 2, 1)
+        assert np.abs(res[1][0] - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+    finally:
+        lib.gnnpp_set_tuning(7, 0)
+        lib.gnnpp_set_tuning(1, 0)
+    assert picked >= 4

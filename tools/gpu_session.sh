@@ -38,6 +38,8 @@ if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path 
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
   stamp "1-rank torchrun nccl"
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
+if has filterab; then stamp "filter kernel A/B"
+  timeout 400 python tools/filter_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_ab.jsonl; fi
 if has fablate; then stamp "filter ablation"
   timeout 300 python tools/ab_bench.py filter_ablation 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_ablation.jsonl; fi
 if has pipelined; then stamp "pipelined steps"
