@@ -35,7 +35,7 @@ constexpr int kLdsBytes = 160 * 1024;
 // builds its own libgnnpp_measure.so); the product library has no knob that changes results.
 #ifdef GNNPP_MEASURE
 #define GNNPP_ABLATE(p, bits) ((p).ablate & (bits))
-#define GNNPP_STOP_AT(stop, phase) ((stop) == (phase))
+#define GNNPP_STOP_AT(stop, phase) (stop == phase)
 #else
 #define GNNPP_ABLATE(p, bits) 0
 #define GNNPP_STOP_AT(stop, phase) false

@@ -54,9 +54,10 @@ struct LsigfArgs {
     int zstride;           // LDS row stride in floats = 16*max(NG,MT) + 8
     int gpw;               // graphs per workgroup
     int rt_total;          // 16-row MFMA tiles of a workgroup's graphs = ceil(gpw*N / 16)
-    int Ns;                // LDS row stride of an S slab (odd)
-    int Nl;                // bytes per neighbour-index list = N rounded up to a multiple of 4
+    int Ns;                // LDS row stride of an S slab in floats = N rounded up to a multiple of 4
+    int Nl;                // bytes per neighbour-index list (= Ns)
     int nsplit;            // 1, or 2: two workgroups per graph share its row tiles (gpw == 1 only)
+    int s_vec4;            // fp32 S slabs are 16-byte aligned multiples of four floats: v4f staging loads
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int bias_per_node;     // bias is [F_all, N] (one value per feature AND node, graphML.py:2300-2302)
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
@@ -170,8 +171,13 @@ __device__ __forceinline__ void split_rows(float* __restrict__ z, int row_lo, in
     }
 }
 
-// Column n of every staged S slab -> ascending list of its non-zero row indices (bytes) + degree.
-__device__ __forceinline__ void build_lists(const LsigfArgs& p, const float* __restrict__ Sl,
+// The S slabs sit in LDS column-major: row c = j*N + n of Sl holds column n of graph j's GSO, i.e. the
+// weights node n gathers with.  Each row is compacted IN PLACE, once: a half-wave reads the whole row
+// into registers (N <= 128: four values per lane), then writes the non-zero weights back to the front
+// of the row in ascending m (ballot + prefix popcount give every non-zero its slot), their row indices
+// m to the byte list idx[c][.], zeros behind them, and the degree to cnt[c].  Exact: structural zeros
+// contribute nothing to the reference's dense product either.
+__device__ __forceinline__ void build_lists(const LsigfArgs& p, float* __restrict__ Sl,
                                             unsigned char* __restrict__ idx,
                                             unsigned char* __restrict__ cnt, int R, int wave, int nwaves,
                                             int lane) {
@@ -180,25 +186,38 @@ __device__ __forceinline__ void build_lists(const LsigfArgs& p, const float* __r
     for (int rb = 2 * wave; rb < R; rb += 2 * nwaves) {          // wave-uniform trip count
         const int c = rb + half;
         const bool cv = c < R;
-        const int cc = cv ? c : rb;
-        const int j = cc / N, n = cc - j * N;
-        const float* Sg = Sl + j * N * p.Ns + n;                 // column n of graph j's slab
-        unsigned char* il = idx + cc * p.Nl;
+        float* wl = Sl + (cv ? c : rb) * p.Ns;
+        unsigned char* il = idx + (cv ? c : rb) * p.Nl;
+        float sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = 32 * u + hl;
+            sv[u] = (cv && m < N) ? wl[m] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();                 // the whole row is in registers before any write
         int base = 0;
-        for (int m0 = 0; m0 < N; m0 += 32) {
-            const int m = m0 + hl;
-            const bool nz = cv && m < N && Sg[m * p.Ns] != 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool nz = sv[u] != 0.f;
             const unsigned long long bal = __ballot(nz);
             const unsigned mine = half ? (unsigned)(bal >> 32) : (unsigned)bal;
-            if (nz) il[base + __popc(mine & ((1u << hl) - 1u))] = (unsigned char)m;
+            if (nz) {
+                const int pos = base + __popc(mine & ((1u << hl) - 1u));
+                il[pos] = (unsigned char)(32 * u + hl);
+                wl[pos] = sv[u];
+            }
             base += __popc(mine);
         }
-        if (cv && hl == 0) cnt[c] = (unsigned char)base;
+        if (cv) {
+            for (int pz = base + hl; pz < p.Ns; pz += 32) wl[pz] = 0.f;      // weights behind the list
+            if (hl == 0) cnt[c] = (unsigned char)base;
+        }
     }
 }
 
 // z_k[r,:] = sum over the neighbours m of node r (ascending) of S[m,n] * z_{k-1}[m,:] for the rows
-// r in [row_lo, row_hi); one half-wave per row, 4 features per lane, 4 neighbours per trip.
+// r in [row_lo, row_hi); one half-wave per row, 4 features per lane, 4 neighbours per trip:
+// one 4-byte read of the index list, one 16-byte read of the weights, four 512-byte row reads.
 __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __restrict__ Sl,
                                             const unsigned char* __restrict__ idx,
                                             const unsigned char* __restrict__ cnt,
@@ -211,28 +230,24 @@ __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __r
         const int r = rb + half;
         const bool rv = r < row_hi;
         const int rr = rv ? r : rb;
-        const int j = rr / N, n = rr - j * N;
-        const float* Sg = Sl + j * N * p.Ns + n;                 // column n of this graph's slab
+        const int j = rr / N;
+        const float* wl = Sl + rr * p.Ns;                        // compacted weights of node rr
         const float* zg = zprev + j * N * zs;
         const unsigned char* il = idx + rr * p.Nl;
         const int deg = rv ? (int)cnt[rr] : 0;
         for (int c0 = 0; c0 < GP; c0 += 128) {
             const int col = c0 + 4 * hl;
             const bool live = rv && col < GP;
-            const int colc = col < GP ? col : 0;
+            const float* zc = zg + (col < GP ? col : 0);
             v4f acc = vzero();
             for (int d = 0; __ballot(d < deg) != 0ull; d += 4) {  // until both halves are done
-                // four list entries at once; entries past the degree are stale bytes of an earlier,
-                // longer list (or the zero fill): valid row indices, weight forced to 0
+                // entries past the degree: weight 0 and a stale (but valid) row index
                 const unsigned pk = *reinterpret_cast<const unsigned*>(il + d);
-                float w[4];
+                const v4f w = *reinterpret_cast<const v4f*>(wl + d);
                 v4f zv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int m = (pk >> (8 * u)) & 255;
-                    w[u] = (d + u < deg) ? Sg[m * p.Ns] : 0.f;
-                    zv[u] = *reinterpret_cast<const v4f*>(zg + m * zs + colc);
-                }
+                for (int u = 0; u < 4; ++u)
+                    zv[u] = *reinterpret_cast<const v4f*>(zc + __umul24((pk >> (8 * u)) & 255u, (unsigned)zs));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     acc[0] = fmaf(w[u], zv[u][0], acc[0]);
@@ -294,27 +309,46 @@ __device__ __forceinline__ void stage_x(const LsigfArgs& p, float* __restrict__ 
     }
 }
 
-// dense S slabs of edge feature e -> LDS (fp64 -> fp32 like `S.float()`), threads [t0, t0+nt)
+// dense S slabs of edge feature e -> LDS (fp64 -> fp32 like `S.float()`), threads [t0, t0+nt).
+// LDS layout: row n = COLUMN n of the GSO (S[m,n] at Sl[n*Ns + m]); with s_transposed the roles of
+// the two indices swap.  fp32 slabs whose size is a multiple of four floats are read 16 bytes at a time.
 __device__ __forceinline__ void stage_s(const LsigfArgs& p, float* __restrict__ Sl, int g0, int ng,
                                         int e, int t0, int nt) {
     const int N = p.N, NN = N * N;
     if (t0 < 0) return;
-    const int dm = nt / N, dn = nt - dm * N;
     for (int j = 0; j < ng; ++j) {
         const size_t sidx = ((size_t)(p.s_batched ? (g0 + j) * p.E : 0) + e) * NN;
         float* dst = Sl + j * N * p.Ns;
-        int m = t0 / N, n = t0 - m * N;
         if (p.s_is_f64) {
             const double* src = reinterpret_cast<const double*>(p.S) + sidx;
+            const int dm = nt / N, dn = nt - dm * N;
+            int m = t0 / N, n = t0 - m * N;
             for (int i = t0; i < NN; i += nt) {
-                dst[p.s_transposed ? n * p.Ns + m : m * p.Ns + n] = (float)src[i];
+                dst[p.s_transposed ? m * p.Ns + n : n * p.Ns + m] = (float)src[i];
+                m += dm; n += dn;
+                if (n >= N) { n -= N; ++m; }
+            }
+        } else if (p.s_vec4) {
+            const v4f* src = reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(p.S) + sidx);
+            const int step = 4 * nt, dm = step / N, dn = step - dm * N;
+            int m = (4 * t0) / N, n = 4 * t0 - m * N;
+            for (int i = t0; i < (NN >> 2); i += nt) {
+                const v4f v = src[i];
+                int mm = m, nn = n;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dst[p.s_transposed ? mm * p.Ns + nn : nn * p.Ns + mm] = v[c];
+                    if (++nn == N) { nn = 0; ++mm; }
+                }
                 m += dm; n += dn;
                 if (n >= N) { n -= N; ++m; }
             }
         } else {
             const float* src = reinterpret_cast<const float*>(p.S) + sidx;
+            const int dm = nt / N, dn = nt - dm * N;
+            int m = t0 / N, n = t0 - m * N;
             for (int i = t0; i < NN; i += nt) {
-                dst[p.s_transposed ? n * p.Ns + m : m * p.Ns + n] = src[i];
+                dst[p.s_transposed ? m * p.Ns + n : n * p.Ns + m] = src[i];
                 m += dm; n += dn;
                 if (n >= N) { n -= N; ++m; }
             }
@@ -355,7 +389,8 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     const int ng = min(p.gpw, p.B - g0);               // graphs actually present
     const int N = p.N;
     const int R = ng * N;                              // valid rows
-    const int RA = p.gpw * N;                          // rows allocated per z buffer
+    const int RA = max(p.gpw * N, 8);                  // rows allocated per z buffer (>= 8: the epilogue
+                                                       // parks act_w [5][F] in the second buffer)
     const int zs = p.zstride;
     const int NG = NGT ? NGT : p.NG;
     constexpr int NGA = NGT ? NGT : 1;
@@ -409,7 +444,8 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     }
     // x and S(e=0) are staged by disjoint thread ranges so their load latencies overlap
     {
-        const int ns = (p.K > 1) ? (NT / 4) : 0;       // last quarter of the threads stage S
+        // the last quarter (small graphs) / half (N >= 32) of the threads stage S
+        const int ns = (p.K > 1) ? (N >= 32 ? NT / 2 : NT / 4) : 0;
         if (ns && !GNNPP_ABLATE(p, 4)) stage_s(p, Sl, g0, ng, 0, tid >= NT - ns ? tid - (NT - ns) : -1, ns);
         stage_x(p, zbuf0, g0, ng, tid < NT - ns ? tid : -1, NT - ns, false);
     }
@@ -701,7 +737,7 @@ static hipError_t launch_rtw(int rtw, const LsigfArgs& a, int grid, size_t smem,
 }
 
 static size_t lsigf_smem(const LsigfArgs& a, int gpw) {
-    const size_t rows = (size_t)gpw * a.N;            // z buffers hold exactly the graphs' rows
+    const size_t rows = (size_t)(gpw * a.N > 8 ? gpw * a.N : 8);   // = RA of the kernel
     const size_t lists = a.K > 1 ? rows * a.Nl + ((rows + 15) & ~(size_t)15) : 0;
     return 2 * rows * a.zstride * 4 + rows * a.Ns * 4 + lists;
 }
@@ -724,8 +760,9 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     if (a.MT > 8) return -2;                          // F > 128 per launch: lsigf_launch splits F
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;
-    a.Ns = a.N | 1;
-    a.Nl = (a.N + 3) & ~3;
+    a.Ns = (a.N + 3) & ~3;                            // 16-byte reads of a row's compacted weights
+    a.Nl = a.Ns;
+    a.s_vec4 = !a.s_is_f64 && ((a.N * a.N) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.S) & 15) == 0;
     if (a.N > kMaxRows) return -2;
     // graphs per workgroup: fill the 16-row MFMA tiles, but keep the 256 CUs busy.  Cost model:
     // rounds over the chip x (fixed staging/latency cost + work per row tile).

@@ -158,7 +158,23 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int) {
     return c;
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+// LDS bounds: everything behind the launch's dynamic shared-memory size is filled with a canary before
+// every workgroup and checked afterwards -- on the GPU an out-of-range LDS write is silently dropped
+// (r02: an epilogue buffer that outgrew a tiny graph's allocation passed here and failed there).
+static void lds_canary(size_t smem_bytes, bool check) {
+    constexpr size_t kLds = 160 * 1024;
+    char* base = gnnpp::gnnpp_smem;
+    for (size_t i = smem_bytes < kLds ? smem_bytes : kLds; i < kLds; ++i) {
+        if (!check) base[i] = (char)0xA5;
+        else if (base[i] != (char)0xA5) {
+            std::fprintf(stderr, "gnnpp emu: LDS write at byte %zu beyond the %zu bytes this launch allocated\n",
+                         i, smem_bytes);
+            std::abort();
+        }
+    }
+}
+
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
     const int nt = (int)block.x;
     static char* arena = nullptr;
     static size_t arena_sz = 0;
@@ -171,6 +187,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     body_fn = &body;
     for (unsigned bb = 0; bb < grid.x * grid.y; ++bb) {
         const unsigned b = bb % grid.x, by = bb / grid.x;
+        lds_canary(smem_bytes, false);
         fibers.assign(nt, Fiber());
         waves.assign((nt + 63) / 64, Wave());
         block_arrived = 0;
@@ -202,6 +219,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 if (fibers[t].done) --live;
             }
         }
+        lds_canary(smem_bytes, true);
     }
     cur = nullptr;
     cur_idx = -1;

@@ -66,7 +66,7 @@ struct Item {                      // per-fiber identity
     dim3 tid, bid, bdim, gdim;
 };
 extern Item* cur;                  // the running fiber
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 void sync_block();
 unsigned long long ballot(int pred);
 int readlane(int v, int src_lane);
@@ -82,7 +82,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define gridDim (gnnpp_emu::cur->gdim)
 
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
-    gnnpp_emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    gnnpp_emu::launch((grid), (block), (size_t)(smem), [=]() { kernel(__VA_ARGS__); })
 
 #define __syncthreads() gnnpp_emu::sync_block()
 #define __ballot(p) gnnpp_emu::ballot((p) ? 1 : 0)
@@ -90,6 +90,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __ffs(x) __builtin_ffs(x)
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
+#define __umul24(a, b) ((unsigned)(a) * (unsigned)(b))
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
