@@ -341,7 +341,7 @@ struct PolicyTail {
 // LDS left behind the filter's z / y rows for the simulator step: positions, move scratch, GSO scratch
 // and the episode's occupancy grid
 constexpr size_t kPolicySimOccBytes =
-    (kBufFloats - 4 * 16 * 136) * sizeof(float) - 4 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
+    (kBufFloats - 4 * 16 * 136) * sizeof(float) - 6 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
 
 template <bool FUSED>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
@@ -821,7 +821,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     {
         int* spos = reinterpret_cast<int*>(z0 + 4 * (16 * kZs));
         int* red = spos + 2 * kMaxAgents;
-        char* gso_smem = reinterpret_cast<char*>(red + 2 * kMaxAgents);
+        char* gso_smem = reinterpret_cast<char*>(red + 4 * kMaxAgents);
         unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
         const int b = blockIdx.x;
         if (tid < 64) move_body(pt.sim, b, tid, red, spos);

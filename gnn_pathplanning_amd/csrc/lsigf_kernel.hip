@@ -230,7 +230,7 @@ __device__ __forceinline__ void gather_rows(const LsigfArgs& p, const float* __r
         const int r = rb + half;
         const bool rv = r < row_hi;
         const int rr = rv ? r : rb;
-        const int j = rr / N;
+        const int j = p.gpw == 1 ? 0 : rr / N;                   // (no integer division for big graphs)
         const float* wl = Sl + rr * p.Ns;                        // compacted weights of node rr
         const float* zg = zprev + j * N * zs;
         const unsigned char* il = idx + rr * p.Nl;

@@ -181,6 +181,9 @@ def rollout_bench():
         net.addGSO(env.S)
         lg = net.forward_logits(env.obs)
         row['move_us'] = round(timeit(lambda: env.move(logits=lg), reps=20), 2)
+        if N <= 32:
+            row['sim_step_us'] = round(timeit(lambda: env.move_and_observe(logits=lg), reps=20), 2)
+        row['policy_us'] = round(timeit(lambda: (net.addGSO(env.S), net.forward_logits(env.obs)), reps=20), 2)
         t = timeit(lambda: env.step(net), reps=20)
         row['step_us'] = round(t, 2)
         row['agent_steps_per_s'] = round(B * N / t * 1e6)
