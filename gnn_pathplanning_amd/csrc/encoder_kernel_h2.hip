@@ -828,7 +828,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         __syncthreads();
         gso_body(pt.sim, b, spos, false, gso_smem, tid, kThreads);
         __syncthreads();
-        observe_body(pt.sim, b, spos, 0, pt.sim.N, occ, tid, kThreads);
+        observe_body(pt.sim, b, spos, 0, pt.sim.N, occ, red, tid, kThreads);    // (red: free again, holds the goals)
     }
 }
 

@@ -47,15 +47,18 @@ __device__ __forceinline__ void projected_goal(int dx, int dy, int& px, int& py)
 constexpr int kObsAgentsPerWg = 16;
 
 // Observations of agents [n0, n1) of episode b by `nt` threads; `pos` may live in LDS (fused step)
-// or in global memory; occ = [H*W] bytes of LDS.
+// or in global memory.  cell = [H*W] bytes of LDS: bit 0 = obstacle (the episode's map, fetched once,
+// coalesced), bit 1 = an agent stands there; goal_l = [2 N] ints of LDS.  The per-element loop then
+// touches LDS only (it was bound by one global-memory round trip per element).
 __device__ __forceinline__ void observe_body(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
-                                             unsigned char* occ, int tid, int nt) {
+                                             unsigned char* cell, int* goal_l, int tid, int nt) {
     const int HW = p.H * p.W;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * HW : 0);
     const int* goal = p.goal + (size_t)b * p.N * 2;
-    for (int i = tid; i < HW; i += nt) occ[i] = 0;
+    for (int i = tid; i < HW; i += nt) cell[i] = grid[i] ? 1 : 0;
+    for (int i = tid; i < 2 * p.N; i += nt) goal_l[i] = goal[i];
     __syncthreads();
-    for (int n = tid; n < p.N; n += nt) occ[pos[2 * n] * p.W + pos[2 * n + 1]] = 1;
+    for (int n = tid; n < p.N; n += nt) cell[pos[2 * n] * p.W + pos[2 * n + 1]] |= 2;   // distinct cells
     __syncthreads();
     float* out = p.obs + ((size_t)b * p.N + n0) * 363;
     for (int e = tid; e < (n1 - n0) * 363; e += nt) {
@@ -65,7 +68,7 @@ __device__ __forceinline__ void observe_body(const RolloutArgs& p, int b, const 
         const int cx = pos[2 * n], cy = pos[2 * n + 1];
         float v = 0.f;
         if (ch == 1) {
-            const int dx = goal[2 * n] - cx, dy = goal[2 * n + 1] - cy;
+            const int dx = goal_l[2 * n] - cx, dy = goal_l[2 * n + 1] - cy;
             int px, py;
             if (dx >= -4 && dx <= 4 && dy >= -4 && dy <= 4) { px = dx + 5; py = dy + 5; }
             else projected_goal(dx, dy, px, py);
@@ -73,8 +76,8 @@ __device__ __forceinline__ void observe_body(const RolloutArgs& p, int b, const 
         } else if (i >= 1 && i <= 9 && j >= 1 && j <= 9) {
             const int x = cx + i - 5, y = cy + j - 5;
             const bool inside = x >= 0 && x < p.H && y >= 0 && y < p.W;
-            if (ch == 0) v = inside ? (float)grid[x * p.W + y] : 1.f;
-            else v = inside ? (float)occ[x * p.W + y] : 0.f;
+            const int c = inside ? (int)cell[x * p.W + y] : 1;               // outside the map = obstacle
+            v = ch == 0 ? (float)(c & 1) : (inside ? (float)(c >> 1) : 0.f);
         }
         out[e] = v;
     }
@@ -86,8 +89,9 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * kObsAgentsPerWg;
+    int* goal_l = reinterpret_cast<int*>(gnnpp_smem);                       // [2 kMaxAgents]
     observe_body(p, b, p.pos + (size_t)b * p.N * 2, n0, min(p.N, n0 + kObsAgentsPerWg),
-                 reinterpret_cast<unsigned char*>(gnnpp_smem), threadIdx.x, 256);
+                 reinterpret_cast<unsigned char*>(goal_l + 2 * kMaxAgents), goal_l, threadIdx.x, 256);
 }
 
 // ---- communication GSO ---------------------------------------------------------------------------
@@ -244,13 +248,34 @@ struct AgentRegs {               // per lane: agents `lane` and `lane + 64`
     int curx[2], cury[2], nxtx[2], nxty[2], last[2];
 };
 
-// Would interRobotCollision change anything?  It reports (and resolves) a collision iff two agents plan
-// the same cell, or two agents plan to swap cells; when neither holds, both of its loops are no-ops and
-// it returns False.  This all-pairs test (positions broadcast through LDS, no cross-lane dependency
-// chains) is ~5x cheaper than the emulation of the python loops below, and after the first resolving
-// pass it is what the remaining passes of move() usually amount to.
-__device__ __forceinline__ bool any_conflict(const AgentRegs& r, int N, int lane, int* __restrict__ xy) {
-    // xy: [kMaxAgents][4] ints of LDS (cur x, cur y, next x, next y); one wave, so wave barriers suffice
+// lowest set bit of a 128-bit mask at or above `from` (-1 if none)
+__device__ __forceinline__ int next_set_bit(MaskPair m, int from) {
+    if (from < 64) {
+        const unsigned long long lo = m.lo & (~0ull << from);
+        if (lo) return __ffsll((long long)lo) - 1;
+        from = 64;
+    }
+    if (from < 128) {
+        const unsigned long long hi = m.hi & (~0ull << (from - 64));
+        if (hi) return 64 + __ffsll((long long)hi) - 1;
+    }
+    return -1;
+}
+
+// interRobotCollision (utils/multirobotsim_dcenlocal.py:462-555).  The python loops visit every agent
+// i = 0..N-1 in order, but an agent only DOES something when (loop 1) its planned cell is planned by
+// somebody else too, or (loop 2) it swaps cells with another agent.  One all-pairs scan (positions
+// broadcast through LDS, no cross-lane dependency chains) marks the agents for which that can be true;
+// the loops then jump from marked agent to marked agent, re-checking each with the LIVE state exactly
+// as the reference does when it reaches it.  The marks are conservative supersets:
+//   loop 1: list_pos only ever changes to the CURRENT cell of an agent that is stopped, so new
+//           duplicates can only appear at those cells -- a ballot per stopped agent adds them;
+//   loop 2: list_nextpos is a snapshot and nxt only ever changes to cur, which cannot create a swap.
+// When nothing is marked the call is the no-op the reference's would be, and returns False.
+__device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
+                                      int& calls, int* __restrict__ xy) {
+    const bool live[2] = {lane < N, lane + 64 < N};
+    // ---- all-pairs scan: xy = [kMaxAgents][4] ints of LDS (cur x, cur y, next x, next y) --------------
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int n = lane + 64 * h;
@@ -259,35 +284,30 @@ __device__ __forceinline__ bool any_conflict(const AgentRegs& r, int N, int lane
             xy[4 * n + 2] = r.nxtx[h]; xy[4 * n + 3] = r.nxty[h];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    bool hit = false;
+    __builtin_amdgcn_wave_barrier();                 // one wave: its LDS writes precede its reads
+    bool dup[2] = {false, false}, swp[2] = {false, false};
     for (int j = 0; j < N; ++j) {
         const int cx = xy[4 * j], cy = xy[4 * j + 1], nx = xy[4 * j + 2], ny = xy[4 * j + 3];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int n = lane + 64 * h;
-            if (n < N && n != j) {
-                hit |= (r.nxtx[h] == nx && r.nxty[h] == ny);                              // same target cell
-                hit |= (r.nxtx[h] == cx && r.nxty[h] == cy && r.curx[h] == nx && r.cury[h] == ny);   // swap
-            }
+            const bool other = live[h] && lane + 64 * h != j;
+            dup[h] |= other && r.nxtx[h] == nx && r.nxty[h] == ny;                    // same planned cell
+            swp[h] |= other && r.curx[h] == nx && r.cury[h] == ny;   // somebody plans MY current cell
         }
     }
     __builtin_amdgcn_wave_barrier();
-    return __ballot(hit) != 0ull;
-}
+    MaskPair todo = ballot2(dup[0], dup[1]);
+    const MaskPair todo2 = ballot2(swp[0], swp[1]);
+    if (!(todo.lo | todo.hi | todo2.lo | todo2.hi)) return false;
 
-__device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
-                                      int& calls, int* __restrict__ xy) {
-    if (!any_conflict(r, N, lane, xy)) return false;
     bool collision = false;
-    const bool live[2] = {lane < N, lane + 64 < N};
     int snx[2], sny[2], lpx[2], lpy[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         snx[h] = r.nxtx[h]; sny[h] = r.nxty[h];              // allagents_pos (never updated)
         lpx[h] = r.nxtx[h]; lpy[h] = r.nxty[h];              // list_pos (updated)
     }
-    for (int i = 0; i < N; ++i) {
+    for (int i = next_set_bit(todo, 0); i >= 0; i = next_set_bit(todo, i + 1)) {
         const int px = lane_get(lpx, i), py = lane_get(lpy, i);
         const MaskPair same = ballot2(live[0] && lpx[0] == px && lpy[0] == py,
                                       live[1] && lpx[1] == px && lpy[1] == py);
@@ -301,20 +321,35 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
             const MaskPair still = ballot2(in0 && r.last[0] == 4, in1 && r.last[1] == 4);
             const bool all_stop = (still.lo | still.hi) != 0;
             const bool in[2] = {in0, in1};
+            bool moved_back[2] = {false, false};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (in[h] && (all_stop || lane + 64 * h != mover)) {
+                    moved_back[h] = lpx[h] != r.curx[h] || lpy[h] != r.cury[h];
                     r.last[h] = 4;
                     r.nxtx[h] = r.curx[h]; r.nxty[h] = r.cury[h];
                     lpx[h] = r.curx[h]; lpy[h] = r.cury[h];
                 }
             }
+            // the cells the stopped agents fell back to may now be claimed twice: mark their claimants
+            MaskPair back = ballot2(moved_back[0], moved_back[1]);
+            for (int s2 = next_set_bit(back, 0); s2 >= 0; s2 = next_set_bit(back, s2 + 1)) {
+                const int qx = lane_get(lpx, s2), qy = lane_get(lpy, s2);
+                const MaskPair claim = ballot2(live[0] && lpx[0] == qx && lpy[0] == qy,
+                                               live[1] && lpx[1] == qx && lpy[1] == qy);
+                if (__popcll(claim.lo) + __popcll(claim.hi) > 1) {
+                    todo.lo |= claim.lo;
+                    todo.hi |= claim.hi;
+                }
+            }
         }
     }
-    // position swaps (:524-553); list_nextpos is a snapshot taken here
+    // position swaps (:524-553); list_nextpos is a snapshot taken here.  Candidates: agents whose
+    // current cell somebody planned at entry -- plus, conservatively, nobody else: plans only ever
+    // change to current cells, and two agents never share a current cell.
 #pragma unroll
     for (int h = 0; h < 2; ++h) { snx[h] = r.nxtx[h]; sny[h] = r.nxty[h]; }
-    for (int i = 0; i < N; ++i) {
+    for (int i = next_set_bit(todo2, 0); i >= 0; i = next_set_bit(todo2, i + 1)) {
         const int cx = lane_get(r.curx, i), cy = lane_get(r.cury, i);
         const MaskPair hit = ballot2(live[0] && snx[0] == cx && sny[0] == cy,
                                      live[1] && snx[1] == cx && sny[1] == cy);
@@ -509,13 +544,14 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     __syncthreads();
     gso_body(p, b, spos, false, gso_smem, tid, nt);
     __syncthreads();
-    observe_body(p, b, spos, 0, p.N, occ, tid, nt);
+    observe_body(p, b, spos, 0, p.N, occ, red, tid, nt);          // (move's scratch is free again: goals)
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
 int rollout_observe_launch(const RolloutArgs& a, hipStream_t st) {
-    const size_t smem = ((size_t)a.H * a.W + 15) & ~(size_t)15;
-    if (smem > 64 * 1024) return -2;
+    const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
+    if (occ > 64 * 1024) return -2;
+    const size_t smem = occ + 2 * kMaxAgents * sizeof(int);
     hipLaunchKernelGGL(rollout_observe_kernel,
                        dim3((a.N + kObsAgentsPerWg - 1) / kObsAgentsPerWg, a.B), dim3(256), smem, st,
                        a);

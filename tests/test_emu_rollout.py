@@ -148,3 +148,54 @@ def test_emu_mixed_maxstep_freezes_finished_episodes():
         assert list(reached[b]) == [int(v) for v in eps[b].reached]
         assert list(end[b]) == eps[b].end_step
     assert list(stats[0]) == [1, N] and limits[0] == 6   # ended by allReachGoal, long before its maxstep
+
+
+def test_emu_move_dense_conflicts_vs_oracle():
+    """Crowded little maps, random joint actions: lots of vertex conflicts, chains of fall-backs and
+    swaps per step.  The kernel's candidate-driven collision passes must reproduce the oracle's
+    agent-by-agent loops exactly (positions, flags, tie-break counts), lowest-index tie-break."""
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    from oracle import rollout_oracle as ro
+    lib = emu_lib.load()
+    rng = np.random.default_rng(21)
+    for (B, N, W) in ((24, 9, 4), (12, 14, 5), (6, 70, 10)):
+        grids = (rng.random((B, W, W)) < 0.04).astype(np.uint8)
+        starts = np.zeros((B, N, 2), np.int32); goals = np.zeros((B, N, 2), np.int32)
+        for b in range(B):
+            free = np.argwhere(grids[b] == 0)
+            while len(free) < N:
+                grids[b] = 0
+                free = np.argwhere(grids[b] == 0)
+            starts[b] = free[rng.choice(len(free), N, replace=False)]
+            goals[b] = free[rng.choice(len(free), N, replace=False)]
+        pos = np.ascontiguousarray(starts.copy())
+        reached = np.zeros((B, N), np.int32)
+        start = np.full((B, N), -1, np.int32); end = np.full((B, N), -1, np.int32)
+        flags = np.zeros((B, 3), np.int32); stats = np.zeros((B, 2), np.int32)
+        ccount = np.zeros(B, np.int32)
+        limits = np.full(B, 50, np.int32)
+        r = RolloutStruct()
+        r.grid, r.grid_batched, r.goal, r.pos = grids.ctypes.data, 1, goals.ctypes.data, pos.ctypes.data
+        r.B, r.N, r.H, r.W = B, N, W, W
+        r.reached, r.start_step, r.end_step = reached.ctypes.data, start.ctypes.data, end.ctypes.data
+        r.maxstep, r.flags, r.stats = limits.ctypes.data, flags.ctypes.data, stats.ctypes.data
+        r.tie_mode, r.choice_count = 0, ccount.ctypes.data
+        eps = [ro.EpisodeState(grids[b], goals[b], starts[b], 50) for b in range(B)]
+        collisions = 0
+        for t in range(6):
+            acts = np.ascontiguousarray(rng.integers(0, 5, size=(B, N)).astype(np.int32))
+            r.logits, r.actions, r.currentstep = None, acts.ctypes.data, t + 1
+            assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == 0
+            for b in range(B):
+                calls = [0]
+
+                def lowest(c, calls=calls):
+                    calls[0] += 1
+                    return c[0]
+                f = ro.move_step(eps[b], acts[b], t + 1, lowest)
+                assert [int(v) for v in f] == list(flags[b]), (N, t, b)
+                assert (pos[b] == eps[b].cur).all(), (N, t, b)
+                assert ccount[b] == calls[0], (N, t, b)
+                collisions += calls[0]
+        assert collisions > 20 * B // 6
