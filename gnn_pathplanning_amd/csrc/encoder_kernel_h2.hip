@@ -341,7 +341,7 @@ struct PolicyTail {
 // LDS left behind the filter's z / y rows for the simulator step: positions, move scratch, GSO scratch
 // and the episode's occupancy grid
 constexpr size_t kPolicySimOccBytes =
-    (kBufFloats - 4 * 16 * 136) * sizeof(float) - 6 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
+    (kBufFloats - 4 * 16 * 136) * sizeof(float) - 8 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
 
 template <bool FUSED>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
@@ -364,6 +364,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     const int a = lane & 15;
     const int q = lane >> 4;
     const int agent0 = blockIdx.x * (FUSED ? pt.N : kTileAgents);   // FUSED: the tile is graph blockIdx.x
+    GNNPP_STAMP(blockIdx.x, 11, tid == 0);
     RangeMask bad = 0;                                              // range guard (see range_note above)
 
     WStreamH ws;
@@ -821,14 +822,19 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     {
         int* spos = reinterpret_cast<int*>(z0 + 4 * (16 * kZs));
         int* red = spos + 2 * kMaxAgents;
-        char* gso_smem = reinterpret_cast<char*>(red + 4 * kMaxAgents);
+        int* goal_l = red + 4 * kMaxAgents;
+        char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
         unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
         const int b = blockIdx.x;
-        if (tid < 64) move_body(pt.sim, b, tid, red, spos);
+        GNNPP_STAMP(b, 10, tid == 0);
+        if (tid < 64) move_body(pt.sim, b, tid, red, spos);                      // wave 0 moves ...
+        else observe_stage(pt.sim, b, occ, goal_l, tid - 64, kThreads - 64);     // ... the others fetch map + goals
         __syncthreads();
+        GNNPP_STAMP(b, 7, tid == 0);
         gso_body(pt.sim, b, spos, false, gso_smem, tid, kThreads);
-        __syncthreads();
-        observe_body(pt.sim, b, spos, 0, pt.sim.N, occ, red, tid, kThreads);    // (red: free again, holds the goals)
+        GNNPP_STAMP(b, 8, tid == 0);
+        observe_finish(pt.sim, b, spos, 0, pt.sim.N, occ, goal_l, tid, kThreads);
+        GNNPP_STAMP(b, 9, tid == 0);
     }
 }
 

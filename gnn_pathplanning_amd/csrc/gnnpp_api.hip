@@ -171,6 +171,16 @@ int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, co
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
+#ifdef GNNPP_MEASURE
+// libgnnpp_measure.so only: copy the kernels' phase time stamps ([1024 workgroups][16 slots], 100 MHz
+// ticks) to a HOST buffer of n entries (synchronises the device).
+int gnnpp_measure_read_stamps(unsigned long long* host, int n) {
+    if (!host || n <= 0 || n > 1024 * 16) return GNNPP_ERR_ARG;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess
+               ? GNNPP_OK : GNNPP_ERR_LAUNCH;
+}
+#endif
+
 int gnnpp_get_tuning(int key) {
     switch (key) {
         case GNNPP_TUNE_ENCODER_VARIANT: return g_encoder_variant.load();

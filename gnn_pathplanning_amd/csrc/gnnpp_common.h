@@ -22,6 +22,10 @@
 
 namespace gnnpp {
 
+#ifdef GNNPP_MEASURE
+__device__ unsigned long long g_stamps[1024 * 16];
+#endif
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));   // one 16x16x32 f16 MFMA operand
@@ -36,9 +40,14 @@ constexpr int kLdsBytes = 160 * 1024;
 #ifdef GNNPP_MEASURE
 #define GNNPP_ABLATE(p, bits) ((p).ablate & (bits))
 #define GNNPP_STOP_AT(stop, phase) (stop == phase)
+// phase time stamps (100 MHz wall clock) of workgroup `wg`, slot 0..15, read back by
+// gnnpp_measure_read_stamps(): where the time goes INSIDE a kernel
+#define GNNPP_STAMP(wg, slot, leader)                                                            \
+    do { if (leader) gnnpp::g_stamps[((wg) & 1023) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define GNNPP_ABLATE(p, bits) 0
 #define GNNPP_STOP_AT(stop, phase) false
+#define GNNPP_STAMP(wg, slot, leader) do { } while (0)
 #endif
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), thread-safe: one

@@ -46,40 +46,63 @@ __device__ __forceinline__ void projected_goal(int dx, int dy, int& px, int& py)
 
 constexpr int kObsAgentsPerWg = 16;
 
-// Observations of agents [n0, n1) of episode b by `nt` threads; `pos` may live in LDS (fused step)
-// or in global memory.  cell = [H*W] bytes of LDS: bit 0 = obstacle (the episode's map, fetched once,
-// coalesced), bit 1 = an agent stands there; goal_l = [2 N] ints of LDS.  The per-element loop then
-// touches LDS only (it was bound by one global-memory round trip per element).
-__device__ __forceinline__ void observe_body(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
-                                             unsigned char* cell, int* goal_l, int tid, int nt) {
+// Observation builder, in two parts so that the static half can run early (in the fused kernels the
+// waves that do not move stage it while wave 0 runs the collision shielding):
+//   observe_stage   cell[H*W] bytes of LDS <- the episode's map (bit 0 = obstacle, fetched once,
+//                   coalesced), goal_l[2N] ints of LDS <- goals; threads [t0, t0+nt)
+//   observe_finish  after a barrier: bit 1 of cell = an agent stands there; per agent the goal's cell in
+//                   the 11x11 channel (in view, or projected onto the border ring) is computed ONCE; then
+//                   one thread per (agent, channel, row): 11 outputs sharing all their index arithmetic.
+//                   Everything in the loops comes from LDS.
+__device__ __forceinline__ void observe_stage(const RolloutArgs& p, int b, unsigned char* cell, int* goal_l,
+                                              int t0, int nt) {
+    if (t0 < 0) return;
     const int HW = p.H * p.W;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * HW : 0);
     const int* goal = p.goal + (size_t)b * p.N * 2;
-    for (int i = tid; i < HW; i += nt) cell[i] = grid[i] ? 1 : 0;
-    for (int i = tid; i < 2 * p.N; i += nt) goal_l[i] = goal[i];
-    __syncthreads();
-    for (int n = tid; n < p.N; n += nt) cell[pos[2 * n] * p.W + pos[2 * n + 1]] |= 2;   // distinct cells
+    for (int i = t0; i < HW; i += nt) cell[i] = grid[i] ? 1 : 0;
+    for (int i = t0; i < 2 * p.N; i += nt) goal_l[i] = goal[i];
+}
+
+__device__ __forceinline__ void observe_finish(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
+                                               unsigned char* cell, int* goal_l, int tid, int nt) {
+    __syncthreads();                                     // staging (and pos, if it lives in LDS) visible
+    for (int n = tid; n < p.N; n += nt) {
+        const int cx = pos[2 * n], cy = pos[2 * n + 1];
+        cell[cx * p.W + cy] |= 2;                        // agents stand on distinct cells
+        const int dx = goal_l[2 * n] - cx, dy = goal_l[2 * n + 1] - cy;
+        int px, py;
+        if (dx >= -4 && dx <= 4 && dy >= -4 && dy <= 4) { px = dx + 5; py = dy + 5; }
+        else projected_goal(dx, dy, px, py);
+        goal_l[2 * n] = px; goal_l[2 * n + 1] = py;      // from here on: the goal's cell in channel 1
+    }
     __syncthreads();
     float* out = p.obs + ((size_t)b * p.N + n0) * 363;
-    for (int e = tid; e < (n1 - n0) * 363; e += nt) {
-        const int n = n0 + e / 363, r = e - (e / 363) * 363;
-        const int ch = r / 121, r2 = r - ch * 121;
-        const int i = r2 / 11, j = r2 - i * 11;
-        const int cx = pos[2 * n], cy = pos[2 * n + 1];
-        float v = 0.f;
+    const int rows = (n1 - n0) * 33;                     // (agent, channel, row i) triples
+    for (int row = tid; row < rows; row += nt) {
+        const int na = row / 33, rr = row - na * 33;
+        const int ch = rr / 11, i = rr - ch * 11;
+        const int n = n0 + na;
+        float* o = out + na * 363 + ch * 121 + i * 11;
         if (ch == 1) {
-            const int dx = goal_l[2 * n] - cx, dy = goal_l[2 * n + 1] - cy;
-            int px, py;
-            if (dx >= -4 && dx <= 4 && dy >= -4 && dy <= 4) { px = dx + 5; py = dy + 5; }
-            else projected_goal(dx, dy, px, py);
-            v = (i == px && j == py) ? 1.f : 0.f;
-        } else if (i >= 1 && i <= 9 && j >= 1 && j <= 9) {
-            const int x = cx + i - 5, y = cy + j - 5;
-            const bool inside = x >= 0 && x < p.H && y >= 0 && y < p.W;
-            const int c = inside ? (int)cell[x * p.W + y] : 1;               // outside the map = obstacle
-            v = ch == 0 ? (float)(c & 1) : (inside ? (float)(c >> 1) : 0.f);
+            const int px = goal_l[2 * n], py = goal_l[2 * n + 1];
+#pragma unroll
+            for (int j = 0; j < 11; ++j) o[j] = (i == px && j == py) ? 1.f : 0.f;
+        } else {
+            const int x = pos[2 * n] + i - 5, y0 = pos[2 * n + 1] - 5;
+            const bool rowin = i >= 1 && i <= 9 && x >= 0 && x < p.H;
+            const bool border = i < 1 || i > 9;          // rows 0 and 10 of the 11x11 frame stay 0
+            const unsigned char* crow = cell + (rowin ? x : 0) * p.W;
+            o[0] = 0.f; o[10] = 0.f;                     // columns 0 and 10 of the frame
+#pragma unroll
+            for (int j = 1; j <= 9; ++j) {
+                const int y = y0 + j;
+                const bool inside = rowin && y >= 0 && y < p.W;
+                const int c = inside ? (int)crow[y] : 1; // outside the map = obstacle
+                const float v = ch == 0 ? (float)(c & 1) : (inside ? (float)(c >> 1) : 0.f);
+                o[j] = border ? 0.f : v;
+            }
         }
-        out[e] = v;
     }
 }
 
@@ -90,8 +113,10 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * kObsAgentsPerWg;
     int* goal_l = reinterpret_cast<int*>(gnnpp_smem);                       // [2 kMaxAgents]
-    observe_body(p, b, p.pos + (size_t)b * p.N * 2, n0, min(p.N, n0 + kObsAgentsPerWg),
-                 reinterpret_cast<unsigned char*>(goal_l + 2 * kMaxAgents), goal_l, threadIdx.x, 256);
+    unsigned char* cell = reinterpret_cast<unsigned char*>(goal_l + 2 * kMaxAgents);
+    observe_stage(p, b, cell, goal_l, threadIdx.x, 256);
+    observe_finish(p, b, p.pos + (size_t)b * p.N * 2, n0, min(p.N, n0 + kObsAgentsPerWg), cell, goal_l,
+                   threadIdx.x, 256);
 }
 
 // ---- communication GSO ---------------------------------------------------------------------------
@@ -109,30 +134,29 @@ __device__ __forceinline__ long long dist2_threshold(double R) {
     return t;
 }
 
-constexpr int kGsoSmemBytes = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;
+constexpr int kGsoSmemBytes = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;   // adj [N][2] | inv [N] | flag
+
+__device__ __forceinline__ unsigned long long lane_get64(const unsigned long long (&v)[2], int agent) {
+    const unsigned long long w = agent < 64 ? v[0] : v[1];
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, agent & 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), agent & 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int* pos, bool grow,
                                          char* smem, int tid, int nt) {
     unsigned long long* adj = reinterpret_cast<unsigned long long*>(smem);          // [N][2]
     double* inv = reinterpret_cast<double*>(adj + 2 * kMaxAgents);                  // [N]
-    double* shared_r = inv + kMaxAgents;                                            // [1]
-    long long* shared_t = reinterpret_cast<long long*>(shared_r + 1);               // [1]
-    int* shared_flag = reinterpret_cast<int*>(shared_t + 1);                        // [1]
+    int* shared_flag = reinterpret_cast<int*>(inv + kMaxAgents + 2);                // [1]
     const int N = p.N;
-    if (tid == 0) {
-        double r = p.radius[b];
-        if (grow) r = r / 1.1;
-        *shared_r = r;
-        *shared_flag = 0;
-    }
-    __syncthreads();
+    // every thread runs the same fp64 radius sequence (R / 1.1, then * 1.1 per attempt): uniform,
+    // bit-identical to the host loop, and no broadcast round trip through LDS
+    double r = p.radius[b];
+    if (grow) r = r / 1.1;
+    int connected = 0;
     for (;;) {
-        if (tid == 0) {
-            if (grow) *shared_r = *shared_r * 1.1;
-            *shared_t = dist2_threshold(*shared_r);
-        }
-        __syncthreads();
-        const long long T = *shared_t;
+        if (grow) r = r * 1.1;
+        const long long T = dist2_threshold(r);
         for (int i = tid; i < N; i += nt) {
             unsigned long long w0 = 0, w1 = 0;
             const int xi = pos[2 * i], yi = pos[2 * i + 1];
@@ -144,7 +168,17 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
             adj[2 * i] = w0; adj[2 * i + 1] = w1;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {
+            // connectivity by graph search from node 0, on wave 0: lane l keeps the adjacency rows of
+            // nodes l and l + 64 in registers, the reached / expanded sets are wave-uniform 128-bit
+            // masks, and a row is fetched with readlane -- no LDS round trip per expanded node
+            unsigned long long a0[2], a1[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = tid + 64 * h;
+                a0[h] = n < N ? adj[2 * n] : 0ull;
+                a1[h] = n < N ? adj[2 * n + 1] : 0ull;
+            }
             unsigned long long r0 = 1ull, r1 = 0, d0 = 0, d1 = 0;      // reached / expanded
             for (;;) {
                 const unsigned long long f0 = r0 & ~d0, f1 = r1 & ~d1;
@@ -152,14 +186,14 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
                 int m;
                 if (f0) { m = __ffsll((long long)f0) - 1; d0 |= 1ull << m; }
                 else { m = 64 + __ffsll((long long)f1) - 1; d1 |= 1ull << (m - 64); }
-                r0 |= adj[2 * m]; r1 |= adj[2 * m + 1];
+                r0 |= lane_get64(a0, m); r1 |= lane_get64(a1, m);
             }
-            const int cnt = __popcll(r0) + __popcll(r1);
-            *shared_flag = (cnt == N);
+            if (tid == 0) *shared_flag = (__popcll(r0) + __popcll(r1) == N);
         }
         __syncthreads();
-        if (*shared_flag || !grow) break;
-        __syncthreads();
+        connected = *shared_flag;
+        if (connected || !grow) break;
+        __syncthreads();                                  // everybody has read the flag before wave 0 rewrites it
     }
     for (int i = tid; i < N; i += nt) {
         const int deg = __popcll(adj[2 * i]) + __popcll(adj[2 * i + 1]);
@@ -176,8 +210,8 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
         }
     }
     if (tid == 0) {
-        p.radius[b] = *shared_r;
-        if (p.connected) p.connected[b] = *shared_flag;
+        p.radius[b] = r;
+        if (p.connected) p.connected[b] = connected;
     }
 }
 
@@ -264,8 +298,8 @@ __device__ __forceinline__ int next_set_bit(MaskPair m, int from) {
 
 // interRobotCollision (utils/multirobotsim_dcenlocal.py:462-555).  The python loops visit every agent
 // i = 0..N-1 in order, but an agent only DOES something when (loop 1) its planned cell is planned by
-// somebody else too, or (loop 2) it swaps cells with another agent.  One all-pairs scan (positions
-// broadcast through LDS, no cross-lane dependency chains) marks the agents for which that can be true;
+// somebody else too, or (loop 2) it swaps cells with another agent.  One all-pairs scan (each agent's
+// planned cell broadcast with readlane) marks the agents for which that can be true;
 // the loops then jump from marked agent to marked agent, re-checking each with the LIVE state exactly
 // as the reference does when it reaches it.  The marks are conservative supersets:
 //   loop 1: list_pos only ever changes to the CURRENT cell of an agent that is stopped, so new
@@ -275,19 +309,11 @@ __device__ __forceinline__ int next_set_bit(MaskPair m, int from) {
 __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
                                       int& calls, int* __restrict__ xy) {
     const bool live[2] = {lane < N, lane + 64 < N};
-    // ---- all-pairs scan: xy = [kMaxAgents][4] ints of LDS (cur x, cur y, next x, next y) --------------
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int n = lane + 64 * h;
-        if (n < N) {
-            xy[4 * n] = r.curx[h]; xy[4 * n + 1] = r.cury[h];
-            xy[4 * n + 2] = r.nxtx[h]; xy[4 * n + 3] = r.nxty[h];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();                 // one wave: its LDS writes precede its reads
+    // ---- all-pairs scan: agent j's planned cell broadcast with readlane (scalar, no LDS latency) -------
+    (void)xy;
     bool dup[2] = {false, false}, swp[2] = {false, false};
     for (int j = 0; j < N; ++j) {
-        const int cx = xy[4 * j], cy = xy[4 * j + 1], nx = xy[4 * j + 2], ny = xy[4 * j + 3];
+        const int nx = lane_get(r.nxtx, j), ny = lane_get(r.nxty, j);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const bool other = live[h] && lane + 64 * h != j;
@@ -295,7 +321,6 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
             swp[h] |= other && r.curx[h] == nx && r.cury[h] == ny;   // somebody plans MY current cell
         }
     }
-    __builtin_amdgcn_wave_barrier();
     MaskPair todo = ballot2(dup[0], dup[1]);
     const MaskPair todo2 = ballot2(swp[0], swp[1]);
     if (!(todo.lo | todo.hi | todo2.lo | todo2.hi)) return false;
@@ -385,6 +410,7 @@ __device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane,
     int* end_step = p.end_step + (size_t)b * N;
     const int step = p.currentstep, maxstep = p.maxstep[b];
 
+    GNNPP_STAMP(b, 0, lane == 0);
     AgentRegs r;
     int key[2], rch[2], sst[2], est[2];
     bool live[2];
@@ -411,6 +437,7 @@ __device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane,
             rch[h] = reached[n]; sst[h] = start_step[n]; est[h] = end_step[n];
         }
     }
+    GNNPP_STAMP(b, 1, lane == 0);
     const MaskPair not_reached = ballot2(live[0] && !rch[0], live[1] && !rch[1]);
     const bool all_reached = !(not_reached.lo | not_reached.hi);
     bool predict_collision = false, move_collision = false;
@@ -458,13 +485,17 @@ __device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane,
         }
         const MaskPair bm = ballot2(bumped[0], bumped[1]);
         predict_collision = (bm.lo | bm.hi) != 0;
+        GNNPP_STAMP(b, 2, lane == 0);
         bool detect = inter_robot_collision(p, r, b, N, lane, calls, red);
+        GNNPP_STAMP(b, 3, lane == 0);
         for (int it = 0; it < N; ++it) {
             if (!detect) break;
             detect = inter_robot_collision(p, r, b, N, lane, calls, red);
             predict_collision = true;
         }
+        GNNPP_STAMP(b, 4, lane == 0);
         move_collision = inter_robot_collision(p, r, b, N, lane, calls, red);
+        GNNPP_STAMP(b, 5, lane == 0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (live[h]) {
@@ -507,6 +538,7 @@ __device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane,
             p.stats[2 * b + 1] = flow;
         }
     }
+    GNNPP_STAMP(b, 6, lane == 0);
     if (lane == 0) {
         p.flags[3 * b] = all_reached;
         p.flags[3 * b + 1] = move_collision;
@@ -537,14 +569,18 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     int* spos = reinterpret_cast<int*>(gnnpp_smem);                        // [N][2]
     int* red = spos + 2 * kMaxAgents;                                      // [4][kMaxAgents]
-    char* gso_smem = reinterpret_cast<char*>(red + 4 * kMaxAgents);
+    int* goal_l = red + 4 * kMaxAgents;                                    // [2][kMaxAgents]
+    char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
     unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (tid < 64) move_body(p, b, tid, red, spos);
+    if (tid < 64) move_body(p, b, tid, red, spos);              // wave 0 moves ...
+    else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);    // ... the others fetch the map and the goals
     __syncthreads();
+    GNNPP_STAMP(b, 7, tid == 0);
     gso_body(p, b, spos, false, gso_smem, tid, nt);
-    __syncthreads();
-    observe_body(p, b, spos, 0, p.N, occ, red, tid, nt);          // (move's scratch is free again: goals)
+    GNNPP_STAMP(b, 8, tid == 0);
+    observe_finish(p, b, spos, 0, p.N, occ, goal_l, tid, nt);
+    GNNPP_STAMP(b, 9, tid == 0);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -572,7 +608,7 @@ int rollout_move_launch(const RolloutArgs& a, hipStream_t st) {
 int rollout_step_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (occ > 64 * 1024) return -2;
-    const size_t smem = 6 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ;
+    const size_t smem = 8 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ;
     const int nt = a.N > 32 ? 1024 : 256;               // enough threads for N * 363 observation cells
     hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B), dim3(nt), smem, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
