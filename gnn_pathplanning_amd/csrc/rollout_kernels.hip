@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
 // fp64 sqrt the reference's pdist uses, once per radius instead of once per agent pair.
 __device__ __forceinline__ long long dist2_threshold(double R) {
     if (!(R > 0.0)) return -1;
-    long long t = (long long)(R * R) + 2;
+    // start at ceil(fl(R*R)) >= the answer (the answer is < R^2 <= fl(R*R) (1 + 2^-53)) and walk down:
+    // two square roots in the common case instead of four
+    long long t = (long long)ceil(R * R);
     while (t >= 0 && !(sqrt((double)t) < R)) --t;
     return t;
 }
@@ -159,11 +161,14 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
         const long long T = dist2_threshold(r);
         for (int i = tid; i < N; i += nt) {
             unsigned long long w0 = 0, w1 = 0;
-            const int xi = pos[2 * i], yi = pos[2 * i + 1];
+            const int2* pj = reinterpret_cast<const int2*>(pos);          // (row, col) pairs, 8-byte aligned
+            const int2 pi = pj[i];
+            const int Ti = T > 0x7fffffffLL ? 0x7fffffff : (int)T;       // d2 < 2^18 on a 256 x 256 map
             for (int j = 0; j < N; ++j) {
-                const int dx = xi - pos[2 * j], dy = yi - pos[2 * j + 1];
-                const bool e = (j != i) && ((long long)(dx * dx + dy * dy) <= T);
-                if (e) { if (j < 64) w0 |= 1ull << j; else w1 |= 1ull << (j - 64); }
+                const int2 q = pj[j];
+                const int dx = pi.x - q.x, dy = pi.y - q.y;
+                const unsigned long long e = (j != i) & (dx * dx + dy * dy <= Ti);
+                if (j < 64) w0 |= e << j; else w1 |= e << (j - 64);
             }
             adj[2 * i] = w0; adj[2 * i + 1] = w1;
         }
@@ -306,62 +311,69 @@ __device__ __forceinline__ int next_set_bit(MaskPair m, int from) {
 //           duplicates can only appear at those cells -- a ballot per stopped agent adds them;
 //   loop 2: list_nextpos is a snapshot and nxt only ever changes to cur, which cannot create a swap.
 // When nothing is marked the call is the no-op the reference's would be, and returns False.
+// (row, col) of a cell as one comparable word; dead lanes carry distinct negative dummies, maps are at
+// most 256 x 256 (the occupancy grid lives in LDS), so keys never collide
+__device__ __forceinline__ int cell_key(int x, int y) { return x * 65536 + y; }
+
+__device__ __forceinline__ MaskPair ballot_eq(const int (&key)[2], int value, bool two) {
+    MaskPair m;
+    m.lo = __ballot(key[0] == value);
+    m.hi = two ? __ballot(key[1] == value) : 0ull;
+    return m;
+}
+
 __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
                                       int& calls, int* __restrict__ xy) {
-    const bool live[2] = {lane < N, lane + 64 < N};
-    // ---- all-pairs scan: agent j's planned cell broadcast with readlane (scalar, no LDS latency) -------
     (void)xy;
-    bool dup[2] = {false, false}, swp[2] = {false, false};
-    for (int j = 0; j < N; ++j) {
-        const int nx = lane_get(r.nxtx, j), ny = lane_get(r.nxty, j);
+    const bool two = N > 64;                         // lanes carry a second agent (wave-uniform)
+    int ckey[2], nkey[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool other = live[h] && lane + 64 * h != j;
-            dup[h] |= other && r.nxtx[h] == nx && r.nxty[h] == ny;                    // same planned cell
-            swp[h] |= other && r.curx[h] == nx && r.cury[h] == ny;   // somebody plans MY current cell
-        }
+    for (int h = 0; h < 2; ++h) {
+        ckey[h] = cell_key(r.curx[h], r.cury[h]);
+        nkey[h] = cell_key(r.nxtx[h], r.nxty[h]);
     }
-    MaskPair todo = ballot2(dup[0], dup[1]);
-    const MaskPair todo2 = ballot2(swp[0], swp[1]);
+    // ---- all-pairs scan, branch-free: agent j's planned cell is broadcast with readlane; one ballot
+    // marks everybody else planning the same cell, one everybody standing on it ------------------------
+    MaskPair todo = {0ull, 0ull}, todo2 = {0ull, 0ull};
+    for (int j = 0; j < N; ++j) {
+        const int nj = lane_get(nkey, j);
+        MaskPair same = ballot_eq(nkey, nj, two), stand = ballot_eq(ckey, nj, two);
+        if (j < 64) { same.lo &= ~(1ull << j); stand.lo &= ~(1ull << j); }
+        else { same.hi &= ~(1ull << (j - 64)); stand.hi &= ~(1ull << (j - 64)); }
+        todo.lo |= same.lo; todo.hi |= same.hi;
+        todo2.lo |= stand.lo; todo2.hi |= stand.hi;
+    }
     if (!(todo.lo | todo.hi | todo2.lo | todo2.hi)) return false;
 
     bool collision = false;
-    int snx[2], sny[2], lpx[2], lpy[2];
+    int skey[2], lkey[2];                            // allagents_pos (never updated), list_pos (updated)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        snx[h] = r.nxtx[h]; sny[h] = r.nxty[h];              // allagents_pos (never updated)
-        lpx[h] = r.nxtx[h]; lpy[h] = r.nxty[h];              // list_pos (updated)
-    }
+    for (int h = 0; h < 2; ++h) { skey[h] = nkey[h]; lkey[h] = nkey[h]; }
     for (int i = next_set_bit(todo, 0); i >= 0; i = next_set_bit(todo, i + 1)) {
-        const int px = lane_get(lpx, i), py = lane_get(lpy, i);
-        const MaskPair same = ballot2(live[0] && lpx[0] == px && lpy[0] == py,
-                                      live[1] && lpx[1] == px && lpy[1] == py);
+        const int pk = lane_get(lkey, i);
+        const MaskPair same = ballot_eq(lkey, pk, two);
         if (__popcll(same.lo) + __popcll(same.hi) > 1) {
             collision = true;
-            const bool in0 = live[0] && snx[0] == px && sny[0] == py;
-            const bool in1 = live[1] && snx[1] == px && sny[1] == py;
-            const MaskPair col = ballot2(in0, in1);
+            const bool in[2] = {skey[0] == pk, skey[1] == pk};
+            const MaskPair col = ballot2(in[0], two && in[1]);
             const int ncol = __popcll(col.lo) + __popcll(col.hi);
             const int mover = kth_set_bit(col, choose_mover(p, b, ncol, calls));
-            const MaskPair still = ballot2(in0 && r.last[0] == 4, in1 && r.last[1] == 4);
+            const MaskPair still = ballot2(in[0] && r.last[0] == 4, two && in[1] && r.last[1] == 4);
             const bool all_stop = (still.lo | still.hi) != 0;
-            const bool in[2] = {in0, in1};
             bool moved_back[2] = {false, false};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (in[h] && (all_stop || lane + 64 * h != mover)) {
-                    moved_back[h] = lpx[h] != r.curx[h] || lpy[h] != r.cury[h];
+                    moved_back[h] = lkey[h] != ckey[h];
                     r.last[h] = 4;
                     r.nxtx[h] = r.curx[h]; r.nxty[h] = r.cury[h];
-                    lpx[h] = r.curx[h]; lpy[h] = r.cury[h];
+                    lkey[h] = ckey[h];
                 }
             }
             // the cells the stopped agents fell back to may now be claimed twice: mark their claimants
-            MaskPair back = ballot2(moved_back[0], moved_back[1]);
+            const MaskPair back = ballot2(moved_back[0], two && moved_back[1]);
             for (int s2 = next_set_bit(back, 0); s2 >= 0; s2 = next_set_bit(back, s2 + 1)) {
-                const int qx = lane_get(lpx, s2), qy = lane_get(lpy, s2);
-                const MaskPair claim = ballot2(live[0] && lpx[0] == qx && lpy[0] == qy,
-                                               live[1] && lpx[1] == qx && lpy[1] == qy);
+                const MaskPair claim = ballot_eq(lkey, lane_get(lkey, s2), two);
                 if (__popcll(claim.lo) + __popcll(claim.hi) > 1) {
                     todo.lo |= claim.lo;
                     todo.hi |= claim.hi;
@@ -370,23 +382,24 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
         }
     }
     // position swaps (:524-553); list_nextpos is a snapshot taken here.  Candidates: agents whose
-    // current cell somebody planned at entry -- plus, conservatively, nobody else: plans only ever
-    // change to current cells, and two agents never share a current cell.
+    // current cell somebody planned at entry -- plans only ever change to current cells, and two
+    // agents never share a current cell, so no other agent can become part of a swap.
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { snx[h] = r.nxtx[h]; sny[h] = r.nxty[h]; }
+    for (int h = 0; h < 2; ++h) {
+        nkey[h] = cell_key(r.nxtx[h], r.nxty[h]);    // live plans
+        skey[h] = nkey[h];                           // the snapshot
+    }
     for (int i = next_set_bit(todo2, 0); i >= 0; i = next_set_bit(todo2, i + 1)) {
-        const int cx = lane_get(r.curx, i), cy = lane_get(r.cury, i);
-        const MaskPair hit = ballot2(live[0] && snx[0] == cx && sny[0] == cy,
-                                     live[1] && snx[1] == cx && sny[1] == cy);
+        const MaskPair hit = ballot_eq(skey, lane_get(ckey, i), two);
         if (hit.lo | hit.hi) {
             const int sidx = hit.lo ? __ffsll((long long)hit.lo) - 1 : 64 + __ffsll((long long)hit.hi) - 1;
-            if (sidx != i && lane_get(r.curx, sidx) == lane_get(r.nxtx, i) &&
-                lane_get(r.cury, sidx) == lane_get(r.nxty, i)) {
+            if (sidx != i && lane_get(ckey, sidx) == lane_get(nkey, i)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int me = lane + 64 * h;
                     if (me == i || me == sidx) {
                         r.nxtx[h] = r.curx[h]; r.nxty[h] = r.cury[h];
+                        nkey[h] = ckey[h];
                         r.last[h] = 4;
                     }
                 }

@@ -35,6 +35,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+struct int2 { int x, y; };
 typedef void* hipStream_t;
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
