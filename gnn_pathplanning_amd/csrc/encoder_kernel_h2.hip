@@ -827,14 +827,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
         const int b = blockIdx.x;
         GNNPP_STAMP(b, 10, tid == 0);
-        if (tid < 64) move_body(pt.sim, b, tid, red, spos);                      // wave 0 moves ...
-        else observe_stage(pt.sim, b, occ, goal_l, tid - 64, kThreads - 64);     // ... the others fetch map + goals
-        __syncthreads();
-        GNNPP_STAMP(b, 7, tid == 0);
-        gso_body(pt.sim, b, spos, false, gso_smem, tid, kThreads);
-        GNNPP_STAMP(b, 8, tid == 0);
-        observe_finish(pt.sim, b, spos, 0, pt.sim.N, occ, goal_l, tid, kThreads);
-        GNNPP_STAMP(b, 9, tid == 0);
+        sim_tail(pt.sim, b, spos, red, goal_l, gso_smem, occ, tid, kThreads);
     }
 }
 

@@ -18,6 +18,21 @@ constexpr int kMaxAgents = GNNPP_ROLLOUT_MAX_AGENTS;
 
 typedef ::gnnpp_rollout RolloutArgs;      // the C-ABI struct itself (include/gnnpp.h)
 
+// ---- wave-level helpers: lane l of a wave holds agents l and l + 64 (teams of up to 128) -------------
+__device__ __forceinline__ int lane_get(const int (&v)[2], int agent) {
+    return __builtin_amdgcn_readlane(agent < 64 ? v[0] : v[1], agent & 63);
+}
+
+struct MaskPair { unsigned long long lo, hi; };
+
+__device__ __forceinline__ MaskPair ballot2(bool p0, bool p1) {
+    MaskPair m;
+    m.lo = __ballot(p0);
+    m.hi = __ballot(p1);
+    return m;
+}
+
+
 // ---- observation builder ----------------------------------------------------------------------
 // Border cell standing for a goal outside the 9x9 field of view (statetransformer.py:47-66).  The
 // reference decides with atan2 against +-pi/4, +-3pi/4 and np.round (half to even); for integer
@@ -50,10 +65,10 @@ constexpr int kObsAgentsPerWg = 16;
 // waves that do not move stage it while wave 0 runs the collision shielding):
 //   observe_stage   cell[H*W] bytes of LDS <- the episode's map (bit 0 = obstacle, fetched once,
 //                   coalesced), goal_l[2N] ints of LDS <- goals; threads [t0, t0+nt)
-//   observe_finish  after a barrier: bit 1 of cell = an agent stands there; per agent the goal's cell in
-//                   the 11x11 channel (in view, or projected onto the border ring) is computed ONCE; then
-//                   one thread per (agent, channel, row): 11 outputs sharing all their index arithmetic.
-//                   Everything in the loops comes from LDS.
+//   observe_prep    after a barrier: bit 1 of cell = an agent stands there; per agent the goal's cell in
+//                   the 11x11 channel (in view, or projected onto the border ring) is computed ONCE;
+//   observe_rows    after another barrier: one thread per (agent, channel, row), 11 outputs sharing all
+//                   their index arithmetic.  Everything in the loops comes from LDS.
 __device__ __forceinline__ void observe_stage(const RolloutArgs& p, int b, unsigned char* cell, int* goal_l,
                                               int t0, int nt) {
     if (t0 < 0) return;
@@ -64,10 +79,12 @@ __device__ __forceinline__ void observe_stage(const RolloutArgs& p, int b, unsig
     for (int i = t0; i < 2 * p.N; i += nt) goal_l[i] = goal[i];
 }
 
-__device__ __forceinline__ void observe_finish(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
-                                               unsigned char* cell, int* goal_l, int tid, int nt) {
-    __syncthreads();                                     // staging (and pos, if it lives in LDS) visible
-    for (int n = tid; n < p.N; n += nt) {
+// agents' cells (bit 1 of cell) and, per agent, the goal's cell in channel 1 (in view, or projected onto
+// the border ring) -- computed ONCE per agent; threads [t0, t0 + nt)
+__device__ __forceinline__ void observe_prep(const RolloutArgs& p, const int* pos, unsigned char* cell,
+                                             int* goal_l, int t0, int nt) {
+    if (t0 < 0) return;
+    for (int n = t0; n < p.N; n += nt) {
         const int cx = pos[2 * n], cy = pos[2 * n + 1];
         cell[cx * p.W + cy] |= 2;                        // agents stand on distinct cells
         const int dx = goal_l[2 * n] - cx, dy = goal_l[2 * n + 1] - cy;
@@ -76,7 +93,11 @@ __device__ __forceinline__ void observe_finish(const RolloutArgs& p, int b, cons
         else projected_goal(dx, dy, px, py);
         goal_l[2 * n] = px; goal_l[2 * n + 1] = py;      // from here on: the goal's cell in channel 1
     }
-    __syncthreads();
+}
+
+// one thread per (agent, channel, row): 11 outputs sharing all their index arithmetic; LDS reads only
+__device__ __forceinline__ void observe_rows(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
+                                             const unsigned char* cell, const int* goal_l, int tid, int nt) {
     float* out = p.obs + ((size_t)b * p.N + n0) * 363;
     const int rows = (n1 - n0) * 33;                     // (agent, channel, row i) triples
     for (int row = tid; row < rows; row += nt) {
@@ -114,9 +135,12 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
     const int n0 = blockIdx.x * kObsAgentsPerWg;
     int* goal_l = reinterpret_cast<int*>(gnnpp_smem);                       // [2 kMaxAgents]
     unsigned char* cell = reinterpret_cast<unsigned char*>(goal_l + 2 * kMaxAgents);
+    const int* pos = p.pos + (size_t)b * p.N * 2;
     observe_stage(p, b, cell, goal_l, threadIdx.x, 256);
-    observe_finish(p, b, p.pos + (size_t)b * p.N * 2, n0, min(p.N, n0 + kObsAgentsPerWg), cell, goal_l,
-                   threadIdx.x, 256);
+    __syncthreads();
+    observe_prep(p, pos, cell, goal_l, threadIdx.x, 256);
+    __syncthreads();
+    observe_rows(p, b, pos, n0, min(p.N, n0 + kObsAgentsPerWg), cell, goal_l, threadIdx.x, 256);
 }
 
 // ---- communication GSO ---------------------------------------------------------------------------
@@ -136,75 +160,84 @@ __device__ __forceinline__ long long dist2_threshold(double R) {
     return t;
 }
 
-constexpr int kGsoSmemBytes = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;   // adj [N][2] | inv [N] | flag
+constexpr int kGsoSmemBytes = 2 * kMaxAgents * 8 + kMaxAgents * 8 + 32;   // adj [N][2] | inv [N] | radius, flag
 
-__device__ __forceinline__ unsigned long long lane_get64(const unsigned long long (&v)[2], int agent) {
-    const unsigned long long w = agent < 64 ? v[0] : v[1];
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, agent & 63);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), agent & 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int* pos, bool grow,
-                                         char* smem, int tid, int nt) {
+// Communication graph of one episode on ONE wavefront (lane l: agents l and l + 64), registers only:
+//   * adjacency row i = ballot over the lanes of "dist(i, me) < R" with agent i's cell broadcast by
+//     readlane (N ballots instead of N^2 / 64 lane-loops; the relation is symmetric);
+//   * connectivity by LEVEL-synchronous search from node 0: a node joins when its row meets the
+//     frontier -- one ballot per level (graph diameter) instead of one LDS round trip per node;
+//   * at step 0 (grow) the radius is divided by 1.1 once and multiplied by 1.1 until connected, the
+//     same fp64 sequence as the host loop (multirobotsim_dcenlocal.py:342-348).
+// Leaves adj [N][2] (128-bit rows), inv [N] (fp64 D^-1/2, 0 for isolated nodes), the flag and the final
+// radius in LDS for gso_store.
+__device__ __forceinline__ void gso_wave0(const RolloutArgs& p, const int* pos, bool grow, double r,
+                                          char* smem, int lane) {
     unsigned long long* adj = reinterpret_cast<unsigned long long*>(smem);          // [N][2]
     double* inv = reinterpret_cast<double*>(adj + 2 * kMaxAgents);                  // [N]
-    int* shared_flag = reinterpret_cast<int*>(inv + kMaxAgents + 2);                // [1]
+    double* shared_r = inv + kMaxAgents;                                            // [1]
+    int* shared_flag = reinterpret_cast<int*>(shared_r + 1);                        // [1]
     const int N = p.N;
-    // every thread runs the same fp64 radius sequence (R / 1.1, then * 1.1 per attempt): uniform,
-    // bit-identical to the host loop, and no broadcast round trip through LDS
-    double r = p.radius[b];
+    const bool two = N > 64;
+    int px[2], py[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = lane + 64 * h;
+        live[h] = n < N;
+        px[h] = live[h] ? pos[2 * n] : -(1 << 20);            // dead lanes: far away from everything
+        py[h] = live[h] ? pos[2 * n + 1] : -(1 << 20);
+    }
+    unsigned long long a0[2] = {0ull, 0ull}, a1[2] = {0ull, 0ull};                 // my agents' rows
     if (grow) r = r / 1.1;
     int connected = 0;
     for (;;) {
         if (grow) r = r * 1.1;
         const long long T = dist2_threshold(r);
-        for (int i = tid; i < N; i += nt) {
-            unsigned long long w0 = 0, w1 = 0;
-            const int2* pj = reinterpret_cast<const int2*>(pos);          // (row, col) pairs, 8-byte aligned
-            const int2 pi = pj[i];
-            const int Ti = T > 0x7fffffffLL ? 0x7fffffff : (int)T;       // d2 < 2^18 on a 256 x 256 map
-            for (int j = 0; j < N; ++j) {
-                const int2 q = pj[j];
-                const int dx = pi.x - q.x, dy = pi.y - q.y;
-                const unsigned long long e = (j != i) & (dx * dx + dy * dy <= Ti);
-                if (j < 64) w0 |= e << j; else w1 |= e << (j - 64);
-            }
-            adj[2 * i] = w0; adj[2 * i + 1] = w1;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            // connectivity by graph search from node 0, on wave 0: lane l keeps the adjacency rows of
-            // nodes l and l + 64 in registers, the reached / expanded sets are wave-uniform 128-bit
-            // masks, and a row is fetched with readlane -- no LDS round trip per expanded node
-            unsigned long long a0[2], a1[2];
+        const int Ti = T > 0x7fffffffLL ? 0x7fffffff : (int)T;       // d2 < 2^18 on a 256 x 256 map
+        for (int i = 0; i < N; ++i) {
+            const int bx = lane_get(px, i), by = lane_get(py, i);
+            bool e[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int n = tid + 64 * h;
-                a0[h] = n < N ? adj[2 * n] : 0ull;
-                a1[h] = n < N ? adj[2 * n + 1] : 0ull;
+                const int dx = px[h] - bx, dy = py[h] - by;
+                e[h] = live[h] && lane + 64 * h != i && dx * dx + dy * dy <= Ti;
             }
-            unsigned long long r0 = 1ull, r1 = 0, d0 = 0, d1 = 0;      // reached / expanded
-            for (;;) {
-                const unsigned long long f0 = r0 & ~d0, f1 = r1 & ~d1;
-                if (!(f0 | f1)) break;
-                int m;
-                if (f0) { m = __ffsll((long long)f0) - 1; d0 |= 1ull << m; }
-                else { m = 64 + __ffsll((long long)f1) - 1; d1 |= 1ull << (m - 64); }
-                r0 |= lane_get64(a0, m); r1 |= lane_get64(a1, m);
+            const MaskPair row = ballot2(e[0], two && e[1]);
+            if (lane == (i & 63)) {
+                a0[i >> 6] = row.lo;
+                a1[i >> 6] = row.hi;
             }
-            if (tid == 0) *shared_flag = (__popcll(r0) + __popcll(r1) == N);
         }
-        __syncthreads();
-        connected = *shared_flag;
+        MaskPair R = {1ull, 0ull}, F = R;                              // reached set, frontier
+        while (F.lo | F.hi) {
+            const MaskPair nb = ballot2(live[0] && ((a0[0] & F.lo) | (a1[0] & F.hi)) != 0ull,
+                                        two && live[1] && ((a0[1] & F.lo) | (a1[1] & F.hi)) != 0ull);
+            F.lo = nb.lo & ~R.lo; F.hi = nb.hi & ~R.hi;
+            R.lo |= nb.lo; R.hi |= nb.hi;
+        }
+        connected = __popcll(R.lo) + __popcll(R.hi) == N;
         if (connected || !grow) break;
-        __syncthreads();                                  // everybody has read the flag before wave 0 rewrites it
     }
-    for (int i = tid; i < N; i += nt) {
-        const int deg = __popcll(adj[2 * i]) + __popcll(adj[2 * i + 1]);
-        inv[i] = deg ? sqrt(1.0 / (double)deg) : 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = lane + 64 * h;
+        if (live[h]) {
+            const int deg = __popcll(a0[h]) + __popcll(a1[h]);
+            adj[2 * n] = a0[h]; adj[2 * n + 1] = a1[h];
+            inv[n] = deg ? sqrt(1.0 / (double)deg) : 0.0;
+        }
     }
-    __syncthreads();
+    if (lane == 0) { *shared_r = r; *shared_flag = connected; }
+}
+
+// S = float(D^-1/2 A D^-1/2) to HBM by all threads, radius / connected by thread 0 (after a barrier)
+__device__ __forceinline__ void gso_store(const RolloutArgs& p, int b, const char* smem, int tid, int nt) {
+    const unsigned long long* adj = reinterpret_cast<const unsigned long long*>(smem);
+    const double* inv = reinterpret_cast<const double*>(adj + 2 * kMaxAgents);
+    const double* shared_r = inv + kMaxAgents;
+    const int* shared_flag = reinterpret_cast<const int*>(shared_r + 1);
+    const int N = p.N;
     float* S = p.S + (size_t)b * N * N;
     for (int i = tid / 16; i < N; i += nt / 16) {               // nt/16 rows in flight, 16 lanes per row
         const unsigned long long w0 = adj[2 * i], w1 = adj[2 * i + 1];
@@ -215,9 +248,42 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
         }
     }
     if (tid == 0) {
-        p.radius[b] = r;
-        if (p.connected) p.connected[b] = connected;
+        p.radius[b] = *shared_r;
+        if (p.connected) p.connected[b] = *shared_flag;
     }
+}
+
+__device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int* pos, bool grow,
+                                         char* smem, int tid, int nt) {
+    if (tid < 64) gso_wave0(p, pos, grow, p.radius[b], smem, tid);
+    __syncthreads();
+    gso_store(p, b, smem, tid, nt);
+}
+
+// The simulator work between two policy forwards of a rollout (move -> GSO -> observations of the new
+// positions) inside one workgroup, two barriers in all:
+//   wave 0 moves                              | the other waves fetch the episode's map and goals
+//   ------------------------------------------- barrier
+//   wave 0 builds the communication graph     | the other waves mark the agents' cells, goal cells
+//   ------------------------------------------- barrier
+//   everybody stores S, then the observation rows
+// red [4 kMaxAgents] + spos [2 kMaxAgents] + goal_l [2 kMaxAgents] ints, gso_smem [kGsoSmemBytes],
+// occ [H*W] bytes of LDS.
+__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos);
+__device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos, int* red, int* goal_l,
+                                         char* gso_smem, unsigned char* occ, int tid, int nt) {
+    const double radius = p.radius[b];                   // (in flight while wave 0 moves)
+    if (tid < 64) move_body(p, b, tid, red, spos);
+    else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);
+    __syncthreads();
+    GNNPP_STAMP(b, 7, tid == 0);
+    if (tid < 64) gso_wave0(p, spos, false, radius, gso_smem, tid);
+    else observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
+    __syncthreads();
+    GNNPP_STAMP(b, 8, tid == 0);
+    gso_store(p, b, gso_smem, tid, nt);
+    observe_rows(p, b, spos, 0, p.N, occ, goal_l, tid, nt);
+    GNNPP_STAMP(b, 9, tid == 0);
 }
 
 __global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
@@ -238,21 +304,6 @@ __global__ __launch_bounds__(256) void rollout_gso_kernel(const RolloutArgs p) {
 //        otherwise all but the chosen one stop"  (an agent's own flag can only flip through the
 //        stop-everybody branch, which is idempotent) -- checked against the simulator's traces;
 //   * list_nextpos.index(cur_i)          -> ffs(ballot(snapshot == cur_i)).
-struct Pos2 { int x, y; };
-
-__device__ __forceinline__ int lane_get(const int (&v)[2], int agent) {
-    return __builtin_amdgcn_readlane(agent < 64 ? v[0] : v[1], agent & 63);
-}
-
-struct MaskPair { unsigned long long lo, hi; };
-
-__device__ __forceinline__ MaskPair ballot2(bool p0, bool p1) {
-    MaskPair m;
-    m.lo = __ballot(p0);
-    m.hi = __ballot(p1);
-    return m;
-}
-
 __device__ __forceinline__ unsigned hash_u32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
@@ -315,17 +366,23 @@ __device__ __forceinline__ int next_set_bit(MaskPair m, int from) {
 // most 256 x 256 (the occupancy grid lives in LDS), so keys never collide
 __device__ __forceinline__ int cell_key(int x, int y) { return x * 65536 + y; }
 
-__device__ __forceinline__ MaskPair ballot_eq(const int (&key)[2], int value, bool two) {
+template <bool two>
+__device__ __forceinline__ MaskPair ballot_eq(const int (&key)[2], int value) {
     MaskPair m;
     m.lo = __ballot(key[0] == value);
     m.hi = two ? __ballot(key[1] == value) : 0ull;
     return m;
 }
+template <bool two>
+__device__ __forceinline__ int lane_get_t(const int (&v)[2], int agent) {
+    return two ? lane_get(v, agent) : __builtin_amdgcn_readlane(v[0], agent);
+}
 
-__device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
-                                      int& calls, int* __restrict__ xy) {
-    (void)xy;
-    const bool two = N > 64;                         // lanes carry a second agent (wave-uniform)
+// two = lanes carry a second agent (N > 64): a compile-time switch, so that teams of up to 64 agents
+// run straight-line scalar code in the scan below
+template <bool two>
+__device__ bool inter_robot_collision_t(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
+                                        int& calls) {
     int ckey[2], nkey[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -335,13 +392,22 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
     // ---- all-pairs scan, branch-free: agent j's planned cell is broadcast with readlane; one ballot
     // marks everybody else planning the same cell, one everybody standing on it ------------------------
     MaskPair todo = {0ull, 0ull}, todo2 = {0ull, 0ull};
-    for (int j = 0; j < N; ++j) {
-        const int nj = lane_get(nkey, j);
-        MaskPair same = ballot_eq(nkey, nj, two), stand = ballot_eq(ckey, nj, two);
-        if (j < 64) { same.lo &= ~(1ull << j); stand.lo &= ~(1ull << j); }
-        else { same.hi &= ~(1ull << (j - 64)); stand.hi &= ~(1ull << (j - 64)); }
-        todo.lo |= same.lo; todo.hi |= same.hi;
-        todo2.lo |= stand.lo; todo2.hi |= stand.hi;
+    const int n_lo = two ? 64 : N;
+    for (int j = 0; j < n_lo; ++j) {
+        const int nj = __builtin_amdgcn_readlane(nkey[0], j);
+        const MaskPair same = ballot_eq<two>(nkey, nj), stand = ballot_eq<two>(ckey, nj);
+        const unsigned long long self = ~(1ull << j);
+        todo.lo |= same.lo & self; todo.hi |= same.hi;
+        todo2.lo |= stand.lo & self; todo2.hi |= stand.hi;
+    }
+    if (two) {
+        for (int j = 64; j < N; ++j) {
+            const int nj = __builtin_amdgcn_readlane(nkey[1], j - 64);
+            const MaskPair same = ballot_eq<two>(nkey, nj), stand = ballot_eq<two>(ckey, nj);
+            const unsigned long long self = ~(1ull << (j - 64));
+            todo.lo |= same.lo; todo.hi |= same.hi & self;
+            todo2.lo |= stand.lo; todo2.hi |= stand.hi & self;
+        }
     }
     if (!(todo.lo | todo.hi | todo2.lo | todo2.hi)) return false;
 
@@ -350,8 +416,8 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
 #pragma unroll
     for (int h = 0; h < 2; ++h) { skey[h] = nkey[h]; lkey[h] = nkey[h]; }
     for (int i = next_set_bit(todo, 0); i >= 0; i = next_set_bit(todo, i + 1)) {
-        const int pk = lane_get(lkey, i);
-        const MaskPair same = ballot_eq(lkey, pk, two);
+        const int pk = lane_get_t<two>(lkey, i);
+        const MaskPair same = ballot_eq<two>(lkey, pk);
         if (__popcll(same.lo) + __popcll(same.hi) > 1) {
             collision = true;
             const bool in[2] = {skey[0] == pk, skey[1] == pk};
@@ -373,7 +439,7 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
             // the cells the stopped agents fell back to may now be claimed twice: mark their claimants
             const MaskPair back = ballot2(moved_back[0], two && moved_back[1]);
             for (int s2 = next_set_bit(back, 0); s2 >= 0; s2 = next_set_bit(back, s2 + 1)) {
-                const MaskPair claim = ballot_eq(lkey, lane_get(lkey, s2), two);
+                const MaskPair claim = ballot_eq<two>(lkey, lane_get_t<two>(lkey, s2));
                 if (__popcll(claim.lo) + __popcll(claim.hi) > 1) {
                     todo.lo |= claim.lo;
                     todo.hi |= claim.hi;
@@ -390,10 +456,10 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
         skey[h] = nkey[h];                           // the snapshot
     }
     for (int i = next_set_bit(todo2, 0); i >= 0; i = next_set_bit(todo2, i + 1)) {
-        const MaskPair hit = ballot_eq(skey, lane_get(ckey, i), two);
+        const MaskPair hit = ballot_eq<two>(skey, lane_get_t<two>(ckey, i));
         if (hit.lo | hit.hi) {
             const int sidx = hit.lo ? __ffsll((long long)hit.lo) - 1 : 64 + __ffsll((long long)hit.hi) - 1;
-            if (sidx != i && lane_get(ckey, sidx) == lane_get(nkey, i)) {
+            if (sidx != i && lane_get_t<two>(ckey, sidx) == lane_get_t<two>(nkey, i)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int me = lane + 64 * h;
@@ -410,10 +476,17 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
     return collision;
 }
 
+__device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
+                                      int& calls, int* __restrict__ xy) {
+    (void)xy;
+    return N > 64 ? inter_robot_collision_t<true>(p, r, b, N, lane, calls)
+                  : inter_robot_collision_t<false>(p, r, b, N, lane, calls);
+}
+
 // One episode's move by ONE wavefront (lane = threadIdx.x & 63; no workgroup barrier inside, so it can
 // run as wave 0 of a larger workgroup).  red = [4][kMaxAgents] ints of LDS (conflict test / statistics
 // scratch); spos (optional) receives the positions after the move ([N][2], LDS) for the fused step kernel.
-__device__ __forceinline__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos) {
+__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos) {
     const int N = p.N;
     int* pos = p.pos + (size_t)b * N * 2;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * p.H * p.W : 0);
@@ -586,14 +659,7 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
     unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (tid < 64) move_body(p, b, tid, red, spos);              // wave 0 moves ...
-    else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);    // ... the others fetch the map and the goals
-    __syncthreads();
-    GNNPP_STAMP(b, 7, tid == 0);
-    gso_body(p, b, spos, false, gso_smem, tid, nt);
-    GNNPP_STAMP(b, 8, tid == 0);
-    observe_finish(p, b, spos, 0, p.N, occ, goal_l, tid, nt);
-    GNNPP_STAMP(b, 9, tid == 0);
+    sim_tail(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------

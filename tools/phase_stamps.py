@@ -19,7 +19,7 @@ M = _native.measure_lib()
 M.gnnpp_measure_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = torch.device('cuda:0')
 SLOTS = {'move:entry': 0, 'move:state_loaded': 1, 'move:proposed': 2, 'move:pass1': 3, 'move:passes': 4,
-         'move:final_pass': 5, 'move:stored': 6, 'sim:move_done': 7, 'sim:gso_done': 8, 'sim:observe_done': 9,
+         'move:final_pass': 5, 'move:stored': 6, 'sim:move_done': 7, 'sim:gso_done': 8, 'sim:observe_done': 9,   # gso_done = graph built + goal cells marked
          'policy:head_done': 10, 'kernel:start': 11}
 
 
