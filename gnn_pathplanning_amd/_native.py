@@ -21,7 +21,8 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
 
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
-           'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
+           'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_encoder_train_workspace_floats', 'gnnpp_encoder_train_fwd',
+           'gnnpp_encoder_train_bwd', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step')
 
 
@@ -96,6 +97,12 @@ class EncoderParams(ctypes.Structure):
                 ('fc_w', ctypes.c_void_p), ('fc_b', ctypes.c_void_p), ('bn_eps', ctypes.c_float)]
 
 
+class EncoderGrads(ctypes.Structure):
+    """struct gnnpp_encoder_grads (include/gnnpp.h)."""
+    _fields_ = [('conv_w', ctypes.c_void_p * 5), ('conv_b', ctypes.c_void_p * 5),
+                ('bn_w', ctypes.c_void_p * 5), ('bn_b', ctypes.c_void_p * 5)]
+
+
 class RolloutStruct(ctypes.Structure):
     """struct gnnpp_rollout (include/gnnpp.h)."""
     _fields_ = [('grid', ctypes.c_void_p), ('grid_batched', ctypes.c_int), ('goal', ctypes.c_void_p),
@@ -135,6 +142,13 @@ def _bind(path):
     L.gnnpp_encoder_packed_floats.argtypes = []
     L.gnnpp_encoder_pack.argtypes = [ctypes.POINTER(EncoderParams), vp, vp]
     L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, vp, vp]
+    L.gnnpp_encoder_train_workspace_floats.restype = cs
+    L.gnnpp_encoder_train_workspace_floats.argtypes = [ci, ci]
+    L.gnnpp_encoder_train_fwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ci, ci, ctypes.c_float, ci, vp]
+    L.gnnpp_encoder_train_fwd.restype = ci
+    L.gnnpp_encoder_train_bwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ctypes.POINTER(EncoderGrads),
+                                          ci, ci, vp]
+    L.gnnpp_encoder_train_bwd.restype = ci
     L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 5 + [vp, vp]
     L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 7 + [vp, vp]
     L.gnnpp_filter_head_fwd.restype = ci

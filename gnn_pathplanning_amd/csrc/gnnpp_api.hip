@@ -11,6 +11,7 @@
 #include "rollout_kernels.hip"       // before the fused policy kernel, which can run the simulator step too
 #include "encoder_kernel_h2.hip"
 #include "lsigf_kernel.hip"
+#include "train_encoder.hip"
 
 using namespace gnnpp;
 
@@ -169,6 +170,47 @@ int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, co
     a.s_is_f64 = s_is_f64; a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1;
     a.range_flag = range_flag;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
+}
+
+size_t gnnpp_encoder_train_workspace_floats(int N, int B) {
+    if (N <= 0 || B <= 0) return 0;
+    return train_ws_layout(N, B).total;
+}
+
+static int train_params_ok(const gnnpp_encoder_params* p, EncRawParams& rp) {
+    if (!p) return 0;
+    for (int i = 0; i < 5; ++i) {
+        if (!p->conv_w[i] || !p->conv_b[i] || !p->bn_w[i] || !p->bn_b[i]) return 0;
+        rp.conv_w[i] = p->conv_w[i]; rp.conv_b[i] = p->conv_b[i];
+        rp.bn_w[i] = p->bn_w[i]; rp.bn_b[i] = p->bn_b[i];
+        rp.bn_mean[i] = p->bn_mean[i]; rp.bn_var[i] = p->bn_var[i];
+    }
+    rp.fc_w = p->fc_w; rp.fc_b = p->fc_b; rp.bn_eps = p->bn_eps;
+    return 1;
+}
+
+int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
+                            int B, int N, float momentum, int update_running, void* stream) {
+    EncRawParams rp;
+    if (!train_params_ok(p, rp) || !obs || !workspace || !feat || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
+    float* rm[5];
+    float* rv[5];
+    for (int i = 0; i < 5; ++i) {
+        if (update_running && (!p->bn_mean[i] || !p->bn_var[i])) return GNNPP_ERR_ARG;
+        rm[i] = update_running ? const_cast<float*>(p->bn_mean[i]) : nullptr;
+        rv[i] = update_running ? const_cast<float*>(p->bn_var[i]) : nullptr;
+    }
+    return train_encoder_fwd(rp, rm, rv, momentum, obs, workspace, feat, N, B, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
+                            const float* dfeat, const gnnpp_encoder_grads* g, int B, int N, void* stream) {
+    EncRawParams rp;
+    if (!train_params_ok(p, rp) || !obs || !workspace || !dfeat || !g || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
+    for (int i = 0; i < 5; ++i)
+        if (!g->conv_w[i] || !g->conv_b[i] || !g->bn_w[i] || !g->bn_b[i]) return GNNPP_ERR_ARG;
+    return train_encoder_bwd(rp, obs, workspace, dfeat, g->conv_w, g->conv_b, g->bn_w, g->bn_b, N, B,
+                             static_cast<hipStream_t>(stream));
 }
 
 #ifdef GNNPP_MEASURE

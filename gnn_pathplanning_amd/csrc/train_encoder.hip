@@ -1,0 +1,493 @@
+// Train-mode CNN encoder, forward AND backward, for gfx950 (BASELINE config 4: dcp_onlineExpert training,
+// loss.backward() at agents/decentralplannerlocal.py:314 over graphs/models/decentralplanner.py:284-290).
+//
+// What makes train mode different from the fused inference kernels: the reference runs ConvLayers once
+// PER AGENT on that agent's mini-batch [B,3,11,11], so every BatchNorm2d normalises with the statistics
+// of (agent n, channel c) over the B samples and the H x W positions of THAT call, and updates its
+// running statistics N times per forward, in agent order.  That is a reduction across the whole batch
+// between every convolution and its ReLU -- a layer-by-layer schedule with the activations in HBM
+// (they are needed again by the backward pass anyway): at B = 64, N = 10 a layer is a few MB.
+//
+// Layout of every activation tensor: [N][B][C][P] (agent-major, P = H*W row-major), fp32.  All kernels
+// are plain fp32 arithmetic (fmaf chains / fp32 MFMA), deterministic: every reduction has a fixed order
+// (per-wave partial sums in LDS, partials summed in index order by a finalize kernel; no atomics).
+//
+//   forward, per conv layer l (3->32 @11x11 pool, 32->32 @5x5, 32->64 @5x5 pool, 64->64 @2x2, 64->128 @2x2 pool)
+//     conv_cols_kernel        y = conv3x3(x) + bias: one lane = one output column (b, y, x) of agent n,
+//                             16 output channels in registers; the weights of the wave's channel tile are
+//                             WAVE-UNIFORM, so they come through scalar loads and enter the FMAs as SGPR
+//                             operands ([ci][co][tap] copy made by pack_train_weights_kernel); per-wave
+//                             partial (sum, sum of squares) per channel for the BatchNorm statistics
+//     bn_stats_kernel         partials -> mean, 1/sqrt(var + eps) per (agent, channel) (+ unbiased variance
+//                             for the running statistics)
+//     bn_relu_pool_kernel     x_{l+1} = maxpool2x2?( relu( (y - mean) * invstd * gamma + beta ) )
+//   then bn_running_kernel    the N sequential momentum updates of every layer's running statistics
+//   backward, per layer from the last to the first
+//     bn_bwd_reduce_kernel    dz = relu'(a) * unpool(d x_{l+1})  (a and the pool's arg-max recomputed from y:
+//                             first maximum in scan order, as torch's max_pool2d backward), written out,
+//                             with per-wave partial sums of dz and dz * yhat
+//     bn_bwd_coef_kernel      partials -> per (agent, channel) coefficients; d gamma, d beta summed over agents
+//     bn_bwd_apply_kernel     dy = gamma * invstd * (dz - mean(dz) - yhat * mean(dz * yhat)), in place
+//     conv_cols_kernel<FLIP>  dx = conv3x3(dy) with the transposed, flipped kernel (skipped for layer 0)
+//     conv_wgrad_kernel       dW[co][ci][tap] (and d bias) = sum over all columns of dy x patch(x): a GEMM with
+//                             the columns as the contraction index, on the fp32 MFMA 16x16x4, split over
+//                             column ranges; conv_wgrad_reduce_kernel sums the splits in order.
+// The 128 -> 128 compress MLP, the graph filter and the action head are not in here: the MLP is one library
+// GEMM each way (torch), the graph filter runs on lsigf_kernel (graphML._LSIGFFunction).
+#include "gnnpp_common.h"
+
+namespace gnnpp {
+
+constexpr int kTrainLayers = 5;
+struct TrainLayerDims { int Cin, Cout, H, W, pool; };
+__host__ __device__ inline TrainLayerDims train_layer(int l) {
+    const TrainLayerDims d[kTrainLayers] = {{3, 32, 11, 11, 1}, {32, 32, 5, 5, 0}, {32, 64, 5, 5, 1},
+                                            {64, 64, 2, 2, 0}, {64, 128, 2, 2, 1}};
+    return d[l];
+}
+constexpr int kConvCT = 16;          // output channels per wave of conv_cols_kernel
+constexpr int kWgSplitMax = 64;      // column-range splits of conv_wgrad_kernel
+
+// ---- weights: [co][ci][9] -> [ci][co][9] (forward conv reads a channel tile x 9 taps contiguously) ------
+__global__ void pack_train_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
+                                          int Cout) {
+    const int total = Cin * Cout * 9;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int tap = i % 9, co = (i / 9) % Cout, ci = i / (9 * Cout);
+        wt[i] = w[(co * Cin + ci) * 9 + tap];
+    }
+}
+
+// ---- convolution over columns ---------------------------------------------------------------------------
+// out[n,b,co,p] = bias[co] + sum_ci sum_tap K(ci,co,tap) * in[n,b,ci,p + off(tap)]   (zero padding)
+//   FLIP = false: K(ci,co,tap) = wk[(ci*Cout + co)*9 + tap]          (wk = packed [ci][co][9] copy; forward)
+//   FLIP = true : K(ci,co,tap) = wk[(ci*Cout + co)*9 + 8 - tap]      (wk = the ORIGINAL [co'][ci'][9] tensor
+//                 of the layer, whose co' is this call's ci and ci' its co: input gradient)
+// grid = (N * chunks, Cout / 16), block = 64: wave (n, chunk) x channel tile; lane = column chunk*64 + lane
+// of agent n (columns = B*P).  x image (n, b) starts at x + n*x_sn + b*x_sb (the observations arrive
+// sample-major [B][N]...; every other tensor is agent-major).  part != nullptr: per-wave (sum, sum sq) of
+// the outputs per channel -> part[((n*chunks + chunk)*Cout + co)*2 + {0,1}].
+template <bool FLIP>
+__global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ wk,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ y, float* __restrict__ part,
+                                                       int B, int Cin, int Cout, int H, int W, long x_sn,
+                                                       long x_sb, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(gnnpp_smem);           // [2 * kConvCT][64]
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int co0 = blockIdx.y * kConvCT;
+    const int P = H * W;
+    const int col = chunk * 64 + lane;
+    const bool active = col < B * P;
+    const int colc = active ? col : 0;
+    const int b = colc / P, pos = colc - b * P;
+    const int py = pos / W, px = pos - py * W;
+    int off[9];
+    float msk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        off[t] = in ? yy * W + xx : pos;                 // (a valid address; the value is masked)
+        msk[t] = in ? 1.f : 0.f;
+    }
+    float acc[kConvCT];
+#pragma unroll
+    for (int c = 0; c < kConvCT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
+    const float* xi = x + n * x_sn + b * x_sb;
+    for (int ci = 0; ci < Cin; ++ci) {
+        float patch[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) patch[t] = xi[(long)ci * P + off[t]] * msk[t];
+        const float* wrow = wk + ((long)ci * Cout + co0) * 9;          // wave-uniform: scalar loads
+#pragma unroll
+        for (int c = 0; c < kConvCT; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c] = fmaf(wrow[c * 9 + (FLIP ? 8 - t : t)], patch[t], acc[c]);
+    }
+    if (active) {
+        float* yo = y + (((long)n * B + b) * Cout + co0) * P + pos;
+#pragma unroll
+        for (int c = 0; c < kConvCT; ++c) yo[(long)c * P] = acc[c];
+    }
+    if (part) {
+        // fixed-order reduction: lane j < 32 sums value j (channel j >> 1, sum / sum of squares) over lanes
+#pragma unroll
+        for (int c = 0; c < kConvCT; ++c) {
+            const float v = active ? acc[c] : 0.f;
+            red[2 * c][lane] = v;
+            red[2 * c + 1][lane] = v * v;
+        }
+        __syncthreads();
+        if (lane < 2 * kConvCT) {
+            float s = 0.f;
+            for (int i = 0; i < 64; ++i) s += red[lane][i];
+            part[(((long)n * chunks + chunk) * Cout + co0 + (lane >> 1)) * 2 + (lane & 1)] = s;
+        }
+    }
+}
+
+// ---- BatchNorm statistics of one layer: grid = N blocks, Cout threads -------------------------------------
+// stat[(n*C + c)*4 + {0: mean, 1: invstd, 2: unbiased variance (running stats), 3: unused}]
+__global__ void bn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int chunks, int C,
+                                int m, float eps) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float* p = part + (((long)n * chunks + k) * C + c) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+    const double mean = s1 / m;
+    double var = s2 / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* o = stat + ((long)n * C + c) * 4;
+    o[0] = (float)mean;
+    o[1] = (float)(1.0 / sqrt(var + (double)eps));
+    o[2] = (float)(m > 1 ? var * m / (m - 1) : var);
+    o[3] = 0.f;
+}
+
+// ---- x_next = maxpool2x2?(relu(bn(y))): one thread per output element ---------------------------------------
+__device__ __forceinline__ float bn_act(float yv, float mean, float invstd, float g, float be) {
+    return fmaxf(fmaf((yv - mean) * invstd, g, be), 0.f);
+}
+
+// grid-stride over the elements of x_next [N][B][C][Po]
+__global__ void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ stat,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float* __restrict__ xn, long total, int B, int C, int H, int W,
+                                    int pool) {
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo, P = H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int po = (int)(i % Po);
+        const long ic = i / Po;                          // (n*B + b)*C + c
+        const int c = (int)(ic % C);
+        const int n = (int)((ic / C) / B);
+        const float* st = stat + ((long)n * C + c) * 4;
+        const float mean = st[0], invstd = st[1], g = gamma[c], be = beta[c];
+        const float* yc = y + ic * P;
+        float v;
+        if (pool) {
+            const int oy = po / Wo, ox = po - oy * Wo;
+            const float* q = yc + (2 * oy) * W + 2 * ox;
+            v = fmaxf(fmaxf(bn_act(q[0], mean, invstd, g, be), bn_act(q[1], mean, invstd, g, be)),
+                      fmaxf(bn_act(q[W], mean, invstd, g, be), bn_act(q[W + 1], mean, invstd, g, be)));
+        } else {
+            v = bn_act(yc[po], mean, invstd, g, be);
+        }
+        xn[i] = v;
+    }
+}
+
+// ---- running statistics: the N per-agent-call updates in agent order (one thread per channel) -------------
+// nn.BatchNorm2d in train mode: r <- (1 - momentum) r + momentum * batch statistic (unbiased variance)
+__global__ void bn_running_kernel(const float* __restrict__ stat, float* __restrict__ rmean,
+                                  float* __restrict__ rvar, int N, int C, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m = rmean[c], v = rvar[c];
+    for (int n = 0; n < N; ++n) {
+        const float* st = stat + ((long)n * C + c) * 4;
+        m = (1.f - momentum) * m + momentum * st[0];
+        v = (1.f - momentum) * v + momentum * st[2];
+    }
+    rmean[c] = m;
+    rvar[c] = v;
+}
+
+// ---- backward through pool / ReLU / BatchNorm, pass 1 --------------------------------------------------------
+// One lane = one column (b, pos) of agent n, looping over ALL channels: dz[c] = relu'(a) * d a, where
+// d a = dxn[window] if this position is the FIRST maximum of its 2x2 window (scan order, like torch's
+// max_pool2d backward; a recomputed from y), 0 for positions the pool never reads; without pool d a = dxn.
+// Writes dz [N][B][C][P] and per-wave partial sums of dz and dz * yhat -> part[((n*chunks+chunk)*C + c)*2].
+__global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restrict__ y,
+                                                           const float* __restrict__ stat,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ dxn,
+                                                           float* __restrict__ dz, float* __restrict__ part,
+                                                           int B, int C, int H, int W, int pool, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(gnnpp_smem);           // [2][64]
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int P = H * W, Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo;
+    const int col = chunk * 64 + lane;
+    const bool active = col < B * P;
+    const int colc = active ? col : 0;
+    const int b = colc / P, pos = colc - b * P;
+    const int py = pos / W, px = pos - py * W;
+    const bool pooled_in = !pool || (py < 2 * Ho && px < 2 * Wo);       // inside the region the pool reads
+    const int oy = pool ? py / 2 : py, ox = pool ? px / 2 : px;
+    const int wpos = pool ? (2 * oy) * W + 2 * ox : pos;                // window origin
+    const int me = pool ? (py - 2 * oy) * 2 + (px - 2 * ox) : 0;        // my slot in the window
+    for (int c = 0; c < C; ++c) {
+        const float* st = stat + ((long)n * C + c) * 4;
+        const float mean = st[0], invstd = st[1], g = gamma[c], be = beta[c];
+        const long ic = ((long)n * B + b) * C + c;
+        const float* yc = y + ic * P;
+        float d = 0.f, yhat = 0.f;
+        if (active && pooled_in) {
+            const float yv = yc[pos];
+            yhat = (yv - mean) * invstd;
+            const float a = fmaxf(fmaf(yhat, g, be), 0.f);
+            bool mine = true;
+            if (pool) {
+                const int po[4] = {0, 1, W, W + 1};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ak = bn_act(yc[wpos + po[k]], mean, invstd, g, be);
+                    mine = mine && (k < me ? ak < a : ak <= a);       // strictly greater than the earlier ones
+                }
+            }
+            const float da = mine ? dxn[ic * Po + oy * Wo + ox] : 0.f;
+            d = a > 0.f ? da : 0.f;
+        } else if (active) {
+            yhat = (yc[pos] - mean) * invstd;
+        }
+        if (active) dz[ic * P + pos] = d;
+        red[0][lane] = d;
+        red[1][lane] = d * yhat;
+        __syncthreads();
+        if (lane < 2) {
+            float s = 0.f;
+            for (int i = 0; i < 64; ++i) s += red[lane][i];
+            part[(((long)n * chunks + chunk) * C + c) * 2 + lane] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2a: coefficients per (agent, channel): coef[(n*C + c)*4 + {k1, k2, k3}] with
+//   dy = k1 * (dz - k2 - yhat * k3),  k1 = gamma * invstd, k2 = mean(dz), k3 = mean(dz * yhat);
+// d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz)   (one thread per channel)
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ part, const float* __restrict__ stat,
+                                   const float* __restrict__ gamma, float* __restrict__ coef,
+                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int chunks,
+                                   int C, int m) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tb = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const float* p = part + (((long)n * chunks + k) * C + c) * 2;
+            s1 += (double)p[0];
+            s2 += (double)p[1];
+        }
+        tb += s1;
+        tg += s2;
+        float* o = coef + ((long)n * C + c) * 4;
+        o[0] = gamma[c] * stat[((long)n * C + c) * 4 + 1];
+        o[1] = (float)(s1 / m);
+        o[2] = (float)(s2 / m);
+        o[3] = 0.f;
+    }
+    dgamma[c] = (float)tg;
+    dbeta[c] = (float)tb;
+}
+
+// pass 2b: dz -> dy in place
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ stat,
+                                    const float* __restrict__ coef, float* __restrict__ dz, long total, int B,
+                                    int C, int P) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long ic = i / P;
+        const int c = (int)(ic % C);
+        const int n = (int)((ic / C) / B);
+        const float* st = stat + ((long)n * C + c) * 4;
+        const float* k = coef + ((long)n * C + c) * 4;
+        const float yhat = (y[i] - st[0]) * st[1];
+        dz[i] = k[0] * (dz[i] - k[1] - yhat * k[2]);
+    }
+}
+
+// ---- weight gradient: dW[co][j], j = ci*9 + tap (j = Cin*9: the bias column) -------------------------------
+//   dW[co][j] = sum over columns (n, b, p) of dy[n,b,co,p] * X[j][(n,b,p)],  X = x[n,b,ci,p + off(tap)] or 1
+// A GEMM with the columns as the contraction index on v_mfma_f32_16x16x4_f32: a wave owns the 16 x 16 tile
+// (co tile, j tile) and a range of images; A[i][k] = dy[co0+i][col k], B[k][j] = X[j0+j][col k], four
+// columns per MFMA.  grid = (co tiles, j tiles, splits); partial results -> wpart[split][Cout][J16].
+__global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ dy,
+                                                        float* __restrict__ wpart, int NB, int Cin, int Cout,
+                                                        int H, int W, long x_sn, long x_sb, int B,
+                                                        int imgs_per_split) {
+    const int lane = threadIdx.x;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.x * 16, j0 = blockIdx.y * 16, split = blockIdx.z;
+    const int P = H * W, J = Cin * 9 + 1, J16 = gridDim.y * 16;
+    const int j = j0 + i16;                              // this lane's B column
+    const bool jb = j == J - 1, jv = j < J - 1;
+    const int ci = jv ? j / 9 : 0, tap = jv ? j - ci * 9 : 4;
+    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
+    v4f acc = vzero();
+    const int img0 = split * imgs_per_split, img1 = min(NB, img0 + imgs_per_split);
+    for (int img = img0; img < img1; ++img) {
+        const int n = img / B, b = img - n * B;
+        const float* dyi = dy + ((long)img * Cout + co0 + i16) * P;      // A rows: channel co0 + i16
+        const float* xi = x + n * x_sn + b * x_sb + (long)ci * P;
+        for (int p0 = 0; p0 < P; p0 += 4) {
+            const int p = p0 + q;                        // this lane's column (k slot q)
+            const bool pv = p < P;
+            const float av = pv ? dyi[p] : 0.f;
+            float bv = 0.f;
+            if (pv) {
+                if (jb) bv = 1.f;
+                else if (jv) {
+                    const int py = p / W, px = p - py * W;
+                    const int yy = py + dyy, xx = px + dxx;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) bv = xi[yy * W + xx];
+                }
+            }
+            acc = mfma16(av, bv, acc);
+        }
+    }
+    // D register r of lane l: D[i = 4 q + r][j = l & 15]
+    float* o = wpart + ((long)split * Cout + co0 + 4 * q) * J16 + j0 + i16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(long)r * J16] = acc[r];
+}
+
+// sum the splits in order; dw [Cout][Cin][9], db [Cout]
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ wpart, float* __restrict__ dw,
+                                         float* __restrict__ db, int nsplit, int Cin, int Cout, int J16) {
+    const int J = Cin * 9 + 1;
+    const int total = Cout * J;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i / J, jj = i - co * J;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += wpart[((long)k * Cout + co) * J16 + jj];
+        if (jj == J - 1) db[co] = s;
+        else dw[(long)co * (J - 1) + jj] = s;
+    }
+}
+
+// ---- host side: workspace layout and the two entry points -----------------------------------------------------
+// Workspace (floats), for N agents and B samples per agent:
+//   per layer l: y_l [N*B*Cout*P] | x_{l+1} [N*B*Cout*Po] | stat_l [N*Cout*4]
+//   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz (largest y) | dxa, dxb
+//            (gradients w.r.t. layer inputs, ping-pong) | coef [N*128*4] | wpart
+struct TrainWs {
+    size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers];
+    size_t part, dz, dxa, dxb, coef, wpart, total;
+    int chunks[kTrainLayers], nsplit[kTrainLayers], ips[kTrainLayers], jt[kTrainLayers];
+};
+
+inline TrainWs train_ws_layout(int N, int B) {
+    TrainWs w;
+    size_t o = 0, max_y = 0, max_part = 0, max_x = 0, max_wp = 0;
+    const size_t NB = (size_t)N * B;
+    for (int l = 0; l < kTrainLayers; ++l) {
+        const TrainLayerDims d = train_layer(l);
+        const int P = d.H * d.W, Po = d.pool ? (d.H / 2) * (d.W / 2) : P;
+        w.y[l] = o; o += NB * d.Cout * P;
+        w.xn[l] = o; o += NB * d.Cout * Po;
+        w.stat[l] = o; o += (size_t)N * d.Cout * 4;
+        w.wt[l] = o; o += (size_t)d.Cin * d.Cout * 9;
+        w.chunks[l] = (B * P + 63) / 64;
+        max_y = max_y > NB * d.Cout * P ? max_y : NB * d.Cout * P;
+        const size_t pp = (size_t)N * w.chunks[l] * d.Cout * 2;
+        max_part = max_part > pp ? max_part : pp;
+        max_x = max_x > NB * d.Cin * P ? max_x : NB * d.Cin * P;
+        // weight-gradient splits: enough waves to fill the chip, at least one image per split
+        w.jt[l] = (d.Cin * 9 + 1 + 15) / 16;
+        const int tiles = (d.Cout / 16) * w.jt[l];
+        int ns = (1024 + tiles - 1) / tiles;
+        if (ns > kWgSplitMax) ns = kWgSplitMax;
+        if ((size_t)ns > NB) ns = (int)NB;
+        w.ips[l] = (int)((NB + ns - 1) / ns);
+        w.nsplit[l] = (int)((NB + w.ips[l] - 1) / w.ips[l]);
+        const size_t wp = (size_t)w.nsplit[l] * d.Cout * w.jt[l] * 16;
+        max_wp = max_wp > wp ? max_wp : wp;
+    }
+    w.part = o; o += max_part;
+    w.dz = o; o += max_y;
+    w.dxa = o; o += max_x;
+    w.dxb = o; o += max_x;
+    w.coef = o; o += (size_t)N * 128 * 4;
+    w.wpart = o; o += max_wp;
+    w.total = o;
+    return w;
+}
+
+static inline bool launched_ok() { return hipGetLastError() == hipSuccess; }
+
+// obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128]
+int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const* rvar, float momentum,
+                      const float* obs, float* ws, float* feat, int N, int B, hipStream_t st) {
+    const TrainWs L = train_ws_layout(N, B);
+    const long NB = (long)N * B;
+    for (int l = 0; l < kTrainLayers; ++l) {
+        const TrainLayerDims d = train_layer(l);
+        const int P = d.H * d.W, Po = d.pool ? (d.H / 2) * (d.W / 2) : P;
+        hipLaunchKernelGGL(pack_train_weights_kernel, dim3(64), dim3(256), 0, st, rp.conv_w[l], ws + L.wt[l],
+                           d.Cin, d.Cout);
+        const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
+        const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
+        const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
+        hipLaunchKernelGGL(conv_cols_kernel<false>, dim3(N * L.chunks[l], d.Cout / kConvCT), dim3(64),
+                           2 * kConvCT * 64 * sizeof(float), st,
+                           xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, B, d.Cin, d.Cout, d.H,
+                           d.W, sn, sb, L.chunks[l]);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
+                           L.chunks[l], d.Cout, B * P, rp.bn_eps);
+        const long tot = NB * d.Cout * Po;
+        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
+                           dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
+                           l == kTrainLayers - 1 ? feat : ws + L.xn[l], tot, B, d.Cout, d.H, d.W, d.pool);
+        if (rmean && rmean[l] && rvar && rvar[l])
+            hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(128), 0, st, ws + L.stat[l], rmean[l], rvar[l],
+                               N, d.Cout, momentum);
+    }
+    return launched_ok() ? 0 : -3;
+}
+
+// dfeat: gradient w.r.t. x_5 [N][B][128]; writes d conv_w / d conv_b / d bn_w / d bn_b of every layer
+int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const float* dfeat,
+                      float* const* dconv_w, float* const* dconv_b, float* const* dbn_w, float* const* dbn_b,
+                      int N, int B, hipStream_t st) {
+    const TrainWs L = train_ws_layout(N, B);
+    const long NB = (long)N * B;
+    const float* dxn = dfeat;
+    float* dx_buf[2] = {ws + L.dxa, ws + L.dxb};
+    for (int l = kTrainLayers - 1; l >= 0; --l) {
+        const TrainLayerDims d = train_layer(l);
+        const int P = d.H * d.W;
+        float* dz = ws + L.dz;
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(N * L.chunks[l]), dim3(64), 2 * 64 * sizeof(float), st,
+                           ws + L.y[l],
+                           ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout, d.H, d.W,
+                           d.pool, L.chunks[l]);
+        hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(1), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
+                           rp.bn_w[l], ws + L.coef, dbn_w[l], dbn_b[l], N, L.chunks[l], d.Cout, B * P);
+        const long tot = NB * d.Cout * P;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
+                           dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], ws + L.coef, dz, tot, B, d.Cout, P);
+        const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
+        const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;
+        const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(d.Cout / 16, L.jt[l], L.nsplit[l]), dim3(64), 0, st, xin, dz,
+                           ws + L.wpart, (int)NB, d.Cin, d.Cout, d.H, d.W, sn, sb, B, L.ips[l]);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, ws + L.wpart, dconv_w[l],
+                           dconv_b[l], L.nsplit[l], d.Cin, d.Cout, L.jt[l] * 16);
+        if (l > 0) {
+            // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
+            float* dx = dx_buf[l & 1];
+            // output channels of this call = d.Cin (a multiple of 16 for l >= 1)
+            hipLaunchKernelGGL(conv_cols_kernel<true>, dim3(N * L.chunks[l], d.Cin / kConvCT), dim3(64),
+                               2 * kConvCT * 64 * sizeof(float), st,
+                               dz, rp.conv_w[l], static_cast<const float*>(nullptr), dx,
+                               static_cast<float*>(nullptr), B, d.Cout, d.Cin, d.H, d.W,
+                               (long)B * d.Cout * P, (long)d.Cout * P, L.chunks[l]);
+            dxn = dx;
+        }
+    }
+    return launched_ok() ? 0 : -3;
+}
+
+}  // namespace gnnpp

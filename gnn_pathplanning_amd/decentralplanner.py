@@ -20,10 +20,11 @@ Eval mode (the rollout loop, agents/decentralplannerlocal.py:489-592) is the ful
 Train mode (agents/decentralplannerlocal.py:283-317) keeps the reference's exact semantics: the
 encoder runs once per agent so BatchNorm normalises with per-agent-call batch statistics and
 updates its running statistics N times per forward (decentralplanner.py:284-290).  That needs
-batch-wide reductions per agent, so in train mode the encoder and the action head are stock aten /
-MIOpen ops on the GPU with autograd (agents as convolution groups instead of a python loop), while
-the graph filter (forward, input gradient, tap gradient) runs on the gnnpp HIP kernels through
-graphML._LSIGFFunction.  There is no CPU path.
+batch-wide reductions per agent between the layers, so train mode is a layer-by-layer schedule of
+hand-written HIP kernels, forward and backward (csrc/train_encoder.hip behind
+gnnpp_encoder_train_fwd / _bwd), plus the graph filter (forward, input gradient, tap gradient) on
+lsigf_kernel through graphML._LSIGFFunction; compressMLP and the action head are library GEMMs.
+There is no CPU path.
 """
 import ctypes
 
@@ -40,6 +41,60 @@ _BN_IDX = (1, 5, 8, 12, 15)
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _EncoderTrainFunction(torch.autograd.Function):
+    """Train-mode ConvLayers of ALL agents on the HIP kernels of csrc/train_encoder.hip.
+
+    obs [B,N,3,11,11] -> feat [N,B,128] (the flattened ConvLayers output of agent call n, i.e. what the
+    reference hands to compressMLP at decentralplanner.py:287-289), with the reference's per-agent-call
+    BatchNorm statistics; the running statistics receive their N momentum updates in place.  backward =
+    gnnpp_encoder_train_bwd: gradients of the 20 conv / BatchNorm parameters (no gradient to obs: it is
+    data).  `tensors` = [conv_w, conv_b, bn_w, bn_b] x 5 layers; `buffers` = [running_mean, running_var] x 5."""
+
+    @staticmethod
+    def forward(ctx, obs, buffers, momentum, eps, *tensors):
+        L = _native.lib()
+        B, N = obs.shape[0], obs.shape[1]
+        dev = obs.device
+        ps = [t.detach().contiguous().float() for t in tensors]
+        p = _native.EncoderParams()
+        for i in range(5):
+            p.conv_w[i], p.conv_b[i] = ps[4 * i].data_ptr(), ps[4 * i + 1].data_ptr()
+            p.bn_w[i], p.bn_b[i] = ps[4 * i + 2].data_ptr(), ps[4 * i + 3].data_ptr()
+            if buffers is not None:
+                p.bn_mean[i], p.bn_var[i] = buffers[2 * i].data_ptr(), buffers[2 * i + 1].data_ptr()
+        p.bn_eps = float(eps)
+        ws = torch.empty(L.gnnpp_encoder_train_workspace_floats(N, B), dtype=torch.float32, device=dev)
+        feat = torch.empty(N, B, 128, dtype=torch.float32, device=dev)
+        with _native.device_guard(dev):
+            _native.check(L.gnnpp_encoder_train_fwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(feat), B, N,
+                                                    ctypes.c_float(momentum), int(buffers is not None),
+                                                    _native.stream_ptr(dev)), 'gnnpp_encoder_train_fwd')
+        ctx.save_for_backward(obs, ws, *ps)
+        ctx.eps = float(eps)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        L = _native.lib()
+        obs, ws = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        ps = ctx.saved_tensors[2:]
+        B, N = obs.shape[0], obs.shape[1]
+        dev = obs.device
+        p, g = _native.EncoderParams(), _native.EncoderGrads()
+        grads = [torch.empty_like(t) for t in ps]
+        for i in range(5):
+            p.conv_w[i], p.conv_b[i] = ps[4 * i].data_ptr(), ps[4 * i + 1].data_ptr()
+            p.bn_w[i], p.bn_b[i] = ps[4 * i + 2].data_ptr(), ps[4 * i + 3].data_ptr()
+            g.conv_w[i], g.conv_b[i] = grads[4 * i].data_ptr(), grads[4 * i + 1].data_ptr()
+            g.bn_w[i], g.bn_b[i] = grads[4 * i + 2].data_ptr(), grads[4 * i + 3].data_ptr()
+        p.bn_eps = ctx.eps
+        d = dfeat.contiguous().float()
+        with _native.device_guard(dev):
+            _native.check(L.gnnpp_encoder_train_bwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(d), ctypes.byref(g),
+                                                    B, N, _native.stream_ptr(dev)), 'gnnpp_encoder_train_bwd')
+        return (None, None, None, None) + tuple(grads)
 
 
 class DecentralPlannerNet(nn.Module):
@@ -338,17 +393,48 @@ class DecentralPlannerNet(nn.Module):
         return out.permute(1, 0, 2).contiguous()
 
     def _forward_train(self, inputTensor):
-        """Differentiable train-mode forward with the reference's semantics
-        (decentralplanner.py:278-318) but without its N-fold python loop: the agents become
-        convolution GROUPS and BatchNorm runs over N*C channels, so the batch statistics of
-        channel (n, c) are exactly those of the reference's n-th ConvLayers call; the N sequential
-        running-statistics updates (momentum m) collapse to
-            r <- (1-m)^N r + m * sum_n (1-m)^(N-1-n) stat_n .
-        Weight gradients accumulate over the N expanded copies, as they do over the N calls."""
+        """Differentiable train-mode forward with the reference's semantics (decentralplanner.py:278-318),
+        on HIP kernels end to end: the per-agent ConvLayers calls (BatchNorm with THAT call's batch
+        statistics, N running-statistics updates per forward) run as _EncoderTrainFunction over all agents
+        at once (csrc/train_encoder.hip, forward and backward); compressMLP and the action head are one
+        library GEMM each; the graph filter layers run on lsigf_kernel (graphML._LSIGFFunction)."""
         import torch.nn.functional as tF
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
         _native.require_gpu(inputTensor, self.S, self.compressMLP[0].weight)
+        B, N = inputTensor.shape[0], self.numAgents
+        obs = inputTensor.detach()
+        if obs.shape[1] != N:
+            obs = obs[:, :N]
+        obs = obs.contiguous().float()
+        tensors, buffers = [], []
+        bn0 = self.ConvLayers[_BN_IDX[0]]
+        track = all(self.ConvLayers[bi].track_running_stats and self.ConvLayers[bi].momentum is not None
+                    for bi in _BN_IDX)
+        for ci, bi in zip(_CONV_IDX, _BN_IDX):
+            conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
+            tensors += [conv.weight, conv.bias, bn.weight, bn.bias]
+            buffers += [bn.running_mean, bn.running_var]
+        feat = _EncoderTrainFunction.apply(obs, buffers if track else None, float(bn0.momentum or 0.0),
+                                           float(bn0.eps), *tensors)                     # [N,B,128]
+        if track:
+            with torch.no_grad():
+                for bi in _BN_IDX:
+                    self.ConvLayers[bi].num_batches_tracked.add_(N)
+        fc = self.compressMLP[0]
+        comp = tF.relu(tF.linear(feat, fc.weight, fc.bias))                             # [N,B,F]
+        for l in range(self.L):
+            self.GFL[2 * l].addGSO(self.S)
+        shared = self.GFL(comp.permute(1, 2, 0).contiguous())       # [B,F,N]: HIP filter fwd/bwd + ReLU
+        act = self.actionsMLP[0]
+        logits = tF.linear(shared.permute(0, 2, 1), act.weight, act.bias)               # B x N x 5
+        return [logits[:, n] for n in range(N)]
+
+    def _forward_train_aten(self, inputTensor):
+        """The same train-mode forward on stock aten / MIOpen ops (agents as convolution groups).  NOT
+        used by forward(): kept as an independent GPU cross-check of the HIP training kernels for the
+        tests (tests/test_gpu_training.py)."""
+        import torch.nn.functional as tF
         B, N = inputTensor.shape[0], self.numAgents
         x = inputTensor[:, :N].reshape(B, N * 3, 11, 11)
         for ci, bi in zip(_CONV_IDX, _BN_IDX):
@@ -358,17 +444,8 @@ class DecentralPlannerNet(nn.Module):
                           padding=1, groups=N)
             bmean = torch.zeros(N * C, device=x.device, dtype=x.dtype)
             bvar = torch.ones(N * C, device=x.device, dtype=x.dtype)
-            # momentum 1 => the dummy buffers receive the batch mean / unbiased variance
             x = tF.batch_norm(x, bmean, bvar, bn.weight.repeat(N), bn.bias.repeat(N), training=True,
                               momentum=1.0, eps=bn.eps)
-            if bn.track_running_stats and bn.momentum is not None:
-                with torch.no_grad():
-                    m = float(bn.momentum)
-                    w = m * (1.0 - m) ** torch.arange(N - 1, -1, -1, device=x.device, dtype=x.dtype)
-                    keep = (1.0 - m) ** N
-                    bn.running_mean.mul_(keep).add_((w[:, None] * bmean.view(N, C)).sum(0))
-                    bn.running_var.mul_(keep).add_((w[:, None] * bvar.view(N, C)).sum(0))
-                    bn.num_batches_tracked.add_(N)
             x = tF.relu(x)
             if isinstance(self.ConvLayers[bi + 2] if bi + 2 < len(self.ConvLayers) else None,
                           nn.MaxPool2d):
@@ -378,9 +455,9 @@ class DecentralPlannerNet(nn.Module):
         comp = tF.relu(tF.linear(feat, fc.weight, fc.bias))          # B x N x F
         for l in range(self.L):
             self.GFL[2 * l].addGSO(self.S)
-        shared = self.GFL(comp.permute(0, 2, 1).contiguous())       # HIP filter fwd/bwd + ReLU
+        shared = self.GFL(comp.permute(0, 2, 1).contiguous())
         act = self.actionsMLP[0]
-        logits = tF.linear(shared.permute(0, 2, 1), act.weight, act.bias)      # B x N x 5
+        logits = tF.linear(shared.permute(0, 2, 1), act.weight, act.bias)
         return [logits[:, n] for n in range(N)]
 
     def forward(self, inputTensor):

@@ -155,6 +155,35 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * TRAIN-mode encoder, forward and backward (BASELINE config 4: loss.backward() at
+ * agents/decentralplannerlocal.py:314 over the per-agent ConvLayers calls of
+ * graphs/models/decentralplanner.py:284-287).  The reference runs the CNN once per agent, so BatchNorm
+ * uses the statistics of (agent n, channel c) over that call's B samples, and updates its running
+ * statistics N times per forward in agent order (momentum, unbiased variance): exactly that.
+ *   obs        [B,N,3,11,11] (inputTensor); feat out [N,B,128] = flattened ConvLayers output per agent
+ *              call (the input of compressMLP); dfeat [N,B,128] its gradient;
+ *   workspace  gnnpp_encoder_train_workspace_floats(N, B) floats: holds the activations between
+ *              forward and backward -- pass the SAME buffer, untouched, to the backward call;
+ *   update_running != 0: p->bn_mean / p->bn_var are UPDATED in place (the one documented exception
+ *              to "inputs are never written"; eval-mode packs must be rebuilt afterwards);
+ *   g          where the gradients of the 20 parameter tensors go (overwritten, not accumulated).
+ * fp32, deterministic (fixed-order reductions, no atomics).  compressMLP, the graph filter and the
+ * action head are separate calls (library GEMM / gnnpp_lsigf_fwd_save).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gnnpp_encoder_grads {
+    float* conv_w[5];           /* d ConvLayers.{0,4,7,11,14}.weight  [Cout,Cin,3,3]             */
+    float* conv_b[5];           /* d ...bias [Cout] (exactly zero in exact arithmetic: BatchNorm follows) */
+    float* bn_w[5];             /* d ConvLayers.{1,5,8,12,15}.weight [Cout]                      */
+    float* bn_b[5];             /* d ...bias                                                      */
+} gnnpp_encoder_grads;
+
+size_t gnnpp_encoder_train_workspace_floats(int N, int B);
+int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
+                            int B, int N, float momentum, int update_running, void* stream);
+int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
+                            const float* dfeat, const gnnpp_encoder_grads* g, int B, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole policy step: DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318):
  * encoder -> GraphFilterBatch(128,128,K,E=1) -> ReLU -> actionsMLP Linear(128,5).
  * ------------------------------------------------------------------------------------------ */

@@ -185,8 +185,8 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
         if (arena == MAP_FAILED) { std::perror("mmap"); std::abort(); }
     }
     body_fn = &body;
-    for (unsigned bb = 0; bb < grid.x * grid.y; ++bb) {
-        const unsigned b = bb % grid.x, by = bb / grid.x;
+    for (unsigned bb = 0; bb < grid.x * grid.y * grid.z; ++bb) {
+        const unsigned b = bb % grid.x, by = (bb / grid.x) % grid.y, bz = bb / (grid.x * grid.y);
         lds_canary(smem_bytes, false);
         fibers.assign(nt, Fiber());
         waves.assign((nt + 63) / 64, Wave());
@@ -195,7 +195,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
         for (int t = 0; t < nt; ++t) {
             Fiber& f = fibers[t];
             f.item.tid = dim3(t, 0, 0);
-            f.item.bid = dim3(b, by, 0);
+            f.item.bid = dim3(b, by, bz);
             f.item.bdim = block;
             f.item.gdim = grid;
             f.wave = t / 64;

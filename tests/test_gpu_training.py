@@ -277,3 +277,44 @@ def test_graphed_train_step_then_eval_uses_new_weights(dev):
         want = torch.stack(orc.policy_forward(sd, S.cpu(), obs.cpu()), 0)
     assert (b.cpu() - want).abs().max().item() <= 1e-4
     assert (a - b).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize('B,N', [(64, 10), (7, 3), (2, 16)])
+def test_hip_training_encoder_matches_aten_path(dev, B, N):
+    """The hand-written train-mode encoder (csrc/train_encoder.hip, forward + backward) against the same
+    forward on stock aten / MIOpen ops (agents as convolution groups) at BASELINE config 4's batch:
+    loss, logits, every parameter gradient and the BatchNorm running statistics."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import policy_loss
+
+    class C:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    sd = orc.init_state_dict(3, seed=B + N)
+    obs = orc.synth_obs(B, N, seed=3).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=3)).float().to(dev)
+    g = torch.Generator().manual_seed(2)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=g), 5).float().to(dev)
+    res = []
+    for which in ('hip', 'aten'):
+        net = DecentralPlannerNet(C()).to(dev)
+        net.load_state_dict(sd)
+        net.train()
+        net.addGSO(S)
+        out = net(obs) if which == 'hip' else net._forward_train_aten(obs)
+        loss = policy_loss(out, tgt)
+        loss.backward()
+        res.append((loss.item(), torch.stack(out, 1).detach().cpu(),
+                    {k: p.grad.detach().cpu() for k, p in net.named_parameters()},
+                    {k: b.detach().cpu().clone() for k, b in net.named_buffers() if 'running' in k}))
+    (l0, o0, g0, r0), (l1, o1, g1, _) = res
+    assert abs(l0 - l1) <= 1e-5 and (o0 - o1).abs().max().item() <= 1e-4
+    for k in g0:
+        if k.startswith('ConvLayers.') and k.endswith('.bias') and int(k.split('.')[1]) in (0, 4, 7, 11, 14):
+            continue                                       # conv bias before train-mode BN: zero gradient, roundoff
+        assert close(g0[k], g1[k], 5e-4), (k, (g0[k] - g1[k]).abs().max().item(), g1[k].abs().max().item())
+    # running statistics after ONE forward against the oracle's per-agent-call loop
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        orc.policy_forward(sd2, S.cpu(), obs.cpu(), training=True)
+    for k, v in r0.items():
+        assert (v - sd2[k]).abs().max().item() <= 2e-5, k
