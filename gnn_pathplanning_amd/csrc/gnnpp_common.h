@@ -109,6 +109,14 @@ __device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) {
     return r;
 }
 
+// sum of `v` over the 64 lanes of the wave, in every lane: xor butterfly, a fixed association order
+// (deterministic), no LDS.  Every lane of the wave must take part.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
 // value of `v` held by lane `src` (src must be wave-uniform)
 __device__ __forceinline__ float wave_read_lane(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));

@@ -45,8 +45,7 @@ __host__ __device__ inline TrainLayerDims train_layer(int l) {
                                             {64, 64, 2, 2, 0}, {64, 128, 2, 2, 1}};
     return d[l];
 }
-constexpr int kConvCT = 16;          // output channels per wave of conv_cols_kernel
-constexpr int kWgSplitMax = 64;      // column-range splits of conv_wgrad_kernel
+constexpr int kWgSplitMax = 640;     // column-range splits of conv_wgrad_kernel
 
 // ---- weights: [co][ci][9] -> [ci][co][9] (forward conv reads a channel tile x 9 taps contiguously) ------
 __global__ void pack_train_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
@@ -67,18 +66,16 @@ __global__ void pack_train_weights_kernel(const float* __restrict__ w, float* __
 // of agent n (columns = B*P).  x image (n, b) starts at x + n*x_sn + b*x_sb (the observations arrive
 // sample-major [B][N]...; every other tensor is agent-major).  part != nullptr: per-wave (sum, sum sq) of
 // the outputs per channel -> part[((n*chunks + chunk)*Cout + co)*2 + {0,1}].
-template <bool FLIP>
+template <bool FLIP, int CT>
 __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ wk,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ y, float* __restrict__ part,
                                                        int B, int Cin, int Cout, int H, int W, long x_sn,
                                                        long x_sb, int chunks) {
-    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    float (*red)[64] = reinterpret_cast<float (*)[64]>(gnnpp_smem);           // [2 * kConvCT][64]
     const int lane = threadIdx.x;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
-    const int co0 = blockIdx.y * kConvCT;
+    const int co0 = blockIdx.y * CT;
     const int P = H * W;
     const int col = chunk * 64 + lane;
     const bool active = col < B * P;
@@ -94,38 +91,48 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
         off[t] = in ? yy * W + xx : pos;                 // (a valid address; the value is masked)
         msk[t] = in ? 1.f : 0.f;
     }
-    float acc[kConvCT];
+    float acc[CT];
 #pragma unroll
-    for (int c = 0; c < kConvCT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
+    for (int c = 0; c < CT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
     const float* xi = x + n * x_sn + b * x_sb;
-    for (int ci = 0; ci < Cin; ++ci) {
-        float patch[9];
+    // input channels four at a time: all 36 patch loads of a group are issued before its FMAs, so one
+    // memory round trip feeds 4 * 9 * CT FMAs (Cin is 3 or a multiple of 4)
+    constexpr int U = 4;
+    for (int ci0 = 0; ci0 < Cin; ci0 += U) {
+        float patch[U][9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) patch[t] = xi[(long)ci * P + off[t]] * msk[t];
-        const float* wrow = wk + ((long)ci * Cout + co0) * 9;          // wave-uniform: scalar loads
+        for (int u = 0; u < U; ++u) {
+            const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
+            const float live = ci0 + u < Cin ? 1.f : 0.f;
 #pragma unroll
-        for (int c = 0; c < kConvCT; ++c)
+            for (int t = 0; t < 9; ++t) patch[u][t] = xi[(long)ci * P + off[t]] * (msk[t] * live);
+        }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[c] = fmaf(wrow[c * 9 + (FLIP ? 8 - t : t)], patch[t], acc[c]);
+        for (int u = 0; u < U; ++u) {
+            const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
+            const float* wrow = wk + ((long)ci * Cout + co0) * 9;      // wave-uniform: scalar loads
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[c] = fmaf(wrow[c * 9 + (FLIP ? 8 - t : t)], patch[u][t], acc[c]);
+        }
     }
     if (active) {
         float* yo = y + (((long)n * B + b) * Cout + co0) * P + pos;
 #pragma unroll
-        for (int c = 0; c < kConvCT; ++c) yo[(long)c * P] = acc[c];
+        for (int c = 0; c < CT; ++c) yo[(long)c * P] = acc[c];
     }
     if (part) {
-        // fixed-order reduction: lane j < 32 sums value j (channel j >> 1, sum / sum of squares) over lanes
 #pragma unroll
-        for (int c = 0; c < kConvCT; ++c) {
+        for (int c = 0; c < CT; ++c) {
             const float v = active ? acc[c] : 0.f;
-            red[2 * c][lane] = v;
-            red[2 * c + 1][lane] = v * v;
-        }
-        __syncthreads();
-        if (lane < 2 * kConvCT) {
-            float s = 0.f;
-            for (int i = 0; i < 64; ++i) s += red[lane][i];
-            part[(((long)n * chunks + chunk) * Cout + co0 + (lane >> 1)) * 2 + (lane & 1)] = s;
+            const float s1 = wave_sum(v), s2 = wave_sum(v * v);
+            if (lane == 0) {
+                float* o = part + (((long)n * chunks + chunk) * Cout + co0 + c) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
         }
     }
 }
@@ -205,6 +212,7 @@ __global__ void bn_running_kernel(const float* __restrict__ stat, float* __restr
 // d a = dxn[window] if this position is the FIRST maximum of its 2x2 window (scan order, like torch's
 // max_pool2d backward; a recomputed from y), 0 for positions the pool never reads; without pool d a = dxn.
 // Writes dz [N][B][C][P] and per-wave partial sums of dz and dz * yhat -> part[((n*chunks+chunk)*C + c)*2].
+constexpr int kBnBwdCG = 8;          // channels per wave of bn_bwd_reduce_kernel (grid.y = C / 8)
 __global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restrict__ y,
                                                            const float* __restrict__ stat,
                                                            const float* __restrict__ gamma,
@@ -212,10 +220,9 @@ __global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restri
                                                            const float* __restrict__ dxn,
                                                            float* __restrict__ dz, float* __restrict__ part,
                                                            int B, int C, int H, int W, int pool, int chunks) {
-    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    float (*red)[64] = reinterpret_cast<float (*)[64]>(gnnpp_smem);           // [2][64]
     const int lane = threadIdx.x;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int c0 = blockIdx.y * kBnBwdCG;
     const int P = H * W, Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo;
     const int col = chunk * 64 + lane;
     const bool active = col < B * P;
@@ -224,69 +231,71 @@ __global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restri
     const int py = pos / W, px = pos - py * W;
     const bool pooled_in = !pool || (py < 2 * Ho && px < 2 * Wo);       // inside the region the pool reads
     const int oy = pool ? py / 2 : py, ox = pool ? px / 2 : px;
-    const int wpos = pool ? (2 * oy) * W + 2 * ox : pos;                // window origin
+    const int wpos = pool && pooled_in ? (2 * oy) * W + 2 * ox : pos;   // window origin (a valid address)
     const int me = pool ? (py - 2 * oy) * 2 + (px - 2 * ox) : 0;        // my slot in the window
-    for (int c = 0; c < C; ++c) {
+    const int wo[4] = {0, 1, W, W + 1};
+#pragma unroll
+    for (int cc = 0; cc < kBnBwdCG; ++cc) {
+        const int c = c0 + cc;
         const float* st = stat + ((long)n * C + c) * 4;
         const float mean = st[0], invstd = st[1], g = gamma[c], be = beta[c];
         const long ic = ((long)n * B + b) * C + c;
         const float* yc = y + ic * P;
-        float d = 0.f, yhat = 0.f;
-        if (active && pooled_in) {
-            const float yv = yc[pos];
-            yhat = (yv - mean) * invstd;
-            const float a = fmaxf(fmaf(yhat, g, be), 0.f);
-            bool mine = true;
-            if (pool) {
-                const int po[4] = {0, 1, W, W + 1};
+        const float yv = yc[pos];
+        const float yhat = (yv - mean) * invstd;
+        const float a = fmaxf(fmaf(yhat, g, be), 0.f);
+        bool mine = active && pooled_in;
+        if (pool) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float ak = bn_act(yc[wpos + po[k]], mean, invstd, g, be);
-                    mine = mine && (k < me ? ak < a : ak <= a);       // strictly greater than the earlier ones
-                }
+            for (int k = 0; k < 4; ++k) {
+                const float ak = bn_act(yc[pooled_in ? wpos + wo[k] : pos], mean, invstd, g, be);
+                mine = mine && (k < me ? ak < a : ak <= a);           // strictly greater than the earlier ones
             }
-            const float da = mine ? dxn[ic * Po + oy * Wo + ox] : 0.f;
-            d = a > 0.f ? da : 0.f;
-        } else if (active) {
-            yhat = (yc[pos] - mean) * invstd;
         }
+        const float da = dxn[ic * Po + (pooled_in ? oy * Wo + ox : 0)];
+        const float d = (mine && a > 0.f) ? da : 0.f;
         if (active) dz[ic * P + pos] = d;
-        red[0][lane] = d;
-        red[1][lane] = d * yhat;
-        __syncthreads();
-        if (lane < 2) {
-            float s = 0.f;
-            for (int i = 0; i < 64; ++i) s += red[lane][i];
-            part[(((long)n * chunks + chunk) * C + c) * 2 + lane] = s;
+        const float s1 = wave_sum(d), s2 = wave_sum(d * yhat);
+        if (lane == 0) {
+            float* o = part + (((long)n * chunks + chunk) * C + c) * 2;
+            o[0] = s1;
+            o[1] = s2;
         }
-        __syncthreads();
     }
 }
 
 // pass 2a: coefficients per (agent, channel): coef[(n*C + c)*4 + {k1, k2, k3}] with
 //   dy = k1 * (dz - k2 - yhat * k3),  k1 = gamma * invstd, k2 = mean(dz), k3 = mean(dz * yhat);
-// d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz)   (one thread per channel)
+// grid = N blocks, C threads; the per-agent sums go to pn[(n*C + c)*2] for bn_bwd_dparam_kernel
 __global__ void bn_bwd_coef_kernel(const float* __restrict__ part, const float* __restrict__ stat,
                                    const float* __restrict__ gamma, float* __restrict__ coef,
-                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int chunks,
-                                   int C, int m) {
+                                   float* __restrict__ pn, int chunks, int C, int m) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float* p = part + (((long)n * chunks + k) * C + c) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+    float* o = coef + ((long)n * C + c) * 4;
+    o[0] = gamma[c] * stat[((long)n * C + c) * 4 + 1];
+    o[1] = (float)(s1 / m);
+    o[2] = (float)(s2 / m);
+    o[3] = 0.f;
+    pn[((long)n * C + c) * 2] = (float)s1;
+    pn[((long)n * C + c) * 2 + 1] = (float)s2;
+}
+
+// d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz): agents in order, one thread per channel
+__global__ void bn_bwd_dparam_kernel(const float* __restrict__ pn, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int N, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double tg = 0.0, tb = 0.0;
+    double tb = 0.0, tg = 0.0;
     for (int n = 0; n < N; ++n) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            const float* p = part + (((long)n * chunks + k) * C + c) * 2;
-            s1 += (double)p[0];
-            s2 += (double)p[1];
-        }
-        tb += s1;
-        tg += s2;
-        float* o = coef + ((long)n * C + c) * 4;
-        o[0] = gamma[c] * stat[((long)n * C + c) * 4 + 1];
-        o[1] = (float)(s1 / m);
-        o[2] = (float)(s2 / m);
-        o[3] = 0.f;
+        tb += (double)pn[((long)n * C + c) * 2];
+        tg += (double)pn[((long)n * C + c) * 2 + 1];
     }
     dgamma[c] = (float)tg;
     dbeta[c] = (float)tb;
@@ -327,25 +336,32 @@ __global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict_
     const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
     v4f acc = vzero();
     const int img0 = split * imgs_per_split, img1 = min(NB, img0 + imgs_per_split);
-    for (int img = img0; img < img1; ++img) {
-        const int n = img / B, b = img - n * B;
-        const float* dyi = dy + ((long)img * Cout + co0 + i16) * P;      // A rows: channel co0 + i16
-        const float* xi = x + n * x_sn + b * x_sb + (long)ci * P;
-        for (int p0 = 0; p0 < P; p0 += 4) {
-            const int p = p0 + q;                        // this lane's column (k slot q)
-            const bool pv = p < P;
-            const float av = pv ? dyi[p] : 0.f;
-            float bv = 0.f;
-            if (pv) {
-                if (jb) bv = 1.f;
-                else if (jv) {
-                    const int py = p / W, px = p - py * W;
-                    const int yy = py + dyy, xx = px + dxx;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) bv = xi[yy * W + xx];
-                }
-            }
-            acc = mfma16(av, bv, acc);
+    // the K loop runs over (image, group of 4 positions) steps; four steps' operands are fetched before
+    // their MFMAs so that one memory round trip feeds four of them
+    const int spi = (P + 3) >> 2;                        // steps per image
+    const int nsteps = (img1 - img0) * spi;
+    constexpr int U = 4;
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sidx = s0 + u;
+            const bool sv = sidx < nsteps;
+            const int sc = sv ? sidx : 0;
+            const int img = img0 + sc / spi, p = (sc - (sc / spi) * spi) * 4 + q;   // this lane's column
+            const bool pv = sv && p < P;
+            const int pc = pv ? p : 0;
+            const int n = img / B, b = img - n * B;
+            const int py = pc / W, px = pc - py * W;
+            const int yy = py + dyy, xx = px + dxx;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float a0 = dy[((long)img * Cout + co0 + i16) * P + pc];                 // A: channel co0 + i16
+            const float x0 = x[n * x_sn + b * x_sb + (long)ci * P + (in ? yy * W + xx : pc)];
+            av[u] = pv ? a0 : 0.f;
+            bv[u] = pv ? (jb ? 1.f : (jv && in ? x0 : 0.f)) : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(av[u], bv[u], acc);
     }
     // D register r of lane l: D[i = 4 q + r][j = l & 15]
     float* o = wpart + ((long)split * Cout + co0 + 4 * q) * J16 + j0 + i16;
@@ -397,7 +413,7 @@ inline TrainWs train_ws_layout(int N, int B) {
         // weight-gradient splits: enough waves to fill the chip, at least one image per split
         w.jt[l] = (d.Cin * 9 + 1 + 15) / 16;
         const int tiles = (d.Cout / 16) * w.jt[l];
-        int ns = (1024 + tiles - 1) / tiles;
+        int ns = (8192 + tiles - 1) / tiles;               // ~8 waves per SIMD: the K loop is latency bound
         if (ns > kWgSplitMax) ns = kWgSplitMax;
         if ((size_t)ns > NB) ns = (int)NB;
         w.ips[l] = (int)((NB + ns - 1) / ns);
@@ -409,13 +425,28 @@ inline TrainWs train_ws_layout(int N, int B) {
     w.dz = o; o += max_y;
     w.dxa = o; o += max_x;
     w.dxb = o; o += max_x;
-    w.coef = o; o += (size_t)N * 128 * 4;
+    w.coef = o; o += (size_t)N * 128 * 6;            // coefficients [N][128][4] + per-agent sums [N][128][2]
     w.wpart = o; o += max_wp;
     w.total = o;
     return w;
 }
 
 static inline bool launched_ok() { return hipGetLastError() == hipSuccess; }
+
+// channel tile per wave: 16 where the layer has plenty of columns, 4 for the 2x2 layers (2560 columns at
+// B = 64, N = 10: more, shorter waves instead of 40 long ones)
+template <bool FLIP>
+static void conv_cols_launch(const float* x, const float* wk, const float* bias, float* y, float* part, int N,
+                             int B, int Cin, int Cout, int H, int W, long sn, long sb, int chunks,
+                             hipStream_t st) {
+    if ((long)N * chunks * (Cout / 16) >= 2048 || (Cout & 3)) {
+        hipLaunchKernelGGL((conv_cols_kernel<FLIP, 16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk,
+                           bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
+    } else {
+        hipLaunchKernelGGL((conv_cols_kernel<FLIP, 4>), dim3(N * chunks, Cout / 4), dim3(64), 0, st, x, wk,
+                           bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
+    }
+}
 
 // obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128]
 int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const* rvar, float momentum,
@@ -430,10 +461,8 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        hipLaunchKernelGGL(conv_cols_kernel<false>, dim3(N * L.chunks[l], d.Cout / kConvCT), dim3(64),
-                           2 * kConvCT * 64 * sizeof(float), st,
-                           xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, B, d.Cin, d.Cout, d.H,
-                           d.W, sn, sb, L.chunks[l]);
+        conv_cols_launch<false>(xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, d.Cin, d.Cout,
+                                d.H, d.W, sn, sb, L.chunks[l], st);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
                            L.chunks[l], d.Cout, B * P, rp.bn_eps);
         const long tot = NB * d.Cout * Po;
@@ -459,12 +488,13 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
         float* dz = ws + L.dz;
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(N * L.chunks[l]), dim3(64), 2 * 64 * sizeof(float), st,
-                           ws + L.y[l],
-                           ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout, d.H, d.W,
-                           d.pool, L.chunks[l]);
-        hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(1), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
-                           rp.bn_w[l], ws + L.coef, dbn_w[l], dbn_b[l], N, L.chunks[l], d.Cout, B * P);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(N * L.chunks[l], d.Cout / kBnBwdCG), dim3(64), 0, st,
+                           ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B,
+                           d.Cout, d.H, d.W, d.pool, L.chunks[l]);
+        hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
+                           rp.bn_w[l], ws + L.coef, ws + L.coef + (size_t)N * 128 * 4, L.chunks[l], d.Cout, B * P);
+        hipLaunchKernelGGL(bn_bwd_dparam_kernel, dim3(1), dim3(128), 0, st, ws + L.coef + (size_t)N * 128 * 4,
+                           dbn_w[l], dbn_b[l], N, d.Cout);
         const long tot = NB * d.Cout * P;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
                            dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], ws + L.coef, dz, tot, B, d.Cout, P);
@@ -479,11 +509,8 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
             // output channels of this call = d.Cin (a multiple of 16 for l >= 1)
-            hipLaunchKernelGGL(conv_cols_kernel<true>, dim3(N * L.chunks[l], d.Cin / kConvCT), dim3(64),
-                               2 * kConvCT * 64 * sizeof(float), st,
-                               dz, rp.conv_w[l], static_cast<const float*>(nullptr), dx,
-                               static_cast<float*>(nullptr), B, d.Cout, d.Cin, d.H, d.W,
-                               (long)B * d.Cout * P, (long)d.Cout * P, L.chunks[l]);
+            conv_cols_launch<true>(dz, rp.conv_w[l], nullptr, dx, nullptr, N, B, d.Cout, d.Cin, d.H, d.W,
+                                   (long)B * d.Cout * P, (long)d.Cout * P, L.chunks[l], st);
             dxn = dx;
         }
     }

@@ -118,6 +118,16 @@ int readlane(int v, int src) {
     return r;
 }
 
+float shfl_xor(float v, int mask) {
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    w.a[f.lane] = v;
+    wave_barrier();
+    const float r = w.a[(f.lane ^ mask) & 63];
+    wave_barrier();
+    return r;
+}
+
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int) {
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];

@@ -71,6 +71,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 void sync_block();
 unsigned long long ballot(int pred);
 int readlane(int v, int src_lane);
+float shfl_xor(float v, int mask);   // value of lane (lane ^ mask); every lane of the wave takes part
 void wave_sync();                 // lockstep point: every lane of the wave reaches it before any leaves
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -93,6 +94,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __popc(x) __builtin_popcount(x)
 #define __umul24(a, b) ((unsigned)(a) * (unsigned)(b))
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
+#define __shfl_xor(v, m) gnnpp_emu::shfl_xor((v), (m))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
