@@ -48,12 +48,17 @@ __host__ __device__ inline TrainLayerDims train_layer(int l) {
 constexpr int kWgSplitMax = 640;     // column-range splits of conv_wgrad_kernel
 
 // ---- weights: [co][ci][9] -> [ci][co][9] (forward conv reads a channel tile x 9 taps contiguously) ------
-__global__ void pack_train_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin,
-                                          int Cout) {
-    const int total = Cin * Cout * 9;
+// all five layers in one launch: blockIdx.y = layer
+struct TrainPtrs5 { const float* a[kTrainLayers]; float* b[kTrainLayers]; float* c[kTrainLayers]; };
+__global__ void pack_train_weights_kernel(const TrainPtrs5 p) {
+    const int l = blockIdx.y;
+    const TrainLayerDims d = train_layer(l);
+    const float* w = p.a[l];
+    float* wt = p.b[l];
+    const int total = d.Cin * d.Cout * 9;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int tap = i % 9, co = (i / 9) % Cout, ci = i / (9 * Cout);
-        wt[i] = w[(co * Cin + ci) * 9 + tap];
+        const int tap = i % 9, co = (i / 9) % d.Cout, ci = i / (9 * d.Cout);
+        wt[i] = w[(co * d.Cin + ci) * 9 + tap];
     }
 }
 
@@ -95,9 +100,9 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
     const float* xi = x + n * x_sn + b * x_sb;
-    // input channels four at a time: all 36 patch loads of a group are issued before its FMAs, so one
-    // memory round trip feeds 4 * 9 * CT FMAs (Cin is 3 or a multiple of 4)
-    constexpr int U = 4;
+    // input channels U at a time: all 9 U patch loads of a group are issued before its FMAs, so one
+    // memory round trip feeds U * 9 * CT FMAs (Cin is 3 or a multiple of 8)
+    constexpr int U = CT >= 16 ? 4 : 8;          // narrower channel tiles leave registers for deeper prefetch
     for (int ci0 = 0; ci0 < Cin; ci0 += U) {
         float patch[U][9];
 #pragma unroll
@@ -193,10 +198,15 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ y, const float* __
 
 // ---- running statistics: the N per-agent-call updates in agent order (one thread per channel) -------------
 // nn.BatchNorm2d in train mode: r <- (1 - momentum) r + momentum * batch statistic (unbiased variance)
-__global__ void bn_running_kernel(const float* __restrict__ stat, float* __restrict__ rmean,
-                                  float* __restrict__ rvar, int N, int C, float momentum) {
+// all five layers in one launch: blockIdx.y = layer (a = stat, b = running_mean, c = running_var)
+__global__ void bn_running_kernel(const TrainPtrs5 p, int N, float momentum) {
+    const int l = blockIdx.y;
+    const int C = train_layer(l).Cout;
+    const float* stat = p.a[l];
+    float* rmean = p.b[l];
+    float* rvar = p.c[l];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (c >= C || !rmean || !rvar) return;
     float m = rmean[c], v = rvar[c];
     for (int n = 0; n < N; ++n) {
         const float* st = stat + ((long)n * C + c) * 4;
@@ -369,17 +379,31 @@ __global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict_
     for (int r = 0; r < 4; ++r) o[(long)r * J16] = acc[r];
 }
 
-// sum the splits in order; dw [Cout][Cin][9], db [Cout]
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ wpart, float* __restrict__ dw,
-                                         float* __restrict__ db, int nsplit, int Cin, int Cout, int J16) {
+// sum the splits: 8 lanes per output element each add every 8th split (in order), then the 8 partial sums
+// are added in lane order -- a fixed association, deterministic.  dw [Cout][Cin][9], db [Cout]
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ wpart,
+                                                                float* __restrict__ dw, float* __restrict__ db,
+                                                                int nsplit, int Cin, int Cout, int J16) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* red = reinterpret_cast<float*>(gnnpp_smem);                 // [256]
     const int J = Cin * 9 + 1;
     const int total = Cout * J;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 7;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    float s = 0.f;
+    if (i < total) {
         const int co = i / J, jj = i - co * J;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += wpart[((long)k * Cout + co) * J16 + jj];
-        if (jj == J - 1) db[co] = s;
-        else dw[(long)co * (J - 1) + jj] = s;
+        for (int k = sub; k < nsplit; k += 8) s += wpart[((long)k * Cout + co) * J16 + jj];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sub == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[threadIdx.x + k];
+        const int co = i / J, jj = i - co * J;
+        if (jj == J - 1) db[co] = t;
+        else dw[(long)co * (J - 1) + jj] = t;
     }
 }
 
@@ -439,8 +463,13 @@ template <bool FLIP>
 static void conv_cols_launch(const float* x, const float* wk, const float* bias, float* y, float* part, int N,
                              int B, int Cin, int Cout, int H, int W, long sn, long sb, int chunks,
                              hipStream_t st) {
-    if ((long)N * chunks * (Cout / 16) >= 2048 || (Cout & 3)) {
+    // the widest channel tile that still gives about one wave per SIMD (1024 on the chip)
+    const long cw = (long)N * chunks;
+    if (cw * (Cout / 16) >= 900) {
         hipLaunchKernelGGL((conv_cols_kernel<FLIP, 16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk,
+                           bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
+    } else if (cw * (Cout / 8) >= 900) {
+        hipLaunchKernelGGL((conv_cols_kernel<FLIP, 8>), dim3(N * chunks, Cout / 8), dim3(64), 0, st, x, wk,
                            bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
     } else {
         hipLaunchKernelGGL((conv_cols_kernel<FLIP, 4>), dim3(N * chunks, Cout / 4), dim3(64), 0, st, x, wk,
@@ -453,11 +482,15 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
                       const float* obs, float* ws, float* feat, int N, int B, hipStream_t st) {
     const TrainWs L = train_ws_layout(N, B);
     const long NB = (long)N * B;
+    TrainPtrs5 pk = {}, run = {};
+    for (int l = 0; l < kTrainLayers; ++l) {
+        pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l];
+        run.a[l] = ws + L.stat[l]; run.b[l] = rmean ? rmean[l] : nullptr; run.c[l] = rvar ? rvar[l] : nullptr;
+    }
+    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(32, kTrainLayers), dim3(256), 0, st, pk);
     for (int l = 0; l < kTrainLayers; ++l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W, Po = d.pool ? (d.H / 2) * (d.W / 2) : P;
-        hipLaunchKernelGGL(pack_train_weights_kernel, dim3(64), dim3(256), 0, st, rp.conv_w[l], ws + L.wt[l],
-                           d.Cin, d.Cout);
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
@@ -469,10 +502,9 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
                            dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
                            l == kTrainLayers - 1 ? feat : ws + L.xn[l], tot, B, d.Cout, d.H, d.W, d.pool);
-        if (rmean && rmean[l] && rvar && rvar[l])
-            hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(128), 0, st, ws + L.stat[l], rmean[l], rvar[l],
-                               N, d.Cout, momentum);
     }
+    if (rmean && rvar)
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, run, N, momentum);
     return launched_ok() ? 0 : -3;
 }
 
@@ -503,8 +535,9 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(d.Cout / 16, L.jt[l], L.nsplit[l]), dim3(64), 0, st, xin, dz,
                            ws + L.wpart, (int)NB, d.Cin, d.Cout, d.H, d.W, sn, sb, B, L.ips[l]);
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, ws + L.wpart, dconv_w[l],
-                           dconv_b[l], L.nsplit[l], d.Cin, d.Cout, L.jt[l] * 16);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((d.Cout * (d.Cin * 9 + 1) + 31) / 32), dim3(256),
+                           256 * sizeof(float), st, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l], d.Cin,
+                           d.Cout, L.jt[l] * 16);
         if (l > 0) {
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];

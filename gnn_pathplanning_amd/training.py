@@ -19,12 +19,12 @@ from . import _native
 
 def policy_loss(predict, batch_target):
     """predict: list of N tensors [B,5]; batch_target [B,N,5] one-hot expert actions.
-    agents/decentralplannerlocal.py:296-312."""
-    tgt = batch_target.permute(1, 0, 2)
-    loss = 0
-    for n in range(len(predict)):
-        loss = loss + tF.cross_entropy(predict[n], torch.max(tgt[n], 1)[1])
-    return loss / len(predict)
+    agents/decentralplannerlocal.py:296-312: loss = (1/N) sum_n CrossEntropy(predict[n], argmax target[:, n]).
+    Every agent's CrossEntropy is a mean over the same B samples, so the mean over agents of the means is
+    the mean over all N*B rows: ONE batched cross-entropy instead of N (10 x fewer launches per step)."""
+    logits = torch.stack(predict, dim=0)                                   # [N,B,5]
+    labels = batch_target.permute(1, 0, 2).argmax(-1)                      # [N,B]: torch.max(.,1)[1], first maximum
+    return tF.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
 
 
 def train_step(model, optimizer, batch_input, batch_target, batch_GSO, dp=None):
