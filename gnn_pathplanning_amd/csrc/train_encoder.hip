@@ -28,7 +28,7 @@
 //                             with per-wave partial sums of dz and dz * yhat
 //     bn_bwd_coef_kernel      partials -> per (agent, channel) coefficients; d gamma, d beta summed over agents
 //     bn_bwd_apply_kernel     dy = gamma * invstd * (dz - mean(dz) - yhat * mean(dz * yhat)), in place
-//     conv_cols_kernel<FLIP>  dx = conv3x3(dy) with the transposed, flipped kernel (skipped for layer 0)
+//     conv_cols_kernel        dx = conv3x3(dy) with the transposed, flipped kernel (skipped for layer 0)
 //     conv_wgrad_kernel       dW[co][ci][tap] (and d bias) = sum over all columns of dy x patch(x): a GEMM with
 //                             the columns as the contraction index, on the fp32 MFMA 16x16x4, split over
 //                             column ranges; conv_wgrad_reduce_kernel sums the splits in order.
@@ -47,31 +47,33 @@ __host__ __device__ inline TrainLayerDims train_layer(int l) {
 }
 constexpr int kWgSplitMax = 640;     // column-range splits of conv_wgrad_kernel
 
-// ---- weights: [co][ci][9] -> [ci][co][9] (forward conv reads a channel tile x 9 taps contiguously) ------
-// all five layers in one launch: blockIdx.y = layer
+// ---- weights in the order conv_cols_kernel consumes them: [input channel][tap][output channel], so that a
+// wave's channel tile of one (input channel, tap) is a run of consecutive floats -- scalar loads deliver
+// aligned SGPR pairs for v_pk_fma_f32 with no re-shuffling.  Two copies per layer, one launch for all:
+//   b (forward):        wf[ci][tap][co]     = W[co][ci][tap]
+//   c (input gradient): wb[co][tap][ci]     = W[co][ci][8 - tap]   (transposed + flipped kernel)
 struct TrainPtrs5 { const float* a[kTrainLayers]; float* b[kTrainLayers]; float* c[kTrainLayers]; };
 __global__ void pack_train_weights_kernel(const TrainPtrs5 p) {
     const int l = blockIdx.y;
     const TrainLayerDims d = train_layer(l);
     const float* w = p.a[l];
-    float* wt = p.b[l];
     const int total = d.Cin * d.Cout * 9;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int tap = i % 9, co = (i / 9) % d.Cout, ci = i / (9 * d.Cout);
-        wt[i] = w[(co * d.Cin + ci) * 9 + tap];
+        const int tap = i % 9, ci = (i / 9) % d.Cin, co = i / (9 * d.Cin);
+        const float v = w[i];                                        // W[co][ci][tap]
+        p.b[l][((long)ci * 9 + tap) * d.Cout + co] = v;
+        p.c[l][((long)co * 9 + (8 - tap)) * d.Cin + ci] = v;
     }
 }
 
 // ---- convolution over columns ---------------------------------------------------------------------------
-// out[n,b,co,p] = bias[co] + sum_ci sum_tap K(ci,co,tap) * in[n,b,ci,p + off(tap)]   (zero padding)
-//   FLIP = false: K(ci,co,tap) = wk[(ci*Cout + co)*9 + tap]          (wk = packed [ci][co][9] copy; forward)
-//   FLIP = true : K(ci,co,tap) = wk[(ci*Cout + co)*9 + 8 - tap]      (wk = the ORIGINAL [co'][ci'][9] tensor
-//                 of the layer, whose co' is this call's ci and ci' its co: input gradient)
+// out[n,b,co,p] = bias[co] + sum_ci sum_tap wk[(ci*9 + tap)*Cout + co] * in[n,b,ci,p + off(tap)]   (zero padding)
+//   forward: wk = the layer's wf copy; input gradient: wk = its wb copy with the roles of Cin / Cout swapped
 // grid = (N * chunks, Cout / 16), block = 64: wave (n, chunk) x channel tile; lane = column chunk*64 + lane
 // of agent n (columns = B*P).  x image (n, b) starts at x + n*x_sn + b*x_sb (the observations arrive
 // sample-major [B][N]...; every other tensor is agent-major).  part != nullptr: per-wave (sum, sum sq) of
 // the outputs per channel -> part[((n*chunks + chunk)*Cout + co)*2 + {0,1}].
-template <bool FLIP, int CT>
+template <int CT>
 __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ wk,
                                                        const float* __restrict__ bias,
@@ -115,12 +117,11 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
-            const float* wrow = wk + ((long)ci * Cout + co0) * 9;      // wave-uniform: scalar loads
+            const float* wrow = wk + (long)ci * 9 * Cout + co0;        // wave-uniform: scalar loads
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    acc[c] = fmaf(wrow[c * 9 + (FLIP ? 8 - t : t)], patch[u][t], acc[c]);
+                for (int c = 0; c < CT; ++c) acc[c] = fmaf(wrow[(long)t * Cout + c], patch[u][t], acc[c]);
         }
     }
     if (active) {
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 //   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz (largest y) | dxa, dxb
 //            (gradients w.r.t. layer inputs, ping-pong) | coef [N*128*4] | wpart
 struct TrainWs {
-    size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers];
+    size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers], wtb[kTrainLayers];
     size_t part, dz, dxa, dxb, coef, wpart, total;
     int chunks[kTrainLayers], nsplit[kTrainLayers], ips[kTrainLayers], jt[kTrainLayers];
 };
@@ -429,6 +430,7 @@ inline TrainWs train_ws_layout(int N, int B) {
         w.xn[l] = o; o += NB * d.Cout * Po;
         w.stat[l] = o; o += (size_t)N * d.Cout * 4;
         w.wt[l] = o; o += (size_t)d.Cin * d.Cout * 9;
+        w.wtb[l] = o; o += (size_t)d.Cin * d.Cout * 9;
         w.chunks[l] = (B * P + 63) / 64;
         max_y = max_y > NB * d.Cout * P ? max_y : NB * d.Cout * P;
         const size_t pp = (size_t)N * w.chunks[l] * d.Cout * 2;
@@ -459,20 +461,19 @@ static inline bool launched_ok() { return hipGetLastError() == hipSuccess; }
 
 // channel tile per wave: 16 where the layer has plenty of columns, 4 for the 2x2 layers (2560 columns at
 // B = 64, N = 10: more, shorter waves instead of 40 long ones)
-template <bool FLIP>
 static void conv_cols_launch(const float* x, const float* wk, const float* bias, float* y, float* part, int N,
                              int B, int Cin, int Cout, int H, int W, long sn, long sb, int chunks,
                              hipStream_t st) {
     // the widest channel tile that still gives about one wave per SIMD (1024 on the chip)
     const long cw = (long)N * chunks;
     if (cw * (Cout / 16) >= 900) {
-        hipLaunchKernelGGL((conv_cols_kernel<FLIP, 16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk,
+        hipLaunchKernelGGL((conv_cols_kernel<16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk,
                            bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
     } else if (cw * (Cout / 8) >= 900) {
-        hipLaunchKernelGGL((conv_cols_kernel<FLIP, 8>), dim3(N * chunks, Cout / 8), dim3(64), 0, st, x, wk,
+        hipLaunchKernelGGL((conv_cols_kernel<8>), dim3(N * chunks, Cout / 8), dim3(64), 0, st, x, wk,
                            bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
     } else {
-        hipLaunchKernelGGL((conv_cols_kernel<FLIP, 4>), dim3(N * chunks, Cout / 4), dim3(64), 0, st, x, wk,
+        hipLaunchKernelGGL((conv_cols_kernel<4>), dim3(N * chunks, Cout / 4), dim3(64), 0, st, x, wk,
                            bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
     }
 }
@@ -484,7 +485,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
     const long NB = (long)N * B;
     TrainPtrs5 pk = {}, run = {};
     for (int l = 0; l < kTrainLayers; ++l) {
-        pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l];
+        pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l]; pk.c[l] = ws + L.wtb[l];
         run.a[l] = ws + L.stat[l]; run.b[l] = rmean ? rmean[l] : nullptr; run.c[l] = rvar ? rvar[l] : nullptr;
     }
     hipLaunchKernelGGL(pack_train_weights_kernel, dim3(32, kTrainLayers), dim3(256), 0, st, pk);
@@ -494,7 +495,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        conv_cols_launch<false>(xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, d.Cin, d.Cout,
+        conv_cols_launch(xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, d.Cin, d.Cout,
                                 d.H, d.W, sn, sb, L.chunks[l], st);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
                            L.chunks[l], d.Cout, B * P, rp.bn_eps);
@@ -542,7 +543,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
             // output channels of this call = d.Cin (a multiple of 16 for l >= 1)
-            conv_cols_launch<true>(dz, rp.conv_w[l], nullptr, dx, nullptr, N, B, d.Cout, d.Cin, d.H, d.W,
+            conv_cols_launch(dz, ws + L.wtb[l], nullptr, dx, nullptr, N, B, d.Cout, d.Cin, d.H, d.W,
                                    (long)B * d.Cout * P, (long)d.Cout * P, L.chunks[l], st);
             dxn = dx;
         }
