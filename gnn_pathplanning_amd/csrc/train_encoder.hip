@@ -102,6 +102,15 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
     const float* xi = x + n * x_sn + b * x_sb;
+    // The weights of a wave are wave-uniform, and hipcc would fetch them with SCALAR loads -- which return
+    // out of order, so every use waits for ALL of them (s_waitcnt lgkmcnt(0)) and nothing can be prefetched
+    // past the SGPR budget.  An opaque zero in the address turns them into VECTOR loads of one address
+    // (one 16-byte request per instruction after coalescing): in-order returns, vmcnt-counted, so the
+    // weights of the next taps are in flight while the FMAs of this one run.
+    int vzero_off = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero_off));
+#endif
     // input channels U at a time: all 9 U patch loads of a group are issued before its FMAs, so one
     // memory round trip feeds U * 9 * CT FMAs (Cin is 3 or a multiple of 8)
     constexpr int U = CT >= 16 ? 4 : 8;          // narrower channel tiles leave registers for deeper prefetch
@@ -117,11 +126,16 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
-            const float* wrow = wk + (long)ci * 9 * Cout + co0;        // wave-uniform: scalar loads
+            const float* wrow = wk + (long)ci * 9 * Cout + co0 + vzero_off;   // same address in every lane
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t) {
+                v4f wv[CT / 4];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[c] = fmaf(wrow[(long)t * Cout + c], patch[u][t], acc[c]);
+                for (int c4 = 0; c4 < CT / 4; ++c4)
+                    wv[c4] = *reinterpret_cast<const v4f*>(wrow + (long)t * Cout + 4 * c4);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = fmaf(wv[c >> 2][c & 3], patch[u][t], acc[c]);
+            }
         }
     }
     if (active) {
