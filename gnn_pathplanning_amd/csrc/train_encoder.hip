@@ -102,15 +102,6 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
     const float* xi = x + n * x_sn + b * x_sb;
-    // The weights of a wave are wave-uniform, and hipcc would fetch them with SCALAR loads -- which return
-    // out of order, so every use waits for ALL of them (s_waitcnt lgkmcnt(0)) and nothing can be prefetched
-    // past the SGPR budget.  An opaque zero in the address turns them into VECTOR loads of one address
-    // (one 16-byte request per instruction after coalescing): in-order returns, vmcnt-counted, so the
-    // weights of the next taps are in flight while the FMAs of this one run.
-    int vzero_off = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero_off));
-#endif
     // input channels U at a time: all 9 U patch loads of a group are issued before its FMAs, so one
     // memory round trip feeds U * 9 * CT FMAs (Cin is 3 or a multiple of 8)
     constexpr int U = CT >= 16 ? 4 : 8;          // narrower channel tiles leave registers for deeper prefetch
@@ -126,16 +117,11 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
-            const float* wrow = wk + (long)ci * 9 * Cout + co0 + vzero_off;   // same address in every lane
+            const float* wrow = wk + (long)ci * 9 * Cout + co0;        // wave-uniform: scalar loads
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                v4f wv[CT / 4];
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int c4 = 0; c4 < CT / 4; ++c4)
-                    wv[c4] = *reinterpret_cast<const v4f*>(wrow + (long)t * Cout + 4 * c4);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) acc[c] = fmaf(wv[c >> 2][c & 3], patch[u][t], acc[c]);
-            }
+                for (int c = 0; c < CT; ++c) acc[c] = fmaf(wrow[(long)t * Cout + c], patch[u][t], acc[c]);
         }
     }
     if (active) {
@@ -154,6 +140,90 @@ __global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__
                 o[1] = s2;
             }
         }
+    }
+}
+
+// ---- convolution with one lane per OUTPUT CHANNEL (layers 1..4, forward and input gradient) ----------------
+// The roles that suit the hardware when the images are tiny (5x5, 2x2): a lane owns an output channel, so
+//   * the WEIGHTS differ per lane and arrive by coalesced vector loads (256 bytes per (input channel, tap),
+//     in-order returns: the next input channel's nine are in flight during this one's FMAs),
+//   * the ACTIVATIONS of the wave's IMG images are the same for every lane: scalar loads into SGPRs, used as
+//     the scalar operand of v_fma -- fetched one input channel AHEAD (two register sets), so the
+//     "wait for all scalar loads" that out-of-order SMEM returns force never waits for a load just issued,
+//   * zero padding is resolved at compile time (H, W are template parameters: taps that fall outside the
+//     image are not issued),
+//   * the BatchNorm partial sums are lane-local (a lane = a channel): no cross-lane reduction at all.
+// grid = (N * chunks, ceil(Cout / 64)), block = 64; wave = images [chunk*IMG, +IMG) of agent n.
+// wk = [ci][tap][Cout] (forward: wf; input gradient: wb with the layer's Cin / Cout swapped).
+template <int H, int W, int IMG>
+__global__ __launch_bounds__(64) void conv_ch_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     float* __restrict__ part, int B, int Cin, int Cout,
+                                                     long x_sn, long x_sb, int chunks) {
+    constexpr int P = H * W;
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int b0 = chunk * IMG;
+    const int co = blockIdx.y * 64 + lane;
+    const bool cv = co < Cout;
+    const int coc = cv ? co : Cout - 1;
+    const float bv = bias ? bias[coc] : 0.f;
+    float acc[IMG][P];
+#pragma unroll
+    for (int i = 0; i < IMG; ++i)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[i][p] = bv;
+    const float* xb[IMG];                                   // wave-uniform image bases (clamped: the extra
+#pragma unroll                                              // images of a ragged tail are computed, not stored)
+    for (int i = 0; i < IMG; ++i) xb[i] = x + n * x_sn + (long)(b0 + i < B ? b0 + i : B - 1) * x_sb;
+    const float* wl = wk + coc;
+
+    auto load_x = [&](float (&xs)[IMG][P], int ci) {
+#pragma unroll
+        for (int i = 0; i < IMG; ++i)
+#pragma unroll
+            for (int p = 0; p < P; ++p) xs[i][p] = xb[i][(long)ci * P + p];
+    };
+    auto fma_all = [&](const float (&xs)[IMG][P], int ci) {
+        float w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = wl[((long)ci * 9 + t) * Cout];
+#pragma unroll
+        for (int i = 0; i < IMG; ++i)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = p / W + t / 3 - 1, xx = p % W + t % 3 - 1;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                        acc[i][p] = fmaf(w[t], xs[i][yy * W + xx], acc[i][p]);
+                }
+    };
+    float xa[IMG][P], xc[IMG][P];
+    load_x(xa, 0);
+    for (int ci = 0; ci < Cin; ci += 2) {                   // Cin is even for every layer this kernel serves
+        load_x(xc, ci + 1);
+        fma_all(xa, ci);
+        if (ci + 2 < Cin) load_x(xa, ci + 2);
+        fma_all(xc, ci + 1);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IMG; ++i) {
+        if (b0 + i < B) {                                   // (wave-uniform)
+            float* yo = y + (((long)n * B + b0 + i) * Cout + coc) * P;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (cv) yo[p] = acc[i][p];
+                s1 += acc[i][p];
+                s2 += acc[i][p] * acc[i][p];
+            }
+        }
+    }
+    if (part && cv) {
+        float* o = part + (((long)n * chunks + chunk) * Cout + co) * 2;
+        o[0] = s1;
+        o[1] = s2;
     }
 }
 
@@ -447,7 +517,8 @@ inline TrainWs train_ws_layout(int N, int B) {
         w.wtb[l] = o; o += (size_t)d.Cin * d.Cout * 9;
         w.chunks[l] = (B * P + 63) / 64;
         max_y = max_y > NB * d.Cout * P ? max_y : NB * d.Cout * P;
-        const size_t pp = (size_t)N * w.chunks[l] * d.Cout * 2;
+        const int cmax = w.chunks[l] > B ? w.chunks[l] : B;          // column chunks (BN backward) vs image chunks (conv)
+        const size_t pp = (size_t)N * cmax * d.Cout * 2;
         max_part = max_part > pp ? max_part : pp;
         max_x = max_x > NB * d.Cin * P ? max_x : NB * d.Cin * P;
         // weight-gradient splits: enough waves to fill the chip, at least one image per split
@@ -473,22 +544,29 @@ inline TrainWs train_ws_layout(int N, int B) {
 
 static inline bool launched_ok() { return hipGetLastError() == hipSuccess; }
 
-// channel tile per wave: 16 where the layer has plenty of columns, 4 for the 2x2 layers (2560 columns at
-// B = 64, N = 10: more, shorter waves instead of 40 long ones)
-static void conv_cols_launch(const float* x, const float* wk, const float* bias, float* y, float* part, int N,
-                             int B, int Cin, int Cout, int H, int W, long sn, long sb, int chunks,
-                             hipStream_t st) {
-    // the widest channel tile that still gives about one wave per SIMD (1024 on the chip)
-    const long cw = (long)N * chunks;
-    if (cw * (Cout / 16) >= 900) {
-        hipLaunchKernelGGL((conv_cols_kernel<16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk,
-                           bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
-    } else if (cw * (Cout / 8) >= 900) {
-        hipLaunchKernelGGL((conv_cols_kernel<8>), dim3(N * chunks, Cout / 8), dim3(64), 0, st, x, wk,
-                           bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
+// Which convolution kernel serves a layer: the 11x11 first layer (3 input channels, 77 440 columns at B = 64,
+// N = 10) keeps one lane per COLUMN with 16 channels in registers; the 5x5 and 2x2 layers (and their input
+// gradients) put one lane per CHANNEL.  Returns the number of per-agent partial-sum chunks it writes.
+static int conv_chunks(int l, int B) {
+    const TrainLayerDims d = train_layer(l);
+    if (l == 0) return (B * d.H * d.W + 63) / 64;
+    return d.H == 5 ? B : (B + 3) / 4;
+}
+
+static void conv_launch(int l, bool input_grad, const float* x, const float* wk, const float* bias, float* y,
+                        float* part, int N, int B, long sn, long sb, hipStream_t st) {
+    const TrainLayerDims d = train_layer(l);
+    const int Cin = input_grad ? d.Cout : d.Cin, Cout = input_grad ? d.Cin : d.Cout;
+    const int chunks = conv_chunks(l, B);
+    if (l == 0) {
+        hipLaunchKernelGGL((conv_cols_kernel<16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk, bias, y,
+                           part, B, Cin, Cout, d.H, d.W, sn, sb, chunks);
+    } else if (d.H == 5) {
+        hipLaunchKernelGGL((conv_ch_kernel<5, 5, 1>), dim3(N * chunks, (Cout + 63) / 64), dim3(64), 0, st, x, wk,
+                           bias, y, part, B, Cin, Cout, sn, sb, chunks);
     } else {
-        hipLaunchKernelGGL((conv_cols_kernel<4>), dim3(N * chunks, Cout / 4), dim3(64), 0, st, x, wk,
-                           bias, y, part, B, Cin, Cout, H, W, sn, sb, chunks);
+        hipLaunchKernelGGL((conv_ch_kernel<2, 2, 4>), dim3(N * chunks, (Cout + 63) / 64), dim3(64), 0, st, x, wk,
+                           bias, y, part, B, Cin, Cout, sn, sb, chunks);
     }
 }
 
@@ -509,10 +587,9 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        conv_cols_launch(xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, d.Cin, d.Cout,
-                                d.H, d.W, sn, sb, L.chunks[l], st);
+        conv_launch(l, false, xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, sn, sb, st);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
-                           L.chunks[l], d.Cout, B * P, rp.bn_eps);
+                           conv_chunks(l, B), d.Cout, B * P, rp.bn_eps);
         const long tot = NB * d.Cout * Po;
         hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
                            dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
@@ -557,8 +634,8 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
             // output channels of this call = d.Cin (a multiple of 16 for l >= 1)
-            conv_cols_launch(dz, ws + L.wtb[l], nullptr, dx, nullptr, N, B, d.Cout, d.Cin, d.H, d.W,
-                                   (long)B * d.Cout * P, (long)d.Cout * P, L.chunks[l], st);
+            conv_launch(l, true, dz, ws + L.wtb[l], nullptr, dx, nullptr, N, B, (long)B * d.Cout * P,
+                        (long)d.Cout * P, st);
             dxn = dx;
         }
     }
