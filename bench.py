@@ -319,7 +319,9 @@ def main():
 
     result = {
         'metric': 'agent-steps/sec (policy fwd)', 'value': value, 'unit': 'agent-steps/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world, 'ranks_in_group': dist.get_world_size() if dist is not None else 1,
+        'dist_backend': dist.get_backend() if dist is not None else None,
+        'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'prewarm_s': args.prewarm_seconds,
         'regions_ms': [round(1e3 * r[0], 4) for r in regions],

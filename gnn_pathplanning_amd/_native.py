@@ -115,7 +115,8 @@ class RolloutStruct(ctypes.Structure):
                 ('done', ctypes.c_void_p), ('flags', ctypes.c_void_p), ('stats', ctypes.c_void_p), ('currentstep', ctypes.c_int),
                 ('tie_mode', ctypes.c_int), ('seed', ctypes.c_uint), ('choices', ctypes.c_void_p),
                 ('choice_count', ctypes.c_void_p), ('max_choices', ctypes.c_int),
-                ('range_flag', ctypes.c_void_p)]
+                ('range_flag', ctypes.c_void_p), ('rng_words', ctypes.c_void_p),
+                ('rng_cursor', ctypes.c_void_p), ('rng_max', ctypes.c_int)]
 
 
 _lib = None

@@ -305,7 +305,8 @@ int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream) {
         r->H <= 0 || r->W <= 0)
         return GNNPP_ERR_ARG;
     if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
-    if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
+    if (r->tie_mode < 0 || r->tie_mode > 3) return GNNPP_ERR_ARG;
+    if (r->tie_mode == GNNPP_TIE_MT19937 && (!r->rng_words || !r->rng_cursor || r->rng_max <= 0)) return GNNPP_ERR_ARG;
     return rollout_move_launch(*r, static_cast<hipStream_t>(stream));
 }
 
@@ -315,7 +316,8 @@ int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream) {
         !r->flags || !r->stats || r->H <= 0 || r->W <= 0)
         return GNNPP_ERR_ARG;
     if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
-    if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
+    if (r->tie_mode < 0 || r->tie_mode > 3) return GNNPP_ERR_ARG;
+    if (r->tie_mode == GNNPP_TIE_MT19937 && (!r->rng_words || !r->rng_cursor || r->rng_max <= 0)) return GNNPP_ERR_ARG;
     return rollout_step_launch(*r, static_cast<hipStream_t>(stream));
 }
 
@@ -327,7 +329,8 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
         r->H <= 0 || r->W <= 0 || !enc_packed || !filt_packed || !act_w || !act_b)
         return GNNPP_ERR_ARG;
     if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
-    if (r->tie_mode < 0 || r->tie_mode > 2) return GNNPP_ERR_ARG;
+    if (r->tie_mode < 0 || r->tie_mode > 3) return GNNPP_ERR_ARG;
+    if (r->tie_mode == GNNPP_TIE_MT19937 && (!r->rng_words || !r->rng_cursor || r->rng_max <= 0)) return GNNPP_ERR_ARG;
     // same conditions as the fused policy kernel of gnnpp_policy_fwd, plus room for the occupancy grid
     if (!(fused_policy_applies(r->B, r->N, K) && (size_t)r->H * r->W <= kPolicySimOccBytes))
         return GNNPP_ERR_UNSUPPORTED;

@@ -310,8 +310,26 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {
 }
 
 // random.choice(collided_agents) of the reference (:489): index into the (ascending) collided list.
+// tie_mode 3 reproduces CPython's random.choice on a Mersenne-Twister stream the host hands over as raw
+// 32-bit outputs: _randbelow(n) = { k = n.bit_length(); do r = getrandbits(k) while r >= n }, and
+// getrandbits(k <= 32) = genrand_uint32() >> (32 - k).  One word per draw, cursor kept per episode.
 __device__ __forceinline__ int choose_mover(const RolloutArgs& p, int b, int ncol, int& calls) {
     int k = 0;
+    if (p.tie_mode == 3) {
+        const int bits = 32 - __builtin_clz((unsigned)ncol);
+        int cur = p.rng_cursor[b];                          // (one wave per episode: uniform, no race)
+        for (;;) {
+            const unsigned w = cur < p.rng_max ? p.rng_words[(size_t)b * p.rng_max + cur] : 0u;
+            ++cur;
+            k = (int)(w >> (32 - bits));
+            if (k < ncol) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if ((threadIdx.x & 63) == 0) p.rng_cursor[b] = cur;
+        __builtin_amdgcn_wave_barrier();
+        ++calls;
+        return k;
+    }
     if (p.tie_mode == 1) {
         k = (int)(hash_u32(p.seed ^ hash_u32((unsigned)b * 0x9E3779B9u +
                                              (unsigned)p.currentstep * 0x85EBCA6Bu + (unsigned)calls)) %

@@ -12,8 +12,10 @@ A step is ONE kernel launch for teams of up to 16 agents (policy forward, move, 
 observations in the same workgroup per episode), otherwise encoder, filter + head and the simulator
 kernels, and never a host synchronisation; `run()` only reads back a "finished"
 flag every few steps.  The reference's random.choice tie-break among colliding agents (:489) is
-replaced by a deterministic rule (`tie_mode`): 'lowest' index, 'hashed' counter-based RNG, or
-'replay' of recorded choices (parity tests).  Positions are (row, col) integers.
+replaced by a deterministic rule (`tie_mode`): 'lowest' index, 'hashed' counter-based RNG, 'replay' of
+recorded choices (parity tests), or 'mt19937' = CPython's random.choice itself on a per-episode
+Mersenne-Twister stream (episode b behaves as the reference does after random.seed(seed[b])).
+Positions are (row, col) integers.
 """
 import ctypes
 
@@ -21,7 +23,7 @@ import torch
 
 from . import _native
 
-_TIE = {'lowest': 0, 'hashed': 1, 'replay': 2}
+_TIE = {'lowest': 0, 'hashed': 1, 'replay': 2, 'mt19937': 3}
 
 
 def _p(t):
@@ -29,7 +31,8 @@ def _p(t):
 
 
 class BatchedRollout:
-    def __init__(self, grid, starts, goals, maxstep, device, commR=6.0, tie_mode='lowest', seed=0):
+    def __init__(self, grid, starts, goals, maxstep, device, commR=6.0, tie_mode='lowest', seed=0,
+                 rng_words=2048):
         """grid [B,H,W] or [H,W] (1 = obstacle); starts, goals [B,N,2]; maxstep int or [B]."""
         dev = torch.device(device)
         if dev.type != 'cuda':
@@ -62,6 +65,19 @@ class BatchedRollout:
         self.stats = torch.zeros(B, 2, dtype=torch.int32, device=dev)
         self.choice_count = torch.zeros(B, dtype=torch.int32, device=dev)
         self.tie_mode = _TIE[tie_mode]
+        self.rng_words = self.rng_cursor = None
+        if self.tie_mode == 3:
+            # raw genrand_uint32() outputs of random.Random(seed_b): the kernel applies random.choice's
+            # own rejection sampling to them (csrc/rollout_kernels.hip::choose_mover)
+            import random
+            seeds = list(seed) if hasattr(seed, '__len__') else [int(seed) + b for b in range(self.B)]
+            assert len(seeds) == self.B
+            import numpy as np
+            rows = np.array([[g.getrandbits(32) for _ in range(int(rng_words))]
+                             for g in (random.Random(int(sd)) for sd in seeds)], dtype=np.uint32)
+            self.rng_words = torch.from_numpy(rows.view(np.int32)).to(dev)
+            self.rng_cursor = torch.zeros(self.B, dtype=torch.int32, device=dev)
+            seed = 0
         self.seed = int(seed) & 0xffffffff
         self.t = 0                                            # steps taken so far
         self._state_step = -1                                 # step whose positions obs / S describe
@@ -74,6 +90,8 @@ class BatchedRollout:
         r.maxstep, r.flags, r.stats = _p(self.maxstep), _p(self.flags), _p(self.stats)
         r.done = _p(self.done)
         r.tie_mode, r.seed, r.choice_count = self.tie_mode, self.seed, _p(self.choice_count)
+        if self.tie_mode == 3:
+            r.rng_words, r.rng_cursor, r.rng_max = _p(self.rng_words), _p(self.rng_cursor), int(rng_words)
         self._r = r
 
     # -- the three simulator calls -------------------------------------------------------------

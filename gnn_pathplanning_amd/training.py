@@ -51,9 +51,11 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, opt, batch_input, batch_target, batch_GSO)
         loss = step(batch_input, batch_target, batch_GSO)          # device tensor, no sync
 
-    Single GPU only in this round (the gradient all-reduce is not captured)."""
+    dp (FlatBucketDP): the one flat-bucket gradient all-reduce is enqueued on the capture stream between
+    backward and the optimizer like every other launch, so RCCL's collective becomes a node of the graph
+    (RCCL, like NCCL, supports stream capture); every rank must build and replay its graph in step."""
 
-    def __init__(self, model, optimizer, batch_input, batch_target, batch_GSO, warmup=3):
+    def __init__(self, model, optimizer, batch_input, batch_target, batch_GSO, warmup=3, dp=None):
         self.inp = batch_input.clone()
         self.tgt = batch_target.clone()
         self.gso = batch_GSO.clone()
@@ -61,11 +63,11 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                                 # warm allocator, packs, MIOpen
-                train_step(model, optimizer, self.inp, self.tgt, self.gso)
+                train_step(model, optimizer, self.inp, self.tgt, self.gso, dp)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = train_step(model, optimizer, self.inp, self.tgt, self.gso)
+            self.loss = train_step(model, optimizer, self.inp, self.tgt, self.gso, dp)
 
     def __call__(self, batch_input, batch_target, batch_GSO):
         self.inp.copy_(batch_input)

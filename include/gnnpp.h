@@ -229,6 +229,8 @@ int gnnpp_decode_actions(const float* logits, int* actions, int B, int N, void* 
 #define GNNPP_TIE_LOWEST  0   /* colliding agent with the lowest index keeps its move          */
 #define GNNPP_TIE_HASHED  1   /* counter-based hash of (seed, episode, step, call)             */
 #define GNNPP_TIE_REPLAY  2   /* replay recorded random.choice outcomes (parity tests)         */
+#define GNNPP_TIE_MT19937 3   /* CPython's random.choice itself on a per-episode Mersenne-Twister stream
+                                 (rng_words): what the reference does at :489 after random.seed(s)  */
 
 typedef struct gnnpp_rollout {
     /* episode state shared by the three calls */
@@ -266,6 +268,10 @@ typedef struct gnnpp_rollout {
     int*         choice_count;  /* out [B] tie-breaks consumed in this call, or NULL            */
     int          max_choices;
     int*         range_flag;    /* gnnpp_rollout_policy_step only: range guard of the policy, or NULL */
+    const unsigned* rng_words;  /* GNNPP_TIE_MT19937: [B,rng_max] successive genrand_uint32() outputs of
+                                   each episode's generator (random.Random(seed).getrandbits(32))   */
+    int*         rng_cursor;    /* [B] in/out: words consumed so far                              */
+    int          rng_max;
 } gnnpp_rollout;
 
 int gnnpp_rollout_observe(const gnnpp_rollout* r, void* stream);

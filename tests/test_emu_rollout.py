@@ -199,3 +199,50 @@ def test_emu_move_dense_conflicts_vs_oracle():
                 assert ccount[b] == calls[0], (N, t, b)
                 collisions += calls[0]
         assert collisions > 20 * B // 6
+
+
+def test_emu_mt19937_tie_break_is_random_choice():
+    """tie_mode = GNNPP_TIE_MT19937: the kernel applies CPython's random.choice (bit_length / getrandbits /
+    rejection) to a Mersenne-Twister word stream -- episode b moves exactly as the oracle does with
+    random.Random(seed_b).choice as the tie-break, i.e. as the reference after random.seed(seed_b)."""
+    import random
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    from oracle import rollout_oracle as ro
+    lib = emu_lib.load()
+    rng = np.random.default_rng(8)
+    B, N, W, NW = 10, 12, 4, 256
+    grids = np.zeros((B, W, W), np.uint8)
+    starts = np.zeros((B, N, 2), np.int32); goals = np.zeros((B, N, 2), np.int32)
+    for b in range(B):
+        free = np.argwhere(grids[b] == 0)
+        starts[b] = free[rng.choice(len(free), N, replace=False)]
+        goals[b] = free[rng.choice(len(free), N, replace=False)]
+    words = np.array([[g.getrandbits(32) for _ in range(NW)] for g in (random.Random(100 + b) for b in range(B))],
+                     dtype=np.uint32)
+    cursor = np.zeros(B, np.int32)
+    pos = np.ascontiguousarray(starts.copy())
+    reached = np.zeros((B, N), np.int32)
+    start = np.full((B, N), -1, np.int32); end = np.full((B, N), -1, np.int32)
+    flags = np.zeros((B, 3), np.int32); stats = np.zeros((B, 2), np.int32)
+    ccount = np.zeros(B, np.int32); limits = np.full(B, 99, np.int32)
+    r = RolloutStruct()
+    r.grid, r.grid_batched, r.goal, r.pos = grids.ctypes.data, 1, goals.ctypes.data, pos.ctypes.data
+    r.B, r.N, r.H, r.W = B, N, W, W
+    r.reached, r.start_step, r.end_step = reached.ctypes.data, start.ctypes.data, end.ctypes.data
+    r.maxstep, r.flags, r.stats = limits.ctypes.data, flags.ctypes.data, stats.ctypes.data
+    r.tie_mode, r.choice_count = 3, ccount.ctypes.data
+    r.rng_words, r.rng_cursor, r.rng_max = words.ctypes.data, cursor.ctypes.data, NW
+    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], 99) for b in range(B)]
+    gens = [random.Random(100 + b) for b in range(B)]
+    draws = 0
+    for t in range(5):
+        acts = np.ascontiguousarray(rng.integers(0, 5, size=(B, N)).astype(np.int32))
+        r.logits, r.actions, r.currentstep = None, acts.ctypes.data, t + 1
+        assert lib.gnnpp_rollout_move(ctypes.byref(r), None) == 0
+        for b in range(B):
+            f = ro.move_step(eps[b], acts[b], t + 1, gens[b].choice)
+            assert [int(v) for v in f] == list(flags[b]), (t, b)
+            assert (pos[b] == eps[b].cur).all(), (t, b)
+        draws += int(ccount.sum())
+    assert draws > 30 and (cursor >= 0).all() and cursor.sum() >= draws      # rejections consume extra words

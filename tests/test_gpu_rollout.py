@@ -258,3 +258,27 @@ def test_observe_kernel_projected_goals_full_grid(dev):
             want[b, n] = (dx + 5, dy + 5) if (abs(dx) <= 4 and abs(dy) <= 4) else ro.projected_goal(dx, dy)
     bi, ni = np.meshgrid(np.arange(B), np.arange(N), indexing='ij')
     assert (ch1[bi, ni, want[..., 0], want[..., 1]] == 1.0).all()
+
+
+def test_mt19937_tie_break_matches_python_random_choice(dev):
+    """tie_mode='mt19937': episode b resolves collisions exactly like the reference's random.choice
+    (utils/multirobotsim_dcenlocal.py:489) after random.seed(seed + b)."""
+    import random
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    rng = np.random.default_rng(31)
+    B, N, W = 48, 12, 5
+    grids, starts, goals = random_episodes(rng, B, N, W, 0.0)
+    env = BatchedRollout(grids, starts, goals, 50, dev, tie_mode='mt19937', seed=500)
+    eps = [ro.EpisodeState(grids[b], goals[b], starts[b], 50) for b in range(B)]
+    gens = [random.Random(500 + b) for b in range(B)]
+    draws = 0
+    for t in range(6):
+        acts = rng.integers(0, 5, size=(B, N))
+        flags = env.move(actions=torch.from_numpy(acts).to(dev)).cpu().numpy()
+        pos = env.pos.cpu().numpy()
+        for b in range(B):
+            f = ro.move_step(eps[b], acts[b], t + 1, gens[b].choice)
+            assert [int(v) for v in f] == flags[b].tolist(), (t, b)
+            assert (pos[b] == eps[b].cur).all(), (t, b)
+        draws += int(env.choice_count.sum().item())
+    assert draws > 100

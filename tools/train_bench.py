@@ -77,7 +77,9 @@ def main():
     thr, units, el = aggregate_throughput(B * N * args.steps, el, device=dev)
     if rank == 0:
         print(json.dumps({'metric': 'training agent-steps/s (fwd+bwd+Adam, config 4)', 'value': thr,
-                          'n_gpus': world, 'batch_per_gpu': B, 'ms_per_step': 1e3 * el / args.steps,
+                          'n_gpus': world, 'ranks_in_group': dist.get_world_size() if world > 1 else 1,
+                          'backend': dist.get_backend() if world > 1 else None,
+                          'batch_per_gpu': B, 'ms_per_step': 1e3 * el / args.steps,
                           'final_loss': float(loss.item()), 'hip_graph': bool(args.graph)}))
     if world > 1:
         dist.destroy_process_group()
