@@ -402,24 +402,31 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 #pragma unroll
     for (int i = 0; i < kRingH; ++i) h2_ring_load<END>(ws, ring, i);
 
-    // ---- observations: all loads first, zero-fill while they fly, then scatter (as v2/v3) -------
+    // ---- observations: all loads first, zero-fill while they fly, then scatter -----------------------
+    // The tile's floats start at an arbitrary 4-byte boundary (a graph of N agents is N * 363 floats), so
+    // the 16-byte loads start at the aligned address below it: vector `idx` holds the tile's elements
+    // 4 idx - shift .. + 3.  Vectors that would reach past the end of the tensor (or before its start)
+    // are assembled from scalar loads instead.
     {
-        constexpr int NV4 = kTileAgents * kObsFloats / 4;
+        constexpr int NV4 = (kTileAgents * kObsFloats + 3) / 4 + 1;
         constexpr int PER = (NV4 + kThreads - 1) / kThreads;
         const int n_agents = FUSED ? pt.N : min(kTileAgents, M - agent0);
         const int valid = n_agents * kObsFloats;
         const float* src = obs + (size_t)agent0 * kObsFloats;
+        const int shift = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3);
+        const float* src4 = src - shift;
+        const long floats_left = (long)(M - agent0) * kObsFloats + shift;   // from src4 to the end of the tensor
+        const bool head_ok = shift == 0 || agent0 > 0;                      // (never read in front of the tensor)
         v4f v[PER];
-        if (!FUSED && n_agents == kTileAgents) {         // (a graph's rows are only 8-byte aligned)
 #pragma unroll
-            for (int k = 0; k < PER; ++k)
-                v[k] = *reinterpret_cast<const v4f*>(src + 4 * min(tid + k * kThreads, NV4 - 1));
-        } else {
+        for (int k = 0; k < PER; ++k) {
+            const int idx = tid + k * kThreads;
+            const int e0 = 4 * idx - shift;
+            if (head_ok && 4L * idx + 4 <= floats_left && e0 < valid) {
+                v[k] = *reinterpret_cast<const v4f*>(src4 + 4 * idx);
+            } else {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int e0 = (tid + k * kThreads) * 4;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[k][c] = src[min(e0 + c, valid - 1)];
+                for (int c = 0; c < 4; ++c) v[k][c] = src[min(max(e0 + c, 0), valid - 1)];
             }
         }
         v4f* z = reinterpret_cast<v4f*>(bufObs);
@@ -427,32 +434,40 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            // (agent, channel, y, x) of the first of four consecutive floats by division, the other
-            // three by carry: the index arithmetic was most of this phase's VALU work
-            const int e0 = (tid + k * kThreads) * 4;
-            int ag = e0 / kObsFloats;
-            const int rem = e0 - ag * kObsFloats;
+            // (agent, channel, y, x) of the first element by division, the following ones by carry: the
+            // index arithmetic was most of this phase's VALU work
+            const int e0 = (tid + k * kThreads) * 4 - shift;
+            const int es = max(e0, 0);
+            int ag = es / kObsFloats;
+            const int rem = es - ag * kObsFloats;
             int ch = rem / 121;
             const int r2 = rem - ch * 121;
             int y = r2 / 11, x = r2 - y * 11;
-            range_note(max4abs(0.f, v[k]), bad);      // (slots past `valid` hold clamped copies of real values)
+            float vmax = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (e0 + c < valid)
-                    bufObs[ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1] =
-                        split_word(v[k][c]);
-                if (++x == 11) {
-                    x = 0;
-                    if (++y == 11) {
-                        y = 0;
-                        if (++ch == 3) { ch = 0; ++ag; }
+                const int e = e0 + c;
+                if (e >= 0) {
+                    if (e < valid) {
+                        vmax = fmaxf(vmax, fabsf(v[k][c]));
+                        bufObs[ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1] =
+                            split_word(v[k][c]);
+                    }
+                    if (++x == 11) {
+                        x = 0;
+                        if (++y == 11) {
+                            y = 0;
+                            if (++ch == 3) { ch = 0; ++ag; }
+                        }
                     }
                 }
             }
+            range_note(vmax, bad);                       // (wave-uniform control flow: a ballot)
         }
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 1)) return;
+    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 0, tid == 0);
 
     // ---- L0: 3 -> 32 @ 11x11 (the 10x10 the pool reads), direct, K = 27 in ONE 32-slot block -------
     // A pixel sits in LDS as the word (lo half << 16 | hi half).  Lane (q, agent) owns k-slots
@@ -533,6 +548,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 2)) return;
+    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 1, tid == 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         if (tid + i * kThreads < EncLayout::kHssFloats) sstab[tid + i * kThreads] = ssv[i];
@@ -571,6 +587,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 3)) return;
+    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 2, tid == 0);
 
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
     {
@@ -603,6 +620,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 4)) return;
+    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 3, tid == 0);
 
     // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
     {
@@ -624,6 +642,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 5)) return;
+    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 4, tid == 0);
 
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
@@ -646,6 +665,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 6)) return;
+    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 5, tid == 0);
 
     // ---- FC 128 -> 128 + ReLU -> feat[agent][128]; tiles 2w, 2w+1 per wave ------------------------
     {
@@ -708,6 +728,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // zero-observation padding lanes; S is zero there, so they never reach a real node.
     float* const z0 = X;
     __syncthreads();                                     // z_0 complete
+    GNNPP_STAMP(blockIdx.x, 12, tid == 0);
 #pragma unroll
     for (int k = 1; k < 3; ++k) {
         const float* zp = z0 + (k - 1) * (16 * kZs);
@@ -725,6 +746,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         }
         __syncthreads();
     }
+    GNNPP_STAMP(blockIdx.x, 13, tid == 0);
     // z_0..z_2 -> (hi, lo) half rows in place: 48 rows, a half-wave per row (as lsigf_kernel's split_rows)
     {
         typedef _Float16 v4h __attribute__((ext_vector_type(4)));
@@ -772,6 +794,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
+    GNNPP_STAMP(blockIdx.x, 14, tid == 0);
     if (range_flag && bad) *range_flag = 1;               // (every split of this kernel is behind us)
     // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA.
     // Wave 0 fetches its A fragments of actionsMLP.0.weight [5,128] now (the weight ring is empty, so a

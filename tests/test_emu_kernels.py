@@ -245,6 +245,7 @@ def test_emu_range_guard(emu):
     """Activations beyond the f16 range of the split-f16 schedules raise the caller's flag (and only
     then); the exact-fp32 contraction has no such limit and leaves the flag alone."""
     el, lib = emu
+    assert lib.gnnpp_set_tuning(0, -1) == 0 and lib.gnnpp_set_tuning(5, 1) == 0     # the default (split-f16) schedules
     g = np.random.default_rng(5)
     B, N, G, F_out, K = 2, 6, 128, 128, 2
     h = (g.standard_normal((F_out, 1, K, G)) / 16).astype(np.float32)

@@ -77,3 +77,29 @@ for (N, B, W) in ((10, 512, 20), (16, 512, 20)):
     report('policy_step (one launch) N=%d B=%d' % (N, B), stamps(min(B, 1024)),
            ['kernel:start', 'policy:head_done', 'move:entry', 'move:state_loaded', 'move:proposed', 'move:pass1',
             'move:passes', 'move:final_pass', 'move:stored', 'sim:move_done', 'sim:gso_done', 'sim:observe_done'])
+
+
+# ---- where the 40 us of the one-launch POLICY kernel go (C2: 512 graphs of 10 agents, two workgroups per CU)
+class Cfg2:
+    num_agents, nGraphFilterTaps, device = 10, 3, dev
+net = DecentralPlannerNet(Cfg2()).to(dev).eval()
+net.load_state_dict(orc.init_state_dict(3))
+B, N = 512, 10
+obs = orc.synth_obs(B, N, seed=1337).to(dev)
+S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337)).float().to(dev)
+net.addGSO(S)
+for _ in range(20):
+    net(obs)
+enc, taps, gb, aw, ab, K = net.policy_pointers()
+ws = torch.empty(B * N, 128, device=dev)
+lg = torch.empty(N, B, 5, device=dev)
+M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+for _ in range(5):
+    assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
+                              B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
+    torch.cuda.synchronize()
+SLOTS.update({'enc:staged': 0, 'enc:L0': 1, 'enc:L1': 2, 'enc:L2': 3, 'enc:L3': 4, 'enc:L4': 5, 'enc:FC(z0)': 12,
+              'filter:shifts': 13, 'filter:contraction': 14})
+report('policy kernel C2 (B=512, N=10)', stamps(512),
+       ['kernel:start', 'enc:staged', 'enc:L0', 'enc:L1', 'enc:L2', 'enc:L3', 'enc:L4', 'enc:FC(z0)', 'filter:shifts',
+        'filter:contraction'])
