@@ -56,6 +56,16 @@ if has prof; then stamp "rocprofv3 kernel trace"
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -12 "$f" | tee $OUT/kernel_stats_head.csv
   find $OUT/prof -name "*kernel_trace.csv" -size +6M -delete; fi
+if has prof35; then for c in c3 c5; do stamp "rocprofv3 kernel trace $c"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$c -o trace -- python $R/bench.py --config $c --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --pipeline-streams 0 --pmc off > $OUT/prof_run_$c.log 2>&1
+  f=$(find $OUT/prof_$c -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && head -8 "$f" | tee $OUT/kernel_stats_head_$c.csv
+  find $OUT/prof_$c -name "*kernel_trace.csv" -size +6M -delete; done; fi
+if has proftrain; then stamp "rocprofv3 kernel trace of the training step"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o trace -- python $R/tools/train_bench.py --steps 30 > $OUT/prof_run_train.log 2>&1
+  f=$(find $OUT/prof_train -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && head -24 "$f" | cut -c1-200 | tee $OUT/kernel_stats_head_train.csv
+  find $OUT/prof_train -name "*kernel_trace.csv" -size +6M -delete; fi
 if has pmc; then stamp "rocprofv3 pmc passes"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
