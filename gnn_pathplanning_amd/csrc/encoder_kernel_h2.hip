@@ -27,7 +27,7 @@
 //     (L1: 7/6/6/6 positions, L2: two pool windows each, 61/60 valid taps -- balanced).
 //   * L3/L4/FC (2x2 and 1x1 images): a wave reads its whole input (64 VGPRs) once and streams
 //     weights only; these layers are bound by the weight stream out of L2 (0.5 MB per tile).
-//   * weights are packed in each wave's consumption order and stream through a 16-deep ring of
+//   * weights are packed in each wave's consumption order and stream through a 12-deep ring of
 //     16-byte loads kept in registers the compiler does not see (h2_ring_load / h2_ring_take below).
 //   * L0 (K = 27) is one 32-slot block on observations staged as (hi, lo) half pairs.
 //
@@ -40,7 +40,7 @@
 
 namespace gnnpp {
 
-constexpr int kRingH = 16;
+constexpr int kRingH = 12;
 constexpr int kZs = 136;               // fused policy tail: row stride of the z / y rows in LDS (floats)
 // per-wave item stream: L1 (36) | L2 (36) | L3 (36) | L4 (72) | FC (16); one item = one 16-byte
 // hi or lo fragment of one (kb, tap, mt)
@@ -71,20 +71,18 @@ __device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx)
 // The loads must stay where the source puts them (a ring that runs ahead of its consumers); hipcc
 // sinks plain loads to their uses, a volatile load is encoded sc0 sc1 (slower), and a register the
 // compiler allocates may be copied or spilled while its load is still in flight.  So the ring
-// lives in sixteen register quads the compiler never sees: the kernel is compiled with a VGPR
-// budget that ends at v191 and v[192:255] belong to the inline asm below (they still count towards
+// lives in twelve register quads the compiler never sees: the kernel is compiled with a VGPR
+// budget that ends at v207 and v[208:255] belong to the inline asm below (they still count towards
 // the kernel's 256-register allocation).  Loads return in order: when item idx is consumed,
 // min(kRingH - 1, kh_END - 1 - idx) ring loads are younger than it, which is the vmcnt to wait for
 // (loads the compiler issues itself only make that wait conservative).  The fragment is then
 // copied out with two v_mov_b64.  tools/check_ring_isa.py verifies on the generated ISA that
-// nothing else touches v[192:255] and that loads and takes follow the ring discipline.
+// nothing else touches v[208:255] and that loads and takes follow the ring discipline.
 #define GNNPP_RING_SLOTS(X)                                                                    \
-    X(0, 192, 193, 194, 195) X(1, 196, 197, 198, 199) X(2, 200, 201, 202, 203)                \
-    X(3, 204, 205, 206, 207) X(4, 208, 209, 210, 211) X(5, 212, 213, 214, 215)                \
-    X(6, 216, 217, 218, 219) X(7, 220, 221, 222, 223) X(8, 224, 225, 226, 227)                \
-    X(9, 228, 229, 230, 231) X(10, 232, 233, 234, 235) X(11, 236, 237, 238, 239)              \
-    X(12, 240, 241, 242, 243) X(13, 244, 245, 246, 247) X(14, 248, 249, 250, 251)             \
-    X(15, 252, 253, 254, 255)
+    X(0, 208, 209, 210, 211) X(1, 212, 213, 214, 215) X(2, 216, 217, 218, 219)                 \
+    X(3, 220, 221, 222, 223) X(4, 224, 225, 226, 227) X(5, 228, 229, 230, 231)                 \
+    X(6, 232, 233, 234, 235) X(7, 236, 237, 238, 239) X(8, 240, 241, 242, 243)                 \
+    X(9, 244, 245, 246, 247) X(10, 248, 249, 250, 251) X(11, 252, 253, 254, 255)
 
 template <int END>
 __device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRingH], int idx) {
@@ -316,9 +314,9 @@ __device__ __forceinline__ void conv_h2(const WStreamH& ws, v4f (&ring)[kRingH],
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// v[192:255] = the weight ring.  On gfx90a+ the backend doubles "amdgpu-num-vgpr" (the unified
-// VGPR+AGPR file), so 96 is what caps the compiler at v191; check_ring_isa.py verifies it.
-#define GNNPP_H2_VGPR_BUDGET __attribute__((amdgpu_num_vgpr(96)))
+// v[208:255] = the weight ring.  On gfx90a+ the backend doubles "amdgpu-num-vgpr" (the unified
+// VGPR+AGPR file), so 104 is what caps the compiler at v207; check_ring_isa.py verifies it.
+#define GNNPP_H2_VGPR_BUDGET __attribute__((amdgpu_num_vgpr(104)))
 #else
 #define GNNPP_H2_VGPR_BUDGET
 #endif
@@ -395,9 +393,9 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     v4f ring[kRingH];
 #if defined(__HIP_DEVICE_COMPILE__)
     // The ONE statement that names a ring register to the compiler: it makes the kernel allocate all
-    // 256 VGPRs (v[192:255] are beyond the compiler's own budget, so hipcc warns that this clobber
+    // 256 VGPRs (v[208:255] are beyond the compiler's own budget, so hipcc warns that this clobber
     // "may not be preserved" -- which is the point: nothing but the ring asm may use them).
-    asm volatile("; weight ring lives in v[192:255]" ::: "v255");
+    asm volatile("; weight ring lives in v[208:255]" ::: "v255");
 #endif
 #pragma unroll
     for (int i = 0; i < kRingH; ++i) h2_ring_load<END>(ws, ring, i);

@@ -1,5 +1,5 @@
 """Static safety check of the split-f16 encoder's inline-asm weight ring (CPU only: hipcc
-cross-compiles gfx950 without a GPU).  The ring lives in v[192:255], registers the compiler must
+cross-compiles gfx950 without a GPU).  The ring lives in v[208:255], registers the compiler must
 never touch; tools/check_ring_isa.py walks the kernel's control-flow graph in the generated ISA and
 verifies that, plus the load -> wait -> take discipline and the register/occupancy budget."""
 import os
@@ -34,14 +34,14 @@ def test_checker_catches_violations(tmp_path):
     with too weak a wait, and a reload of a pending slot must all be reported."""
     import check_ring_isa
     good = '''_ZN5gnnpp17encoder_kernel_h2ILb0EEEvPKfS2_Pfii:
-\tglobal_load_dwordx4 v[192:195], v1, s[0:1] ; RINGLOAD 0
-\tglobal_load_dwordx4 v[196:199], v1, s[0:1] ; RINGLOAD 1
+\tglobal_load_dwordx4 v[208:211], v1, s[0:1] ; RINGLOAD 0
+\tglobal_load_dwordx4 v[212:215], v1, s[0:1] ; RINGLOAD 1
 \ts_waitcnt vmcnt(1) ; RINGWAIT
-\tv_mov_b64 v[2:3], v[192:193] ; RINGTAKE 0
-\tv_mov_b64 v[4:5], v[194:195] ; RINGTAKE 0
+\tv_mov_b64 v[2:3], v[208:209] ; RINGTAKE 0
+\tv_mov_b64 v[4:5], v[210:211] ; RINGTAKE 0
 \ts_waitcnt vmcnt(0) ; RINGWAIT
-\tv_mov_b64 v[2:3], v[196:197] ; RINGTAKE 1
-\tv_mov_b64 v[4:5], v[198:199] ; RINGTAKE 1
+\tv_mov_b64 v[2:3], v[212:213] ; RINGTAKE 1
+\tv_mov_b64 v[4:5], v[214:215] ; RINGTAKE 1
 \ts_endpgm
 .Lfunc_end0:
 ; NumVgprs: 256
@@ -51,10 +51,10 @@ def test_checker_catches_violations(tmp_path):
     f = tmp_path / 'a.s'
     f.write_text(good)
     assert check_ring_isa.check(str(f))[0] == []
-    for bad in (good.replace('\ts_waitcnt vmcnt(1) ; RINGWAIT', '\tv_add_f32 v200, v193, v193\n\ts_waitcnt vmcnt(1) ; RINGWAIT'),
+    for bad in (good.replace('\ts_waitcnt vmcnt(1) ; RINGWAIT', '\tv_add_f32 v220, v209, v209\n\ts_waitcnt vmcnt(1) ; RINGWAIT'),
                 good.replace('vmcnt(1) ; RINGWAIT', 'vmcnt(2) ; RINGWAIT'),
                 good.replace('\ts_waitcnt vmcnt(1) ; RINGWAIT',
-                             '\tglobal_load_dwordx4 v[192:195], v1, s[0:1] ; RINGLOAD 0\n\ts_waitcnt vmcnt(1) ; RINGWAIT'),
+                             '\tglobal_load_dwordx4 v[208:211], v1, s[0:1] ; RINGLOAD 0\n\ts_waitcnt vmcnt(1) ; RINGWAIT'),
                 good.replace('; ScratchSize: 0', '; ScratchSize: 16')):
         f.write_text(bad)
         assert check_ring_isa.check(str(f))[0], bad

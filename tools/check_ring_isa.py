@@ -1,10 +1,10 @@
 """Static check of the split-f16 encoder's weight ring in the generated gfx950 ISA.
 
-encoder_kernel_h2.hip keeps its weight ring in v[192:255], registers the compiler is told not to
-allocate (amdgpu_num_vgpr(192)); inline asm loads them (`global_load_dwordx4 ... ; RINGLOAD s`),
+encoder_kernel_h2.hip keeps its weight ring in v[208:255], registers the compiler is told not to
+allocate (amdgpu_num_vgpr(104), doubled by the backend); inline asm loads them (`global_load_dwordx4 ... ; RINGLOAD s`),
 waits (`s_waitcnt vmcnt(n) ; RINGWAIT`) and copies a fragment out (`v_mov_b64 ... ; RINGTAKE s`).
 This script verifies on the ISA hipcc produced that
-  1. no other instruction of the kernel mentions v192..v255,
+  1. no other instruction of the kernel mentions v208..v255,
   2. along every control-flow path, a RINGTAKE of slot s follows a load of that slot and a RINGWAIT
      whose vmcnt is <= the number of ring loads issued after that load (loads return in order), and
      a slot is never reloaded before it was taken,
@@ -19,7 +19,7 @@ import re
 import sys
 
 REG = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
-RING_LO, NSLOT = 192, 16
+RING_LO, NSLOT = 208, 12
 
 
 def regs_of(text):
