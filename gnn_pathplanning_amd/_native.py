@@ -22,7 +22,8 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_encoder_train_workspace_floats', 'gnnpp_encoder_train_fwd',
-           'gnnpp_encoder_train_bwd', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
+           'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_policy_loss',
+           'gnnpp_adam_step', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step')
 
 
@@ -103,6 +104,12 @@ class EncoderGrads(ctypes.Structure):
                 ('bn_w', ctypes.c_void_p * 5), ('bn_b', ctypes.c_void_p * 5)]
 
 
+class AdamTensors(ctypes.Structure):
+    """struct gnnpp_adam_tensors (include/gnnpp.h)."""
+    _fields_ = [('p', ctypes.c_void_p * 32), ('g', ctypes.c_void_p * 32), ('m', ctypes.c_void_p * 32),
+                ('v', ctypes.c_void_p * 32), ('numel', ctypes.c_longlong * 32), ('count', ctypes.c_int)]
+
+
 class RolloutStruct(ctypes.Structure):
     """struct gnnpp_rollout (include/gnnpp.h)."""
     _fields_ = [('grid', ctypes.c_void_p), ('grid_batched', ctypes.c_int), ('goal', ctypes.c_void_p),
@@ -150,6 +157,15 @@ def _bind(path):
     L.gnnpp_encoder_train_bwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ctypes.POINTER(EncoderGrads),
                                           ci, ci, vp]
     L.gnnpp_encoder_train_bwd.restype = ci
+    ll, cf = ctypes.c_longlong, ctypes.c_float
+    L.gnnpp_gemm_workspace_floats.restype = cs
+    L.gnnpp_gemm_workspace_floats.argtypes = [ci] * 4
+    L.gnnpp_gemm_kmajor.argtypes = [vp, ll, ll, ll, vp, ll, ll, vp, ll, ll, ci, ci, ci, ci, vp, vp]
+    L.gnnpp_gemm_kmajor.restype = ci
+    L.gnnpp_policy_loss.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
+    L.gnnpp_policy_loss.restype = ci
+    L.gnnpp_adam_step.argtypes = [ctypes.POINTER(AdamTensors), vp, cf, cf, cf, cf, cf, ci, vp]
+    L.gnnpp_adam_step.restype = ci
     L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 5 + [vp, vp]
     L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 7 + [vp, vp]
     L.gnnpp_filter_head_fwd.restype = ci
@@ -192,6 +208,22 @@ def measure_lib():
 def check(rc, what):
     if rc != 0:
         raise GnnppError('%s failed: %s (code %d)' % (what, lib().gnnpp_error_string(rc).decode(), rc))
+
+
+def gemm_kmajor(A, a_strides, Bm, b_strides, C, c_strides, batch, M, N, K):
+    """C_b(m,n) = sum_k A_b(m,k) B_b(k,n) on gnnpp_gemm_kmajor (split-K fp32 MFMA, deterministic).
+    a_strides = (batch, m, k), b_strides = (batch, k) [n contiguous], c_strides = (batch, m) [n contiguous],
+    in floats; A, Bm, C are fp32 device tensors that own the addressed storage."""
+    import torch
+    dev = require_gpu(A, Bm, C)
+    L = lib()
+    nws = L.gnnpp_gemm_workspace_floats(batch, M, N, K)
+    ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dev)
+    with device_guard(dev):
+        check(L.gnnpp_gemm_kmajor(A.data_ptr(), a_strides[0], a_strides[1], a_strides[2], Bm.data_ptr(),
+                                  b_strides[0], b_strides[1], C.data_ptr(), c_strides[0], c_strides[1],
+                                  batch, M, N, K, ws.data_ptr(), stream_ptr(dev)), 'gnnpp_gemm_kmajor')
+    return C
 
 
 def require_gpu(*tensors):

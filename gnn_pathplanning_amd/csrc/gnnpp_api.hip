@@ -12,6 +12,7 @@
 #include "encoder_kernel_h2.hip"
 #include "lsigf_kernel.hip"
 #include "train_encoder.hip"
+#include "train_ops.hip"
 
 using namespace gnnpp;
 
@@ -213,11 +214,54 @@ int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, flo
                              static_cast<hipStream_t>(stream));
 }
 
+size_t gnnpp_gemm_workspace_floats(int batch, int M, int N, int K) {
+    if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
+    return gemm_workspace_floats(batch, M, N, K);
+}
+
+int gnnpp_gemm_kmajor(const float* A, long long a_sb, long long a_sm, long long a_sk, const float* B,
+                      long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int batch,
+                      int M, int N, int K, float* workspace, void* stream) {
+    if (!A || !B || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0) return GNNPP_ERR_ARG;
+    if (gemm_workspace_floats(batch, M, N, K) > 0 && !workspace) return GNNPP_ERR_ARG;
+    if ((long long)batch * gemm_plan(batch, M, N, K).ksplit > 65535) return GNNPP_ERR_UNSUPPORTED;
+    return gemm_kmajor_launch(A, a_sb, a_sm, a_sk, B, b_sb, b_sk, C, c_sb, c_sm, batch, M, N, K, workspace,
+                              static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_policy_loss(const float* logits, const float* target, float* loss, float* dlogits, int B, int N,
+                      int C, void* stream) {
+    if (!logits || !target || !loss || B <= 0 || N <= 0 || C <= 0 || C > 64) return GNNPP_ERR_ARG;
+    hipLaunchKernelGGL(policy_loss_kernel, dim3(1), dim3(1024), 1024 * sizeof(double),
+                       static_cast<hipStream_t>(stream), logits, target, loss, dlogits, B, N, C);
+    return hipGetLastError() == hipSuccess ? GNNPP_OK : GNNPP_ERR_LAUNCH;
+}
+
+int gnnpp_adam_step(const gnnpp_adam_tensors* t, float* state, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int tick, void* stream) {
+    if (!t || !state || t->count <= 0 || t->count > kAdamTensors) return GNNPP_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AdamTable tb = {};
+    int blocks = 0;
+    for (int i = 0; i < t->count; ++i) {
+        if (!t->p[i] || !t->g[i] || !t->m[i] || !t->v[i] || t->numel[i] <= 0) return GNNPP_ERR_ARG;
+        tb.p[i] = t->p[i]; tb.g[i] = t->g[i]; tb.m[i] = t->m[i]; tb.v[i] = t->v[i];
+        tb.numel[i] = (long)t->numel[i];
+        tb.first[i] = blocks;
+        blocks += (int)((t->numel[i] + 1023) / 1024);
+    }
+    tb.first[t->count] = blocks;
+    tb.count = t->count;
+    if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, lr, beta1, beta2);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tb, state, beta1, beta2, eps, weight_decay);
+    return hipGetLastError() == hipSuccess ? GNNPP_OK : GNNPP_ERR_LAUNCH;
+}
+
 #ifdef GNNPP_MEASURE
-// libgnnpp_measure.so only: copy the kernels' phase time stamps ([1024 workgroups][16 slots], 100 MHz
+// libgnnpp_measure.so only: copy the kernels' phase time stamps ([1024 workgroups][16 wall + 16 cycle slots], 100 MHz
 // ticks) to a HOST buffer of n entries (synchronises the device).
 int gnnpp_measure_read_stamps(unsigned long long* host, int n) {
-    if (!host || n <= 0 || n > 1024 * 16) return GNNPP_ERR_ARG;
+    if (!host || n <= 0 || n > 1024 * 32) return GNNPP_ERR_ARG;
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess
                ? GNNPP_OK : GNNPP_ERR_LAUNCH;
 }

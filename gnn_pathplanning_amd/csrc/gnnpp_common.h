@@ -23,7 +23,7 @@
 namespace gnnpp {
 
 #ifdef GNNPP_MEASURE
-__device__ unsigned long long g_stamps[1024 * 16];
+__device__ unsigned long long g_stamps[1024 * 32];
 #endif
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -40,10 +40,12 @@ constexpr int kLdsBytes = 160 * 1024;
 #ifdef GNNPP_MEASURE
 #define GNNPP_ABLATE(p, bits) ((p).ablate & (bits))
 #define GNNPP_STOP_AT(stop, phase) (stop == phase)
-// phase time stamps (100 MHz wall clock) of workgroup `wg`, slot 0..15, read back by
-// gnnpp_measure_read_stamps(): where the time goes INSIDE a kernel
+// phase time stamps of workgroup `wg`, slot 0..15, read back by gnnpp_measure_read_stamps(): where the
+// time goes INSIDE a kernel.  [slot] = 100 MHz wall clock, [16 + slot] = shader clock cycles (their ratio
+// is the engine clock the kernel really ran at, which prices the MFMA-pipe bound of a phase)
 #define GNNPP_STAMP(wg, slot, leader)                                                            \
-    do { if (leader) gnnpp::g_stamps[((wg) & 1023) * 16 + (slot)] = wall_clock64(); } while (0)
+    do { if (leader) { gnnpp::g_stamps[((wg) & 1023) * 32 + (slot)] = wall_clock64();             \
+                       gnnpp::g_stamps[((wg) & 1023) * 32 + 16 + (slot)] = clock64(); } } while (0)
 #else
 #define GNNPP_ABLATE(p, bits) 0
 #define GNNPP_STOP_AT(stop, phase) false

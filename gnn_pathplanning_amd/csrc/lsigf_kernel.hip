@@ -75,8 +75,27 @@ __global__ void filter_scale_kernel(const float* __restrict__ h, float* __restri
                                     size_t n) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* red = reinterpret_cast<float*>(gnnpp_smem);
+    // 16-byte loads, four of them in flight per thread before the first maximum (max is order-free:
+    // exact whatever the association); cudaMalloc-style base alignment makes h 16-byte aligned, checked
     float m = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(h[i]));
+    size_t done = 0;
+    if ((reinterpret_cast<size_t>(h) & 15) == 0) {
+        const v4f* h4 = reinterpret_cast<const v4f*>(h);
+        const size_t n4 = n >> 2;
+        for (size_t i0 = threadIdx.x; i0 < n4; i0 += 4 * (size_t)blockDim.x) {
+            v4f v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + u * (size_t)blockDim.x;
+                v[u] = h4[i < n4 ? i : i0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+        }
+        done = n4 << 2;
+    }
+    for (size_t i = done + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(h[i]));
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = blockDim.x >> 1; s > 0; s >>= 1) {          // tree reduction (blockDim.x = 2^k)

@@ -9,29 +9,31 @@
 // (they are needed again by the backward pass anyway): at B = 64, N = 10 a layer is a few MB.
 //
 // Layout of every activation tensor: [N][B][C][P] (agent-major, P = H*W row-major), fp32.  All kernels
-// are plain fp32 arithmetic (fmaf chains / fp32 MFMA), deterministic: every reduction has a fixed order
-// (per-wave partial sums in LDS, partials summed in index order by a finalize kernel; no atomics).
+// are plain fp32 arithmetic (exact fp32 MFMA 16x16x4 / fmaf), deterministic: every reduction has a fixed
+// order (per-wave partial sums, partials summed in index order by the kernel that consumes them; no atomics).
 //
-//   forward, per conv layer l (3->32 @11x11 pool, 32->32 @5x5, 32->64 @5x5 pool, 64->64 @2x2, 64->128 @2x2 pool)
-//     conv_cols_kernel        y = conv3x3(x) + bias: one lane = one output column (b, y, x) of agent n,
-//                             16 output channels in registers; the weights of the wave's channel tile are
-//                             WAVE-UNIFORM, so they come through scalar loads and enter the FMAs as SGPR
-//                             operands ([ci][co][tap] copy made by pack_train_weights_kernel); per-wave
+//   forward: pack_train_weights_kernel (the ten weight packs of the step, one launch), then per conv layer l
+//   (3->32 @11x11 pool, 32->32 @5x5, 32->64 @5x5 pool, 64->64 @2x2, 64->128 @2x2 pool)
+//     conv_mfma_kernel        y = conv3x3(x) + bias as a GEMM on the fp32 MFMA: rows = output channels,
+//                             columns = (image, position), contraction = (tap, input channel); images
+//                             zero-bordered in LDS, A fragments from the pack; the 2x2 layers run as DENSE
+//                             maps of the flattened image (no multiplications spent on the border); per-workgroup
 //                             partial (sum, sum of squares) per channel for the BatchNorm statistics
-//     bn_stats_kernel         partials -> mean, 1/sqrt(var + eps) per (agent, channel) (+ unbiased variance
-//                             for the running statistics)
-//     bn_relu_pool_kernel     x_{l+1} = maxpool2x2?( relu( (y - mean) * invstd * gamma + beta ) )
+//     bn_relu_pool_kernel     partials -> mean, 1/sqrt(var + eps) per (agent, channel) (+ unbiased variance for
+//                             the running statistics) in the workgroup's prologue, then
+//                             x_{l+1} = maxpool2x2?( relu( (y - mean) * invstd * gamma + beta ) )
 //   then bn_running_kernel    the N sequential momentum updates of every layer's running statistics
 //   backward, per layer from the last to the first
 //     bn_bwd_reduce_kernel    dz = relu'(a) * unpool(d x_{l+1})  (a and the pool's arg-max recomputed from y:
 //                             first maximum in scan order, as torch's max_pool2d backward), written out,
 //                             with per-wave partial sums of dz and dz * yhat
-//     bn_bwd_coef_kernel      partials -> per (agent, channel) coefficients; d gamma, d beta summed over agents
-//     bn_bwd_apply_kernel     dy = gamma * invstd * (dz - mean(dz) - yhat * mean(dz * yhat)), in place
-//     conv_cols_kernel        dx = conv3x3(dy) with the transposed, flipped kernel (skipped for layer 0)
+//     bn_bwd_apply_kernel     partials -> per (agent, channel) coefficients in the workgroup's prologue, then
+//                             dy = gamma * invstd * (dz - mean(dz) - yhat * mean(dz * yhat)), in place
+//     (after the last layer)  bn_bwd_dparam_kernel: d gamma, d beta of every layer, summed over agents in order
 //     conv_wgrad_kernel       dW[co][ci][tap] (and d bias) = sum over all columns of dy x patch(x): a GEMM with
-//                             the columns as the contraction index, on the fp32 MFMA 16x16x4, split over
-//                             column ranges; conv_wgrad_reduce_kernel sums the splits in order.
+//                             the columns as the contraction index, on the fp32 MFMA 16x16x4, operands staged
+//                             through LDS, split over image ranges; conv_wgrad_reduce_kernel sums the splits in order
+//     conv_mfma_kernel        dx = conv3x3(dy) with the transposed, flipped kernel (skipped for layer 0)
 // The 128 -> 128 compress MLP, the graph filter and the action head are not in here: the MLP is one library
 // GEMM each way (torch), the graph filter runs on lsigf_kernel (graphML._LSIGFFunction).
 #include "gnnpp_common.h"
@@ -45,228 +47,351 @@ __host__ __device__ inline TrainLayerDims train_layer(int l) {
                                             {64, 64, 2, 2, 0}, {64, 128, 2, 2, 1}};
     return d[l];
 }
-constexpr int kWgSplitMax = 640;     // column-range splits of conv_wgrad_kernel
 
-// ---- weights in the order conv_cols_kernel consumes them: [input channel][tap][output channel], so that a
-// wave's channel tile of one (input channel, tap) is a run of consecutive floats -- scalar loads deliver
-// aligned SGPR pairs for v_pk_fma_f32 with no re-shuffling.  Two copies per layer, one launch for all:
-//   b (forward):        wf[ci][tap][co]     = W[co][ci][tap]
-//   c (input gradient): wb[co][tap][ci]     = W[co][ci][8 - tap]   (transposed + flipped kernel)
+// ---- convolution geometry: every layer, forward and input gradient, as ONE GEMM shape ------------------------------
+// out[img][m][p] = bias[m / RPC] + sum over (tap, c) A[m][(tap, c)] * in[img][c][p + off(tap)]   (zero padding)
+//   11x11 and 5x5 layers: the 3x3 convolution itself (TAPS = 9; rows m = output channels; RPC = 1);
+//   2x2 layers: every output position sees every input position through exactly one tap, so the layer is a
+//   DENSE map of the flattened image: rows m = (channel, position) (RPC = 4 rows per channel), contraction
+//   index c = (input channel, input position), TAPS = 1, "image" of one position.  The 3x3 form would spend
+//   5/9 of its multiplications on the zero border.
+//   input gradient: the same with the transposed, flipped kernel (rows = the layer's input channels).
+// IB images per workgroup, CC contraction channels per LDS stage.
+struct ConvGeom { int H, W, P, TAPS, RPC, IB, CC, M, Ck, nchunk, SPC, chunks_per_agent; };
+__host__ __device__ inline ConvGeom conv_geom(int l, bool input_grad, int B) {
+    const TrainLayerDims d = train_layer(l);
+    ConvGeom g;
+    const bool dense = d.H == 2;
+    g.H = dense ? 1 : d.H; g.W = dense ? 1 : d.W; g.P = g.H * g.W;
+    g.TAPS = dense ? 1 : 9;
+    g.RPC = dense ? 4 : 1;
+    g.IB = dense ? 64 : d.H == 5 ? 4 : 2;
+    g.CC = dense ? 128 : d.H == 5 ? 32 : 4;
+    const int rows = input_grad ? d.Cin : d.Cout, ck = input_grad ? d.Cout : d.Cin;
+    g.M = rows * g.RPC;
+    g.Ck = ck * g.RPC;
+    g.nchunk = (g.Ck + g.CC - 1) / g.CC;
+    g.SPC = g.TAPS * g.CC / 4;
+    g.chunks_per_agent = (B + g.IB - 1) / g.IB;
+    return g;
+}
+__host__ __device__ inline size_t conv_pack_floats(int l, bool input_grad) {
+    const ConvGeom g = conv_geom(l, input_grad, 1);
+    return (size_t)g.M * g.nchunk * g.SPC * 4;
+}
+
+// ---- weights as MFMA A fragments: pack[((mt*nchunk + ch)*SPC + s)*64 + lane] = A[m = mt*16 + (lane & 15)]
+// [k-step s of stage ch: tap = s / (CC/4), c = ch*CC + 4*(s % (CC/4)) + (lane >> 4)], 0 for c >= Ck.  One launch for
+// the ten packs of a step (blockIdx.y = layer*2 + {0: forward -> b, 1: input gradient -> c}).
 struct TrainPtrs5 { const float* a[kTrainLayers]; float* b[kTrainLayers]; float* c[kTrainLayers]; };
 __global__ void pack_train_weights_kernel(const TrainPtrs5 p) {
-    const int l = blockIdx.y;
+    const int l = blockIdx.y >> 1;
+    const bool ig = blockIdx.y & 1;
     const TrainLayerDims d = train_layer(l);
+    const ConvGeom g = conv_geom(l, ig, 1);
     const float* w = p.a[l];
-    const int total = d.Cin * d.Cout * 9;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int tap = i % 9, ci = (i / 9) % d.Cin, co = i / (9 * d.Cin);
-        const float v = w[i];                                        // W[co][ci][tap]
-        p.b[l][((long)ci * 9 + tap) * d.Cout + co] = v;
-        p.c[l][((long)co * 9 + (8 - tap)) * d.Cin + ci] = v;
+    float* out = ig ? p.c[l] : p.b[l];
+    if (ig && l == 0) return;                                        // (no input gradient of the observations)
+    const int total = g.M * g.nchunk * g.SPC * 4, spm = g.nchunk * g.SPC;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, sg = (e >> 6) % spm, mt = (e >> 6) / spm;
+        const int m = mt * 16 + (lane & 15);
+        const int ch = sg / g.SPC, s0 = sg - ch * g.SPC;
+        const int tap = s0 / (g.CC / 4), cig = s0 - tap * (g.CC / 4);
+        const int c = ch * g.CC + 4 * cig + (lane >> 4);
+        float v = 0.f;
+        if (c < g.Ck) {
+            int co, ci, t;
+            if (g.RPC == 1) {                                        // the 3x3 convolution
+                co = ig ? c : m; ci = ig ? m : c; t = ig ? 8 - tap : tap;
+            } else {                                                 // dense 2x2: positions po (output), pi (input)
+                const int row_ch = m >> 2, row_p = m & 3, k_ch = c >> 2, k_p = c & 3;
+                co = ig ? k_ch : row_ch; ci = ig ? row_ch : k_ch;
+                const int po = ig ? k_p : row_p, pi = ig ? row_p : k_p;
+                t = ((pi >> 1) - (po >> 1) + 1) * 3 + ((pi & 1) - (po & 1) + 1);
+            }
+            v = w[((long)co * d.Cin + ci) * 9 + t];
+        }
+        out[e] = v;
     }
 }
 
-// ---- convolution over columns ---------------------------------------------------------------------------
-// out[n,b,co,p] = bias[co] + sum_ci sum_tap wk[(ci*9 + tap)*Cout + co] * in[n,b,ci,p + off(tap)]   (zero padding)
-//   forward: wk = the layer's wf copy; input gradient: wk = its wb copy with the roles of Cin / Cout swapped
-// grid = (N * chunks, Cout / 16), block = 64: wave (n, chunk) x channel tile; lane = column chunk*64 + lane
-// of agent n (columns = B*P).  x image (n, b) starts at x + n*x_sn + b*x_sb (the observations arrive
-// sample-major [B][N]...; every other tensor is agent-major).  part != nullptr: per-wave (sum, sum sq) of
-// the outputs per channel -> part[((n*chunks + chunk)*Cout + co)*2 + {0,1}].
-template <int CT>
-__global__ __launch_bounds__(64) void conv_cols_kernel(const float* __restrict__ x,
-                                                       const float* __restrict__ wk,
-                                                       const float* __restrict__ bias,
-                                                       float* __restrict__ y, float* __restrict__ part,
-                                                       int B, int Cin, int Cout, int H, int W, long x_sn,
-                                                       long x_sb, int chunks) {
-    const int lane = threadIdx.x;
+// ---- the convolution on v_mfma_f32_16x16x4_f32 -------------------------------------------------------------------
+// grid = (N * chunks_per_agent, M / 16), block = 256.  A workgroup owns 16 output rows and the IB images
+// [b0, b0 + IB) of agent n, i.e. IB*P columns in tiles of 16; wave w holds the accumulators of column tiles
+// w, w + 4, ... (TN of them).  Per stage of CC contraction channels: the A fragments of the stage (one
+// coalesced copy of the pack) and the raw images go to LDS -- the images ZERO-BORDERED, [c][img][(H+2)(W+2)],
+// so the operand of any (tap, c) is the lane's column offset plus a compile-time constant: the inner loop is
+// ds_read (immediate offsets) + MFMA and nothing else.  Lane (i = lane & 15, q = lane >> 4): A value (row i,
+// k = 4s + q), B value (k = 4s + q, column i);  D register r: (row 4q + r, column i).
+// Epilogue: + bias, store, and (part != nullptr) the BatchNorm partial sums of the workgroup's channels over
+// its valid columns -> part[((n*chunks + chunk)*C + c)*2 + {sum, sum of squares}] (16-lane butterflies, then
+// the four waves in order: deterministic).
+template <int H, int W>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        float* __restrict__ part, int B, int Ck, int M, long x_sn,
+                                                        long x_sb, int chunks, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    constexpr bool kDense = H == 1 && W == 1;
+    constexpr int P = H * W, TAPS = kDense ? 1 : 9, RPC = kDense ? 4 : 1;
+    constexpr int PP = kDense ? 1 : (H + 2) * (W + 2);
+    constexpr int IB = kDense ? 64 : H == 5 ? 4 : 2, CC = kDense ? 128 : H == 5 ? 32 : 4;
+    constexpr int SPC = TAPS * CC / 4, NT = (IB * P + 15) / 16, TN = (NT + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
-    const int co0 = blockIdx.y * CT;
-    const int P = H * W;
-    const int col = chunk * 64 + lane;
-    const bool active = col < B * P;
-    const int colc = active ? col : 0;
-    const int b = colc / P, pos = colc - b * P;
-    const int py = pos / W, px = pos - py * W;
-    int off[9];
-    float msk[9];
+    const int b0 = chunk * IB, nimg = min(IB, B - b0);
+    const int m0 = blockIdx.y * 16;
+    float* wsm = reinterpret_cast<float*>(gnnpp_smem);          // [SPC][64]
+    float* xs = wsm + SPC * 64;                                  // [CC][IB][PP]
+    int cb[TN], cimg[TN], cp[TN];
+    bool cv[TN];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        off[t] = in ? yy * W + xx : pos;                 // (a valid address; the value is masked)
-        msk[t] = in ? 1.f : 0.f;
+    for (int t = 0; t < TN; ++t) {
+        const int col = (wave + 4 * t) * 16 + i16;
+        cv[t] = col < nimg * P;
+        cimg[t] = cv[t] ? col / P : 0;
+        cp[t] = cv[t] ? col - cimg[t] * P : 0;
+        cb[t] = cimg[t] * PP + (kDense ? 0 : (cp[t] / W + 1) * (W + 2) + cp[t] % W + 1) + q * IB * PP;
     }
-    float acc[CT];
+    v4f acc[TN];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) acc[c] = bias ? bias[co0 + c] : 0.f;
-    const float* xi = x + n * x_sn + b * x_sb;
-    // input channels U at a time: all 9 U patch loads of a group are issued before its FMAs, so one
-    // memory round trip feeds U * 9 * CT FMAs (Cin is 3 or a multiple of 8)
-    constexpr int U = CT >= 16 ? 4 : 8;          // narrower channel tiles leave registers for deeper prefetch
-    for (int ci0 = 0; ci0 < Cin; ci0 += U) {
-        float patch[U][9];
+    for (int t = 0; t < TN; ++t) acc[t] = vzero();
+
+    // Staging = two phases so that global latency is paid once per stage, not once per element: issue() puts
+    // every load of a stage in flight (16-byte loads: five for the A fragments, up to eight for the images; the
+    // 11x11 layer's odd-sized observations go element-wise), commit() scatters the registers into LDS.  The
+    // next stage's issue() runs BEFORE this stage's MFMAs, its commit() after them.
+    const float* xa = x + n * x_sn + (long)b0 * x_sb;
+    constexpr bool kVec = H != 11;                              // 16-byte image loads (runs and bases are aligned)
+    constexpr int NWV = (SPC * 16 + 255) / 256;                 // float4 A-fragment loads per thread
+    constexpr int XE = CC * IB * P;                             // image elements of a full stage
+    constexpr int NXV = kVec ? (XE / 4 + 255) / 256 : (XE + 255) / 256;
+    v4f wv[NWV];
+    v4f xv[kVec ? NXV : 1];
+    float xsc[kVec ? 1 : NXV];
+    auto issue = [&](int ch) {
+        const v4f* wsrc = reinterpret_cast<const v4f*>(wp + ((long)(blockIdx.y * nchunk + ch) * SPC) * 64);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
-            const float live = ci0 + u < Cin ? 1.f : 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) patch[u][t] = xi[(long)ci * P + off[t]] * (msk[t] * live);
+        for (int u = 0; u < NWV; ++u) {
+            const int i = tid + u * 256;
+            wv[u] = wsrc[i < SPC * 16 ? i : 0];
         }
+        const int c0 = ch * CC;
+        if constexpr (kVec) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ci = ci0 + u < Cin ? ci0 + u : Cin - 1;
-            const float* wrow = wk + (long)ci * 9 * Cout + co0;        // wave-uniform: scalar loads
+            for (int u = 0; u < NXV; ++u) {
+                const int e = (tid + u * 256) * 4;
+                const int im = e / (CC * P), r = e - im * (CC * P);
+                const bool ok = e < XE && im < nimg;
+                xv[u] = *reinterpret_cast<const v4f*>(xa + (ok ? (long)im * x_sb + (long)c0 * P + r : 0));
+            }
+        } else {
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int u = 0; u < NXV; ++u) {
+                const int e = tid + u * 256;
+                const int im = e / (CC * P), r = e - im * (CC * P);
+                const bool ok = e < XE && im < nimg && c0 + r / P < Ck;
+                xsc[u] = xa[ok ? (long)im * x_sb + (long)c0 * P + r : 0];
+            }
+        }
+    };
+    auto xs_at = [&](int im, int r) {                           // LDS slot of element r = cl*P + pp of image im
+        const int cl = r / P, pp = r - cl * P;
+        return (cl * IB + im) * PP + (kDense ? 0 : (pp / W + 1) * (W + 2) + pp % W + 1);
+    };
+    auto commit = [&](int ch) {
+        v4f* wdst = reinterpret_cast<v4f*>(wsm);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[c] = fmaf(wrow[(long)t * Cout + c], patch[u][t], acc[c]);
+        for (int u = 0; u < NWV; ++u) {
+            const int i = tid + u * 256;
+            if (i < SPC * 16) wdst[i] = wv[u];
+        }
+        if constexpr (kVec) {
+#pragma unroll
+            for (int u = 0; u < NXV; ++u) {
+                const int e = (tid + u * 256) * 4;
+                const int im = e / (CC * P), r = e - im * (CC * P);
+                if (e < XE && im < nimg) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xs[xs_at(im, r + k)] = xv[u][k];
+                }
+            }
+        } else {
+            const int c0 = ch * CC;
+#pragma unroll
+            for (int u = 0; u < NXV; ++u) {
+                const int e = tid + u * 256;
+                const int im = e / (CC * P), r = e - im * (CC * P);
+                if (e < XE && im < nimg) xs[xs_at(im, r)] = c0 + r / P < Ck ? xsc[u] : 0.f;
+            }
+        }
+    };
+    issue(0);
+    for (int i = tid; i < CC * IB * PP; i += 256) xs[i] = 0.f;   // borders / missing images stay zero
+    __syncthreads();
+    commit(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) issue(ch + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = kDense ? 0 : (tap / 3 - 1) * (W + 2) + (tap % 3 - 1);
+#pragma unroll
+            for (int cig = 0; cig < CC / 4; ++cig) {
+                const float a = wsm[(tap * (CC / 4) + cig) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+                    acc[t] = mfma16(a, xs[cb[t] + toff + cig * 4 * IB * PP], acc[t]);
+            }
+        }
+        if (ch + 1 < nchunk) {
+            __syncthreads();                                     // every wave is done reading this stage
+            commit(ch + 1);
+            __syncthreads();
         }
     }
-    if (active) {
-        float* yo = y + (((long)n * B + b) * Cout + co0) * P + pos;
+
+    // ---- epilogue
+    const int C = M / RPC;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < CT; ++c) yo[(long)c * P] = acc[c];
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * q + r;
+        const float bv = bias ? bias[m / RPC] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float v = acc[t][r] + bv;
+            if (cv[t]) {
+                y[(((long)n * B + b0 + cimg[t]) * M + m) * P + cp[t]] = v;
+                s1[RPC == 1 ? r : 0] += v;
+                s2[RPC == 1 ? r : 0] += v * v;
+            }
+        }
     }
     if (part) {
+        constexpr int NS = RPC == 1 ? 4 : 1;                     // channel slots per lane
+        __syncthreads();                                         // the A fragments are dead: reuse their LDS
+        float* red = wsm;                                        // [4 waves][16 / RPC channels][2]
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const float v = active ? acc[c] : 0.f;
-            const float s1 = wave_sum(v), s2 = wave_sum(v * v);
-            if (lane == 0) {
-                float* o = part + (((long)n * chunks + chunk) * Cout + co0 + c) * 2;
-                o[0] = s1;
-                o[1] = s2;
+        for (int k = 0; k < NS; ++k) {
+            float a1 = s1[k], a2 = s2[k];
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) {
+                a1 += __shfl_xor(a1, msk);
+                a2 += __shfl_xor(a2, msk);
             }
+            if (i16 == 0) {
+                const int slot = RPC == 1 ? 4 * q + k : q;
+                red[(wave * 16 + slot) * 2] = a1;
+                red[(wave * 16 + slot) * 2 + 1] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 / RPC) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                t1 += red[(w * 16 + tid) * 2];
+                t2 += red[(w * 16 + tid) * 2 + 1];
+            }
+            float* o = part + (((long)n * chunks + chunk) * C + m0 / RPC + tid) * 2;
+            o[0] = t1;
+            o[1] = t2;
         }
     }
 }
 
-// ---- convolution with one lane per OUTPUT CHANNEL (layers 1..4, forward and input gradient) ----------------
-// The roles that suit the hardware when the images are tiny (5x5, 2x2): a lane owns an output channel, so
-//   * the WEIGHTS differ per lane and arrive by coalesced vector loads (256 bytes per (input channel, tap),
-//     in-order returns: the next input channel's nine are in flight during this one's FMAs),
-//   * the ACTIVATIONS of the wave's IMG images are the same for every lane: scalar loads into SGPRs, used as
-//     the scalar operand of v_fma -- fetched one input channel AHEAD (two register sets), so the
-//     "wait for all scalar loads" that out-of-order SMEM returns force never waits for a load just issued,
-//   * zero padding is resolved at compile time (H, W are template parameters: taps that fall outside the
-//     image are not issued),
-//   * the BatchNorm partial sums are lane-local (a lane = a channel): no cross-lane reduction at all.
-// grid = (N * chunks, ceil(Cout / 64)), block = 64; wave = images [chunk*IMG, +IMG) of agent n.
-// wk = [ci][tap][Cout] (forward: wf; input gradient: wb with the layer's Cin / Cout swapped).
-template <int H, int W, int IMG>
-__global__ __launch_bounds__(64) void conv_ch_kernel(const float* __restrict__ x, const float* __restrict__ wk,
-                                                     const float* __restrict__ bias, float* __restrict__ y,
-                                                     float* __restrict__ part, int B, int Cin, int Cout,
-                                                     long x_sn, long x_sb, int chunks) {
-    constexpr int P = H * W;
-    const int lane = threadIdx.x;
-    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
-    const int b0 = chunk * IMG;
-    const int co = blockIdx.y * 64 + lane;
-    const bool cv = co < Cout;
-    const int coc = cv ? co : Cout - 1;
-    const float bv = bias ? bias[coc] : 0.f;
-    float acc[IMG][P];
-#pragma unroll
-    for (int i = 0; i < IMG; ++i)
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[i][p] = bv;
-    const float* xb[IMG];                                   // wave-uniform image bases (clamped: the extra
-#pragma unroll                                              // images of a ragged tail are computed, not stored)
-    for (int i = 0; i < IMG; ++i) xb[i] = x + n * x_sn + (long)(b0 + i < B ? b0 + i : B - 1) * x_sb;
-    const float* wl = wk + coc;
-
-    auto load_x = [&](float (&xs)[IMG][P], int ci) {
-#pragma unroll
-        for (int i = 0; i < IMG; ++i)
-#pragma unroll
-            for (int p = 0; p < P; ++p) xs[i][p] = xb[i][(long)ci * P + p];
-    };
-    auto fma_all = [&](const float (&xs)[IMG][P], int ci) {
-        float w[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = wl[((long)ci * 9 + t) * Cout];
-#pragma unroll
-        for (int i = 0; i < IMG; ++i)
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = p / W + t / 3 - 1, xx = p % W + t % 3 - 1;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                        acc[i][p] = fmaf(w[t], xs[i][yy * W + xx], acc[i][p]);
-                }
-    };
-    float xa[IMG][P], xc[IMG][P];
-    load_x(xa, 0);
-    for (int ci = 0; ci < Cin; ci += 2) {                   // Cin is even for every layer this kernel serves
-        load_x(xc, ci + 1);
-        fma_all(xa, ci);
-        if (ci + 2 < Cin) load_x(xa, ci + 2);
-        fma_all(xc, ci + 1);
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < IMG; ++i) {
-        if (b0 + i < B) {                                   // (wave-uniform)
-            float* yo = y + (((long)n * B + b0 + i) * Cout + coc) * P;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                if (cv) yo[p] = acc[i][p];
-                s1 += acc[i][p];
-                s2 += acc[i][p] * acc[i][p];
-            }
-        }
-    }
-    if (part && cv) {
-        float* o = part + (((long)n * chunks + chunk) * Cout + co) * 2;
-        o[0] = s1;
-        o[1] = s2;
-    }
-}
-
-// ---- BatchNorm statistics of one layer: grid = N blocks, Cout threads -------------------------------------
-// stat[(n*C + c)*4 + {0: mean, 1: invstd, 2: unbiased variance (running stats), 3: unused}]
-__global__ void bn_stats_kernel(const float* __restrict__ part, float* __restrict__ stat, int chunks, int C,
-                                int m, float eps) {
-    const int n = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
+// ---- sums of per-chunk partial pairs, inside the kernel that consumes them -----------------------------------
+// A workgroup that needs the (sum, sum) pairs of CG channels of agent n adds the `chunks` partial pairs of each
+// channel itself: 256 / CG threads per channel take every (256/CG)-th chunk in order (doubles), then a fixed
+// binary tree in LDS.  The association is a function of (chunks, CG) only: deterministic, and every workgroup
+// that reduces the same channel obtains the same bits.  Costs a few hundred loads per workgroup instead of
+// a launch with N blocks walking the chunks serially.  red: LDS, 512 doubles.  Result of channel cc (all
+// threads, after the call): red[(cc * (256 / CG)) * 2 + {0, 1}].
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int C, int c0,
+                                                int CG, double* red) {
+    const int tpc = 256 / CG;                               // threads per channel (CG is a power of two <= 32)
+    const int cc = threadIdx.x / tpc, r = threadIdx.x - cc * tpc;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        const float* p = part + (((long)n * chunks + k) * C + c) * 2;
+    for (int k = r; k < chunks; k += tpc) {
+        const float* p = part + (((long)n * chunks + k) * C + c0 + cc) * 2;
         s1 += (double)p[0];
         s2 += (double)p[1];
     }
-    const double mean = s1 / m;
-    double var = s2 / m - mean * mean;
-    if (var < 0.0) var = 0.0;
-    float* o = stat + ((long)n * C + c) * 4;
-    o[0] = (float)mean;
-    o[1] = (float)(1.0 / sqrt(var + (double)eps));
-    o[2] = (float)(m > 1 ? var * m / (m - 1) : var);
-    o[3] = 0.f;
+    red[threadIdx.x * 2] = s1;
+    red[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    for (int off = tpc >> 1; off > 0; off >>= 1) {
+        if (r < off) {
+            red[threadIdx.x * 2] += red[(threadIdx.x + off) * 2];
+            red[threadIdx.x * 2 + 1] += red[(threadIdx.x + off) * 2 + 1];
+        }
+        __syncthreads();
+    }
 }
 
-// ---- x_next = maxpool2x2?(relu(bn(y))): one thread per output element ---------------------------------------
+// Workgroup shape of the two BatchNorm element-wise kernels: (channels per workgroup, images per workgroup)
+// chosen so that a workgroup's slice of one image is a contiguous run of >= 64 floats and a layer has a
+// few hundred workgroups.
+constexpr size_t kBnSmem = 512 * sizeof(double) + 32 * 5 * sizeof(float);
+struct BnTile { int CG, BR; };
+__host__ __device__ inline BnTile bn_tile(int l) {
+    const BnTile t[kTrainLayers] = {{2, 16}, {8, 8}, {8, 8}, {32, 16}, {32, 16}};
+    return t[l];
+}
+
+// ---- x_next = maxpool2x2?(relu(bn(y))) ----------------------------------------------------------------------
 __device__ __forceinline__ float bn_act(float yv, float mean, float invstd, float g, float be) {
     return fmaxf(fmaf((yv - mean) * invstd, g, be), 0.f);
 }
 
-// grid-stride over the elements of x_next [N][B][C][Po]
-__global__ void bn_relu_pool_kernel(const float* __restrict__ y, const float* __restrict__ stat,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    float* __restrict__ xn, long total, int B, int C, int H, int W,
-                                    int pool) {
+// grid = (C / CG, ceil(B / BR), N), block = 256: BatchNorm statistics of the workgroup's channels from the
+// convolution's partial sums (m = B * P values each), then the element-wise part over images [b0, b0 + BR).
+// stat[(n*C + c)*4 + {0: mean, 1: invstd, 2: unbiased variance (running stats), 3: unused}] is written by
+// the workgroups of the first image range (the backward pass and bn_running_kernel read it).
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y,
+                                                           const float* __restrict__ part,
+                                                           float* __restrict__ stat,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ xn, int B, int C, int H, int W,
+                                                           int pool, int chunks, int CG, int BR, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    double* red = reinterpret_cast<double*>(gnnpp_smem);                               // [512]
+    float (*sm)[5] = reinterpret_cast<float (*)[5]>(gnnpp_smem + 512 * sizeof(double));  // mean, invstd, gamma, beta
+    const int n = blockIdx.z, c0 = blockIdx.x * CG, b0 = blockIdx.y * BR;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo, P = H * W;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int po = (int)(i % Po);
-        const long ic = i / Po;                          // (n*B + b)*C + c
-        const int c = (int)(ic % C);
-        const int n = (int)((ic / C) / B);
-        const float* st = stat + ((long)n * C + c) * 4;
-        const float mean = st[0], invstd = st[1], g = gamma[c], be = beta[c];
+    reduce_partials(part, n, chunks, C, c0, CG, red);
+    if (threadIdx.x < CG) {
+        const int cc = threadIdx.x, c = c0 + cc;
+        const int m = B * P;
+        const double s1 = red[cc * (256 / CG) * 2], s2 = red[cc * (256 / CG) * 2 + 1];
+        const double mean = s1 / m;
+        double var = s2 / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        sm[cc][0] = (float)mean;
+        sm[cc][1] = invstd;
+        sm[cc][2] = gamma[c];
+        sm[cc][3] = beta[c];
+        if (blockIdx.y == 0) {
+            float* o = stat + ((long)n * C + c) * 4;
+            o[0] = (float)mean;
+            o[1] = invstd;
+            o[2] = (float)(m > 1 ? var * m / (m - 1) : var);
+            o[3] = 0.f;
+        }
+    }
+    __syncthreads();
+    const int nb = min(BR, B - b0);
+    const int per_img = CG * Po;
+    for (int i = threadIdx.x; i < nb * per_img; i += 256) {
+        const int bi = i / per_img, rem = i - bi * per_img;
+        const int cc = rem / Po, po = rem - cc * Po;
+        const float mean = sm[cc][0], invstd = sm[cc][1], g = sm[cc][2], be = sm[cc][3];
+        const long ic = ((long)n * B + b0 + bi) * C + c0 + cc;
         const float* yc = y + ic * P;
         float v;
         if (pool) {
@@ -277,7 +402,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ y, const float* __
         } else {
             v = bn_act(yc[po], mean, invstd, g, be);
         }
-        xn[i] = v;
+        xn[ic * Po + po] = v;
     }
 }
 
@@ -359,109 +484,223 @@ __global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restri
     }
 }
 
-// pass 2a: coefficients per (agent, channel): coef[(n*C + c)*4 + {k1, k2, k3}] with
-//   dy = k1 * (dz - k2 - yhat * k3),  k1 = gamma * invstd, k2 = mean(dz), k3 = mean(dz * yhat);
-// grid = N blocks, C threads; the per-agent sums go to pn[(n*C + c)*2] for bn_bwd_dparam_kernel
-__global__ void bn_bwd_coef_kernel(const float* __restrict__ part, const float* __restrict__ stat,
-                                   const float* __restrict__ gamma, float* __restrict__ coef,
-                                   float* __restrict__ pn, int chunks, int C, int m) {
-    const int n = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        const float* p = part + (((long)n * chunks + k) * C + c) * 2;
-        s1 += (double)p[0];
-        s2 += (double)p[1];
+// pass 2: dz -> dy in place,  dy = k1 * (dz - k2 - yhat * k3),  k1 = gamma * invstd, k2 = mean(dz),
+// k3 = mean(dz * yhat) over the m = B * P values of (agent, channel).  Same workgroup shape as
+// bn_relu_pool_kernel: the workgroup sums pass 1's partial pairs of its channels itself; the workgroups of the
+// first image range leave the per-agent sums in pn[(n*C + c)*2] for bn_bwd_dparam_kernel.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y,
+                                                           const float* __restrict__ stat,
+                                                           const float* __restrict__ part,
+                                                           const float* __restrict__ gamma,
+                                                           float* __restrict__ dz, float* __restrict__ pn, int B,
+                                                           int C, int P, int chunks, int CG, int BR) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    double* red = reinterpret_cast<double*>(gnnpp_smem);                               // [512]
+    float (*sm)[5] = reinterpret_cast<float (*)[5]>(gnnpp_smem + 512 * sizeof(double));  // mean, invstd, k1, k2, k3
+    const int n = blockIdx.z, c0 = blockIdx.x * CG, b0 = blockIdx.y * BR;
+    reduce_partials(part, n, chunks, C, c0, CG, red);
+    if (threadIdx.x < CG) {
+        const int cc = threadIdx.x, c = c0 + cc;
+        const int m = B * P;
+        const double s1 = red[cc * (256 / CG) * 2], s2 = red[cc * (256 / CG) * 2 + 1];
+        const float* st = stat + ((long)n * C + c) * 4;
+        sm[cc][0] = st[0];
+        sm[cc][1] = st[1];
+        sm[cc][2] = gamma[c] * st[1];
+        sm[cc][3] = (float)(s1 / m);
+        sm[cc][4] = (float)(s2 / m);
+        if (blockIdx.y == 0) {
+            pn[((long)n * C + c) * 2] = (float)s1;
+            pn[((long)n * C + c) * 2 + 1] = (float)s2;
+        }
     }
-    float* o = coef + ((long)n * C + c) * 4;
-    o[0] = gamma[c] * stat[((long)n * C + c) * 4 + 1];
-    o[1] = (float)(s1 / m);
-    o[2] = (float)(s2 / m);
-    o[3] = 0.f;
-    pn[((long)n * C + c) * 2] = (float)s1;
-    pn[((long)n * C + c) * 2 + 1] = (float)s2;
+    __syncthreads();
+    const int nb = min(BR, B - b0);
+    const int per_img = CG * P;                              // a contiguous run of y / dz per image
+    for (int i = threadIdx.x; i < nb * per_img; i += 256) {
+        const int bi = i / per_img, rem = i - bi * per_img;
+        const int cc = rem / P;
+        const long at = (((long)n * B + b0 + bi) * C + c0) * P + rem;
+        const float yhat = (y[at] - sm[cc][0]) * sm[cc][1];
+        dz[at] = sm[cc][2] * (dz[at] - sm[cc][3] - yhat * sm[cc][4]);
+    }
 }
 
-// d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz): agents in order, one thread per channel
-__global__ void bn_bwd_dparam_kernel(const float* __restrict__ pn, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int N, int C) {
+// d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz): agents in order, one thread per channel;
+// all five layers in one launch at the end of the backward pass (blockIdx.y = layer; a = pn of the layer,
+// b = d gamma, c = d beta)
+__global__ void bn_bwd_dparam_kernel(const TrainPtrs5 p, int N) {
+    const int l = blockIdx.y;
+    const int C = train_layer(l).Cout;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const float* pn = p.a[l];
     double tb = 0.0, tg = 0.0;
     for (int n = 0; n < N; ++n) {
         tb += (double)pn[((long)n * C + c) * 2];
         tg += (double)pn[((long)n * C + c) * 2 + 1];
     }
-    dgamma[c] = (float)tg;
-    dbeta[c] = (float)tb;
-}
-
-// pass 2b: dz -> dy in place
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ stat,
-                                    const float* __restrict__ coef, float* __restrict__ dz, long total, int B,
-                                    int C, int P) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long ic = i / P;
-        const int c = (int)(ic % C);
-        const int n = (int)((ic / C) / B);
-        const float* st = stat + ((long)n * C + c) * 4;
-        const float* k = coef + ((long)n * C + c) * 4;
-        const float yhat = (y[i] - st[0]) * st[1];
-        dz[i] = k[0] * (dz[i] - k[1] - yhat * k[2]);
-    }
+    p.b[l][c] = (float)tg;
+    p.c[l][c] = (float)tb;
 }
 
 // ---- weight gradient: dW[co][j], j = ci*9 + tap (j = Cin*9: the bias column) -------------------------------
 //   dW[co][j] = sum over columns (n, b, p) of dy[n,b,co,p] * X[j][(n,b,p)],  X = x[n,b,ci,p + off(tap)] or 1
-// A GEMM with the columns as the contraction index on v_mfma_f32_16x16x4_f32: a wave owns the 16 x 16 tile
-// (co tile, j tile) and a range of images; A[i][k] = dy[co0+i][col k], B[k][j] = X[j0+j][col k], four
-// columns per MFMA.  grid = (co tiles, j tiles, splits); partial results -> wpart[split][Cout][J16].
-__global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict__ x,
-                                                        const float* __restrict__ dy,
-                                                        float* __restrict__ wpart, int NB, int Cin, int Cout,
-                                                        int H, int W, long x_sn, long x_sb, int B,
-                                                        int imgs_per_split) {
-    const int lane = threadIdx.x;
+// A GEMM with the columns as the contraction index on v_mfma_f32_16x16x4_f32 (A[i][k] = dy[co0+i][col k],
+// B[k][j] = X[j0+j][col k], four columns per MFMA), operands staged through LDS:
+//   grid = (Cout / 16, splits), block = 256.  A workgroup owns one tile of 16 output channels and a range of
+//   images, which it walks IB images at a time: the raw x images go to LDS once, ZERO-BORDERED
+//   ([ci][img][(H+2)*(W+2)]), so the im2col operand of ANY (ci, tap) is the same per-lane position offset plus
+//   a per-j constant -- no bounds tests, no address arithmetic in the loop; dy goes to LDS as [16][img][P
+//   rounded up to 4] (zero tail: a short last step contributes nothing).  Global reads are contiguous runs
+//   (an image's Cin*P floats, a tile's 16*P floats) and happen once per workgroup.
+//   Wave w holds the accumulators of j tiles  (w % JW) + JW*t, t < TJ  at once: one A read feeds TJ MFMAs.
+//   KW > 1 (layer 0: only two j tiles): the waves also split the images of a batch KW ways, each K group
+//   writing its own partial.  Partials -> wpart[split*KW + kgroup][Cout][J16], summed by conv_wgrad_reduce_kernel.
+__host__ __device__ constexpr int wgrad_ib(int H) { return H == 11 ? 4 : H == 5 ? 6 : 8; }   // images per LDS batch
+
+template <int H, int W, int Cin, int TJ, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ dy,
+                                                         float* __restrict__ wpart, int NB, int Cout,
+                                                         long x_sn, long x_sb, int B, int imgs_per_split, int JT) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    constexpr int P = H * W, PP = (H + 2) * (W + 2), SPI = (P + 3) / 4, P4 = SPI * 4, JW = 4 / KW;
+    constexpr int IB = wgrad_ib(H);
+    constexpr int dstride = ((IB * P4 + 63) / 64) * 64 + 4;      // rows 4 banks apart: conflict-free A reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int co0 = blockIdx.x * 16, j0 = blockIdx.y * 16, split = blockIdx.z;
-    const int P = H * W, J = Cin * 9 + 1, J16 = gridDim.y * 16;
-    const int j = j0 + i16;                              // this lane's B column
-    const bool jb = j == J - 1, jv = j < J - 1;
-    const int ci = jv ? j / 9 : 0, tap = jv ? j - ci * 9 : 4;
-    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
-    v4f acc = vzero();
-    const int img0 = split * imgs_per_split, img1 = min(NB, img0 + imgs_per_split);
-    // the K loop runs over (image, group of 4 positions) steps; four steps' operands are fetched before
-    // their MFMAs so that one memory round trip feeds four of them
-    const int spi = (P + 3) >> 2;                        // steps per image
-    const int nsteps = (img1 - img0) * spi;
-    constexpr int U = 4;
-    for (int s0 = 0; s0 < nsteps; s0 += U) {
-        float av[U], bv[U];
+    const int jw = wave % JW, kw = wave / JW;
+    const int co0 = blockIdx.x * 16, split = blockIdx.y;
+    const int J = Cin * 9 + 1, J16 = JT * 16;
+    float* xs = reinterpret_cast<float*>(gnnpp_smem);            // [Cin][IB][PP]
+    float* dys = xs + Cin * IB * PP;                             // [16][dstride]
+
+    int joff[TJ];
+    bool jbias[TJ];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int sidx = s0 + u;
-            const bool sv = sidx < nsteps;
-            const int sc = sv ? sidx : 0;
-            const int img = img0 + sc / spi, p = (sc - (sc / spi) * spi) * 4 + q;   // this lane's column
-            const bool pv = sv && p < P;
-            const int pc = pv ? p : 0;
-            const int n = img / B, b = img - n * B;
-            const int py = pc / W, px = pc - py * W;
-            const int yy = py + dyy, xx = px + dxx;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float a0 = dy[((long)img * Cout + co0 + i16) * P + pc];                 // A: channel co0 + i16
-            const float x0 = x[n * x_sn + b * x_sb + (long)ci * P + (in ? yy * W + xx : pc)];
-            av[u] = pv ? a0 : 0.f;
-            bv[u] = pv ? (jb ? 1.f : (jv && in ? x0 : 0.f)) : 0.f;
+    for (int t = 0; t < TJ; ++t) {
+        const int j = min(jw + JW * t, JT - 1) * 16 + i16;  // (a slot past the last tile recomputes it; not stored)
+        const bool jv = j < J - 1;
+        const int ci = jv ? j / 9 : 0, tap = jv ? j - ci * 9 : 4;
+        joff[t] = ci * IB * PP + (tap / 3 - 1) * (W + 2) + (tap % 3 - 1);
+        jbias[t] = j == J - 1;
+    }
+    int ppos[SPI];
+#pragma unroll
+    for (int sidx = 0; sidx < SPI; ++sidx) {
+        const int p = sidx * 4 + q;
+        ppos[sidx] = p < P ? (p / W + 1) * (W + 2) + p % W + 1 : (W + 2) + 1;
+    }
+    v4f acc[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) acc[t] = vzero();
+
+    // Staging in two phases (as conv_mfma_kernel): issue() puts all the loads of a batch of IB images in flight
+    // -- 16-byte loads on the contiguous runs (an image's Cin*P floats, a tile's 16*P floats); the 11x11 layer's
+    // observations are neither contiguous across images nor 16-byte aligned and go element-wise -- and
+    // commit() scatters them into LDS.  The next batch is issued before this batch's MFMAs.
+    constexpr bool kVecX = H != 11;
+    constexpr int XE = IB * Cin * P, DE = IB * 16 * P;           // elements of a full batch (DE is a multiple of 4)
+    constexpr int NX = kVecX ? (XE / 4 + 255) / 256 : (XE + 255) / 256, ND = (DE / 4 + 255) / 256;
+    v4f xv[kVecX ? NX : 1], dv[ND];
+    float xsc[kVecX ? 1 : NX];
+    auto issue = [&](int base, int nimg) {
+        if constexpr (kVecX) {
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int e = (tid + u * 256) * 4;
+                const int im = e / (Cin * P), r = e - im * (Cin * P);
+                const bool ok = e < XE && im < nimg;
+                xv[u] = *reinterpret_cast<const v4f*>(x + (ok ? (long)(base + im) * (Cin * P) + r : 0));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int e = tid + u * 256;
+                const int im = e / (Cin * P), r = e - im * (Cin * P);
+                const bool ok = e < XE && im < nimg;
+                const int img = base + (ok ? im : 0), n = img / B, b = img - n * B;
+                xsc[u] = x[n * x_sn + b * x_sb + (ok ? r : 0)];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = mfma16(av[u], bv[u], acc);
+        for (int u = 0; u < ND; ++u) {
+            const int e = (tid + u * 256) * 4;
+            const int im = e / (16 * P), r = e - im * (16 * P);
+            const bool ok = e < DE && im < nimg;
+            dv[u] = *reinterpret_cast<const v4f*>(dy + (ok ? ((long)(base + im) * Cout + co0) * P + r : 0));
+        }
+    };
+    auto commit = [&](int nimg) {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = kVecX ? (tid + u * 256) * 4 : tid + u * 256;
+            const int im = e / (Cin * P), r = e - im * (Cin * P);
+            if (e < XE && im < nimg) {
+#pragma unroll
+                for (int k = 0; k < (kVecX ? 4 : 1); ++k) {
+                    const int ci = (r + k) / P, p = (r + k) - ci * P;
+                    float v;
+                    if constexpr (kVecX) v = xv[u][k];
+                    else v = xsc[u];
+                    xs[(ci * IB + im) * PP + (p / W + 1) * (W + 2) + p % W + 1] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int e = (tid + u * 256) * 4;
+            const int im = e / (16 * P), r = e - im * (16 * P);
+            if (e < DE && im < nimg) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = (r + k) / P, p = (r + k) - i * P;
+                    dys[i * dstride + im * P4 + p] = dv[u][k];
+                }
+            }
+        }
+    };
+
+    const int img0 = split * imgs_per_split, img1 = min(NB, img0 + imgs_per_split);
+    issue(img0, min(IB, img1 - img0));
+    for (int i = tid; i < Cin * IB * PP + 16 * dstride; i += 256) xs[i] = 0.f;   // borders and tails stay zero
+    __syncthreads();
+    commit(min(IB, img1 - img0));
+    __syncthreads();
+    for (int base = img0; base < img1; base += IB) {
+        const int nimg = min(IB, img1 - base);
+        const int nnext = min(IB, img1 - base - IB);             // (<= 0: this is the last batch)
+        if (nnext > 0) issue(base + IB, nnext);
+        for (int im = kw; im < nimg; im += KW) {                 // no branches inside: the reads batch up
+            const float* xi = xs + im * PP;
+            const float* di = dys + i16 * dstride + im * P4 + q;
+#pragma unroll
+            for (int sidx = 0; sidx < SPI; ++sidx) {
+                const float a = di[sidx * 4];
+#pragma unroll
+                for (int t = 0; t < TJ; ++t) {
+                    const float bx = xi[joff[t] + ppos[sidx]];
+                    acc[t] = mfma16(a, jbias[t] ? 1.f : bx, acc[t]);
+                }
+            }
+        }
+        if (nnext > 0) {
+            __syncthreads();                                     // every wave is done reading this batch
+            commit(nnext);
+            __syncthreads();
+        }
     }
     // D register r of lane l: D[i = 4 q + r][j = l & 15]
-    float* o = wpart + ((long)split * Cout + co0 + 4 * q) * J16 + j0 + i16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[(long)r * J16] = acc[r];
+    for (int t = 0; t < TJ; ++t) {
+        const int jt = jw + JW * t;
+        if (jt < JT) {
+            float* o = wpart + ((long)(split * KW + kw) * Cout + co0 + 4 * q) * J16 + jt * 16 + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(long)r * J16] = acc[t][r];
+        }
+    }
 }
 
 // sum the splits: 8 lanes per output element each add every 8th split (in order), then the 8 partial sums
@@ -496,78 +735,90 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 // Workspace (floats), for N agents and B samples per agent:
 //   per layer l: y_l [N*B*Cout*P] | x_{l+1} [N*B*Cout*Po] | stat_l [N*Cout*4]
 //   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz (largest y) | dxa, dxb
-//            (gradients w.r.t. layer inputs, ping-pong) | coef [N*128*4] | wpart
+//            (gradients w.r.t. layer inputs, ping-pong) | coef (per-agent BN-backward sums) | wpart
 struct TrainWs {
     size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers], wtb[kTrainLayers];
     size_t part, dz, dxa, dxb, coef, wpart, total;
-    int chunks[kTrainLayers], nsplit[kTrainLayers], ips[kTrainLayers], jt[kTrainLayers];
+    int chunks[kTrainLayers];
+    // conv_wgrad_kernel: image splits, images per split, images per LDS batch, j tiles, K groups per workgroup
+    int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
 };
 
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
     size_t o = 0, max_y = 0, max_part = 0, max_x = 0, max_wp = 0;
+    // every region starts on a 16-byte boundary (the kernels use 16-byte loads on image runs and packs)
+    auto take = [&o](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
     const size_t NB = (size_t)N * B;
     for (int l = 0; l < kTrainLayers; ++l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W, Po = d.pool ? (d.H / 2) * (d.W / 2) : P;
-        w.y[l] = o; o += NB * d.Cout * P;
-        w.xn[l] = o; o += NB * d.Cout * Po;
-        w.stat[l] = o; o += (size_t)N * d.Cout * 4;
-        w.wt[l] = o; o += (size_t)d.Cin * d.Cout * 9;
-        w.wtb[l] = o; o += (size_t)d.Cin * d.Cout * 9;
+        w.y[l] = take(NB * d.Cout * P);
+        w.xn[l] = take(NB * d.Cout * Po);
+        w.stat[l] = take((size_t)N * d.Cout * 4);
+        w.wt[l] = take(conv_pack_floats(l, false));
+        w.wtb[l] = take(conv_pack_floats(l, true));
         w.chunks[l] = (B * P + 63) / 64;
         max_y = max_y > NB * d.Cout * P ? max_y : NB * d.Cout * P;
         const int cmax = w.chunks[l] > B ? w.chunks[l] : B;          // column chunks (BN backward) vs image chunks (conv)
         const size_t pp = (size_t)N * cmax * d.Cout * 2;
         max_part = max_part > pp ? max_part : pp;
         max_x = max_x > NB * d.Cin * P ? max_x : NB * d.Cin * P;
-        // weight-gradient splits: enough waves to fill the chip, at least one image per split
+        // weight-gradient splits: ~320 workgroups per layer (one per 16 output channels and image range)
         w.jt[l] = (d.Cin * 9 + 1 + 15) / 16;
-        const int tiles = (d.Cout / 16) * w.jt[l];
-        int ns = (8192 + tiles - 1) / tiles;               // ~8 waves per SIMD: the K loop is latency bound
-        if (ns > kWgSplitMax) ns = kWgSplitMax;
+        w.kw[l] = w.jt[l] <= 2 ? 2 : 1;
+        int ns = (320 + d.Cout / 16 - 1) / (d.Cout / 16);
         if ((size_t)ns > NB) ns = (int)NB;
         w.ips[l] = (int)((NB + ns - 1) / ns);
         w.nsplit[l] = (int)((NB + w.ips[l] - 1) / w.ips[l]);
-        const size_t wp = (size_t)w.nsplit[l] * d.Cout * w.jt[l] * 16;
+        w.ib[l] = wgrad_ib(d.H);                           // LDS: [Cin][IB][(H+2)(W+2)] + [16][IB*P4] floats <= 64 KB
+        const size_t wp = (size_t)w.nsplit[l] * w.kw[l] * d.Cout * w.jt[l] * 16;
         max_wp = max_wp > wp ? max_wp : wp;
     }
-    w.part = o; o += max_part;
-    w.dz = o; o += max_y;
-    w.dxa = o; o += max_x;
-    w.dxb = o; o += max_x;
-    w.coef = o; o += (size_t)N * 128 * 6;            // coefficients [N][128][4] + per-agent sums [N][128][2]
-    w.wpart = o; o += max_wp;
+    w.part = take(max_part);
+    w.dz = take(max_y);
+    w.dxa = take(max_x);
+    w.dxb = take(max_x);
+    w.coef = take((size_t)kTrainLayers * N * 128 * 2);   // per-agent sums of the BN backward, [layer][N][128][2]
+    w.wpart = take(max_wp);
     w.total = o;
     return w;
 }
 
 static inline bool launched_ok() { return hipGetLastError() == hipSuccess; }
 
-// Which convolution kernel serves a layer: the 11x11 first layer (3 input channels, 77 440 columns at B = 64,
-// N = 10) keeps one lane per COLUMN with 16 channels in registers; the 5x5 and 2x2 layers (and their input
-// gradients) put one lane per CHANNEL.  Returns the number of per-agent partial-sum chunks it writes.
-static int conv_chunks(int l, int B) {
-    const TrainLayerDims d = train_layer(l);
-    if (l == 0) return (B * d.H * d.W + 63) / 64;
-    return d.H == 5 ? B : (B + 3) / 4;
+// per-agent partial-sum chunks the forward convolution of layer l writes (= its workgroups per agent)
+static int conv_chunks(int l, int B) { return conv_geom(l, false, B).chunks_per_agent; }
+
+static void conv_launch(int l, bool input_grad, const float* x, const float* wpack, const float* bias, float* y,
+                        float* part, int N, int B, long sn, long sb, hipStream_t st) {
+    const ConvGeom g = conv_geom(l, input_grad, B);
+    const dim3 grid(N * g.chunks_per_agent, g.M / 16);
+    const size_t smem = ((size_t)g.SPC * 64 + (size_t)g.CC * g.IB * (g.TAPS == 1 ? 1 : (g.H + 2) * (g.W + 2))) *
+                        sizeof(float);
+#define GNNPP_CONV(HH, WW)                                                                                     \
+    hipLaunchKernelGGL((conv_mfma_kernel<HH, WW>), grid, dim3(256), smem, st, x, wpack, bias, y, part, B, g.Ck, \
+                       g.M, sn, sb, g.chunks_per_agent, g.nchunk)
+    if (g.H == 11) GNNPP_CONV(11, 11);
+    else if (g.H == 5) GNNPP_CONV(5, 5);
+    else GNNPP_CONV(1, 1);
+#undef GNNPP_CONV
 }
 
-static void conv_launch(int l, bool input_grad, const float* x, const float* wk, const float* bias, float* y,
-                        float* part, int N, int B, long sn, long sb, hipStream_t st) {
+static void wgrad_launch(int l, const TrainWs& L, const float* x, const float* dy, float* wpart, int NB, long sn,
+                         long sb, int B, hipStream_t st) {
     const TrainLayerDims d = train_layer(l);
-    const int Cin = input_grad ? d.Cout : d.Cin, Cout = input_grad ? d.Cin : d.Cout;
-    const int chunks = conv_chunks(l, B);
-    if (l == 0) {
-        hipLaunchKernelGGL((conv_cols_kernel<16>), dim3(N * chunks, Cout / 16), dim3(64), 0, st, x, wk, bias, y,
-                           part, B, Cin, Cout, d.H, d.W, sn, sb, chunks);
-    } else if (d.H == 5) {
-        hipLaunchKernelGGL((conv_ch_kernel<5, 5, 1>), dim3(N * chunks, (Cout + 63) / 64), dim3(64), 0, st, x, wk,
-                           bias, y, part, B, Cin, Cout, sn, sb, chunks);
-    } else {
-        hipLaunchKernelGGL((conv_ch_kernel<2, 2, 4>), dim3(N * chunks, (Cout + 63) / 64), dim3(64), 0, st, x, wk,
-                           bias, y, part, B, Cin, Cout, sn, sb, chunks);
-    }
+    const int P = d.H * d.W, PP = (d.H + 2) * (d.W + 2), P4 = (P + 3) / 4 * 4;
+    const int IB = L.ib[l], dstride = ((IB * P4 + 63) / 64) * 64 + 4;
+    const size_t smem = ((size_t)d.Cin * IB * PP + 16 * (size_t)dstride) * sizeof(float);
+    const dim3 grid(d.Cout / 16, L.nsplit[l]);
+#define GNNPP_WGRAD(HH, WW, CI, TJ, KW)                                                                       \
+    hipLaunchKernelGGL((conv_wgrad_kernel<HH, WW, CI, TJ, KW>), grid, dim3(256), smem, st, x, dy, wpart, NB,    \
+                       d.Cout, sn, sb, B, L.ips[l], L.jt[l])
+    if (l == 0) GNNPP_WGRAD(11, 11, 3, 1, 2);
+    else if (d.H == 5) GNNPP_WGRAD(5, 5, 32, 5, 1);
+    else GNNPP_WGRAD(2, 2, 64, 10, 1);
+#undef GNNPP_WGRAD
 }
 
 // obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128]
@@ -580,20 +831,19 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l]; pk.c[l] = ws + L.wtb[l];
         run.a[l] = ws + L.stat[l]; run.b[l] = rmean ? rmean[l] : nullptr; run.c[l] = rvar ? rvar[l] : nullptr;
     }
-    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(32, kTrainLayers), dim3(256), 0, st, pk);
+    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(32, 2 * kTrainLayers), dim3(256), 0, st, pk);
     for (int l = 0; l < kTrainLayers; ++l) {
         const TrainLayerDims d = train_layer(l);
-        const int P = d.H * d.W, Po = d.pool ? (d.H / 2) * (d.W / 2) : P;
+        const int P = d.H * d.W;
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
         conv_launch(l, false, xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, sn, sb, st);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
-                           conv_chunks(l, B), d.Cout, B * P, rp.bn_eps);
-        const long tot = NB * d.Cout * Po;
-        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
-                           dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
-                           l == kTrainLayers - 1 ? feat : ws + L.xn[l], tot, B, d.Cout, d.H, d.W, d.pool);
+        const BnTile t = bn_tile(l);
+        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N), dim3(256), kBnSmem, st,
+                           ws + L.y[l], ws + L.part, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
+                           l == kTrainLayers - 1 ? feat : ws + L.xn[l], B, d.Cout, d.H, d.W, d.pool,
+                           conv_chunks(l, B), t.CG, t.BR, rp.bn_eps);
     }
     if (rmean && rvar)
         hipLaunchKernelGGL(bn_running_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, run, N, momentum);
@@ -608,6 +858,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     const long NB = (long)N * B;
     const float* dxn = dfeat;
     float* dx_buf[2] = {ws + L.dxa, ws + L.dxb};
+    TrainPtrs5 dp = {};
     for (int l = kTrainLayers - 1; l >= 0; --l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
@@ -615,21 +866,19 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(N * L.chunks[l], d.Cout / kBnBwdCG), dim3(64), 0, st,
                            ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B,
                            d.Cout, d.H, d.W, d.pool, L.chunks[l]);
-        hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(N), dim3(128), 0, st, ws + L.part, ws + L.stat[l],
-                           rp.bn_w[l], ws + L.coef, ws + L.coef + (size_t)N * 128 * 4, L.chunks[l], d.Cout, B * P);
-        hipLaunchKernelGGL(bn_bwd_dparam_kernel, dim3(1), dim3(128), 0, st, ws + L.coef + (size_t)N * 128 * 4,
-                           dbn_w[l], dbn_b[l], N, d.Cout);
-        const long tot = NB * d.Cout * P;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048)),
-                           dim3(256), 0, st, ws + L.y[l], ws + L.stat[l], ws + L.coef, dz, tot, B, d.Cout, P);
+        const BnTile t = bn_tile(l);
+        float* pn = ws + L.coef + (size_t)l * N * 128 * 2;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N), dim3(256), kBnSmem, st,
+                           ws + L.y[l], ws + L.stat[l], ws + L.part, rp.bn_w[l], dz, pn, B, d.Cout, P, L.chunks[l],
+                           t.CG, t.BR);
+        dp.a[l] = pn; dp.b[l] = dbn_w[l]; dp.c[l] = dbn_b[l];
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(d.Cout / 16, L.jt[l], L.nsplit[l]), dim3(64), 0, st, xin, dz,
-                           ws + L.wpart, (int)NB, d.Cin, d.Cout, d.H, d.W, sn, sb, B, L.ips[l]);
+        wgrad_launch(l, L, xin, dz, ws + L.wpart, (int)NB, sn, sb, B, st);
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((d.Cout * (d.Cin * 9 + 1) + 31) / 32), dim3(256),
-                           256 * sizeof(float), st, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l], d.Cin,
-                           d.Cout, L.jt[l] * 16);
+                           256 * sizeof(float), st, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l] * L.kw[l],
+                           d.Cin, d.Cout, L.jt[l] * 16);
         if (l > 0) {
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
@@ -639,6 +888,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
             dxn = dx;
         }
     }
+    hipLaunchKernelGGL(bn_bwd_dparam_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, dp, N);
     return launched_ok() ? 0 : -3;
 }
 

@@ -97,6 +97,59 @@ class _EncoderTrainFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _LinearFunction(torch.autograd.Function):
+    """y = x W^T + b for x [..., I] with a handful of hundred rows (compressMLP, the action head in train
+    mode).  Forward is the library GEMM; the backward's three products are "small output, long or short
+    contraction" shapes that a library GEMM serves with one macro tile -- they run on gnnpp_gemm_kmajor
+    (contraction split over workgroups, deterministic):  dx = dy W,  dW = dy^T x,  db = 1^T dy."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.nn.functional.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        O, I = W.shape
+        dy2 = dy.reshape(-1, O).contiguous().float()
+        x2 = x.detach().reshape(-1, I).contiguous().float()
+        R = dy2.shape[0]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(R, I, dtype=torch.float32, device=dy.device)
+            _native.gemm_kmajor(dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O)
+            dx = dx.reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(O, I, dtype=torch.float32, device=dy.device)
+            _native.gemm_kmajor(dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R)
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(O, dtype=torch.float32, device=dy.device)
+            _native.gemm_kmajor(_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R)
+        return dx, dW, db
+
+
+_ones_cache = {}
+
+
+def _ones(n, device):
+    key = (str(device), n)
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ones_cache[key]
+
+
+class LogitList(list):
+    """The reference's return value -- a python list of N tensors [B,5] -- built as the N views of ONE
+    tensor [N,B,5], which stays reachable as .stacked.  Autograd sees one unbind (its backward is one
+    concatenation) instead of N selects (N x zero-fill + copy + accumulate per step), and
+    training.policy_loss() takes .stacked directly instead of re-stacking the list."""
+
+    def __init__(self, stacked):
+        super().__init__(stacked.unbind(0))
+        self.stacked = stacked
+
+
 class DecentralPlannerNet(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -303,7 +356,7 @@ class DecentralPlannerNet(nn.Module):
         """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
         contiguous [B,5] block) -- what forward() unbinds into the reference's list."""
         if self.training:
-            return torch.stack(self._forward_train(inputTensor), 0)
+            return self._forward_train(inputTensor)
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
         logits = self._forward_eval(inputTensor)
@@ -422,13 +475,12 @@ class DecentralPlannerNet(nn.Module):
                 for bi in _BN_IDX:
                     self.ConvLayers[bi].num_batches_tracked.add_(N)
         fc = self.compressMLP[0]
-        comp = tF.relu(tF.linear(feat, fc.weight, fc.bias))                             # [N,B,F]
+        comp = tF.relu(_LinearFunction.apply(feat, fc.weight, fc.bias))                 # [N,B,F]
         for l in range(self.L):
             self.GFL[2 * l].addGSO(self.S)
         shared = self.GFL(comp.permute(1, 2, 0).contiguous())       # [B,F,N]: HIP filter fwd/bwd + ReLU
         act = self.actionsMLP[0]
-        logits = tF.linear(shared.permute(0, 2, 1), act.weight, act.bias)               # B x N x 5
-        return [logits[:, n] for n in range(N)]
+        return _LinearFunction.apply(shared.permute(2, 0, 1), act.weight, act.bias)     # [N,B,5]
 
     def _forward_train_aten(self, inputTensor):
         """The same train-mode forward on stock aten / MIOpen ops (agents as convolution groups).  NOT
@@ -463,7 +515,7 @@ class DecentralPlannerNet(nn.Module):
     def forward(self, inputTensor):
         """[B,N,3,11,11] -> python list of N tensors [B,5] (decentralplanner.py:278-318)."""
         if self.training:
-            return self._forward_train(inputTensor)
+            return LogitList(self._forward_train(inputTensor))
         return list(self.forward_logits(inputTensor).unbind(0))
 
     def decode_actions(self, logits):

@@ -142,9 +142,12 @@ class _LSIGFFunction(torch.autograd.Function):
                                transposed=True)
         if ctx.needs_input_grad[0]:
             dyp = dy if ctx.Nin == N else torch.nn.functional.pad(dy, (0, N - ctx.Nin))
-            dy2 = dyp.permute(1, 0, 2).reshape(F_out, B * N)             # [F, B*N]
-            dh = torch.matmul(dy2.unsqueeze(0), zs)                      # [E*K, F, G]
-            dh = dh.reshape(E, K, F_out, G).permute(2, 0, 1, 3).contiguous()
+            dy2 = dyp.permute(1, 0, 2).reshape(F_out, B * N)             # [F, B*N] (one copy)
+            # dh[f,e,k,g] = sum_(b,n) dy2[f,(b,n)] zs[(e,k),(b,n),g]: E*K small GEMMs with a long contraction,
+            # split over workgroups by gnnpp_gemm_kmajor and written straight into the [F,E,K,G] layout
+            dh = torch.empty(F_out, E, K, G, dtype=torch.float32, device=dy.device)
+            _native.gemm_kmajor(dy2, (0, B * N, 1), zs, (B * N * G, G), dh, (G, E * K * G), E * K, F_out, G,
+                                B * N)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
                 db = dy.sum(dim=(0, 2)).reshape(ctx.bias_shape)

@@ -10,6 +10,8 @@
                   local afterwards (each rank sees its own shard, like torch DDP without SyncBN).
 The reference has no distributed code at all; this is the build's addition.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as tF
@@ -17,14 +19,98 @@ import torch.nn.functional as tF
 from . import _native
 
 
+class _PolicyLossFunction(torch.autograd.Function):
+    """gnnpp_policy_loss: the loss and d loss / d logits in one launch (one workgroup, fixed-order sums)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        N, B, C = logits.shape
+        lg = logits.detach().contiguous().float()
+        tg = target.detach().contiguous().float()
+        dev = _native.require_gpu(lg, tg)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dlogits = torch.empty_like(lg)
+        with _native.device_guard(dev):
+            _native.check(_native.lib().gnnpp_policy_loss(lg.data_ptr(), tg.data_ptr(), loss.data_ptr(),
+                                                          dlogits.data_ptr(), B, N, C,
+                                                          _native.stream_ptr(dev)), 'gnnpp_policy_loss')
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
 def policy_loss(predict, batch_target):
     """predict: list of N tensors [B,5]; batch_target [B,N,5] one-hot expert actions.
     agents/decentralplannerlocal.py:296-312: loss = (1/N) sum_n CrossEntropy(predict[n], argmax target[:, n]).
     Every agent's CrossEntropy is a mean over the same B samples, so the mean over agents of the means is
     the mean over all N*B rows: ONE batched cross-entropy instead of N (10 x fewer launches per step)."""
-    logits = torch.stack(predict, dim=0)                                   # [N,B,5]
+    logits = getattr(predict, 'stacked', None)                             # [N,B,5] (decentralplanner.LogitList)
+    if logits is None:
+        logits = torch.stack(list(predict), dim=0)
     labels = batch_target.permute(1, 0, 2).argmax(-1)                      # [N,B]: torch.max(.,1)[1], first maximum
     return tF.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
+
+
+def policy_loss_fused(predict, batch_target):
+    """policy_loss() on one HIP launch (forward and backward together); same value, same gradient."""
+    logits = getattr(predict, 'stacked', None)
+    if logits is None:
+        logits = torch.stack(list(predict), dim=0)
+    return _PolicyLossFunction.apply(logits, batch_target)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) (amsgrad=False) on gnnpp_adam_step: ONE launch
+    (plus a one-thread tick of the device-side step counter) for up to 32 parameter tensors instead of the
+    eight multi-tensor passes of the stock implementation; graph-capturable (nothing is read on the host).
+    The reference builds optim.Adam(lr, weight_decay) (agents/decentralplannerlocal.py:77-79); the update
+    rule is the same, the results agree to rounding (tests/test_gpu_training.py)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _native.lib()
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            dev = _native.require_gpu(*ps)
+            st = self.state.setdefault('gnnpp_%d' % id(group), {})
+            if 'counter' not in st:
+                st['counter'] = torch.zeros(3, dtype=torch.float32, device=dev)
+            for p in ps:
+                s = self.state[p]
+                if 'exp_avg' not in s:
+                    assert p.dtype is torch.float32 and p.is_contiguous()
+                    s['exp_avg'] = torch.zeros_like(p)
+                    s['exp_avg_sq'] = torch.zeros_like(p)
+            b1, b2 = group['betas']
+            with _native.device_guard(dev):
+                for i0 in range(0, len(ps), 32):
+                    chunk = ps[i0:i0 + 32]
+                    tb = _native.AdamTensors()
+                    for i, p in enumerate(chunk):
+                        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                        tb.p[i], tb.g[i] = p.data_ptr(), g.data_ptr()
+                        tb.m[i], tb.v[i] = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
+                        tb.numel[i] = p.numel()
+                    tb.count = len(chunk)
+                    _native.check(L.gnnpp_adam_step(ctypes.byref(tb), st['counter'].data_ptr(), group['lr'], b1, b2,
+                                                    group['eps'], group['weight_decay'], int(i0 == 0),
+                                                    _native.stream_ptr(dev)), 'gnnpp_adam_step')
+        # the parameters changed behind torch's version counters: packed / BN-folded copies are stale
+        _native.invalidate_packs()
+        return loss
 
 
 def train_step(model, optimizer, batch_input, batch_target, batch_GSO, dp=None):
@@ -32,7 +118,8 @@ def train_step(model, optimizer, batch_input, batch_target, batch_GSO, dp=None):
     optimizer.zero_grad()
     model.addGSO(batch_GSO)
     predict = model(batch_input)
-    loss = policy_loss(predict, batch_target)
+    on_gpu = getattr(predict, 'stacked', None) is not None and predict.stacked.is_cuda
+    loss = (policy_loss_fused if on_gpu else policy_loss)(predict, batch_target)
     loss.backward()
     if dp is not None:
         dp.reduce_gradients()

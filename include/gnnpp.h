@@ -184,6 +184,45 @@ int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, flo
                             const float* dfeat, const gnnpp_encoder_grads* g, int B, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The rest of the optimisation step of config 4 (agents/decentralplannerlocal.py:287-317): the weight
+ * gradients that are tall-contraction GEMMs, the loss, and the Adam update.  fp32, deterministic.
+ * ------------------------------------------------------------------------------------------ */
+/* C[b][m][n] = sum_k A_b(m,k) * B_b(k,n), b < batch, with element addresses
+ *   A_b(m,k) = A + b*a_sb + m*a_sm + k*a_sk,   B_b(k,n) = B + b*b_sb + k*b_sk + n,   C_b(m,n) = C + b*c_sb + m*c_sm + n
+ * (strides in floats).  The contraction is split over workgroups (fp32 MFMA) and the partial results are
+ * summed in order: meant for small M x N (<= a few hundred) and long K, where a library GEMM runs on one
+ * macro tile.  Serves the graph filter's tap gradient dh (graphML.py:2345-2352 backwards: A = dy [F,(b n)],
+ * B = the saved shifted signals z_k [(b n),G], batch = E*K) and Linear weight gradients (A = dY^T, B = X).
+ * workspace: gnnpp_gemm_workspace_floats(batch, M, N, K) floats (may be 0 -> NULL allowed). */
+size_t gnnpp_gemm_workspace_floats(int batch, int M, int N, int K);
+int gnnpp_gemm_kmajor(const float* A, long long a_sb, long long a_sm, long long a_sk, const float* B,
+                      long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int batch,
+                      int M, int N, int K, float* workspace, void* stream);
+
+/* The training loop's loss (agents/decentralplannerlocal.py:296-312), forward and backward in one launch:
+ *   logits [N,B,C] (agent-major: the list forward() returns, stacked), target [B,N,C] one-hot expert actions;
+ *   loss[0] = (1/N) sum_n CrossEntropyLoss(logits[n], argmax_c target[:, n])   (first maximum, like torch.max);
+ *   dlogits [N,B,C] = d loss / d logits, or NULL.  C <= 64. */
+int gnnpp_policy_loss(const float* logits, const float* target, float* loss, float* dlogits, int B, int N,
+                      int C, void* stream);
+
+/* torch.optim.Adam's update (amsgrad = False; L2 weight decay added to the gradient; bias correction) of up
+ * to 32 tensors in one launch:  p, m (exp_avg), v (exp_avg_sq) are updated in place from g.
+ *   state  3 floats on the device: state[0] = number of steps taken so far (start at 0), [1], [2] scratch;
+ *   tick   != 0: advance state[0] first (pass 1 for the first table of a step, 0 for further tables of the
+ *          same step).  The counter lives on the device so that the call can be captured in a HIP graph. */
+typedef struct gnnpp_adam_tensors {
+    float* p[32];
+    const float* g[32];
+    float* m[32];
+    float* v[32];
+    long long numel[32];
+    int count;
+} gnnpp_adam_tensors;
+int gnnpp_adam_step(const gnnpp_adam_tensors* t, float* state, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int tick, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole policy step: DecentralPlannerNet.addGSO + forward (decentralplanner.py:266-318):
  * encoder -> GraphFilterBatch(128,128,K,E=1) -> ReLU -> actionsMLP Linear(128,5).
  * ------------------------------------------------------------------------------------------ */

@@ -102,3 +102,90 @@ def test_emu_train_encoder_forward_backward(N, B, seed):
         # conv biases in front of train-mode BatchNorm: exactly zero in exact arithmetic, roundoff on both sides
         tol = 2e-4 * scale + (2e-4 if ('bias' in key and int(key.split('.')[1]) in CONV) else 1e-6)
         assert np.isfinite(o).all() and np.abs(o - want).max() <= tol, (key, np.abs(o - want).max(), scale)
+
+
+class AdamTensors(ctypes.Structure):
+    _fields_ = [('p', ctypes.c_void_p * 32), ('g', ctypes.c_void_p * 32), ('m', ctypes.c_void_p * 32),
+                ('v', ctypes.c_void_p * 32), ('numel', ctypes.c_longlong * 32), ('count', ctypes.c_int)]
+
+
+@pytest.mark.parametrize('batch,M,N,K', [(3, 128, 128, 70), (1, 5, 128, 33), (1, 1, 40, 57), (2, 70, 20, 300)])
+def test_emu_gemm_kmajor(batch, M, N, K):
+    """gnnpp_gemm_kmajor (split contraction, ordered partial sums) against numpy, strided operands included:
+    the first case is the graph filter's tap gradient written straight into the [F,E,K,G] layout."""
+    import emu_lib as el
+    lib = el.load()
+    lib.gnnpp_gemm_workspace_floats.restype = ctypes.c_size_t
+    ll = ctypes.c_longlong
+    rng = np.random.default_rng(batch * 1000 + M)
+    A = rng.standard_normal((M, K)).astype(np.float32)              # shared by every batch entry (a_sb = 0)
+    Bm = rng.standard_normal((batch, K, N)).astype(np.float32)
+    C = np.full((M, batch, N), np.nan, np.float32)                  # C_b(m,n) at m*batch*N + b*N + n
+    nws = lib.gnnpp_gemm_workspace_floats(batch, M, N, K)
+    ws = np.zeros(max(nws, 1), np.float32)
+    rc = lib.gnnpp_gemm_kmajor(el.ptr(A), ll(0), ll(K), ll(1), el.ptr(Bm), ll(K * N), ll(N), el.ptr(C), ll(N),
+                               ll(batch * N), batch, M, N, K, el.ptr(ws), None)
+    assert rc == 0
+    want = np.einsum('mk,bkn->mbn', A.astype(np.float64), Bm.astype(np.float64))
+    np.testing.assert_allclose(C, want, rtol=0, atol=2e-5 * np.sqrt(K))
+    # transposed A (the Linear weight gradient dW = dY^T X: A(m,k) = dY[k][m])
+    dY = rng.standard_normal((K, M)).astype(np.float32)
+    C2 = np.full((M, N), np.nan, np.float32)
+    rc = lib.gnnpp_gemm_kmajor(el.ptr(dY), ll(0), ll(1), ll(M), el.ptr(Bm[0]), ll(0), ll(N), el.ptr(C2), ll(0),
+                               ll(N), 1, M, N, K, el.ptr(ws), None)
+    assert rc == 0
+    np.testing.assert_allclose(C2, dY.astype(np.float64).T @ Bm[0].astype(np.float64), rtol=0,
+                               atol=2e-5 * np.sqrt(K))
+
+
+@pytest.mark.parametrize('B,N', [(3, 2), (64, 10), (130, 9)])
+def test_emu_policy_loss(B, N):
+    """gnnpp_policy_loss == mean over agents of torch CrossEntropyLoss on argmax labels, and its gradient
+    (agents/decentralplannerlocal.py:296-312); ties in the target resolve to the first maximum."""
+    import emu_lib as el
+    import torch.nn.functional as tF
+    lib = el.load()
+    g = torch.Generator().manual_seed(B + N)
+    logits = (3 * torch.randn(N, B, 5, generator=g)).requires_grad_(True)
+    labels = torch.randint(0, 5, (B, N), generator=g)
+    target = tF.one_hot(labels, 5).float()
+    target[0, 0] = 0.0                                             # an all-equal row: label 0
+    labels[0, 0] = 0
+    loss = sum(tF.cross_entropy(logits[n], labels[:, n]) for n in range(N)) / N
+    loss.backward()
+    lg = el.f32(logits.detach().numpy()); tg = el.f32(target.numpy())
+    out = np.zeros(1, np.float32); dl = np.full_like(lg, np.nan)
+    assert lib.gnnpp_policy_loss(el.ptr(lg), el.ptr(tg), el.ptr(out), el.ptr(dl), B, N, 5, None) == 0
+    assert abs(out[0] - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+    np.testing.assert_allclose(dl, logits.grad.numpy(), rtol=0, atol=2e-7)
+
+
+def test_emu_adam_matches_torch():
+    """gnnpp_adam_step against torch.optim.Adam (L2 weight decay, bias correction) over several steps and
+    tensors of ragged sizes (one launch covers them all; the step counter lives in `state`)."""
+    import emu_lib as el
+    lib = el.load()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(32, 3, 3, 3), (32,), (128, 128), (5,), (1030,)]
+    ps = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    opt = torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-5)
+    mine = [el.f32(p.detach().numpy().copy()) for p in ps]
+    m = [np.zeros_like(a) for a in mine]; v = [np.zeros_like(a) for a in mine]
+    state = np.zeros(3, np.float32)
+    cf = ctypes.c_float
+    for it in range(4):
+        grads = [torch.randn(*s, generator=g) for s in shapes]
+        for p, gr in zip(ps, grads):
+            p.grad = gr.clone()
+        opt.step()
+        gn = [el.f32(gr.numpy()) for gr in grads]
+        tb = AdamTensors()
+        for i in range(len(ps)):
+            tb.p[i], tb.g[i], tb.m[i], tb.v[i] = mine[i].ctypes.data, gn[i].ctypes.data, m[i].ctypes.data, v[i].ctypes.data
+            tb.numel[i] = mine[i].size
+        tb.count = len(ps)
+        rc = lib.gnnpp_adam_step(ctypes.byref(tb), el.ptr(state), cf(1e-3), cf(0.9), cf(0.999), cf(1e-8), cf(1e-5),
+                                 1, None)
+        assert rc == 0 and state[0] == it + 1
+        for a, p in zip(mine, ps):
+            np.testing.assert_allclose(a, p.detach().numpy(), rtol=0, atol=3e-7)

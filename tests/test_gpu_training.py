@@ -318,3 +318,82 @@ def test_hip_training_encoder_matches_aten_path(dev, B, N):
         orc.policy_forward(sd2, S.cpu(), obs.cpu(), training=True)
     for k, v in r0.items():
         assert (v - sd2[k]).abs().max().item() <= 2e-5, k
+
+
+def test_fused_adam_and_loss_match_torch(dev):
+    """The one-launch pieces of the optimisation step against stock torch on the same model and batches:
+    policy_loss_fused == policy_loss (value and gradient of every parameter), and FusedAdam (gnnpp_adam_step)
+    tracks torch.optim.Adam(lr, weight_decay) over several steps."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet, LogitList
+    from gnn_pathplanning_amd.training import FusedAdam, policy_loss, policy_loss_fused
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    B = 24
+    obs = orc.synth_obs(B, 10, seed=8).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, 10, 20, seed=8)).float().to(dev)
+    g = torch.Generator().manual_seed(4)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, 10), generator=g), 5).float().to(dev)
+    torch.manual_seed(5)
+    net_a = DecentralPlannerNet(Cfg()).to(dev).train()
+    net_b = DecentralPlannerNet(Cfg()).to(dev).train()
+    net_b.load_state_dict(net_a.state_dict())
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt_b = FusedAdam(net_b.parameters(), lr=1e-3, weight_decay=1e-5)
+    for it in range(5):
+        losses = []
+        for net, opt, lossf in ((net_a, opt_a, policy_loss), (net_b, opt_b, policy_loss_fused)):
+            opt.zero_grad()
+            net.addGSO(S)
+            out = net(obs)
+            assert isinstance(out, LogitList) and len(out) == 10 and out[0].shape == (B, 5)
+            loss = lossf(out, tgt)
+            loss.backward()
+            losses.append(loss.item())
+        assert abs(losses[0] - losses[1]) <= 2e-6 * max(1.0, abs(losses[0])), (it, losses)
+        if it == 0:                                      # identical weights: gradients comparable one to one
+            for (k, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+                assert (pa.grad - pb.grad).abs().max().item() <= 1e-6 + 1e-5 * pa.grad.abs().max().item(), k
+        opt_a.step()
+        opt_b.step()
+    conv_bias = {'ConvLayers.%d.bias' % i for i in (0, 4, 7, 11, 14)}
+    for (k, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        if k in conv_bias:
+            # a bias in front of a train-mode BatchNorm has a gradient of exactly zero: what arrives is rounding
+            # noise (~1e-9), which Adam's normalisation turns into full-size +-lr steps -- two correct
+            # implementations whose last bits differ walk these (inert) parameters apart
+            continue
+        assert (pa - pb).abs().max().item() <= 2e-5, k         # 5 steps of lr 1e-3: updates ~5e-3
+
+
+def test_graphed_train_step_with_fused_adam(dev):
+    """The whole step with FusedAdam captured in a HIP graph (the step counter lives on the device) replays
+    to the same losses as eager steps from the same start."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import FusedAdam, GraphedTrainStep, train_step
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    B = 16
+    batches = []
+    for i in range(6):
+        obs = orc.synth_obs(B, 10, seed=60 + i).to(dev)
+        S = torch.from_numpy(orc.synth_gso_geometric(B, 10, 20, seed=60 + i)).float().to(dev)
+        g = torch.Generator().manual_seed(i)
+        tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, 10), generator=g), 5).float().to(dev)
+        batches.append((obs, tgt, S))
+
+    def make():
+        torch.manual_seed(11)
+        net = DecentralPlannerNet(Cfg()).to(dev).train()
+        return net, FusedAdam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    net_e, opt_e = make()
+    for _ in range(3):                                   # GraphedTrainStep warms up with 3 steps on batch 0
+        train_step(net_e, opt_e, *batches[0])
+    eager = [train_step(net_e, opt_e, *b).item() for b in batches]
+    net_g, opt_g = make()
+    step = GraphedTrainStep(net_g, opt_g, *batches[0])
+    first = step(*batches[0]).item()                     # the capture itself is not a step
+    graphed = [first] + [step(*b).item() for b in batches[1:]]
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (eager, graphed)

@@ -24,9 +24,11 @@ SLOTS = {'move:entry': 0, 'move:state_loaded': 1, 'move:proposed': 2, 'move:pass
 
 
 def stamps(nwg):
-    buf = np.zeros(1024 * 16, np.uint64)
+    buf = np.zeros(1024 * 32, np.uint64)
     assert M.gnnpp_measure_read_stamps(buf.ctypes.data, buf.size) == 0
-    return buf.reshape(1024, 16)[:nwg].astype(np.float64) * 0.01          # microseconds
+    rows = buf.reshape(1024, 32)[:nwg].astype(np.float64)
+    stamps.cycles = rows[:, 16:]                                          # shader clock cycles
+    return rows[:, :16] * 0.01                                            # microseconds (100 MHz wall clock)
 
 
 def report(tag, st, order):
@@ -35,6 +37,8 @@ def report(tag, st, order):
         d = st[:, SLOTS[b]] - st[:, SLOTS[a]]
         row['%s -> %s' % (a, b)] = round(float(np.median(d)), 2)
     row['total'] = round(float(np.median(st[:, SLOTS[order[-1]]] - st[:, SLOTS[order[0]]])), 2)
+    cyc = stamps.cycles[:, SLOTS[order[-1]]] - stamps.cycles[:, SLOTS[order[0]]]
+    row['engine_clock_GHz'] = round(float(np.median(cyc / (st[:, SLOTS[order[-1]]] - st[:, SLOTS[order[0]]]))) * 1e-3, 3)
     print(json.dumps(row), flush=True)
 
 
@@ -79,27 +83,29 @@ for (N, B, W) in ((10, 512, 20), (16, 512, 20)):
             'move:passes', 'move:final_pass', 'move:stored', 'sim:move_done', 'sim:gso_done', 'sim:observe_done'])
 
 
-# ---- where the 40 us of the one-launch POLICY kernel go (C2: 512 graphs of 10 agents, two workgroups per CU)
+# ---- where the 40 us of the one-launch POLICY kernel go (C2: 512 graphs of 10 agents, two workgroups per CU;
+# 256 graphs: one workgroup per CU, the kernel's latency without a neighbour on the CU)
 class Cfg2:
     num_agents, nGraphFilterTaps, device = 10, 3, dev
 net = DecentralPlannerNet(Cfg2()).to(dev).eval()
 net.load_state_dict(orc.init_state_dict(3))
-B, N = 512, 10
-obs = orc.synth_obs(B, N, seed=1337).to(dev)
-S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337)).float().to(dev)
-net.addGSO(S)
-for _ in range(20):
-    net(obs)
-enc, taps, gb, aw, ab, K = net.policy_pointers()
-ws = torch.empty(B * N, 128, device=dev)
-lg = torch.empty(N, B, 5, device=dev)
 M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
-for _ in range(5):
-    assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
-                              B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
-    torch.cuda.synchronize()
 SLOTS.update({'enc:staged': 0, 'enc:L0': 1, 'enc:L1': 2, 'enc:L2': 3, 'enc:L3': 4, 'enc:L4': 5, 'enc:FC(z0)': 12,
               'filter:shifts': 13, 'filter:contraction': 14})
-report('policy kernel C2 (B=512, N=10)', stamps(512),
-       ['kernel:start', 'enc:staged', 'enc:L0', 'enc:L1', 'enc:L2', 'enc:L3', 'enc:L4', 'enc:FC(z0)', 'filter:shifts',
-        'filter:contraction'])
+N = 10
+for B in (512, 256):
+    obs = orc.synth_obs(B, N, seed=1337).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337)).float().to(dev)
+    net.addGSO(S)
+    for _ in range(20):
+        net(obs)
+    enc, taps, gb, aw, ab, K = net.policy_pointers()
+    ws = torch.empty(B * N, 128, device=dev)
+    lg = torch.empty(N, B, 5, device=dev)
+    for _ in range(5):
+        assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
+                                  B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
+        torch.cuda.synchronize()
+    report('policy kernel (B=%d, N=10: %d workgroup(s) per CU)' % (B, B // 256), stamps(B),
+           ['kernel:start', 'enc:staged', 'enc:L0', 'enc:L1', 'enc:L2', 'enc:L3', 'enc:L4', 'enc:FC(z0)',
+            'filter:shifts', 'filter:contraction'])

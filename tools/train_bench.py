@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--graph', action='store_true', help='capture the train step in a HIP graph')
+    ap.add_argument('--adam', choices=('fused', 'torch'), default='fused',
+                    help='optimizer: training.FusedAdam (gnnpp_adam_step) or torch.optim.Adam')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -33,7 +35,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
     from gnn_pathplanning_amd.sharding import aggregate_throughput
-    from gnn_pathplanning_amd.training import FlatBucketDP, train_step
+    from gnn_pathplanning_amd.training import FlatBucketDP, FusedAdam, train_step
     from oracle import policy_oracle as orc                   # synthetic inputs only
 
     class Cfg:
@@ -41,7 +43,10 @@ def main():
     torch.manual_seed(1337)
     net = DecentralPlannerNet(Cfg()).to(dev).train()
     dp = FlatBucketDP(net) if world > 1 else None
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, capturable=args.graph)
+    if args.adam == 'torch':
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, capturable=args.graph)
+    else:                                                     # the same update on one HIP launch
+        opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=1e-5)
     B, N = args.batch, 10
     obs = orc.synth_obs(B, N, seed=1337 + rank).to(dev)
     S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337 + rank)).float().to(dev)
@@ -80,7 +85,8 @@ def main():
                           'n_gpus': world, 'ranks_in_group': dist.get_world_size() if world > 1 else 1,
                           'backend': dist.get_backend() if world > 1 else None,
                           'batch_per_gpu': B, 'ms_per_step': 1e3 * el / args.steps,
-                          'final_loss': float(loss.item()), 'hip_graph': bool(args.graph)}))
+                          'final_loss': float(loss.item()), 'hip_graph': bool(args.graph),
+                          'adam': args.adam}))
     if world > 1:
         dist.destroy_process_group()
 
