@@ -53,6 +53,7 @@ CONFIGS = {
 FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, chip-level parameters
 F16_MFMA_PEAK_TFLOPS = 2500.0           # dense f16/bf16 MFMA peak (~2.5 PF), same table
 HBM_PEAK_TBPS = 8.0
+NOMINAL_CLOCK_GHZ = 2.4                 # engine clock the peaks above are quoted at
 ENC_MACS_PER_AGENT = 1238112 + 16384    # CNN + compress MLP
 ENC_WEIGHT_FLOATS = 156288              # conv + BN-folded scale/shift + FC, read once per launch
 
@@ -141,8 +142,9 @@ def pmc_target(args):
 
 
 def measure_traffic(config, kernel_substr, timeout_s=150):
-    """HBM bytes per launch of the dominant kernel: two rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE do not fit one pass on gfx950) over `bench.py --pmc-target`, mean counter value per
+    """HBM bytes per launch of the dominant kernel: rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do
+    not fit one pass on gfx950; a third pass reads GRBM_GUI_ACTIVE for the effective engine clock) over
+    `bench.py --pmc-target`, mean counter value per
     dispatch of the kernel, combined as the microarch guide prescribes for gfx950:
     bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE counts half of wide coalesced reads;
     both counters are in KB).  Returns (bytes | None, detail dict)."""
@@ -151,19 +153,29 @@ def measure_traffic(config, kernel_substr, timeout_s=150):
         return None, {'note': 'rocprofv3 not found'}
     vals, detail = {}, {}
     env = dict(os.environ, TMPDIR='/tmp')
-    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE'):
         d = tempfile.mkdtemp(prefix='gnnpp_pmc_', dir='/tmp')
         try:
             cmd = [exe, '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
                    sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-target', '--config', config]
             r = subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT)
-            tot, n = 0.0, 0
+            tot, n, ns = 0.0, 0, 0.0
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row.get('Counter_Name') == ctr and kernel_substr in row.get('Kernel_Name', ''):
                         tot += float(row.get('Counter_Value', 0) or 0)
+                        ns += float(row.get('End_Timestamp', 0) or 0) - float(row.get('Start_Timestamp', 0) or 0)
                         n += 1
+            if ctr == 'GRBM_GUI_ACTIVE':
+                # shader-engine cycles of the dispatch / its wall time = the clock the kernel really ran at
+                # (DVFS: a dense MFMA kernel is power-limited below the 2.4 GHz the peak is quoted at;
+                # MI355X_MICROARCH.md "DVFS give-back"; profiled passes clock 2-5 % lower than free runs)
+                if n and ns > 0:
+                    detail['effective_clock_GHz'] = tot / ns
+                    detail['effective_clock_how'] = ('GRBM_GUI_ACTIVE / dispatch wall time, mean of %d dispatches '
+                                                     'under rocprofv3 --pmc' % n)
+                continue
             if n == 0:
                 return None, {'note': '%s pass produced no rows for %s (rc=%d)' % (ctr, kernel_substr, r.returncode)}
             vals[ctr] = tot / n
@@ -414,6 +426,14 @@ def main():
             'executed_mfma_flops_per_launch': exe,
             'pipe_busy_frac': exe / t_dom / 1e12 / (F16_MFMA_PEAK_TFLOPS if split_f16 else FP32_MFMA_PEAK_TFLOPS),
         }
+        clk = traffic_detail.get('effective_clock_GHz') if isinstance(traffic_detail, dict) else None
+        if clk:
+            # the same two ratios against the pipe's rate at the clock the kernel was measured to run at (the
+            # peak above assumes 2.4 GHz); `frac` stays the contract's figure
+            rl = result['roofline']
+            rl['effective_clock_GHz'] = clk
+            rl['frac_at_effective_clock'] = rl['frac'] * NOMINAL_CLOCK_GHZ / clk
+            rl['pipe_busy_frac_at_effective_clock'] = rl['pipe_busy_frac'] * NOMINAL_CLOCK_GHZ / clk
         result['encoder_schedule'] = variant
         if split_f16:
             result['dtype'] = ('f32 operands as f16 hi+lo pairs on the f16 MFMA pipe (encoder, filter contraction), '
@@ -506,8 +526,11 @@ def main():
                 starts[b_i], goals[b_i] = free[pick[:N]], free[pick[N:]]
             env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed', seed=1337)
             with torch.no_grad():
-                t_roll = time_kernel(lambda: env.step(net), reps=40)
+                t_roll1 = time_kernel(lambda: env.step(net), reps=40)
+                t_roll = time_kernel(lambda: env.steps(net, 8), reps=10) / 8
             result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
+                                      'us_one_step_per_call': t_roll1 * 1e6,
+                                      'how': 'BatchedRollout.steps(model, 8): eight steps enqueued per host call',
                                       'what': 'observe + gso + policy forward + move (collision shielding), '
                                               'all on the device, %d episodes' % B}
 

@@ -22,9 +22,10 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
            'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_encoder_train_workspace_floats', 'gnnpp_encoder_train_fwd',
-           'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_policy_loss',
+           'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_gemm_multi_workspace_floats',
+           'gnnpp_gemm_kmajor_multi', 'gnnpp_policy_loss',
            'gnnpp_adam_step', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
-           'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step')
+           'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step', 'gnnpp_rollout_policy_steps')
 
 
 class GnnppError(RuntimeError):
@@ -104,6 +105,15 @@ class EncoderGrads(ctypes.Structure):
                 ('bn_w', ctypes.c_void_p * 5), ('bn_b', ctypes.c_void_p * 5)]
 
 
+class GemmDesc(ctypes.Structure):
+    """struct gnnpp_gemm_desc (include/gnnpp.h)."""
+    _fields_ = [('A', ctypes.c_void_p), ('a_sb', ctypes.c_longlong), ('a_sm', ctypes.c_longlong),
+                ('a_sk', ctypes.c_longlong), ('B', ctypes.c_void_p), ('b_sb', ctypes.c_longlong),
+                ('b_sk', ctypes.c_longlong), ('C', ctypes.c_void_p), ('c_sb', ctypes.c_longlong),
+                ('c_sm', ctypes.c_longlong), ('batch', ctypes.c_int), ('M', ctypes.c_int), ('N', ctypes.c_int),
+                ('K', ctypes.c_int)]
+
+
 class AdamTensors(ctypes.Structure):
     """struct gnnpp_adam_tensors (include/gnnpp.h)."""
     _fields_ = [('p', ctypes.c_void_p * 32), ('g', ctypes.c_void_p * 32), ('m', ctypes.c_void_p * 32),
@@ -152,7 +162,8 @@ def _bind(path):
     L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, vp, vp]
     L.gnnpp_encoder_train_workspace_floats.restype = cs
     L.gnnpp_encoder_train_workspace_floats.argtypes = [ci, ci]
-    L.gnnpp_encoder_train_fwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ci, ci, ctypes.c_float, ci, vp]
+    L.gnnpp_encoder_train_fwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ci, ci, ctypes.c_float, ci,
+                                          ctypes.POINTER(ctypes.c_void_p), vp]
     L.gnnpp_encoder_train_fwd.restype = ci
     L.gnnpp_encoder_train_bwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ctypes.POINTER(EncoderGrads),
                                           ci, ci, vp]
@@ -162,6 +173,10 @@ def _bind(path):
     L.gnnpp_gemm_workspace_floats.argtypes = [ci] * 4
     L.gnnpp_gemm_kmajor.argtypes = [vp, ll, ll, ll, vp, ll, ll, vp, ll, ll, ci, ci, ci, ci, vp, vp]
     L.gnnpp_gemm_kmajor.restype = ci
+    L.gnnpp_gemm_multi_workspace_floats.restype = cs
+    L.gnnpp_gemm_multi_workspace_floats.argtypes = [ctypes.POINTER(GemmDesc), ci]
+    L.gnnpp_gemm_kmajor_multi.argtypes = [ctypes.POINTER(GemmDesc), ci, vp, vp]
+    L.gnnpp_gemm_kmajor_multi.restype = ci
     L.gnnpp_policy_loss.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
     L.gnnpp_policy_loss.restype = ci
     L.gnnpp_adam_step.argtypes = [ctypes.POINTER(AdamTensors), vp, cf, cf, cf, cf, cf, ci, vp]
@@ -175,6 +190,8 @@ def _bind(path):
         getattr(L, f).restype = ci
     L.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, vp]
     L.gnnpp_rollout_policy_step.restype = ci
+    L.gnnpp_rollout_policy_steps.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, ci, vp]
+    L.gnnpp_rollout_policy_steps.restype = ci
     for f in ('gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_encoder_pack', 'gnnpp_encoder_fwd',
               'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move'):
@@ -224,6 +241,23 @@ def gemm_kmajor(A, a_strides, Bm, b_strides, C, c_strides, batch, M, N, K):
                                   b_strides[0], b_strides[1], C.data_ptr(), c_strides[0], c_strides[1],
                                   batch, M, N, K, ws.data_ptr(), stream_ptr(dev)), 'gnnpp_gemm_kmajor')
     return C
+
+
+def gemm_kmajor_multi(specs):
+    """Several gemm_kmajor products in one launch (gnnpp_gemm_kmajor_multi).  specs: list of tuples
+    (A, a_strides, Bm, b_strides, C, c_strides, batch, M, N, K) as for gemm_kmajor (at most 8)."""
+    import torch
+    dev = require_gpu(*[t for s in specs for t in (s[0], s[2], s[4])])
+    L = lib()
+    arr = (GemmDesc * len(specs))()
+    for d, (A, a_st, Bm, b_st, C, c_st, batch, M, N, K) in zip(arr, specs):
+        d.A, d.a_sb, d.a_sm, d.a_sk = A.data_ptr(), a_st[0], a_st[1], a_st[2]
+        d.B, d.b_sb, d.b_sk = Bm.data_ptr(), b_st[0], b_st[1]
+        d.C, d.c_sb, d.c_sm = C.data_ptr(), c_st[0], c_st[1]
+        d.batch, d.M, d.N, d.K = batch, M, N, K
+    ws = torch.empty(max(L.gnnpp_gemm_multi_workspace_floats(arr, len(specs)), 1), dtype=torch.float32, device=dev)
+    with device_guard(dev):
+        check(L.gnnpp_gemm_kmajor_multi(arr, len(specs), ws.data_ptr(), stream_ptr(dev)), 'gnnpp_gemm_kmajor_multi')
 
 
 def require_gpu(*tensors):

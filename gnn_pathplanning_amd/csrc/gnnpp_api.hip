@@ -191,7 +191,8 @@ static int train_params_ok(const gnnpp_encoder_params* p, EncRawParams& rp) {
 }
 
 int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
-                            int B, int N, float momentum, int update_running, void* stream) {
+                            int B, int N, float momentum, int update_running,
+                            long long* const* bn_num_batches, void* stream) {
     EncRawParams rp;
     if (!train_params_ok(p, rp) || !obs || !workspace || !feat || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     float* rm[5];
@@ -201,7 +202,9 @@ int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, flo
         rm[i] = update_running ? const_cast<float*>(p->bn_mean[i]) : nullptr;
         rv[i] = update_running ? const_cast<float*>(p->bn_var[i]) : nullptr;
     }
-    return train_encoder_fwd(rp, rm, rv, momentum, obs, workspace, feat, N, B, static_cast<hipStream_t>(stream));
+    if (reinterpret_cast<size_t>(workspace) & 15) return GNNPP_ERR_ARG;      // (16-byte loads on its regions)
+    return train_encoder_fwd(rp, rm, rv, update_running ? bn_num_batches : nullptr, momentum, obs, workspace, feat,
+                             N, B, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
@@ -223,10 +226,34 @@ int gnnpp_gemm_kmajor(const float* A, long long a_sb, long long a_sm, long long 
                       long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int batch,
                       int M, int N, int K, float* workspace, void* stream) {
     if (!A || !B || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0) return GNNPP_ERR_ARG;
-    if (gemm_workspace_floats(batch, M, N, K) > 0 && !workspace) return GNNPP_ERR_ARG;
-    if ((long long)batch * gemm_plan(batch, M, N, K).ksplit > 65535) return GNNPP_ERR_UNSUPPORTED;
-    return gemm_kmajor_launch(A, a_sb, a_sm, a_sk, B, b_sb, b_sk, C, c_sb, c_sm, batch, M, N, K, workspace,
-                              static_cast<hipStream_t>(stream));
+    const gnnpp_gemm_desc d = {A, a_sb, a_sm, a_sk, B, b_sb, b_sk, C, c_sb, c_sm, batch, M, N, K};
+    return gnnpp_gemm_kmajor_multi(&d, 1, workspace, stream);
+}
+
+size_t gnnpp_gemm_multi_workspace_floats(const gnnpp_gemm_desc* d, int count) {
+    if (!d || count <= 0 || count > kGemmMax) return 0;
+    size_t n = 0;
+    for (int i = 0; i < count; ++i)
+        if (d[i].batch > 0 && d[i].M > 0 && d[i].N > 0 && d[i].K > 0)
+            n += gemm_workspace_floats(d[i].batch, d[i].M, d[i].N, d[i].K);
+    return n;
+}
+
+int gnnpp_gemm_kmajor_multi(const gnnpp_gemm_desc* d, int count, float* workspace, void* stream) {
+    if (!d || count <= 0 || count > kGemmMax) return GNNPP_ERR_ARG;
+    GemmTable tb = {};
+    for (int i = 0; i < count; ++i) {
+        if (!d[i].A || !d[i].B || !d[i].C || d[i].batch <= 0 || d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0)
+            return GNNPP_ERR_ARG;
+        GemmOne& g = tb.g[i];
+        g.A = d[i].A; g.a_sb = (long)d[i].a_sb; g.a_sm = (long)d[i].a_sm; g.a_sk = (long)d[i].a_sk;
+        g.B = d[i].B; g.b_sb = (long)d[i].b_sb; g.b_sk = (long)d[i].b_sk;
+        g.C = d[i].C; g.c_sb = (long)d[i].c_sb; g.c_sm = (long)d[i].c_sm;
+        g.batch = d[i].batch; g.M = d[i].M; g.N = d[i].N; g.K = d[i].K;
+    }
+    tb.count = count;
+    if (gnnpp_gemm_multi_workspace_floats(d, count) > 0 && !workspace) return GNNPP_ERR_ARG;
+    return gemm_multi_launch(tb, workspace, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_policy_loss(const float* logits, const float* target, float* loss, float* dlogits, int B, int N,
@@ -388,6 +415,19 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
     pt.sim.grow = 0;
     pt.sim.actions = nullptr;
     return policy_launch_fused(r->obs, enc_packed, pt, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_rollout_policy_steps(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
+                               const float* gf_bias, const float* act_w, const float* act_b, int K,
+                               int nsteps, void* stream) {
+    if (!r || nsteps <= 0 || r->tie_mode == GNNPP_TIE_REPLAY) return GNNPP_ERR_ARG;
+    gnnpp_rollout rs = *r;
+    for (int s = 0; s < nsteps; ++s) {
+        rs.currentstep = r->currentstep + s;
+        const int rc = gnnpp_rollout_policy_step(&rs, enc_packed, filt_packed, gf_bias, act_w, act_b, K, stream);
+        if (rc != GNNPP_OK) return rc;                   // (argument / shape errors surface at s = 0)
+    }
+    return GNNPP_OK;
 }
 
 }  // extern "C"

@@ -66,7 +66,7 @@ __host__ __device__ inline ConvGeom conv_geom(int l, bool input_grad, int B) {
     g.TAPS = dense ? 1 : 9;
     g.RPC = dense ? 4 : 1;
     g.IB = dense ? 64 : d.H == 5 ? 4 : 2;
-    g.CC = dense ? 128 : d.H == 5 ? 32 : 4;
+    g.CC = dense ? 256 : d.H == 5 ? 32 : 4;
     const int rows = input_grad ? d.Cin : d.Cout, ck = input_grad ? d.Cout : d.Cin;
     g.M = rows * g.RPC;
     g.Ck = ck * g.RPC;
@@ -74,6 +74,9 @@ __host__ __device__ inline ConvGeom conv_geom(int l, bool input_grad, int B) {
     g.SPC = g.TAPS * g.CC / 4;
     g.chunks_per_agent = (B + g.IB - 1) / g.IB;
     return g;
+}
+__host__ __device__ constexpr int conv_row_stride(int ibpp, bool dense) {
+    return dense ? ibpp + 1 : (ibpp - 16 + 63) / 64 * 64 + 16;
 }
 __host__ __device__ inline size_t conv_pack_floats(int l, bool input_grad) {
     const ConvGeom g = conv_geom(l, input_grad, 1);
@@ -136,15 +139,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     constexpr bool kDense = H == 1 && W == 1;
     constexpr int P = H * W, TAPS = kDense ? 1 : 9, RPC = kDense ? 4 : 1;
     constexpr int PP = kDense ? 1 : (H + 2) * (W + 2);
-    constexpr int IB = kDense ? 64 : H == 5 ? 4 : 2, CC = kDense ? 128 : H == 5 ? 32 : 4;
+    constexpr int IB = kDense ? 64 : H == 5 ? 4 : 2, CC = kDense ? 256 : H == 5 ? 32 : 4;
     constexpr int SPC = TAPS * CC / 4, NT = (IB * P + 15) / 16, TN = (NT + 3) / 4;
+    // floats between two channels' rows in LDS, padded against bank conflicts (64 banks): the B read's four
+    // channel groups q sit 16 banks apart (stride = 16 mod 64); the dense layers' 64 one-float "images" get a
+    // stride of 65 (a 16-byte load holds four CHANNELS of one image: with 64 every lane's scatter would hit
+    // one bank)
+    constexpr int RS = conv_row_stride(IB * PP, kDense);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
     const int b0 = chunk * IB, nimg = min(IB, B - b0);
     const int m0 = blockIdx.y * 16;
     float* wsm = reinterpret_cast<float*>(gnnpp_smem);          // [SPC][64]
-    float* xs = wsm + SPC * 64;                                  // [CC][IB][PP]
+    float* xs = wsm + SPC * 64;                                  // [CC][RS >= IB*PP]
     int cb[TN], cimg[TN], cp[TN];
     bool cv[TN];
 #pragma unroll
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
         cv[t] = col < nimg * P;
         cimg[t] = cv[t] ? col / P : 0;
         cp[t] = cv[t] ? col - cimg[t] * P : 0;
-        cb[t] = cimg[t] * PP + (kDense ? 0 : (cp[t] / W + 1) * (W + 2) + cp[t] % W + 1) + q * IB * PP;
+        cb[t] = cimg[t] * PP + (kDense ? 0 : (cp[t] / W + 1) * (W + 2) + cp[t] % W + 1) + q * RS;
     }
     v4f acc[TN];
 #pragma unroll
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     };
     auto xs_at = [&](int im, int r) {                           // LDS slot of element r = cl*P + pp of image im
         const int cl = r / P, pp = r - cl * P;
-        return (cl * IB + im) * PP + (kDense ? 0 : (pp / W + 1) * (W + 2) + pp % W + 1);
+        return cl * RS + im * PP + (kDense ? 0 : (pp / W + 1) * (W + 2) + pp % W + 1);
     };
     auto commit = [&](int ch) {
         v4f* wdst = reinterpret_cast<v4f*>(wsm);
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
         }
     };
     issue(0);
-    for (int i = tid; i < CC * IB * PP; i += 256) xs[i] = 0.f;   // borders / missing images stay zero
+    for (int i = tid; i < CC * RS; i += 256) xs[i] = 0.f;        // borders / missing images stay zero
     __syncthreads();
     commit(0);
     __syncthreads();
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
                 const float a = wsm[(tap * (CC / 4) + cig) * 64 + lane];
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
-                    acc[t] = mfma16(a, xs[cb[t] + toff + cig * 4 * IB * PP], acc[t]);
+                    acc[t] = mfma16(a, xs[cb[t] + toff + cig * 4 * RS], acc[t]);
             }
         }
         if (ch + 1 < nchunk) {
@@ -409,8 +417,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
 // ---- running statistics: the N per-agent-call updates in agent order (one thread per channel) -------------
 // nn.BatchNorm2d in train mode: r <- (1 - momentum) r + momentum * batch statistic (unbiased variance)
 // all five layers in one launch: blockIdx.y = layer (a = stat, b = running_mean, c = running_var)
-__global__ void bn_running_kernel(const TrainPtrs5 p, int N, float momentum) {
+struct TrainCounters { long long* c[kTrainLayers]; };
+__global__ void bn_running_kernel(const TrainPtrs5 p, const TrainCounters nb, int N, float momentum) {
     const int l = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nb.c[l]) *nb.c[l] += N;   // num_batches_tracked: N forward calls
     const int C = train_layer(l).Cout;
     const float* stat = p.a[l];
     float* rmean = p.b[l];
@@ -428,59 +438,61 @@ __global__ void bn_running_kernel(const TrainPtrs5 p, int N, float momentum) {
 }
 
 // ---- backward through pool / ReLU / BatchNorm, pass 1 --------------------------------------------------------
-// One lane = one column (b, pos) of agent n, looping over ALL channels: dz[c] = relu'(a) * d a, where
-// d a = dxn[window] if this position is the FIRST maximum of its 2x2 window (scan order, like torch's
-// max_pool2d backward; a recomputed from y), 0 for positions the pool never reads; without pool d a = dxn.
-// Writes dz [N][B][C][P] and per-wave partial sums of dz and dz * yhat -> part[((n*chunks+chunk)*C + c)*2].
-constexpr int kBnBwdCG = 8;          // channels per wave of bn_bwd_reduce_kernel (grid.y = C / 8)
-__global__ __launch_bounds__(64) void bn_bwd_reduce_kernel(const float* __restrict__ y,
-                                                           const float* __restrict__ stat,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta,
-                                                           const float* __restrict__ dxn,
-                                                           float* __restrict__ dz, float* __restrict__ part,
-                                                           int B, int C, int H, int W, int pool, int chunks) {
-    const int lane = threadIdx.x;
-    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
-    const int c0 = blockIdx.y * kBnBwdCG;
-    const int P = H * W, Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo;
-    const int col = chunk * 64 + lane;
-    const bool active = col < B * P;
-    const int colc = active ? col : 0;
-    const int b = colc / P, pos = colc - b * P;
-    const int py = pos / W, px = pos - py * W;
-    const bool pooled_in = !pool || (py < 2 * Ho && px < 2 * Wo);       // inside the region the pool reads
-    const int oy = pool ? py / 2 : py, ox = pool ? px / 2 : px;
-    const int wpos = pool && pooled_in ? (2 * oy) * W + 2 * ox : pos;   // window origin (a valid address)
-    const int me = pool ? (py - 2 * oy) * 2 + (px - 2 * ox) : 0;        // my slot in the window
+// dz[c] = relu'(a) * d a, where d a = dxn[window] if this position is the FIRST maximum of its 2x2 window (scan
+// order, like torch's max_pool2d backward; a recomputed from y), 0 for positions the pool never reads; without
+// pool d a = dxn.  grid = (N * splits, C / 4), block = 256: wave w serves channel 4*blockIdx.y + w of agent n over
+// the columns (b, pos) of split s, 64 at a time; the sums of dz and dz * yhat stay in the lanes until ONE
+// butterfly per wave at the end -> part[((n*splits + s)*C + c)*2].  Writes dz [N][B][C][P].
+template <int H, int W, bool pool>                               // (constant geometry: no runtime divisions)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y,
+                                                            const float* __restrict__ stat,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ dxn,
+                                                            float* __restrict__ dz, float* __restrict__ part,
+                                                            int B, int C, int splits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x / splits, sp = blockIdx.x - n * splits;
+    const int c = blockIdx.y * 4 + wave;
+    constexpr int P = H * W, Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo;
+    const int cols = B * P, per = ((cols + splits - 1) / splits + 63) / 64 * 64;
+    const int col0 = sp * per, col1 = min(cols, col0 + per);
+    const float* st = stat + ((long)n * C + c) * 4;
+    const float mean = st[0], invstd = st[1], g = gamma[c], be = beta[c];
     const int wo[4] = {0, 1, W, W + 1};
-#pragma unroll
-    for (int cc = 0; cc < kBnBwdCG; ++cc) {
-        const int c = c0 + cc;
-        const float* st = stat + ((long)n * C + c) * 4;
-        const float mean = st[0], invstd = st[1], g = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int col = col0 + lane; col < col1; col += 64) {
+        const int b = col / P, pos = col - b * P;
+        const int py = pos / W, px = pos - py * W;
+        const bool pooled_in = !pool || (py < 2 * Ho && px < 2 * Wo);   // inside the region the pool reads
+        const int oy = pool ? py / 2 : py, ox = pool ? px / 2 : px;
         const long ic = ((long)n * B + b) * C + c;
         const float* yc = y + ic * P;
         const float yv = yc[pos];
         const float yhat = (yv - mean) * invstd;
         const float a = fmaxf(fmaf(yhat, g, be), 0.f);
-        bool mine = active && pooled_in;
-        if (pool) {
+        bool mine = pooled_in;
+        if (pool && pooled_in) {
+            const int wpos = (2 * oy) * W + 2 * ox;                    // window origin
+            const int me = (py - 2 * oy) * 2 + (px - 2 * ox);          // my slot in the window
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float ak = bn_act(yc[pooled_in ? wpos + wo[k] : pos], mean, invstd, g, be);
-                mine = mine && (k < me ? ak < a : ak <= a);           // strictly greater than the earlier ones
+                const float ak = bn_act(yc[wpos + wo[k]], mean, invstd, g, be);
+                mine = mine && (k < me ? ak < a : ak <= a);            // strictly greater than the earlier ones
             }
         }
-        const float da = dxn[ic * Po + (pooled_in ? oy * Wo + ox : 0)];
+        const float da = pooled_in ? dxn[ic * Po + oy * Wo + ox] : 0.f;
         const float d = (mine && a > 0.f) ? da : 0.f;
-        if (active) dz[ic * P + pos] = d;
-        const float s1 = wave_sum(d), s2 = wave_sum(d * yhat);
-        if (lane == 0) {
-            float* o = part + (((long)n * chunks + chunk) * C + c) * 2;
-            o[0] = s1;
-            o[1] = s2;
-        }
+        dz[ic * P + pos] = d;
+        s1 += d;
+        s2 += d * yhat;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        float* o = part + (((long)n * splits + sp) * C + c) * 2;
+        o[0] = s1;
+        o[1] = s2;
     }
 }
 
@@ -567,14 +579,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     constexpr int P = H * W, PP = (H + 2) * (W + 2), SPI = (P + 3) / 4, P4 = SPI * 4, JW = 4 / KW;
     constexpr int IB = wgrad_ib(H);
+    constexpr int RS = (IB * PP) | 1;                            // odd channel-row stride: the scatter of a 16-byte
+                                                                 // load (2x2: four positions of consecutive channels)
+                                                                 // and the B reads spread over the banks
     constexpr int dstride = ((IB * P4 + 63) / 64) * 64 + 4;      // rows 4 banks apart: conflict-free A reads
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, q = lane >> 4;
     const int jw = wave % JW, kw = wave / JW;
     const int co0 = blockIdx.x * 16, split = blockIdx.y;
     const int J = Cin * 9 + 1, J16 = JT * 16;
-    float* xs = reinterpret_cast<float*>(gnnpp_smem);            // [Cin][IB][PP]
-    float* dys = xs + Cin * IB * PP;                             // [16][dstride]
+    float* xs = reinterpret_cast<float*>(gnnpp_smem);            // [Cin][RS >= IB*PP]
+    float* dys = xs + Cin * RS;                                  // [16][dstride]
 
     int joff[TJ];
     bool jbias[TJ];
@@ -583,7 +598,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         const int j = min(jw + JW * t, JT - 1) * 16 + i16;  // (a slot past the last tile recomputes it; not stored)
         const bool jv = j < J - 1;
         const int ci = jv ? j / 9 : 0, tap = jv ? j - ci * 9 : 4;
-        joff[t] = ci * IB * PP + (tap / 3 - 1) * (W + 2) + (tap % 3 - 1);
+        joff[t] = ci * RS + (tap / 3 - 1) * (W + 2) + (tap % 3 - 1);
         jbias[t] = j == J - 1;
     }
     int ppos[SPI];
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                     float v;
                     if constexpr (kVecX) v = xv[u][k];
                     else v = xsc[u];
-                    xs[(ci * IB + im) * PP + (p / W + 1) * (W + 2) + p % W + 1] = v;
+                    xs[ci * RS + im * PP + (p / W + 1) * (W + 2) + p % W + 1] = v;
                 }
             }
         }
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 
     const int img0 = split * imgs_per_split, img1 = min(NB, img0 + imgs_per_split);
     issue(img0, min(IB, img1 - img0));
-    for (int i = tid; i < Cin * IB * PP + 16 * dstride; i += 256) xs[i] = 0.f;   // borders and tails stay zero
+    for (int i = tid; i < Cin * RS + 16 * dstride; i += 256) xs[i] = 0.f;   // borders and tails stay zero
     __syncthreads();
     commit(min(IB, img1 - img0));
     __syncthreads();
@@ -758,7 +773,12 @@ inline TrainWs train_ws_layout(int N, int B) {
         w.stat[l] = take((size_t)N * d.Cout * 4);
         w.wt[l] = take(conv_pack_floats(l, false));
         w.wtb[l] = take(conv_pack_floats(l, true));
-        w.chunks[l] = (B * P + 63) / 64;
+        {   // column splits of bn_bwd_reduce_kernel: >= ~2 500 waves per layer and at most four 64-column trips
+            // per wave (each trip is one dependent round of loads), at least 64 columns each
+            const int by_waves = (2560 + N * d.Cout - 1) / (N * d.Cout), by_trips = (B * P + 255) / 256;
+            const int sp = by_waves > by_trips ? by_waves : by_trips, spmax = (B * P + 63) / 64;
+            w.chunks[l] = sp < 1 ? 1 : sp > spmax ? spmax : sp > 64 ? 64 : sp;
+        }
         max_y = max_y > NB * d.Cout * P ? max_y : NB * d.Cout * P;
         const int cmax = w.chunks[l] > B ? w.chunks[l] : B;          // column chunks (BN backward) vs image chunks (conv)
         const size_t pp = (size_t)N * cmax * d.Cout * 2;
@@ -794,11 +814,16 @@ static void conv_launch(int l, bool input_grad, const float* x, const float* wpa
                         float* part, int N, int B, long sn, long sb, hipStream_t st) {
     const ConvGeom g = conv_geom(l, input_grad, B);
     const dim3 grid(N * g.chunks_per_agent, g.M / 16);
-    const size_t smem = ((size_t)g.SPC * 64 + (size_t)g.CC * g.IB * (g.TAPS == 1 ? 1 : (g.H + 2) * (g.W + 2))) *
-                        sizeof(float);
+    const size_t smem = ((size_t)g.SPC * 64 +
+                         (size_t)g.CC * conv_row_stride(g.TAPS == 1 ? g.IB : g.IB * (g.H + 2) * (g.W + 2),
+                                                        g.TAPS == 1)) * sizeof(float);
 #define GNNPP_CONV(HH, WW)                                                                                     \
-    hipLaunchKernelGGL((conv_mfma_kernel<HH, WW>), grid, dim3(256), smem, st, x, wpack, bias, y, part, B, g.Ck, \
-                       g.M, sn, sb, g.chunks_per_agent, g.nchunk)
+    do {                                                                                                       \
+        static LdsAttrOnce once;                               /* (the dense stages use 80 KB of LDS) */     \
+        set_lds_attr_once(once, reinterpret_cast<const void*>(&conv_mfma_kernel<HH, WW>), (int)smem);          \
+        hipLaunchKernelGGL((conv_mfma_kernel<HH, WW>), grid, dim3(256), smem, st, x, wpack, bias, y, part, B,  \
+                           g.Ck, g.M, sn, sb, g.chunks_per_agent, g.nchunk);                                   \
+    } while (0)
     if (g.H == 11) GNNPP_CONV(11, 11);
     else if (g.H == 5) GNNPP_CONV(5, 5);
     else GNNPP_CONV(1, 1);
@@ -810,7 +835,7 @@ static void wgrad_launch(int l, const TrainWs& L, const float* x, const float* d
     const TrainLayerDims d = train_layer(l);
     const int P = d.H * d.W, PP = (d.H + 2) * (d.W + 2), P4 = (P + 3) / 4 * 4;
     const int IB = L.ib[l], dstride = ((IB * P4 + 63) / 64) * 64 + 4;
-    const size_t smem = ((size_t)d.Cin * IB * PP + 16 * (size_t)dstride) * sizeof(float);
+    const size_t smem = ((size_t)d.Cin * ((IB * PP) | 1) + 16 * (size_t)dstride) * sizeof(float);
     const dim3 grid(d.Cout / 16, L.nsplit[l]);
 #define GNNPP_WGRAD(HH, WW, CI, TJ, KW)                                                                       \
     hipLaunchKernelGGL((conv_wgrad_kernel<HH, WW, CI, TJ, KW>), grid, dim3(256), smem, st, x, dy, wpart, NB,    \
@@ -822,7 +847,8 @@ static void wgrad_launch(int l, const TrainWs& L, const float* x, const float* d
 }
 
 // obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128]
-int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const* rvar, float momentum,
+int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const* rvar,
+                      long long* const* num_batches, float momentum,
                       const float* obs, float* ws, float* feat, int N, int B, hipStream_t st) {
     const TrainWs L = train_ws_layout(N, B);
     const long NB = (long)N * B;
@@ -831,7 +857,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l]; pk.c[l] = ws + L.wtb[l];
         run.a[l] = ws + L.stat[l]; run.b[l] = rmean ? rmean[l] : nullptr; run.c[l] = rvar ? rvar[l] : nullptr;
     }
-    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(32, 2 * kTrainLayers), dim3(256), 0, st, pk);
+    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(128, 2 * kTrainLayers), dim3(256), 0, st, pk);
     for (int l = 0; l < kTrainLayers; ++l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
@@ -845,8 +871,11 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
                            l == kTrainLayers - 1 ? feat : ws + L.xn[l], B, d.Cout, d.H, d.W, d.pool,
                            conv_chunks(l, B), t.CG, t.BR, rp.bn_eps);
     }
-    if (rmean && rvar)
-        hipLaunchKernelGGL(bn_running_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, run, N, momentum);
+    if (rmean && rvar) {
+        TrainCounters nb = {};
+        for (int l = 0; l < kTrainLayers; ++l) nb.c[l] = num_batches ? num_batches[l] : nullptr;
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, run, nb, N, momentum);
+    }
     return launched_ok() ? 0 : -3;
 }
 
@@ -863,9 +892,16 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
         float* dz = ws + L.dz;
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(N * L.chunks[l], d.Cout / kBnBwdCG), dim3(64), 0, st,
-                           ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B,
-                           d.Cout, d.H, d.W, d.pool, L.chunks[l]);
+#define GNNPP_BNR(HH, WW, PL)                                                                                    \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<HH, WW, PL>), dim3(N * L.chunks[l], d.Cout / 4), dim3(256), 0, st,  \
+                       ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout,    \
+                       L.chunks[l])
+        if (d.H == 11) GNNPP_BNR(11, 11, true);
+        else if (d.H == 5 && d.pool) GNNPP_BNR(5, 5, true);
+        else if (d.H == 5) GNNPP_BNR(5, 5, false);
+        else if (d.pool) GNNPP_BNR(2, 2, true);
+        else GNNPP_BNR(2, 2, false);
+#undef GNNPP_BNR
         const BnTile t = bn_tile(l);
         float* pn = ws + L.coef + (size_t)l * N * 128 * 2;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N), dim3(256), kBnSmem, st,

@@ -16,35 +16,57 @@
 
 namespace gnnpp {
 
-// ---- C[b][m][n] = sum_k A_b(m,k) * B_b(k,n) ---------------------------------------------------------------------
-// A_b(m,k) at A + b*a_sb + m*a_sm + k*a_sk;  B_b(k,n) at B + b*b_sb + k*b_sk + n;  grid = (ceil(N/64), ceil(M/64),
-// batch*ksplit), block = 256: wave w owns rows [m0 + 16w, +16) x 64 columns (four 16x16 accumulators) over the
-// K range of its split.  Lane (i = lane & 15, q = lane >> 4): A value (row i, k = 4s + q), B values (k = 4s + q,
+// ---- C[b][m][n] = sum_k A_b(m,k) * B_b(k,n), several independent products per launch ------------------------------
+// A_b(m,k) at A + b*a_sb + m*a_sm + k*a_sk;  B_b(k,n) at B + b*b_sb + k*b_sk + n;  C_b(m,n) at C + b*c_sb + m*c_sm + n.
+// One launch serves up to kGemmMax products (a Linear's dx, dW and db are three): the 1-D grid is the
+// concatenation of every product's (column tiles x row tiles x batch*ksplit) workgroups; a workgroup finds its
+// product by its index.  block = 256: wave w owns rows [m0 + 16w, +16) x 64 columns (four 16x16 accumulators) over
+// the K range of its split.  Lane (i = lane & 15, q = lane >> 4): A value (row i, k = 4s + q), B values (k = 4s + q,
 // column 16t + i).  Four k-steps of operands (4 + 16 loads) are in flight before their 16 MFMAs.
-// out: ksplit == 1 -> C directly (c_sb, c_sm strides, n contiguous); else part[(split*batch + b)][M][N].
-__global__ __launch_bounds__(256) void gemm_kmajor_kernel(const float* __restrict__ A, long a_sb, long a_sm,
-                                                          long a_sk, const float* __restrict__ Bm, long b_sb,
-                                                          long b_sk, float* __restrict__ out, long o_sb, long o_sm,
-                                                          int batch, int M, int N, int K, int ksplit, int kper) {
+// out: ksplit == 1 -> C directly; else the partial of (split, b) -> ws + ws_off + ((split*batch + b)*M + m)*N + n,
+// summed in split order by gemm_reduce_kernel (one launch for all products that were split).
+constexpr int kGemmMax = 8;
+struct GemmOne {
+    const float* A; long a_sb, a_sm, a_sk;
+    const float* B; long b_sb, b_sk;
+    float* C; long c_sb, c_sm;
+    int batch, M, N, K, ksplit, kper, nx, ny;
+    long ws_off;
+};
+struct GemmTable {
+    GemmOne g[kGemmMax];
+    int first[kGemmMax + 1];          // first workgroup of product i (multiply kernel)
+    int rfirst[kGemmMax + 1];         // first workgroup of product i (reduce kernel; empty range when ksplit == 1)
+    int count;
+};
+
+__global__ __launch_bounds__(256) void gemm_kmajor_kernel(const GemmTable tb, float* __restrict__ ws) {
+    int gi = 0;
+    while (gi + 1 < tb.count && (int)blockIdx.x >= tb.first[gi + 1]) ++gi;   // (scalar: at most 7 steps)
+    const GemmOne& g = tb.g[gi];
+    const int local = (int)blockIdx.x - tb.first[gi];
+    const int bx = local % g.nx, by = (local / g.nx) % g.ny, bz = local / (g.nx * g.ny);
+    const int M = g.M, N = g.N, K = g.K, batch = g.batch;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z % batch, split = blockIdx.z / batch;
-    const int m = blockIdx.y * 64 + wave * 16 + i16;
-    const int n0 = blockIdx.x * 64;
+    const int b = bz % batch, split = bz / batch;
+    const int m = by * 64 + wave * 16 + i16;
+    const int n0 = bx * 64;
     const bool mv = m < M;
-    const float* a = A + b * a_sb + (long)(mv ? m : 0) * a_sm;
+    const long a_sk = g.a_sk, b_sk = g.b_sk;
+    const float* a = g.A + b * g.a_sb + (long)(mv ? m : 0) * g.a_sm;
     const float* bp[4];
     bool nv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = n0 + 16 * t + i16;
         nv[t] = n < N;
-        bp[t] = Bm + b * b_sb + (nv[t] ? n : 0);
+        bp[t] = g.B + b * g.b_sb + (nv[t] ? n : 0);
     }
     v4f acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = vzero();
-    const int k0 = split * kper, k1 = min(K, k0 + kper);
+    const int k0 = split * g.kper, k1 = min(K, k0 + g.kper);
     constexpr int U = 4;
     for (int ks = k0; ks < k1; ks += 4 * U) {
         float av[U], bv[U][4];
@@ -67,8 +89,10 @@ __global__ __launch_bounds__(256) void gemm_kmajor_kernel(const float* __restric
             for (int t = 0; t < 4; ++t) acc[t] = mfma16(av[u], bv[u][t], acc[t]);
     }
     // D register r of lane l: D[i = 4 q + r][j = l & 15]
-    const int mr = blockIdx.y * 64 + wave * 16 + 4 * q;
-    float* o = out + (ksplit == 1 ? b * o_sb : ((long)split * batch + b) * o_sb);
+    const int mr = by * 64 + wave * 16 + 4 * q;
+    const bool direct = g.ksplit == 1;
+    float* o = direct ? g.C + b * g.c_sb : ws + g.ws_off + ((long)split * batch + b) * M * N;
+    const long o_sm = direct ? g.c_sm : (long)N;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = n0 + 16 * t + i16;
@@ -78,18 +102,21 @@ __global__ __launch_bounds__(256) void gemm_kmajor_kernel(const float* __restric
     }
 }
 
-// C[b][m][n] = sum over splits (in order) of part[(split*batch + b)][m][n]
-__global__ void gemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long c_sb, long c_sm,
-                                   int batch, int M, int N, int ksplit) {
-    const long total = (long)batch * M * N;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// C_b(m,n) = sum over splits (in order) of the partials; 256 outputs per workgroup, products concatenated
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmTable tb, const float* __restrict__ ws) {
+    int gi = 0;
+    while (gi + 1 < tb.count && (int)blockIdx.x >= tb.rfirst[gi + 1]) ++gi;
+    const GemmOne& g = tb.g[gi];
+    const long total = (long)g.batch * g.M * g.N;
+    const long i = (long)((int)blockIdx.x - tb.rfirst[gi]) * 256 + threadIdx.x;
     if (i >= total) return;
+    const float* part = ws + g.ws_off;
     float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += part[(long)k * total + i];
-    const int n = (int)(i % N);
-    const long bm = i / N;
-    const int m = (int)(bm % M), b = (int)(bm / M);
-    C[b * c_sb + (long)m * c_sm + n] = s;
+    for (int k = 0; k < g.ksplit; ++k) s += part[(long)k * total + i];
+    const int n = (int)(i % g.N);
+    const long bm = i / g.N;
+    const int m = (int)(bm % g.M), b = (int)(bm / g.M);
+    g.C[b * g.c_sb + (long)m * g.c_sm + n] = s;
 }
 
 struct GemmPlan { int ksplit, kper; };
@@ -107,24 +134,30 @@ inline GemmPlan gemm_plan(int batch, int M, int N, int K) {
 
 inline size_t gemm_workspace_floats(int batch, int M, int N, int K) {
     const GemmPlan p = gemm_plan(batch, M, N, K);
-    return p.ksplit > 1 ? (size_t)p.ksplit * batch * M * N : 0;
+    return p.ksplit > 1 ? ((size_t)p.ksplit * batch * M * N + 3) & ~(size_t)3 : 0;
 }
 
-inline int gemm_kmajor_launch(const float* A, long a_sb, long a_sm, long a_sk, const float* Bm, long b_sb, long b_sk,
-                              float* C, long c_sb, long c_sm, int batch, int M, int N, int K, float* ws,
-                              hipStream_t st) {
-    const GemmPlan p = gemm_plan(batch, M, N, K);
-    const dim3 grid((N + 63) / 64, (M + 63) / 64, batch * p.ksplit);
-    if (p.ksplit == 1) {
-        hipLaunchKernelGGL(gemm_kmajor_kernel, grid, dim3(256), 0, st, A, a_sb, a_sm, a_sk, Bm, b_sb, b_sk, C, c_sb,
-                           c_sm, batch, M, N, K, 1, p.kper);
-    } else {
-        hipLaunchKernelGGL(gemm_kmajor_kernel, grid, dim3(256), 0, st, A, a_sb, a_sm, a_sk, Bm, b_sb, b_sk, ws,
-                           (long)M * N, (long)N, batch, M, N, K, p.ksplit, p.kper);
-        const long total = (long)batch * M * N;
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, C, c_sb,
-                           c_sm, batch, M, N, p.ksplit);
+// fills plan / grid fields of tb.g[0..count) (A..K set by the caller), launches the multiply and, when any
+// product was split, ONE reduce
+inline int gemm_multi_launch(GemmTable& tb, float* ws, hipStream_t st) {
+    int blocks = 0, rblocks = 0;
+    long off = 0;
+    for (int i = 0; i < tb.count; ++i) {
+        GemmOne& g = tb.g[i];
+        const GemmPlan p = gemm_plan(g.batch, g.M, g.N, g.K);
+        g.ksplit = p.ksplit; g.kper = p.kper;
+        g.nx = (g.N + 63) / 64; g.ny = (g.M + 63) / 64;
+        g.ws_off = off;
+        off += (long)gemm_workspace_floats(g.batch, g.M, g.N, g.K);
+        tb.first[i] = blocks;
+        blocks += g.nx * g.ny * g.batch * g.ksplit;
+        tb.rfirst[i] = rblocks;
+        if (g.ksplit > 1) rblocks += (int)(((long)g.batch * g.M * g.N + 255) / 256);
     }
+    tb.first[tb.count] = blocks;
+    tb.rfirst[tb.count] = rblocks;
+    hipLaunchKernelGGL(gemm_kmajor_kernel, dim3(blocks), dim3(256), 0, st, tb, ws);
+    if (rblocks > 0) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(rblocks), dim3(256), 0, st, tb, ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

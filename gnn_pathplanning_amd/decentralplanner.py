@@ -53,7 +53,7 @@ class _EncoderTrainFunction(torch.autograd.Function):
     data).  `tensors` = [conv_w, conv_b, bn_w, bn_b] x 5 layers; `buffers` = [running_mean, running_var] x 5."""
 
     @staticmethod
-    def forward(ctx, obs, buffers, momentum, eps, *tensors):
+    def forward(ctx, obs, buffers, counters, momentum, eps, *tensors):
         L = _native.lib()
         B, N = obs.shape[0], obs.shape[1]
         dev = obs.device
@@ -70,6 +70,8 @@ class _EncoderTrainFunction(torch.autograd.Function):
         with _native.device_guard(dev):
             _native.check(L.gnnpp_encoder_train_fwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(feat), B, N,
                                                     ctypes.c_float(momentum), int(buffers is not None),
+                                                    (ctypes.c_void_p * 5)(*[c.data_ptr() for c in counters])
+                                                    if counters is not None else None,
                                                     _native.stream_ptr(dev)), 'gnnpp_encoder_train_fwd')
         ctx.save_for_backward(obs, ws, *ps)
         ctx.eps = float(eps)
@@ -94,7 +96,7 @@ class _EncoderTrainFunction(torch.autograd.Function):
         with _native.device_guard(dev):
             _native.check(L.gnnpp_encoder_train_bwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(d), ctypes.byref(g),
                                                     B, N, _native.stream_ptr(dev)), 'gnnpp_encoder_train_bwd')
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class _LinearFunction(torch.autograd.Function):
@@ -116,17 +118,19 @@ class _LinearFunction(torch.autograd.Function):
         x2 = x.detach().reshape(-1, I).contiguous().float()
         R = dy2.shape[0]
         dx = dW = db = None
+        specs = []                                             # the three products: ONE launch (+ one for the sums)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(R, I, dtype=torch.float32, device=dy.device)
-            _native.gemm_kmajor(dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O)
-            dx = dx.reshape(x.shape)
+            specs.append((dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O))
         if ctx.needs_input_grad[1]:
             dW = torch.empty(O, I, dtype=torch.float32, device=dy.device)
-            _native.gemm_kmajor(dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R)
+            specs.append((dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R))
         if ctx.needs_input_grad[2]:
             db = torch.empty(O, dtype=torch.float32, device=dy.device)
-            _native.gemm_kmajor(_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R)
-        return dx, dW, db
+            specs.append((_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R))
+        if specs:
+            _native.gemm_kmajor_multi(specs)
+        return (dx.reshape(x.shape) if dx is not None else None), dW, db
 
 
 _ones_cache = {}
@@ -468,12 +472,9 @@ class DecentralPlannerNet(nn.Module):
             conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
             tensors += [conv.weight, conv.bias, bn.weight, bn.bias]
             buffers += [bn.running_mean, bn.running_var]
-        feat = _EncoderTrainFunction.apply(obs, buffers if track else None, float(bn0.momentum or 0.0),
+        counters = [self.ConvLayers[bi].num_batches_tracked for bi in _BN_IDX] if track else None   # += N each
+        feat = _EncoderTrainFunction.apply(obs, buffers if track else None, counters, float(bn0.momentum or 0.0),
                                            float(bn0.eps), *tensors)                     # [N,B,128]
-        if track:
-            with torch.no_grad():
-                for bi in _BN_IDX:
-                    self.ConvLayers[bi].num_batches_tracked.add_(N)
         fc = self.compressMLP[0]
         comp = tF.relu(_LinearFunction.apply(feat, fc.weight, fc.bias))                 # [N,B,F]
         for l in range(self.L):

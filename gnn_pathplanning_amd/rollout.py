@@ -150,9 +150,10 @@ class BatchedRollout:
         self._state_step = self.t                          # obs / S describe the positions after step t
         return self.flags
 
-    def _policy_step(self, model):
-        """gnnpp_rollout_policy_step: policy forward + move + next gso/observe in ONE kernel, when the
-        model and the team qualify (eval mode, N = model.numAgents <= 16, K = 3, not 'replay')."""
+    def _policy_step(self, model, nsteps=1):
+        """gnnpp_rollout_policy_step(s): policy forward + move + next gso/observe in ONE kernel per step, when
+        the model and the team qualify (eval mode, N = model.numAgents <= 16, K = 3, not 'replay'); nsteps
+        launches are enqueued by one C call."""
         if (self.N > 16 or self.tie_mode == 2 or getattr(model, 'training', True)
                 or getattr(model, 'numAgents', -1) != self.N or not hasattr(model, 'policy_pointers')):
             return False
@@ -167,12 +168,12 @@ class BatchedRollout:
         r.range_flag = _p(model._flag(self.device))          # range guard of the split-f16 policy
         r.currentstep = self.t + 1
         with _native.device_guard(self.device):
-            rc = _native.lib().gnnpp_rollout_policy_step(ctypes.byref(r), enc, taps, gb, aw, ab, K,
-                                                         _native.stream_ptr(self.device))
+            rc = _native.lib().gnnpp_rollout_policy_steps(ctypes.byref(r), enc, taps, gb, aw, ab, K, nsteps,
+                                                          _native.stream_ptr(self.device))
         if rc == -2:                                         # shape not supported by the fused kernel
             return False
-        _native.check(rc, 'gnnpp_rollout_policy_step')
-        self.t += 1
+        _native.check(rc, 'gnnpp_rollout_policy_steps')
+        self.t += nsteps
         self._state_step = self.t
         return True
 
@@ -191,6 +192,19 @@ class BatchedRollout:
         # keep the three launches (16 agents per observation workgroup)
         return self.move_and_observe(logits=logits) if self.N <= 32 else self.move(logits=logits)
 
+    def steps(self, model, n):
+        """n rollout steps.  Small teams (the one-launch step): the launches of all n steps are enqueued by ONE
+        C call (gnnpp_rollout_policy_steps) -- no interpreter between two steps."""
+        done = 0
+        if n > 1 and (self._state_step != self.t or self.t == 0):
+            self.step(model)                                 # (the first step may grow the radius)
+            done = 1
+        if n - done > 1 and self._policy_step(model, n - done):
+            return self.flags
+        for _ in range(n - done):
+            self.step(model)
+        return self.flags
+
     def run(self, model, max_steps=None, check_every=8):
         """Step until every episode's loop has ended: the call after its last agent arrived (that call
         writes its statistics, like the reference loop agents/decentralplannerlocal.py:560-605), or
@@ -200,8 +214,9 @@ class BatchedRollout:
         limit = int(self.maxstep.max().item()) if max_steps is None else int(max_steps)
         steps = 0
         while steps < limit:
-            self.step(model)
-            steps += 1
+            burst = min(check_every - steps % check_every, limit - steps)
+            self.steps(model, burst)
+            steps += burst
             if steps % check_every == 0:
                 if hasattr(model, 'check_range'):
                     model.check_range()                      # an activation left the f16 range: error

@@ -166,6 +166,8 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
  *              forward and backward -- pass the SAME buffer, untouched, to the backward call;
  *   update_running != 0: p->bn_mean / p->bn_var are UPDATED in place (the one documented exception
  *              to "inputs are never written"; eval-mode packs must be rebuilt afterwards);
+ *   bn_num_batches  NULL, or the five BatchNorm2d.num_batches_tracked counters (int64, device): each is
+ *              advanced by N, as the N forward calls of the reference do (with update_running only);
  *   g          where the gradients of the 20 parameter tensors go (overwritten, not accumulated).
  * fp32, deterministic (fixed-order reductions, no atomics).  compressMLP, the graph filter and the
  * action head are separate calls (library GEMM / gnnpp_lsigf_fwd_save).
@@ -179,7 +181,8 @@ typedef struct gnnpp_encoder_grads {
 
 size_t gnnpp_encoder_train_workspace_floats(int N, int B);
 int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
-                            int B, int N, float momentum, int update_running, void* stream);
+                            int B, int N, float momentum, int update_running,
+                            long long* const* bn_num_batches, void* stream);
 int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
                             const float* dfeat, const gnnpp_encoder_grads* g, int B, int N, void* stream);
 
@@ -198,6 +201,17 @@ size_t gnnpp_gemm_workspace_floats(int batch, int M, int N, int K);
 int gnnpp_gemm_kmajor(const float* A, long long a_sb, long long a_sm, long long a_sk, const float* B,
                       long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int batch,
                       int M, int N, int K, float* workspace, void* stream);
+/* Up to 8 independent products of that kind in ONE launch (plus one for the ordered sums): the three
+ * products of a Linear layer's backward pass (dx = dY W, dW = dY^T X, db = 1^T dY) cost two launches
+ * instead of six.  workspace: gnnpp_gemm_multi_workspace_floats(d, count) floats. */
+typedef struct gnnpp_gemm_desc {
+    const float* A; long long a_sb, a_sm, a_sk;
+    const float* B; long long b_sb, b_sk;
+    float*       C; long long c_sb, c_sm;
+    int batch, M, N, K;
+} gnnpp_gemm_desc;
+size_t gnnpp_gemm_multi_workspace_floats(const gnnpp_gemm_desc* d, int count);
+int gnnpp_gemm_kmajor_multi(const gnnpp_gemm_desc* d, int count, float* workspace, void* stream);
 
 /* The training loop's loss (agents/decentralplannerlocal.py:296-312), forward and backward in one launch:
  *   logits [N,B,C] (agent-major: the list forward() returns, stacked), target [B,N,C] one-hot expert actions;
@@ -329,6 +343,13 @@ int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream);
 int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
                               const float* gf_bias, const float* act_w, const float* act_b, int K,
                               void* stream);
+/* nsteps consecutive calls of gnnpp_rollout_policy_step with currentstep = r->currentstep, +1, ...: the
+ * inner loop of a rollout (agents/decentralplannerlocal.py:560-599) enqueued back to back, so the host
+ * returns to its interpreter once per nsteps launches.  Episodes that end on the way freeze (see `done`);
+ * GNNPP_TIE_REPLAY is per-call state and is refused (GNNPP_ERR_ARG). */
+int gnnpp_rollout_policy_steps(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
+                               const float* gf_bias, const float* act_w, const float* act_b, int K,
+                               int nsteps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,9 +76,12 @@ def test_emu_train_encoder_forward_backward(N, B, seed):
     ws = np.zeros(lib.gnnpp_encoder_train_workspace_floats(N, B), np.float32)
     feat = np.full((N, B, 128), np.nan, np.float32)
     obs_np = el.f32(obs.numpy())
+    nbt = [np.full(1, 7, np.int64) for _ in range(5)]              # BatchNorm2d.num_batches_tracked: += N
     rc = lib.gnnpp_encoder_train_fwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(feat), B, N,
-                                     ctypes.c_float(0.1), 1, None)
+                                     ctypes.c_float(0.1), 1, (ctypes.c_void_p * 5)(*[a.ctypes.data for a in nbt]),
+                                     None)
     assert rc == 0
+    assert all(int(a[0]) == 7 + N for a in nbt)
     assert np.abs(feat - want_feat.numpy()).max() <= 2e-5 * max(1.0, want_feat.abs().max().item())
     for i in range(5):                                       # N sequential running-statistics updates
         for nm in ('running_mean', 'running_var'):
@@ -189,3 +192,40 @@ def test_emu_adam_matches_torch():
         assert rc == 0 and state[0] == it + 1
         for a, p in zip(mine, ps):
             np.testing.assert_allclose(a, p.detach().numpy(), rtol=0, atol=3e-7)
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [('A', ctypes.c_void_p), ('a_sb', ctypes.c_longlong), ('a_sm', ctypes.c_longlong),
+                ('a_sk', ctypes.c_longlong), ('B', ctypes.c_void_p), ('b_sb', ctypes.c_longlong),
+                ('b_sk', ctypes.c_longlong), ('C', ctypes.c_void_p), ('c_sb', ctypes.c_longlong),
+                ('c_sm', ctypes.c_longlong), ('batch', ctypes.c_int), ('M', ctypes.c_int), ('N', ctypes.c_int),
+                ('K', ctypes.c_int)]
+
+
+def test_emu_gemm_multi_linear_backward():
+    """gnnpp_gemm_kmajor_multi: the three products of a Linear layer's backward pass (dx = dY W, dW = dY^T X,
+    db = 1^T dY) in one call, against numpy -- one of them split over the contraction, one not."""
+    import emu_lib as el
+    lib = el.load()
+    lib.gnnpp_gemm_multi_workspace_floats.restype = ctypes.c_size_t
+    rng = np.random.default_rng(5)
+    R, I, O = 90, 128, 5
+    dY = rng.standard_normal((R, O)).astype(np.float32)
+    X = rng.standard_normal((R, I)).astype(np.float32)
+    Wt = rng.standard_normal((O, I)).astype(np.float32)
+    ones = np.ones(R, np.float32)
+    dx = np.full((R, I), np.nan, np.float32); dW = np.full((O, I), np.nan, np.float32); db = np.full(O, np.nan, np.float32)
+    arr = (GemmDesc * 3)()
+    for d, (A, a_st, Bm, b_st, C, c_st, M, N, K) in zip(arr, (
+            (dY, (0, O, 1), Wt, (0, I), dx, (0, I), R, I, O),
+            (dY, (0, 1, O), X, (0, I), dW, (0, I), O, I, R),
+            (ones, (0, 0, 1), dY, (0, O), db, (0, O), 1, O, R))):
+        d.A, d.a_sb, d.a_sm, d.a_sk = A.ctypes.data, *a_st
+        d.B, d.b_sb, d.b_sk = Bm.ctypes.data, *b_st
+        d.C, d.c_sb, d.c_sm = C.ctypes.data, *c_st
+        d.batch, d.M, d.N, d.K = 1, M, N, K
+    ws = np.zeros(max(lib.gnnpp_gemm_multi_workspace_floats(arr, 3), 1), np.float32)
+    assert lib.gnnpp_gemm_kmajor_multi(arr, 3, el.ptr(ws), None) == 0
+    np.testing.assert_allclose(dx, dY.astype(np.float64) @ Wt.astype(np.float64), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dW, dY.astype(np.float64).T @ X.astype(np.float64), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(db, dY.astype(np.float64).sum(0), rtol=0, atol=2e-4)

@@ -178,6 +178,35 @@ def test_one_launch_rollout_step_equals_separate_launches(dev, B, N, W):
             assert torch.equal(getattr(a, name), getattr(b, name)), (t, name)
 
 
+def test_steps_burst_equals_single_steps(dev):
+    """BatchedRollout.steps(model, n) (gnnpp_rollout_policy_steps: n launches enqueued by one C call) leaves
+    exactly the state that n single step() calls leave, for mixed per-episode step limits and both tie rules
+    that carry state on the device."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    B, N, W = 24, 10, 20
+    rng = np.random.default_rng(77)
+    grids, starts, goals = random_episodes(rng, B, N, W, 0.08)
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(orc.init_state_dict(3, seed=9))
+    maxstep = rng.integers(3, 20, size=B)
+    for tie in ('hashed', 'mt19937'):
+        a = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode=tie, seed=5)
+        b = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode=tie, seed=5)
+        for n in (1, 5, 8, 3):
+            a.steps(net, n)
+            for _ in range(n):
+                b.step(net)
+            assert a.t == b.t
+            for name in ('pos', 'obs', 'S', 'radius', 'reached', 'start_step', 'end_step', 'stats', 'flags',
+                         'done'):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (tie, n, name)
+            assert torch.equal(a._logits, b._logits)
+
+
 def test_closed_loop_rollout_with_policy(dev):
     """observe -> gso -> forward -> move on the GPU; every stage checked against the CPU oracles
     fed with the GPU's own state, so a near-tie in the logits cannot make the trajectories drift."""
