@@ -465,7 +465,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 1)) return;
-    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 0, tid == 0);
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 0, tid == 0);
 
     // ---- L0: 3 -> 32 @ 11x11 (the 10x10 the pool reads), direct, K = 27 in ONE 32-slot block -------
     // A pixel sits in LDS as the word (lo half << 16 | hi half).  Lane (q, agent) owns k-slots
@@ -546,7 +546,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 2)) return;
-    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 1, tid == 0);
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 1, tid == 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         if (tid + i * kThreads < EncLayout::kHssFloats) sstab[tid + i * kThreads] = ssv[i];
@@ -585,7 +585,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 3)) return;
-    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 2, tid == 0);
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 2, tid == 0);
 
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2] : X -> Y -------------------
     {
@@ -618,7 +618,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 4)) return;
-    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 3, tid == 0);
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 3, tid == 0);
 
     // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers : Y -> X ------------
     {
@@ -640,7 +640,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 5)) return;
-    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 4, tid == 0);
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 4, tid == 0);
 
     // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave : X -> Y -------------------
     {
@@ -663,7 +663,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 6)) return;
-    if (FUSED && !pt.with_sim) GNNPP_STAMP(blockIdx.x, 5, tid == 0);
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 5, tid == 0);
 
     // ---- FC 128 -> 128 + ReLU -> feat[agent][128]; tiles 2w, 2w+1 per wave ------------------------
     {
