@@ -163,10 +163,10 @@ def _bind(path):
     L.gnnpp_encoder_train_workspace_floats.restype = cs
     L.gnnpp_encoder_train_workspace_floats.argtypes = [ci, ci]
     L.gnnpp_encoder_train_fwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ci, ci, ctypes.c_float, ci,
-                                          ctypes.POINTER(ctypes.c_void_p), vp]
+                                          ctypes.POINTER(ctypes.c_void_p), ci, vp]
     L.gnnpp_encoder_train_fwd.restype = ci
     L.gnnpp_encoder_train_bwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ctypes.POINTER(EncoderGrads),
-                                          ci, ci, vp]
+                                          ci, ci, ci, vp]
     L.gnnpp_encoder_train_bwd.restype = ci
     ll, cf = ctypes.c_longlong, ctypes.c_float
     L.gnnpp_gemm_workspace_floats.restype = cs
@@ -177,7 +177,7 @@ def _bind(path):
     L.gnnpp_gemm_multi_workspace_floats.argtypes = [ctypes.POINTER(GemmDesc), ci]
     L.gnnpp_gemm_kmajor_multi.argtypes = [ctypes.POINTER(GemmDesc), ci, vp, vp]
     L.gnnpp_gemm_kmajor_multi.restype = ci
-    L.gnnpp_policy_loss.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
+    L.gnnpp_policy_loss.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.gnnpp_policy_loss.restype = ci
     L.gnnpp_adam_step.argtypes = [ctypes.POINTER(AdamTensors), vp, cf, cf, cf, cf, cf, ci, vp]
     L.gnnpp_adam_step.restype = ci

@@ -192,7 +192,7 @@ static int train_params_ok(const gnnpp_encoder_params* p, EncRawParams& rp) {
 
 int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
                             int B, int N, float momentum, int update_running,
-                            long long* const* bn_num_batches, void* stream) {
+                            long long* const* bn_num_batches, int feat_sample_major, void* stream) {
     EncRawParams rp;
     if (!train_params_ok(p, rp) || !obs || !workspace || !feat || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     float* rm[5];
@@ -204,17 +204,18 @@ int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, flo
     }
     if (reinterpret_cast<size_t>(workspace) & 15) return GNNPP_ERR_ARG;      // (16-byte loads on its regions)
     return train_encoder_fwd(rp, rm, rv, update_running ? bn_num_batches : nullptr, momentum, obs, workspace, feat,
-                             N, B, static_cast<hipStream_t>(stream));
+                             N, B, feat_sample_major, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
-                            const float* dfeat, const gnnpp_encoder_grads* g, int B, int N, void* stream) {
+                            const float* dfeat, const gnnpp_encoder_grads* g, int B, int N,
+                            int feat_sample_major, void* stream) {
     EncRawParams rp;
     if (!train_params_ok(p, rp) || !obs || !workspace || !dfeat || !g || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     for (int i = 0; i < 5; ++i)
         if (!g->conv_w[i] || !g->conv_b[i] || !g->bn_w[i] || !g->bn_b[i]) return GNNPP_ERR_ARG;
     return train_encoder_bwd(rp, obs, workspace, dfeat, g->conv_w, g->conv_b, g->bn_w, g->bn_b, N, B,
-                             static_cast<hipStream_t>(stream));
+                             feat_sample_major, static_cast<hipStream_t>(stream));
 }
 
 size_t gnnpp_gemm_workspace_floats(int batch, int M, int N, int K) {
@@ -257,10 +258,10 @@ int gnnpp_gemm_kmajor_multi(const gnnpp_gemm_desc* d, int count, float* workspac
 }
 
 int gnnpp_policy_loss(const float* logits, const float* target, float* loss, float* dlogits, int B, int N,
-                      int C, void* stream) {
+                      int C, int logits_sample_major, void* stream) {
     if (!logits || !target || !loss || B <= 0 || N <= 0 || C <= 0 || C > 64) return GNNPP_ERR_ARG;
     hipLaunchKernelGGL(policy_loss_kernel, dim3(1), dim3(1024), 1024 * sizeof(double),
-                       static_cast<hipStream_t>(stream), logits, target, loss, dlogits, B, N, C);
+                       static_cast<hipStream_t>(stream), logits, target, loss, dlogits, B, N, C, logits_sample_major);
     return hipGetLastError() == hipSuccess ? GNNPP_OK : GNNPP_ERR_LAUNCH;
 }
 

@@ -365,14 +365,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ xn, int B, int C, int H, int W,
-                                                           int pool, int chunks, int CG, int BR, float eps) {
+                                                           int pool, int chunks, int CG, int BR, float eps,
+                                                           int out_bn) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     double* red = reinterpret_cast<double*>(gnnpp_smem);                               // [512]
     float (*sm)[5] = reinterpret_cast<float (*)[5]>(gnnpp_smem + 512 * sizeof(double));  // mean, invstd, gamma, beta
     const int n = blockIdx.z, c0 = blockIdx.x * CG, b0 = blockIdx.y * BR;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo, P = H * W;
     reduce_partials(part, n, chunks, C, c0, CG, red);
-    if (threadIdx.x < CG) {
+    if ((int)threadIdx.x < CG) {
         const int cc = threadIdx.x, c = c0 + cc;
         const int m = B * P;
         const double s1 = red[cc * (256 / CG) * 2], s2 = red[cc * (256 / CG) * 2 + 1];
@@ -410,7 +411,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
         } else {
             v = bn_act(yc[po], mean, invstd, g, be);
         }
-        xn[ic * Po + po] = v;
+        // out_bn: image (n, b) of the OUTPUT sits at b*N + n (sample-major, what the graph filter reads
+        // node-major) instead of n*B + b
+        const long io = out_bn ? ((long)(b0 + bi) * gridDim.z + n) * C + c0 + cc : ic;
+        xn[io * Po + po] = v;
     }
 }
 
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ dxn,
                                                             float* __restrict__ dz, float* __restrict__ part,
-                                                            int B, int C, int splits) {
+                                                            int B, int C, int splits, int N, int dxn_bn) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x / splits, sp = blockIdx.x - n * splits;
     const int c = blockIdx.y * 4 + wave;
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 mine = mine && (k < me ? ak < a : ak <= a);            // strictly greater than the earlier ones
             }
         }
-        const float da = pooled_in ? dxn[ic * Po + oy * Wo + ox] : 0.f;
+        const long icx = dxn_bn ? ((long)b * N + n) * C + c : ic;       // (sample-major d x_next: see bn_relu_pool)
+        const float da = pooled_in ? dxn[icx * Po + oy * Wo + ox] : 0.f;
         const float d = (mine && a > 0.f) ? da : 0.f;
         dz[ic * P + pos] = d;
         s1 += d;
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float (*sm)[5] = reinterpret_cast<float (*)[5]>(gnnpp_smem + 512 * sizeof(double));  // mean, invstd, k1, k2, k3
     const int n = blockIdx.z, c0 = blockIdx.x * CG, b0 = blockIdx.y * BR;
     reduce_partials(part, n, chunks, C, c0, CG, red);
-    if (threadIdx.x < CG) {
+    if ((int)threadIdx.x < CG) {
         const int cc = threadIdx.x, c = c0 + cc;
         const int m = B * P;
         const double s1 = red[cc * (256 / CG) * 2], s2 = red[cc * (256 / CG) * 2 + 1];
@@ -846,12 +851,12 @@ static void wgrad_launch(int l, const TrainWs& L, const float* x, const float* d
 #undef GNNPP_WGRAD
 }
 
-// obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128]
+// obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128], or
+// [B][N][128] with feat_bn (sample-major: node-major rows for the graph filter, no transposing copy)
 int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const* rvar,
                       long long* const* num_batches, float momentum,
-                      const float* obs, float* ws, float* feat, int N, int B, hipStream_t st) {
+                      const float* obs, float* ws, float* feat, int N, int B, int feat_bn, hipStream_t st) {
     const TrainWs L = train_ws_layout(N, B);
-    const long NB = (long)N * B;
     TrainPtrs5 pk = {}, run = {};
     for (int l = 0; l < kTrainLayers; ++l) {
         pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l]; pk.c[l] = ws + L.wtb[l];
@@ -869,7 +874,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N), dim3(256), kBnSmem, st,
                            ws + L.y[l], ws + L.part, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
                            l == kTrainLayers - 1 ? feat : ws + L.xn[l], B, d.Cout, d.H, d.W, d.pool,
-                           conv_chunks(l, B), t.CG, t.BR, rp.bn_eps);
+                           conv_chunks(l, B), t.CG, t.BR, rp.bn_eps, (l == kTrainLayers - 1 && feat_bn) ? 1 : 0);
     }
     if (rmean && rvar) {
         TrainCounters nb = {};
@@ -882,7 +887,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
 // dfeat: gradient w.r.t. x_5 [N][B][128]; writes d conv_w / d conv_b / d bn_w / d bn_b of every layer
 int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const float* dfeat,
                       float* const* dconv_w, float* const* dconv_b, float* const* dbn_w, float* const* dbn_b,
-                      int N, int B, hipStream_t st) {
+                      int N, int B, int feat_bn, hipStream_t st) {
     const TrainWs L = train_ws_layout(N, B);
     const long NB = (long)N * B;
     const float* dxn = dfeat;
@@ -895,7 +900,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
 #define GNNPP_BNR(HH, WW, PL)                                                                                    \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<HH, WW, PL>), dim3(N * L.chunks[l], d.Cout / 4), dim3(256), 0, st,  \
                        ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout,    \
-                       L.chunks[l])
+                       L.chunks[l], N, (l == kTrainLayers - 1 && feat_bn) ? 1 : 0)
         if (d.H == 11) GNNPP_BNR(11, 11, true);
         else if (d.H == 5 && d.pool) GNNPP_BNR(5, 5, true);
         else if (d.H == 5) GNNPP_BNR(5, 5, false);

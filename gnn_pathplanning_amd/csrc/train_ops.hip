@@ -162,7 +162,8 @@ inline int gemm_multi_launch(GemmTable& tb, float* ws, hipStream_t st) {
 }
 
 // ---- loss of the training loop, forward and backward in one launch ------------------------------------------------
-// logits [N][B][C] (agent-major, the LogitList's stacked tensor), target [B][N][C] one-hot expert actions.
+// logits [N][B][C] (agent-major, the LogitList's stacked tensor) or, with logits_bn, [B][N][C] (the same tensor
+// as the train-mode forward produces it); target [B][N][C] one-hot expert actions.
 //   label(n,b) = first maximum of target[b][n][:]           (torch.max(batchTarget[:, n], 1)[1])
 //   loss = (1 / (N*B)) sum_{n,b} ( logsumexp(logits[n][b]) - logits[n][b][label] )
 //        = mean over agents of CrossEntropyLoss(predict[n], label[:, n])   (every agent averages the same B rows)
@@ -171,7 +172,7 @@ inline int gemm_multi_launch(GemmTable& tb, float* ws, hipStream_t st) {
 __global__ __launch_bounds__(1024) void policy_loss_kernel(const float* __restrict__ logits,
                                                            const float* __restrict__ target,
                                                            float* __restrict__ loss, float* __restrict__ dlogits,
-                                                           int B, int N, int C) {
+                                                           int B, int N, int C, int logits_bn) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     double* red = reinterpret_cast<double*>(gnnpp_smem);             // [1024]
     const int R = N * B;
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(1024) void policy_loss_kernel(const float* __restri
     double part = 0.0;
     for (int r = threadIdx.x; r < R; r += 1024) {
         const int n = r / B, b = r - n * B;
-        const float* lg = logits + (long)r * C;
+        const long row = logits_bn ? (long)b * N + n : (long)r;    // logits / dlogits [B][N][C] or [N][B][C]
+        const float* lg = logits + row * C;
         const float* tg = target + ((long)b * N + n) * C;
         int label = 0;
         float tbest = tg[0], mx = lg[0];
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(1024) void policy_loss_kernel(const float* __restri
         part += (double)(lse - lg[label]);
         if (dlogits)
             for (int c = 0; c < C; ++c)
-                dlogits[(long)r * C + c] = (expf(lg[c] - lse) - (c == label ? 1.f : 0.f)) * inv;
+                dlogits[row * C + c] = (expf(lg[c] - lse) - (c == label ? 1.f : 0.f)) * inv;
     }
     red[threadIdx.x] = part;
     __syncthreads();

@@ -66,12 +66,12 @@ class _EncoderTrainFunction(torch.autograd.Function):
                 p.bn_mean[i], p.bn_var[i] = buffers[2 * i].data_ptr(), buffers[2 * i + 1].data_ptr()
         p.bn_eps = float(eps)
         ws = torch.empty(L.gnnpp_encoder_train_workspace_floats(N, B), dtype=torch.float32, device=dev)
-        feat = torch.empty(N, B, 128, dtype=torch.float32, device=dev)
+        feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)     # sample-major: node-major rows
         with _native.device_guard(dev):
             _native.check(L.gnnpp_encoder_train_fwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(feat), B, N,
                                                     ctypes.c_float(momentum), int(buffers is not None),
                                                     (ctypes.c_void_p * 5)(*[c.data_ptr() for c in counters])
-                                                    if counters is not None else None,
+                                                    if counters is not None else None, 1,
                                                     _native.stream_ptr(dev)), 'gnnpp_encoder_train_fwd')
         ctx.save_for_backward(obs, ws, *ps)
         ctx.eps = float(eps)
@@ -95,7 +95,7 @@ class _EncoderTrainFunction(torch.autograd.Function):
         d = dfeat.contiguous().float()
         with _native.device_guard(dev):
             _native.check(L.gnnpp_encoder_train_bwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(d), ctypes.byref(g),
-                                                    B, N, _native.stream_ptr(dev)), 'gnnpp_encoder_train_bwd')
+                                                    B, N, 1, _native.stream_ptr(dev)), 'gnnpp_encoder_train_bwd')
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -474,14 +474,17 @@ class DecentralPlannerNet(nn.Module):
             buffers += [bn.running_mean, bn.running_var]
         counters = [self.ConvLayers[bi].num_batches_tracked for bi in _BN_IDX] if track else None   # += N each
         feat = _EncoderTrainFunction.apply(obs, buffers if track else None, counters, float(bn0.momentum or 0.0),
-                                           float(bn0.eps), *tensors)                     # [N,B,128]
+                                           float(bn0.eps), *tensors)                     # [B,N,128]
         fc = self.compressMLP[0]
-        comp = tF.relu(_LinearFunction.apply(feat, fc.weight, fc.bias))                 # [N,B,F]
+        x = tF.relu(_LinearFunction.apply(feat, fc.weight, fc.bias))                    # [B,N,F]
+        # every activation stays node-major [B,N,*] (the layout the filter kernel keeps in LDS): no transposing
+        # copy between encoder, filter layers and head; each GFL ReLU runs inside its filter launch
         for l in range(self.L):
-            self.GFL[2 * l].addGSO(self.S)
-        shared = self.GFL(comp.permute(1, 2, 0).contiguous())       # [B,F,N]: HIP filter fwd/bwd + ReLU
+            gf = self.GFL[2 * l]
+            gf.addGSO(self.S)
+            x = gf.forward_node_major(x, relu=True)                                     # [B,N,F_l]
         act = self.actionsMLP[0]
-        return _LinearFunction.apply(shared.permute(2, 0, 1), act.weight, act.bias)     # [N,B,5]
+        return _LinearFunction.apply(x, act.weight, act.bias).permute(1, 0, 2)          # [N,B,5] (a view of [B,N,5])
 
     def _forward_train_aten(self, inputTensor):
         """The same train-mode forward on stock aten / MIOpen ops (agents as convolution groups).  NOT

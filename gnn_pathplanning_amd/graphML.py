@@ -67,9 +67,10 @@ def _bias_arg(b, F_out, N):
 
 
 def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
-                  save_taps=False):
+                  save_taps=False, node_major=False):
     """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
-    (and, with save_taps, zs [E*K, B*N, G]).  Any F: the C entry point splits wide filters."""
+    (and, with save_taps, zs [E*K, B*N, G]).  Any F: the C entry point splits wide filters.
+    node_major: x [B,N,G] -> y [B,N,F] (rows = nodes, the layout the kernel keeps in LDS anyway)."""
     dev = _native.require_gpu(h, S, x, b)
     L = _native.lib()
     F_out, E, K, G = h.shape
@@ -86,17 +87,18 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
     if packed is None:
         packed = pack_filter_taps(h)
     bias, per_node = _bias_arg(b, F_out, N)
-    y = torch.empty(B, F_out, Nin, dtype=torch.float32, device=dev)
+    nm = int(node_major)
+    y = torch.empty((B, Nin, F_out) if node_major else (B, F_out, Nin), dtype=torch.float32, device=dev)
     zs = torch.empty(E * K, B * N, G, dtype=torch.float32, device=dev) if save_taps else None
     s64 = int(Sc.dtype == torch.float64)
     with _native.device_guard(dev):
         if transposed or save_taps:
             rc = L.gnnpp_lsigf_fwd_save(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y), _ptr(zs),
                                         B, N, Nin, G, F_out, K, E, s64, int(batched), int(transposed),
-                                        0, 0, int(relu), per_node, None, _native.stream_ptr(dev))
+                                        nm, nm, int(relu), per_node, None, _native.stream_ptr(dev))
         else:
             rc = L.gnnpp_lsigf_fwd(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y),
-                                   B, N, Nin, G, F_out, K, E, s64, int(batched), 0, 0, int(relu),
+                                   B, N, Nin, G, F_out, K, E, s64, int(batched), nm, nm, int(relu),
                                    per_node, None, _native.stream_ptr(dev))
     _native.check(rc, 'gnnpp_lsigf_fwd')
     return (y, zs) if save_taps else y
@@ -120,21 +122,28 @@ class _LSIGFFunction(torch.autograd.Function):
     """y = LSIGF(h, S, x, b) with gradients for h, x and b (none for S)."""
 
     @staticmethod
-    def forward(ctx, h, S, x, b, batched, packed):
-        Nin = x.shape[2]
-        y, zs = _lsigf_device(h, S, x, b, batched, Nin, packed, save_taps=True)
-        ctx.save_for_backward(h, S, zs)
+    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False):
+        """node_major: x [B,N,G] -> y [B,N,F] (train-mode planner: no transposing copies around the filter);
+        relu: y = relu(filter) in the same launch (the mask for the backward pass is y > 0)."""
+        Nin = x.shape[1] if node_major else x.shape[2]
+        y, zs = _lsigf_device(h, S, x, b, batched, Nin, packed, relu=relu, save_taps=True, node_major=node_major)
+        ctx.save_for_backward(h, S, zs, y if relu else None)
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
+        ctx.node_major, ctx.relu = node_major, relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        h, S, zs = ctx.saved_tensors
+        h, S, zs, yrelu = ctx.saved_tensors
         F_out, E, K, G = h.shape
         N = S.shape[-1]
         B = dy.shape[0]
         dy = dy.contiguous().float()
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, yrelu, 0)          # dy where y > 0, else 0
+        if ctx.node_major:
+            return _LSIGFFunction._backward_node_major(ctx, h, S, zs, dy)
         dh = dx = db = None
         if ctx.needs_input_grad[2]:
             hT = h.detach().permute(3, 1, 2, 0)                          # [G,E,K,F] (shape only)
@@ -153,7 +162,43 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=(0, 2)).reshape(ctx.bias_shape)
             else:                                                         # per-node bias [F,N]
                 db = torch.nn.functional.pad(dy.sum(dim=0), (0, N - ctx.Nin)).reshape(ctx.bias_shape)
-        return dh, None, dx, db, None, None
+        return dh, None, dx, db, None, None, None, None
+
+    @staticmethod
+    def _backward_node_major(ctx, h, S, zs, dy):
+        """dy [B,N,F] (rows (b,n), the row order of the saved tap signals): the input gradient is the
+        transposed filter on dy, node-major in and out; dh and db come from ONE multi-product GEMM launch."""
+        F_out, E, K, G = h.shape
+        B, N = dy.shape[0], dy.shape[1]
+        assert ctx.Nin == N
+        dh = dx = db = None
+        if ctx.needs_input_grad[2]:
+            hT = h.detach().permute(3, 1, 2, 0)
+            dx = _lsigf_device(hT, S, dy, None, ctx.batched, N, _packed_transposed_taps(h), transposed=True,
+                               node_major=True)
+        specs = []
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(F_out, E, K, G, dtype=torch.float32, device=dy.device)
+            specs.append((dy, (0, 1, F_out), zs, (B * N * G, G), dh, (G, E * K * G), E * K, F_out, G, B * N))
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
+                db = torch.empty(ctx.bias_shape, dtype=torch.float32, device=dy.device)      # sum over (b, n)
+                specs.append((_ones(B * N, dy.device), (0, 0, 1), dy, (0, F_out), db, (0, F_out), 1, 1, F_out, B * N))
+            else:                                                         # per-node bias [F,N]: sum over b
+                db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
+        if specs:
+            _native.gemm_kmajor_multi(specs)
+        return dh, None, dx, db, None, None, None, None
+
+
+_ones_cache = {}
+
+
+def _ones(n, device):
+    key = (str(device), n)
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ones_cache[key]
 
 
 def _wants_grad(*tensors):
@@ -244,6 +289,19 @@ class _GraphFilterBase(nn.Module):
                                         self.packed_taps())
         return _lsigf_device(self.weight, self.S, x, self.bias, self._batched, Nin,
                              packed=self.packed_taps())
+
+    def forward_node_major(self, x, relu=False):
+        """The same filter on x [B,N,G] -> [B,N,F] (rows = nodes; optionally followed by ReLU in the same launch),
+        differentiable: the train-mode planner's path, which keeps every activation node-major so that no
+        transposing copy sits between encoder, filter and action head.  Needs all N nodes (no Nin < N)."""
+        if self.S is None:
+            raise TypeError('addGSO() must be called before forward()')
+        _native.require_gpu(self.weight, self.S, x)
+        assert x.shape[2] == self.G and x.shape[1] == self.N
+        if self._batched:
+            assert self.S.shape[0] == x.shape[0]
+        return _LSIGFFunction.apply(self.weight, self.S, x, self.bias, self._batched, self.packed_taps(), True,
+                                    bool(relu))
 
     def extra_repr(self):
         s = 'in_features=%d, out_features=%d, ' % (self.G, self.F)

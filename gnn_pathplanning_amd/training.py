@@ -24,16 +24,7 @@ class _PolicyLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, target):
-        N, B, C = logits.shape
-        lg = logits.detach().contiguous().float()
-        tg = target.detach().contiguous().float()
-        dev = _native.require_gpu(lg, tg)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        dlogits = torch.empty_like(lg)
-        with _native.device_guard(dev):
-            _native.check(_native.lib().gnnpp_policy_loss(lg.data_ptr(), tg.data_ptr(), loss.data_ptr(),
-                                                          dlogits.data_ptr(), B, N, C,
-                                                          _native.stream_ptr(dev)), 'gnnpp_policy_loss')
+        loss, dlogits = _policy_loss_and_grad(logits, target)
         ctx.save_for_backward(dlogits)
         return loss
 
@@ -41,6 +32,28 @@ class _PolicyLossFunction(torch.autograd.Function):
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
         return dlogits * g, None
+
+
+def _policy_loss_and_grad(logits, target):
+    """(loss, d loss / d logits) of logits [N,B,C] by ONE gnnpp_policy_loss launch.  The train-mode forward
+    hands out [N,B,C] as a view of a contiguous [B,N,C] tensor: the kernel reads (and writes the gradient in)
+    that layout directly."""
+    N, B, C = logits.shape
+    lg = logits.detach()
+    sample_major = lg.permute(1, 0, 2).is_contiguous() and not lg.is_contiguous()
+    if sample_major:
+        lg = lg.permute(1, 0, 2)                                           # the [B,N,C] storage itself
+    if lg.dtype is not torch.float32 or not lg.is_contiguous():
+        lg = lg.contiguous().float()
+    tg = target.detach().contiguous().float()
+    dev = _native.require_gpu(lg, tg)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(lg)
+    with _native.device_guard(dev):
+        _native.check(_native.lib().gnnpp_policy_loss(lg.data_ptr(), tg.data_ptr(), loss.data_ptr(),
+                                                      dlogits.data_ptr(), B, N, C, int(sample_major),
+                                                      _native.stream_ptr(dev)), 'gnnpp_policy_loss')
+    return loss, (dlogits.permute(1, 0, 2) if sample_major else dlogits)
 
 
 def policy_loss(predict, batch_target):
@@ -95,18 +108,26 @@ class FusedAdam(torch.optim.Optimizer):
                     s['exp_avg'] = torch.zeros_like(p)
                     s['exp_avg_sq'] = torch.zeros_like(p)
             b1, b2 = group['betas']
-            with _native.device_guard(dev):
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            # the pointer tables are rebuilt only when a pointer moved (the caching allocator hands the
+            # gradients the same blocks step after step; filling a ctypes struct costs more than the launch)
+            key = tuple(p.data_ptr() for p in ps) + tuple(g.data_ptr() for g in grads)
+            cache = self.__dict__.setdefault('_gnnpp_tables', {}).setdefault(id(group), {})   # (not optimizer state)
+            if cache.get('key') != key:
+                tables = []
                 for i0 in range(0, len(ps), 32):
-                    chunk = ps[i0:i0 + 32]
                     tb = _native.AdamTensors()
-                    for i, p in enumerate(chunk):
-                        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    for i, (p, g) in enumerate(zip(ps[i0:i0 + 32], grads[i0:i0 + 32])):
                         tb.p[i], tb.g[i] = p.data_ptr(), g.data_ptr()
                         tb.m[i], tb.v[i] = self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()
                         tb.numel[i] = p.numel()
-                    tb.count = len(chunk)
+                    tb.count = min(32, len(ps) - i0)
+                    tables.append(tb)
+                cache['key'], cache['tables'] = key, tables
+            with _native.device_guard(dev):
+                for k, tb in enumerate(cache['tables']):
                     _native.check(L.gnnpp_adam_step(ctypes.byref(tb), st['counter'].data_ptr(), group['lr'], b1, b2,
-                                                    group['eps'], group['weight_decay'], int(i0 == 0),
+                                                    group['eps'], group['weight_decay'], int(k == 0),
                                                     _native.stream_ptr(dev)), 'gnnpp_adam_step')
         # the parameters changed behind torch's version counters: packed / BN-folded copies are stale
         _native.invalidate_packs()
@@ -118,9 +139,15 @@ def train_step(model, optimizer, batch_input, batch_target, batch_GSO, dp=None):
     optimizer.zero_grad()
     model.addGSO(batch_GSO)
     predict = model(batch_input)
-    on_gpu = getattr(predict, 'stacked', None) is not None and predict.stacked.is_cuda
-    loss = (policy_loss_fused if on_gpu else policy_loss)(predict, batch_target)
-    loss.backward()
+    stacked = getattr(predict, 'stacked', None)
+    if stacked is not None and stacked.is_cuda:
+        # loss and d loss / d logits from one launch; backward starts at the logits (what loss.backward() does,
+        # minus the ones_like fill and the multiplication by it)
+        loss, dlogits = _policy_loss_and_grad(stacked, batch_target)
+        stacked.backward(dlogits)
+    else:
+        loss = policy_loss(predict, batch_target)
+        loss.backward()
     if dp is not None:
         dp.reduce_gradients()
     optimizer.step()

@@ -166,6 +166,8 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
  *              forward and backward -- pass the SAME buffer, untouched, to the backward call;
  *   update_running != 0: p->bn_mean / p->bn_var are UPDATED in place (the one documented exception
  *              to "inputs are never written"; eval-mode packs must be rebuilt afterwards);
+ *   feat_sample_major != 0: feat and dfeat are [B,N,128] instead (node-major rows: what gnnpp_lsigf_fwd takes
+ *              with x_node_major, so that no transposing copy sits between encoder and graph filter);
  *   bn_num_batches  NULL, or the five BatchNorm2d.num_batches_tracked counters (int64, device): each is
  *              advanced by N, as the N forward calls of the reference do (with update_running only);
  *   g          where the gradients of the 20 parameter tensors go (overwritten, not accumulated).
@@ -182,9 +184,10 @@ typedef struct gnnpp_encoder_grads {
 size_t gnnpp_encoder_train_workspace_floats(int N, int B);
 int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
                             int B, int N, float momentum, int update_running,
-                            long long* const* bn_num_batches, void* stream);
+                            long long* const* bn_num_batches, int feat_sample_major, void* stream);
 int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
-                            const float* dfeat, const gnnpp_encoder_grads* g, int B, int N, void* stream);
+                            const float* dfeat, const gnnpp_encoder_grads* g, int B, int N,
+                            int feat_sample_major, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The rest of the optimisation step of config 4 (agents/decentralplannerlocal.py:287-317): the weight
@@ -216,9 +219,10 @@ int gnnpp_gemm_kmajor_multi(const gnnpp_gemm_desc* d, int count, float* workspac
 /* The training loop's loss (agents/decentralplannerlocal.py:296-312), forward and backward in one launch:
  *   logits [N,B,C] (agent-major: the list forward() returns, stacked), target [B,N,C] one-hot expert actions;
  *   loss[0] = (1/N) sum_n CrossEntropyLoss(logits[n], argmax_c target[:, n])   (first maximum, like torch.max);
- *   dlogits [N,B,C] = d loss / d logits, or NULL.  C <= 64. */
+ *   dlogits [N,B,C] = d loss / d logits, or NULL.  C <= 64.
+ *   logits_sample_major != 0: logits and dlogits are [B,N,C] (the layout the train-mode forward computes). */
 int gnnpp_policy_loss(const float* logits, const float* target, float* loss, float* dlogits, int B, int N,
-                      int C, void* stream);
+                      int C, int logits_sample_major, void* stream);
 
 /* torch.optim.Adam's update (amsgrad = False; L2 weight decay added to the gradient; bias correction) of up
  * to 32 tensors in one launch:  p, m (exp_avg), v (exp_avg_sq) are updated in place from g.

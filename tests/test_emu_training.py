@@ -48,8 +48,8 @@ def reference(sd, obs, cot):
     return feat.detach(), p, run
 
 
-@pytest.mark.parametrize('N,B,seed', [(2, 3, 0), (3, 5, 1)])
-def test_emu_train_encoder_forward_backward(N, B, seed):
+@pytest.mark.parametrize('N,B,seed,fbn', [(2, 3, 0, 0), (3, 5, 1, 1)])
+def test_emu_train_encoder_forward_backward(N, B, seed, fbn):
     import emu_lib as el
     from oracle import policy_oracle as orc
     lib = el.load()
@@ -79,9 +79,11 @@ def test_emu_train_encoder_forward_backward(N, B, seed):
     nbt = [np.full(1, 7, np.int64) for _ in range(5)]              # BatchNorm2d.num_batches_tracked: += N
     rc = lib.gnnpp_encoder_train_fwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(feat), B, N,
                                      ctypes.c_float(0.1), 1, (ctypes.c_void_p * 5)(*[a.ctypes.data for a in nbt]),
-                                     None)
+                                     fbn, None)
     assert rc == 0
     assert all(int(a[0]) == 7 + N for a in nbt)
+    if fbn:                                                  # feat_sample_major: the same rows as [B,N,128]
+        feat = np.ascontiguousarray(feat.reshape(B, N, 128).transpose(1, 0, 2))
     assert np.abs(feat - want_feat.numpy()).max() <= 2e-5 * max(1.0, want_feat.abs().max().item())
     for i in range(5):                                       # N sequential running-statistics updates
         for nm in ('running_mean', 'running_var'):
@@ -95,9 +97,9 @@ def test_emu_train_encoder_forward_backward(N, B, seed):
                            ('bn_w', 'ConvLayers.%d.weight' % BN[i]), ('bn_b', 'ConvLayers.%d.bias' % BN[i])):
             o = np.full(tuple(sd[key].shape), np.nan, np.float32); outs[key] = o
             getattr(G, field)[i] = o.ctypes.data
-    cot_np = el.f32(cot.numpy())
+    cot_np = el.f32(cot.permute(1, 0, 2).numpy() if fbn else cot.numpy())
     rc = lib.gnnpp_encoder_train_bwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(cot_np), ctypes.byref(G),
-                                     B, N, None)
+                                     B, N, fbn, None)
     assert rc == 0
     for key, o in outs.items():
         want = p_ref[key].grad.numpy()
@@ -158,9 +160,13 @@ def test_emu_policy_loss(B, N):
     loss.backward()
     lg = el.f32(logits.detach().numpy()); tg = el.f32(target.numpy())
     out = np.zeros(1, np.float32); dl = np.full_like(lg, np.nan)
-    assert lib.gnnpp_policy_loss(el.ptr(lg), el.ptr(tg), el.ptr(out), el.ptr(dl), B, N, 5, None) == 0
+    assert lib.gnnpp_policy_loss(el.ptr(lg), el.ptr(tg), el.ptr(out), el.ptr(dl), B, N, 5, 0, None) == 0
     assert abs(out[0] - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
     np.testing.assert_allclose(dl, logits.grad.numpy(), rtol=0, atol=2e-7)
+    # the same rows laid out [B,N,5] (what the train-mode forward computes): same loss, transposed gradient
+    lg2 = np.ascontiguousarray(lg.transpose(1, 0, 2)); out2 = np.zeros(1, np.float32); dl2 = np.full_like(lg2, np.nan)
+    assert lib.gnnpp_policy_loss(el.ptr(lg2), el.ptr(tg), el.ptr(out2), el.ptr(dl2), B, N, 5, 1, None) == 0
+    assert out2[0] == out[0] and np.array_equal(dl2.transpose(1, 0, 2), dl)
 
 
 def test_emu_adam_matches_torch():
