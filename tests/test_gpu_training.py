@@ -279,7 +279,7 @@ def test_graphed_train_step_then_eval_uses_new_weights(dev):
     assert (a - b).abs().max().item() > 1e-3
 
 
-@pytest.mark.parametrize('B,N', [(64, 10), (7, 3), (2, 16)])
+@pytest.mark.parametrize('B,N', [(64, 10), (7, 3), (2, 16), (130, 4)])
 def test_hip_training_encoder_matches_aten_path(dev, B, N):
     """The hand-written train-mode encoder (csrc/train_encoder.hip, forward + backward) against the same
     forward on stock aten / MIOpen ops (agents as convolution groups) at BASELINE config 4's batch:
