@@ -23,16 +23,22 @@ def main():
     ap.add_argument('--graph', action='store_true', help='capture the train step in a HIP graph')
     ap.add_argument('--adam', choices=('fused', 'torch'), default='fused',
                     help='optimizer: training.FusedAdam (gnnpp_adam_step) or torch.optim.Adam')
+    ap.add_argument('--dist-backend', default='nccl',
+                    help='nccl (= RCCL, default); gloo only to exercise the data-parallel code path on a box with '
+                         'fewer GPUs than ranks (with GNNPP_BENCH_DEVICE=0; eager mode only)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('GNNPP_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
     from gnn_pathplanning_amd.sharding import aggregate_throughput
     from gnn_pathplanning_amd.training import FlatBucketDP, FusedAdam, train_step
