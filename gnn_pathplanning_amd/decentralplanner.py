@@ -399,8 +399,15 @@ class DecentralPlannerNet(nn.Module):
         gfs, act = self._mods
         dev = _native.require_gpu(obs, S, gfs[0].weight, act.weight)
         if Ns > gml.MAX_NODES:
-            raise _native.GnnppError('graphs with N=%d > %d nodes are not supported'
-                                     % (Ns, gml.MAX_NODES))
+            # larger graphs than one workgroup's LDS holds: encoder kernel, then every filter layer as dense
+            # exact-fp32 GEMMs (graphML._lsigf_large) and the head as one small library GEMM
+            x = self.encode(obs)
+            if Ns != N:
+                x = torch.cat([x, x.new_zeros(B, Ns - N, x.shape[2])], 1)
+            for gf in gfs:
+                x = gml._lsigf_large(gf.weight, S, x, gf.bias, True, relu=True)
+            out = torch.nn.functional.linear(x[:, :N], act.weight.detach().float(), act.bias.detach().float())
+            return out.permute(1, 0, 2).contiguous()
         L = _native.lib()
         s64 = int(S.dtype is torch.float64)
         flag = self._flag(dev).data_ptr()

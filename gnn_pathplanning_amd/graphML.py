@@ -66,6 +66,38 @@ def _bias_arg(b, F_out, N):
     return b.detach().contiguous().float(), 1
 
 
+def _lsigf_large(h, S, x, b, batched, relu=False):
+    """The same filter for graphs of MORE than MAX_NODES nodes (whose rows do not fit one workgroup's LDS), node-major:
+    x [B,N,G] -> [B,N,F].  Dense and exact fp32 throughout on gnnpp_gemm_kmajor (fp32 MFMA, ordered partial sums):
+      z_{e,k} = S_e^T z_{e,k-1}  (rows = nodes: z_k[n][g] = sum_m S[m][n] z_{k-1}[m][g], graphML.py:2345-2352),
+      one GEMM per (e, k >= 1) over the batch, written into its column block of Z [B*N, E*K*G];
+      y = Z . h^T  (one GEMM, contraction E*K*G), then bias and ReLU.
+    The reference has no size limit (BatchLSIGF is a chain of torch.matmul); this keeps the drop-in true for any N
+    at dense-GEMM speed -- the reference's configurations (N <= 100) never take this path."""
+    dev = _native.require_gpu(h, S, x, b)
+    F_out, E, K, G = h.shape
+    B, N, _ = x.shape
+    S32 = S.detach()
+    S32 = (S32 if S32.dtype is torch.float32 else S32.float()).contiguous()       # S.float() of the reference (:2350)
+    EKG = E * K * G
+    Z = torch.empty(B, N, E * K, G, dtype=torch.float32, device=dev)
+    xc = x.detach().float()
+    for e in range(E):
+        Z[:, :, e * K] = xc
+        for k in range(1, K):
+            Se = S32[:, e] if batched else S32[e]                                   # [B,N,N] view | [N,N] view
+            _native.gemm_kmajor(Se, (E * N * N if batched else 0, 1, N),           # A(m = n_out, k = m_in) = S[m_in][n_out]
+                                Z[:, :, e * K + k - 1], (N * EKG, EKG),             # B(k = m_in, n = g)
+                                Z[:, :, e * K + k], (N * EKG, EKG), B, N, G, N)
+    hT = h.detach().float().permute(1, 2, 3, 0).reshape(EKG, F_out).contiguous()   # [(e,k,g), f]
+    y = torch.empty(B, N, F_out, dtype=torch.float32, device=dev)
+    _native.gemm_kmajor(Z, (0, EKG, 1), hT, (0, F_out), y, (0, F_out), 1, B * N, F_out, EKG)
+    if b is not None:
+        bb = b.detach().float()
+        y += bb.reshape(1, 1, F_out) if bb.numel() == F_out else bb.t().reshape(1, N, F_out)
+    return torch.relu_(y) if relu else y
+
+
 def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
                   save_taps=False, node_major=False):
     """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
@@ -77,7 +109,13 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
     N = S.shape[-1]
     B = x.shape[0]
     if N > MAX_NODES:
-        raise _native.GnnppError('graphs with N=%d > %d nodes are not supported' % (N, MAX_NODES))
+        if transposed or save_taps:
+            raise _native.GnnppError('training on graphs with N=%d > %d nodes is not supported' % (N, MAX_NODES))
+        if node_major:
+            return _lsigf_large(h, S, x, b, batched, relu)
+        xn = torch.zeros(B, N, G, dtype=torch.float32, device=dev)                 # zero padding of missing nodes
+        xn[:, :Nin] = x.detach().permute(0, 2, 1)
+        return _lsigf_large(h, S, xn, b, batched, relu)[:, :Nin].permute(0, 2, 1).contiguous()
     xc = x.detach().contiguous()
     if xc.dtype != torch.float32:
         xc = xc.float()

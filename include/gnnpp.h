@@ -38,7 +38,10 @@ extern "C" {
 #define GNNPP_MAX_NODES    100       /* N <= 100 nodes per graph always fits (G, F <= 128)       */
 #define GNNPP_MAX_ROWS     112       /* hard limit: a workgroup keeps <= 112 node rows in LDS; N in
                                         101..112 works when the 160 KB LDS budget allows (narrower
-                                        G / F), else GNNPP_ERR_UNSUPPORTED                          */
+                                        G / F), else GNNPP_ERR_UNSUPPORTED.  Larger graphs: the same
+                                        filter as dense GEMMs, one gnnpp_gemm_kmajor call per shift
+                                        (A = S with strides (1, N), B = z_{k-1}) and one for the tap
+                                        contraction -- what graphML._lsigf_large does              */
 
 int         gnnpp_version(void);
 const char* gnnpp_error_string(int code);

@@ -135,6 +135,63 @@ def test_filter_vs_oracle_asymmetric_gso(dev, B, N, K):
     assert (yT - want).abs().max().item() > 1e-2
 
 
+@pytest.mark.parametrize('N,E,Nin', [(130, 1, 130), (150, 2, 141)])
+def test_filter_larger_than_one_workgroup(dev, N, E, Nin):
+    """Graphs with more nodes than one workgroup's LDS holds (N > 112) run as dense exact-fp32 GEMMs
+    (graphML._lsigf_large on gnnpp_gemm_kmajor): BatchLSIGF (fp64 GSO, several edge features, Nin < N through the
+    module), LSIGF with one shared GSO, and the per-node bias -- against the oracle."""
+    import gnn_pathplanning_amd.graphML as gml
+    g = torch.Generator().manual_seed(N + E)
+    B, K, G, F_out = 3, 3, 48, 40
+    h = (torch.rand(F_out, E, K, G, generator=g) * 2 - 1) / (G * K * E) ** 0.5
+    b = torch.randn(F_out, 1, generator=g) * 0.1
+    bn = torch.randn(F_out, N, generator=g) * 0.1
+    x = orc.synth_features(B, G, N, seed=N)
+    S = torch.stack([orc.synth_gso_sparse(B, N, 8.0, seed=e + 1) for e in range(E)], 1)       # [B,E,N,N]
+    want = orc.batch_lsigf(h, S, x, b)
+    y = gml.BatchLSIGF(h.to(dev), S.double().to(dev), x.to(dev), b.to(dev)).cpu()
+    assert (y - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+    want_n = orc.batch_lsigf(h, S, x, bn)
+    y_n = gml.BatchLSIGF(h.to(dev), S.to(dev), x.to(dev), bn.to(dev)).cpu()
+    assert (y_n - want_n).abs().max().item() <= TOL * max(1.0, want_n.abs().max().item())
+    want_s = orc.lsigf(h, S[0], x, b)                                                          # one GSO for the batch
+    y_s = gml.LSIGF(h.to(dev), S[0].to(dev), x.to(dev), b.to(dev)).cpu()
+    assert (y_s - want_s).abs().max().item() <= TOL * max(1.0, want_s.abs().max().item())
+    gf = gml.GraphFilterBatch(G, F_out, K, E).to(dev)
+    with torch.no_grad():
+        gf.weight.copy_(h); gf.bias.copy_(b)
+    gf.addGSO(S.to(dev))
+    with torch.no_grad():
+        y_m = gf(x[:, :, :Nin].to(dev)).cpu()                                                  # zero-padded nodes
+    xp = torch.zeros_like(x); xp[:, :, :Nin] = x[:, :, :Nin]
+    want_m = orc.batch_lsigf(h, S, xp, b)[:, :, :Nin]
+    assert y_m.shape == (B, F_out, Nin)
+    assert (y_m - want_m).abs().max().item() <= TOL * max(1.0, want_m.abs().max().item())
+
+
+def test_planner_with_more_agents_than_one_workgroup(dev):
+    """DecentralPlannerNet with 120 agents (the reference has no limit): encoder kernel + dense-GEMM filter + head
+    against the oracle; identical actions on clear rows."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    B, N = 2, 120
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    sd = orc.init_state_dict(3, seed=21)
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(sd)
+    obs = orc.synth_obs(B, N, seed=4)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 100, seed=4))                           # float64
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd, S, obs), 0)                                  # [N,B,5]
+        net.addGSO(S.to(dev))
+        out = net(obs.to(dev))
+    got = torch.stack([o.cpu() for o in out], 0)
+    assert len(out) == N and (got - want).abs().max().item() <= 1e-4
+    clear = orc.top2_margin(list(want)) > 1e-5
+    assert torch.equal(got.argmax(-1).t()[clear], want.argmax(-1).t()[clear])
+
+
 def test_filter_algebra_properties(dev):
     import gnn_pathplanning_amd.graphML as gml
     g = torch.Generator().manual_seed(99)
