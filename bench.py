@@ -404,9 +404,9 @@ def main():
         enc_flops = 2.0 * ENC_MACS_PER_AGENT * M
         pol_flops = policy_flops_per_agent(K, mean_deg) * M
         if fused:
-            kernel = ('gnnpp::encoder_kernel_h2<true> (fused policy kernel: encoder + graph filter + action '
+            kernel = ('gnnpp::encoder_kernel_h2<true, K=%d> (fused policy kernel: encoder + graph filter + action ' % K +
                       'head, one workgroup per graph)')
-            kname = 'encoder_kernel_h2<true>'
+            kname = 'encoder_kernel_h2<true'                    # (<true, K>: the fused instantiation)
             t_dom = dev_elapsed / args.steps                   # HIP events around the reported region
             how = ('HIP events on the launch stream around the reported timed region / its %d launches '
                    '(the step is this one kernel; includes the inter-launch gap)' % args.steps)
@@ -416,8 +416,8 @@ def main():
             lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
                     'algorithmic work' % (N, N)
         else:
-            kernel = 'gnnpp::encoder_kernel_h2<false>' if split_f16 else 'gnnpp::encoder_kernel_f32'
-            kname = 'encoder_kernel_h2<false>' if split_f16 else 'encoder_kernel_f32'
+            kernel = 'gnnpp::encoder_kernel_h2<false, 3>' if split_f16 else 'gnnpp::encoder_kernel_f32'
+            kname = 'encoder_kernel_h2<false' if split_f16 else 'encoder_kernel_f32'
             t_dom = t_enc
             how = ('HIP events around back-to-back launches of the kernel (median of 5 regions); the step is '
                    'this kernel followed by gnnpp::lsigf_kernel')

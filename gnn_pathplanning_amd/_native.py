@@ -68,11 +68,14 @@ def build(force=False, verbose=False, measure=False):
     return out
 
 
-RING_KERNELS = (('encoder_kernel_h2ILb0', 196, 0), ('encoder_kernel_h2ILb1', 244, 32))
+# (mangled-name substring, stream items, scratch bytes allowed): the encoder and the fused policy kernels for
+# K = 2, 3, 4 filter taps (16 more fragments per tap)
+RING_KERNELS = (('encoder_kernel_h2ILb0ELi3E', 196, 0), ('encoder_kernel_h2ILb1ELi2E', 228, 32),
+                ('encoder_kernel_h2ILb1ELi3E', 244, 32), ('encoder_kernel_h2ILb1ELi4E', 260, 32))
 
 
 def check_ring_isa(isa_path, verbose=False):
-    """tools/check_ring_isa.py on both instantiations of the split-f16 encoder kernel: ring
+    """tools/check_ring_isa.py on every instantiation of the split-f16 encoder kernel: ring
     registers private to the asm, load -> wait -> take discipline on every path, every stream item
     loaded and taken exactly once, 256 VGPRs, occupancy 2, no (encoder) / tiny (policy) scratch."""
     import importlib.util

@@ -46,8 +46,9 @@ constexpr int kZs = 136;               // fused policy tail: row stride of the z
 // hi or lo fragment of one (kb, tap, mt)
 constexpr int kh_L1 = 0, kh_L2 = 36, kh_L3 = 72, kh_L4 = 108, kh_FC = 180, kh_END = 196;
 // fused policy kernel (one graph per workgroup): the graph filter's split-f16 taps follow,
-// [tap 3][kb 4][mt_local 2][hi/lo] = 48 items, read in place from gnnpp_filter_pack's buffer
-constexpr int kh_FILT = kh_END, kh_END_POLICY = kh_FILT + 48;
+// [tap K][kb 4][mt_local 2][hi/lo] = 16 K items, read in place from gnnpp_filter_pack's buffer
+constexpr int kh_FILT = kh_END;
+constexpr int kPolicyTapsMin = 2, kPolicyTapsMax = 4;     // K of the instantiated fused kernels
 
 struct WStreamH {                 // per-wave segment bases (wave-uniform: SGPRs) + this lane's offset
     const float* seg[6];
@@ -337,17 +338,18 @@ struct PolicyTail {
     gnnpp_rollout sim;        //    move on these logits -> gso -> observations of the new positions
 };
 // LDS left behind the filter's z / y rows for the simulator step: positions, move scratch, GSO scratch
-// and the episode's occupancy grid
-constexpr size_t kPolicySimOccBytes =
-    (kBufFloats - 4 * 16 * 136) * sizeof(float) - 8 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
+// and the episode's occupancy grid (K taps: z_0 .. z_{K-1} and the y rows precede the simulator's state)
+constexpr size_t policy_sim_occ_bytes(int K) {
+    return (kBufFloats - (K + 1) * 16 * 136) * sizeof(float) - 8 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
+}
 
-template <bool FUSED>
+template <bool FUSED, int KT>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_h2(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M,
                                                                  int stop, int* __restrict__ range_flag,
                                                                  const PolicyTail pt) {
-    constexpr int END = FUSED ? kh_END_POLICY : kh_END;
+    constexpr int END = FUSED ? kh_FILT + 16 * KT : kh_END;
     // `stop` (GNNPP_MEASURE builds only, gnnpp_set_tuning): return after phase 1 = staging, 2 = L0, 3 = L1,
     // 4 = L2, 5 = L3, 6 = L4; 0 = the whole encoder
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
@@ -720,7 +722,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         return;
     }
 
-    // ==== graph filter + action head of this graph (K = 3, G = F = 128) ===========================
+    // ==== graph filter + action head of this graph (K = KT taps, G = F = 128) =====================
     // z_k = z_{k-1} S as a dense product on the fp32 MFMA, all m in ascending order: bit-identical to
     // lsigf_kernel's sparse gather (fmaf(0, z, acc) == acc).  Rows >= N hold the features of the
     // zero-observation padding lanes; S is zero there, so they never reach a real node.
@@ -728,7 +730,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     __syncthreads();                                     // z_0 complete
     GNNPP_STAMP(blockIdx.x, 12, tid == 0);
 #pragma unroll
-    for (int k = 1; k < 3; ++k) {
+    for (int k = 1; k < KT; ++k) {
         const float* zp = z0 + (k - 1) * (16 * kZs);
         float* zn = z0 + k * (16 * kZs);
 #pragma unroll
@@ -745,11 +747,11 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         __syncthreads();
     }
     GNNPP_STAMP(blockIdx.x, 13, tid == 0);
-    // z_0..z_2 -> (hi, lo) half rows in place: 48 rows, a half-wave per row (as lsigf_kernel's split_rows)
+    // z_0..z_{K-1} -> (hi, lo) half rows in place: 16 K rows, a half-wave per row (as lsigf_kernel's split_rows)
     {
         typedef _Float16 v4h __attribute__((ext_vector_type(4)));
         const int half = lane >> 5, hl = lane & 31;
-        for (int rb = 2 * wave; rb < 48; rb += 2 * kWaves) {
+        for (int rb = 2 * wave; rb < 16 * KT; rb += 2 * kWaves) {
             float* row = z0 + (rb + half) * kZs;
             const v4f v = *reinterpret_cast<const v4f*>(row + 4 * hl);
             __builtin_amdgcn_wave_barrier();             // all reads of a row precede its writes
@@ -768,7 +770,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // contraction on the f16 pipe: channel tiles 2w, 2w+1; same term order as lsigf_kernel
     v4f fa[2] = {vzero(), vzero()}, fc[2] = {vzero(), vzero()};
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
+    for (int tap = 0; tap < KT; ++tap) {
         const float* zr = z0 + (tap * 16 + a) * kZs + 4 * q;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -797,7 +799,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA.
     // Wave 0 fetches its A fragments of actionsMLP.0.weight [5,128] now (the weight ring is empty, so a
     // compiler-issued load no longer interferes); they land while the y rows are written.
-    float* const yb = z0 + 3 * (16 * kZs);
+    float* const yb = z0 + KT * (16 * kZs);
     v4f headA[8];
     if (wave == 0) {
 #pragma unroll
@@ -805,7 +807,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             headA[gg] = a < 5 ? *reinterpret_cast<const v4f*>(pt.act_w + a * 128 + gg * 16 + 4 * q) : vzero();
     }
     {
-        const float finv = pt.filt_h2[filter_packed_h2_floats(128, 128, 3, 1) + 1];
+        const float finv = pt.filt_h2[filter_packed_h2_floats(128, 128, KT, 1) + 1];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int f0 = (2 * wave + m) * 16 + 4 * q;
@@ -841,7 +843,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     __threadfence_block();
     __syncthreads();
     {
-        int* spos = reinterpret_cast<int*>(z0 + 4 * (16 * kZs));
+        int* spos = reinterpret_cast<int*>(z0 + (KT + 1) * (16 * kZs));
         int* red = spos + 2 * kMaxAgents;
         int* goal_l = red + 4 * kMaxAgents;
         char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
@@ -863,21 +865,31 @@ int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M,
                       hipStream_t st) {
     static LdsAttrOnce once;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
-    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_h2<false>), (int)smem);
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_h2<false, 3>), (int)smem);
     const int grid = (M + kTileAgents - 1) / kTileAgents;
-    hipLaunchKernelGGL(encoder_kernel_h2<false>, dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
+    hipLaunchKernelGGL((encoder_kernel_h2<false, 3>), dim3(grid), dim3(kThreads), smem, st, obs, packed, feat, M,
                        GNNPP_ENCODER_STOP_VALUE, range_flag, PolicyTail{});   // (zero-initialised: unused by <false>)
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// whole policy step of B graphs with N <= 16 agents, K = 3: one workgroup per graph
-int policy_launch_fused(const float* obs, const float* packed, const PolicyTail& pt, hipStream_t st) {
+// whole policy step of B graphs with N <= 16 agents and K = 2, 3 or 4 taps: one workgroup per graph
+template <int KT>
+static int policy_launch_fused_k(const float* obs, const float* packed, const PolicyTail& pt, hipStream_t st) {
     static LdsAttrOnce once;
     constexpr size_t smem = (kBufFloats + kObsFloatsLds) * sizeof(float);
-    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_h2<true>), (int)smem);
-    hipLaunchKernelGGL(encoder_kernel_h2<true>, dim3(pt.B), dim3(kThreads), smem, st, obs, packed,
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_h2<true, KT>), (int)smem);
+    hipLaunchKernelGGL((encoder_kernel_h2<true, KT>), dim3(pt.B), dim3(kThreads), smem, st, obs, packed,
                        static_cast<float*>(nullptr), pt.B * pt.N, 0, pt.range_flag, pt);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int policy_launch_fused(const float* obs, const float* packed, const PolicyTail& pt, int K, hipStream_t st) {
+    switch (K) {
+        case 2: return policy_launch_fused_k<2>(obs, packed, pt, st);
+        case 3: return policy_launch_fused_k<3>(obs, packed, pt, st);
+        case 4: return policy_launch_fused_k<4>(obs, packed, pt, st);
+        default: return -2;
+    }
 }
 
 }  // namespace gnnpp

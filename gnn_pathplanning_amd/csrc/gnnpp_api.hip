@@ -119,7 +119,8 @@ static bool fused_policy_applies(int B, int N, int K) {
     const bool fused_pays = B <= 2 * 256 || N >= 13;
     return g_fused_policy.load(std::memory_order_relaxed) && fused_pays &&
            g_encoder_variant.load(std::memory_order_relaxed) == 7 &&
-           g_filter_f16.load(std::memory_order_relaxed) && N <= kTileAgents && K == 3;
+           g_filter_f16.load(std::memory_order_relaxed) && N <= kTileAgents && K >= kPolicyTapsMin &&
+           K <= kPolicyTapsMax;
 }
 
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
@@ -150,7 +151,7 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
         pt.logits = logits; pt.B = B; pt.N = N; pt.s_is_f64 = s_is_f64;
         pt.range_flag = range_flag;
         pt.with_sim = 0;
-        return policy_launch_fused(obs, enc_packed, pt, st);
+        return policy_launch_fused(obs, enc_packed, pt, K, st);
     }
     rc = encoder_launch(obs, enc_packed, feat_ws, B * N, range_flag, st);
     return rc ? rc : lsigf_dispatch(a, plan, st);
@@ -404,7 +405,7 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
     if (r->tie_mode < 0 || r->tie_mode > 3) return GNNPP_ERR_ARG;
     if (r->tie_mode == GNNPP_TIE_MT19937 && (!r->rng_words || !r->rng_cursor || r->rng_max <= 0)) return GNNPP_ERR_ARG;
     // same conditions as the fused policy kernel of gnnpp_policy_fwd, plus room for the occupancy grid
-    if (!(fused_policy_applies(r->B, r->N, K) && (size_t)r->H * r->W <= kPolicySimOccBytes))
+    if (!(fused_policy_applies(r->B, r->N, K) && (size_t)r->H * r->W <= policy_sim_occ_bytes(K)))
         return GNNPP_ERR_UNSUPPORTED;
     PolicyTail pt;
     pt.S = r->S; pt.filt_h2 = filt_packed + filter_packed_f32_floats(GNNPP_FEAT, GNNPP_FEAT, K, 1);
@@ -415,7 +416,7 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
     pt.sim = *r;
     pt.sim.grow = 0;
     pt.sim.actions = nullptr;
-    return policy_launch_fused(r->obs, enc_packed, pt, static_cast<hipStream_t>(stream));
+    return policy_launch_fused(r->obs, enc_packed, pt, K, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_rollout_policy_steps(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,

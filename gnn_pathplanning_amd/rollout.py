@@ -152,13 +152,13 @@ class BatchedRollout:
 
     def _policy_step(self, model, nsteps=1):
         """gnnpp_rollout_policy_step(s): policy forward + move + next gso/observe in ONE kernel per step, when
-        the model and the team qualify (eval mode, N = model.numAgents <= 16, K = 3, not 'replay'); nsteps
+        the model and the team qualify (eval mode, N = model.numAgents <= 16, K = 2..4, not 'replay'); nsteps
         launches are enqueued by one C call."""
         if (self.N > 16 or self.tie_mode == 2 or getattr(model, 'training', True)
                 or getattr(model, 'numAgents', -1) != self.N or not hasattr(model, 'policy_pointers')):
             return False
         ptrs = model.policy_pointers()
-        if ptrs is None or ptrs[5] != 3:
+        if ptrs is None or not 2 <= ptrs[5] <= 4:            # (the fused kernel exists for K = 2, 3, 4 taps)
             return False
         enc, taps, gb, aw, ab, K = ptrs
         if self._logits is None:

@@ -61,7 +61,7 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
                                          on the f16 matrix pipe with hi+lo split operands (shifts
                                          stay exact fp32); 0: fp32 MFMA contraction              */
-#define GNNPP_TUNE_FUSED_POLICY     6  /* 1 (default): for teams of N <= 16 agents and K = 3 taps (with
+#define GNNPP_TUNE_FUSED_POLICY     6  /* 1 (default): for teams of N <= 16 agents and K = 2, 3 or 4 taps (with
                                          encoder schedule 7 and FILTER_F16 = 1), when B <= 512 graphs
                                          or N >= 13, gnnpp_policy_fwd is ONE kernel -- a workgroup
                                          encodes one graph's agents, then runs that graph's filter and
@@ -342,7 +342,7 @@ int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream);
  * then getCurrentState + getGSO of the next iteration).  Same results as the three calls in
  * sequence; fields as for those calls. */
 int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream);
-/* A WHOLE rollout step in one launch for teams of N <= 16 agents (K = 3): policy forward on r->obs /
+/* A WHOLE rollout step in one launch for teams of N <= 16 agents (K = 2, 3 or 4): policy forward on r->obs /
  * r->S (fp32) with the packed encoder / filter weights, logits to r->logits [N,B,5], then move ->
  * gso -> observe as gnnpp_rollout_step; r->obs and r->S are overwritten with the next step's.
  * GNNPP_ERR_UNSUPPORTED (nothing enqueued) when the shape does not qualify (see GNNPP_TUNE_FUSED_POLICY;

@@ -130,6 +130,42 @@ def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden):
     assert ran >= 2
 
 
+@pytest.mark.parametrize('K', [2, 4])
+def test_emu_fused_policy_kernel_other_tap_counts(emu, K):
+    """The fused policy kernel is instantiated for K = 2, 3, 4 filter taps (16 more weight-ring items and one
+    more z buffer per tap): same logits as the two-kernel path, and as the oracle."""
+    import torch
+    from oracle import policy_oracle as orc
+    el, lib = emu
+    B, N = 2, 5
+    sd_t = orc.init_state_dict(K, seed=50 + K)
+    sd = {k: v.numpy() for k, v in sd_t.items()}
+    enc = el.pack_encoder(lib, sd)
+    filt = el.pack_filter(lib, sd['GFL.0.weight'])
+    gb = el.f32(sd['GFL.0.bias'].reshape(-1))
+    aw, ab = el.f32(sd['actionsMLP.0.weight']), el.f32(sd['actionsMLP.0.bias'])
+    obs_t = orc.synth_obs(B, N, seed=K)
+    S_t = torch.from_numpy(orc.synth_gso_geometric(B, N, 12, seed=K)).float()
+    obs, S = el.f32(obs_t.numpy()), el.f32(S_t.numpy())
+    outs = []
+    try:
+        for mode in (1, 0):
+            assert lib.gnnpp_set_tuning(6, mode) == 0
+            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+            ws = np.zeros((B * N, 128), dtype=np.float32)
+            assert lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb), el.ptr(aw),
+                                        el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K, 1, 0, None, None) == 0
+            outs.append(logits)
+            if mode == 1:
+                assert not ws.any()                          # one kernel: the feature workspace is not written
+    finally:
+        lib.gnnpp_set_tuning(6, 1)
+    assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd_t, S_t, obs_t), 0).numpy()
+    assert np.abs(outs[0] - want).max() <= TOL
+
+
 def test_emu_filter_forced_gpw(emu, lsigf_golden):
     """The graphs-per-workgroup choice only changes the schedule, never the result."""
     el, lib = emu

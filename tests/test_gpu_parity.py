@@ -244,15 +244,17 @@ def test_non_binary_observations(dev, enc_variant):
     assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize('B,N,W', [(512, 10, 20), (33, 16, 24), (5, 1, 8), (64, 7, 12), (600, 14, 20), (2048, 10, 20)])
-def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W):
-    """For N <= 16 and K = 3 the policy step is ONE kernel (a workgroup per graph: encoder, dense-MFMA
+@pytest.mark.parametrize('B,N,W,K', [(512, 10, 20, 3), (33, 16, 24, 3), (5, 1, 8, 3), (64, 7, 12, 3), (600, 14, 20, 3),
+                                     (2048, 10, 20, 3), (512, 10, 20, 2), (33, 16, 24, 4), (64, 7, 12, 4),
+                                     (5, 3, 8, 2)])
+def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W, K):
+    """For N <= 16 and K = 2, 3, 4 taps the policy step is ONE kernel (a workgroup per graph: encoder, dense-MFMA
     shifts, split-f16 contraction, head).  It performs the same arithmetic in the same order as the
     encoder kernel + filter kernel, so the logits must be identical; fp64 and fp32 GSOs both."""
     from gnn_pathplanning_amd import _native
     L = _native.lib()
-    sd = orc.init_state_dict(3, seed=31)
-    net = _net(N, 3, dev, sd)
+    sd = orc.init_state_dict(K, seed=31)
+    net = _net(N, K, dev, sd)
     obs = orc.synth_obs(B, N, seed=B + 3 * N).to(dev)
     S64 = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=N))
     try:

@@ -21,8 +21,10 @@ def test_ring_registers_are_private_to_the_asm(tmp_path):
     subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
                            '-Wno-unused-result', '-w',
                            os.path.join(ROOT, 'gnn_pathplanning_amd', 'csrc', 'gnnpp_api.hip'), '-o', out])
-    # encoder only (196 stream items) and fused policy kernel (+ 48 filter-tap fragments)
-    for kern, items, scratch in (('encoder_kernel_h2ILb0', 196, 0), ('encoder_kernel_h2ILb1', 244, 32)):
+    # encoder only (196 stream items) and the fused policy kernels (+ 16 filter-tap fragments per tap, K = 2, 3, 4)
+    from gnn_pathplanning_amd._native import RING_KERNELS
+    assert [k[1] for k in RING_KERNELS] == [196, 228, 244, 260]
+    for kern, items, scratch in RING_KERNELS:
         errors, stats, meta = check_ring_isa.check(out, kern, scratch)
         assert not errors, (kern, errors[:10])
         assert stats['loads'] == items and stats['takes'] == items, (kern, stats)   # each item exactly once

@@ -10,8 +10,8 @@ This script verifies on the ISA hipcc produced that
      a slot is never reloaded before it was taken,
   3. the kernel allocates 256 VGPRs, spills nothing and keeps two waves per SIMD.
 
-Both instantiations are checked: encoder_kernel_h2<false> (196 stream items) and the fused policy
-kernel encoder_kernel_h2<true> (244: + the graph filter's taps).
+Every instantiation is checked: encoder_kernel_h2<false, 3> (196 stream items) and the fused policy
+kernels encoder_kernel_h2<true, K> for K = 2, 3, 4 filter taps (196 + 16 K items).
 
     python tools/check_ring_isa.py file.s [mangled-name-substring]   (exit status 1 on any violation)
 """
@@ -172,8 +172,9 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
 
 if __name__ == '__main__':
     bad = 0
-    for kern in (sys.argv[2:3] or ['encoder_kernel_h2ILb0', 'encoder_kernel_h2ILb1']):
-        errs, st, meta = check(sys.argv[1], kern, 0 if kern.endswith('ILb0') else 32)
+    for kern in (sys.argv[2:3] or ['encoder_kernel_h2ILb0ELi3E', 'encoder_kernel_h2ILb1ELi2E',
+                                   'encoder_kernel_h2ILb1ELi3E', 'encoder_kernel_h2ILb1ELi4E']):
+        errs, st, meta = check(sys.argv[1], kern, 0 if 'ILb0' in kern else 32)
         print('%s: ring loads: %d, fragments taken: %d, %r, violations: %d'
               % (kern, st['loads'], st['takes'], meta, len(errs)))
         for e in errs[:40]:
