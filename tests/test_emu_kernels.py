@@ -148,6 +148,8 @@ def test_emu_fused_policy_kernel_other_tap_counts(emu, K):
     S_t = torch.from_numpy(orc.synth_gso_geometric(B, N, 12, seed=K)).float()
     obs, S = el.f32(obs_t.numpy()), el.f32(S_t.numpy())
     outs = []
+    lib.gnnpp_set_tuning(0, -1)                              # default schedules, whatever an earlier test left
+    lib.gnnpp_set_tuning(5, 1)
     try:
         for mode in (1, 0):
             assert lib.gnnpp_set_tuning(6, mode) == 0
