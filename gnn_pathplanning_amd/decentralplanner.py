@@ -35,6 +35,13 @@ from . import _native
 from . import graphML as gml
 from .weights_initializer import weights_init
 
+# The architecture the kernels implement (graphs/models/decentralplanner.py:93-197: 3 -> 32 -> 32 -> 64 -> 64 -> 128
+# channels of 3x3 convolutions on the 11x11 field of view, a 2x2 max-pool after layers 0, 2 and 4, 128 features,
+# 5 actions): (input channels, output channels, pooled) per layer, and where that puts Conv2d / BatchNorm2d in
+# the reference's nn.Sequential -- the state_dict keys.
+_ENCODER_LAYERS = ((3, 32, True), (32, 32, False), (32, 64, True), (64, 64, False), (64, 128, True))
+_FEATURES = 128
+_ACTIONS = 5
 _CONV_IDX = (0, 4, 7, 11, 14)
 _BN_IDX = (1, 5, 8, 12, 15)
 
@@ -46,7 +53,7 @@ def _ptr(t):
 class _EncoderTrainFunction(torch.autograd.Function):
     """Train-mode ConvLayers of ALL agents on the HIP kernels of csrc/train_encoder.hip.
 
-    obs [B,N,3,11,11] -> feat [N,B,128] (the flattened ConvLayers output of agent call n, i.e. what the
+    obs [B,N,3,11,11] -> feat [B,N,128] (row (b,n) = the flattened ConvLayers output of agent call n, i.e. what the
     reference hands to compressMLP at decentralplanner.py:287-289), with the reference's per-agent-call
     BatchNorm statistics; the running statistics receive their N momentum updates in place.  backward =
     gnnpp_encoder_train_bwd: gradients of the 20 conv / BatchNorm parameters (no gradient to obs: it is
@@ -161,65 +168,39 @@ class DecentralPlannerNet(nn.Module):
         self.S = None
         self.numAgents = self.config.num_agents
 
-        inW = inH = 11
-        numAction = 5
-        numChannel = [3] + [32, 32, 64, 64, 128]
-        numStride = [1, 1, 1, 1, 1]
-        dimCompressMLP = 1
-        numCompressFeatures = [2 ** 7]
-        nMaxPoolFilterTaps = 2
-        numMaxPoolStride = 2
-        # The reference fixes one graph-filter layer in its source (decentralplanner.py:130-131:
-        # dimNodeSignals = [2**7], nGraphFilterTaps = [config.nGraphFilterTaps], E = 1 at :208) but builds
-        # and runs L layers / E edge features generically (:205-224, :266-276, :293-298).  The same
-        # generality is reachable here without editing source: optional config fields
-        # `dimNodeSignals` (list), a LIST in `nGraphFilterTaps`, `numEdgeFeatures`.
+        # The module tree below IS the state_dict contract with the reference (graphs/models/decentralplanner.py:
+        # ConvLayers.{0,1,4,5,7,8,11,12,14,15}, compressMLP.0, GFL.0, actionsMLP.0); the kernels fix the
+        # architecture (_ENCODER_LAYERS: 11x11 observations -> 128 features), so it is written out as a table.
+        convs = []
+        for cin, cout, pool in _ENCODER_LAYERS:
+            convs += [nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True), nn.BatchNorm2d(cout),
+                      nn.ReLU(inplace=True)]
+            if pool:
+                convs.append(nn.MaxPool2d(kernel_size=2))
+        self.ConvLayers = nn.Sequential(*convs)
+        assert [i for i, m in enumerate(convs) if isinstance(m, nn.Conv2d)] == list(_CONV_IDX)
+        self.compressMLP = nn.Sequential(nn.Linear(_FEATURES, _FEATURES, bias=True), nn.ReLU(inplace=True))
+        self.numFeatures2Share = _FEATURES
+
+        # Graph-filter layers.  The reference fixes ONE layer in its source (dimNodeSignals = [2**7],
+        # nGraphFilterTaps = [config.nGraphFilterTaps] at :130-131, E = 1 at :208) but builds and runs L layers /
+        # E edge features generically (:205-224, :266-276, :293-298).  The same generality is reachable here
+        # without editing source, through optional config fields: a LIST in `nGraphFilterTaps`,
+        # `dimNodeSignals` (list of layer widths), `numEdgeFeatures`.
         taps = self.config.nGraphFilterTaps
-        nGraphFilterTaps = list(taps) if isinstance(taps, (list, tuple)) else [taps]
-        dimNodeSignals = list(getattr(self.config, 'dimNodeSignals', None) or [2 ** 7] * len(nGraphFilterTaps))
-        assert len(dimNodeSignals) == len(nGraphFilterTaps)
-        numActionFeatures = [numAction]
-
-        # ---- CNN (parameter container; layout fixed by the fused kernel) ----
-        layers = []
-        w, h = inW, inH
-        for l in range(len(numChannel) - 1):
-            layers.append(nn.Conv2d(numChannel[l], numChannel[l + 1], kernel_size=3,
-                                    stride=numStride[l], padding=1, bias=True))
-            layers.append(nn.BatchNorm2d(numChannel[l + 1]))
-            layers.append(nn.ReLU(inplace=True))
-            if l % 2 == 0:
-                layers.append(nn.MaxPool2d(kernel_size=2))
-                w = (w - nMaxPoolFilterTaps) // numMaxPoolStride + 1
-                h = (h - nMaxPoolFilterTaps) // numMaxPoolStride + 1
-        self.ConvLayers = nn.Sequential(*layers)
-        numFeatureMap = numChannel[-1] * w * h
-        assert numFeatureMap == 128
-
-        numCompressFeatures = [numFeatureMap] + numCompressFeatures
-        mlp = []
-        for l in range(dimCompressMLP):
-            mlp.append(nn.Linear(numCompressFeatures[l], numCompressFeatures[l + 1], bias=True))
-            mlp.append(nn.ReLU(inplace=True))
-        self.compressMLP = nn.Sequential(*mlp)
-        self.numFeatures2Share = numCompressFeatures[-1]
-
-        # ---- graph filter layers ----
-        self.L = len(nGraphFilterTaps)
-        self.F = [numCompressFeatures[-1]] + dimNodeSignals
-        self.K = nGraphFilterTaps
+        self.K = list(taps) if isinstance(taps, (list, tuple)) else [taps]
+        widths = list(getattr(self.config, 'dimNodeSignals', None) or [_FEATURES] * len(self.K))
+        assert len(widths) == len(self.K)
+        self.L = len(self.K)
+        self.F = [_FEATURES] + widths
         self.E = int(getattr(self.config, 'numEdgeFeatures', 1))
         self.bias = True
         gfl = []
         for l in range(self.L):
-            gfl.append(gml.GraphFilterBatch(self.F[l], self.F[l + 1], self.K[l], self.E, self.bias))
-            gfl.append(nn.ReLU(inplace=True))
+            gfl += [gml.GraphFilterBatch(self.F[l], self.F[l + 1], self.K[l], self.E, self.bias),
+                    nn.ReLU(inplace=True)]
         self.GFL = nn.Sequential(*gfl)
-
-        # ---- action head ----
-        numActionFeatures = [self.F[-1]] + numActionFeatures
-        self.actionsMLP = nn.Sequential(nn.Linear(numActionFeatures[0], numActionFeatures[1],
-                                                  bias=True))
+        self.actionsMLP = nn.Sequential(nn.Linear(self.F[-1], _ACTIONS, bias=True))
         self.apply(weights_init)
         self._enc_cache = _native.PackCache()
         self._head_cache = _native.PackCache()
