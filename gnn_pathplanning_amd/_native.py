@@ -25,7 +25,8 @@ EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get
            'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_gemm_multi_workspace_floats',
            'gnnpp_gemm_kmajor_multi', 'gnnpp_policy_loss',
            'gnnpp_adam_step', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
-           'gnnpp_rollout_move', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step', 'gnnpp_rollout_policy_steps')
+           'gnnpp_rollout_move', 'gnnpp_rollout_gso_observe', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step',
+           'gnnpp_rollout_policy_steps')
 
 
 class GnnppError(RuntimeError):
@@ -188,7 +189,8 @@ def _bind(path):
     L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 7 + [vp, vp]
     L.gnnpp_filter_head_fwd.restype = ci
     L.gnnpp_decode_actions.argtypes = [vp, vp, ci, ci, vp]
-    for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move', 'gnnpp_rollout_step'):
+    for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move', 'gnnpp_rollout_gso_observe',
+              'gnnpp_rollout_step'):
         getattr(L, f).argtypes = [ctypes.POINTER(RolloutStruct), vp]
         getattr(L, f).restype = ci
     L.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, vp]

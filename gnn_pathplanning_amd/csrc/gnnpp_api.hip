@@ -372,6 +372,12 @@ int gnnpp_rollout_gso(const gnnpp_rollout* r, void* stream) {
     return rollout_gso_launch(*r, static_cast<hipStream_t>(stream));
 }
 
+int gnnpp_rollout_gso_observe(const gnnpp_rollout* r, void* stream) {
+    if (!rollout_common_ok(r) || !r->radius || !r->S || !r->grid || !r->goal || !r->obs || r->H <= 0 || r->W <= 0)
+        return GNNPP_ERR_ARG;
+    return rollout_gso_observe_launch(*r, static_cast<hipStream_t>(stream));
+}
+
 int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream) {
     if (!rollout_common_ok(r) || !r->grid || !r->goal || (!r->logits && !r->actions) ||
         !r->reached || !r->start_step || !r->end_step || !r->maxstep || !r->flags || !r->stats ||

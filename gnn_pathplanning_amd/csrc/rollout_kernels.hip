@@ -680,7 +680,40 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     sim_tail(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);
 }
 
+// Communication GSO and observations of the CURRENT positions in one launch, for teams too large for one workgroup
+// per episode (rollout_step_kernel): both depend only on the positions, so their workgroups run side by side --
+// per episode `groups` observation workgroups (16 agents each) and one GSO workgroup.  The two kernels in
+// sequence leave most of the chip idle twice (B graph workgroups, then B * groups observation workgroups).
+__global__ __launch_bounds__(256) void rollout_gso_observe_kernel(const RolloutArgs p, int groups) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    const int per = groups + 1;
+    const int b = blockIdx.x / per, r = blockIdx.x - b * per;
+    const int* pos = p.pos + (size_t)b * p.N * 2;
+    if (r == groups) {                                   // (workgroup-uniform)
+        gso_body(p, b, pos, false, gnnpp_smem, threadIdx.x, 256);
+        return;
+    }
+    const int n0 = r * kObsAgentsPerWg;
+    int* goal_l = reinterpret_cast<int*>(gnnpp_smem);                       // [2 kMaxAgents]
+    unsigned char* cell = reinterpret_cast<unsigned char*>(goal_l + 2 * kMaxAgents);
+    observe_stage(p, b, cell, goal_l, threadIdx.x, 256);
+    __syncthreads();
+    observe_prep(p, pos, cell, goal_l, threadIdx.x, 256);
+    __syncthreads();
+    observe_rows(p, b, pos, n0, min(p.N, n0 + kObsAgentsPerWg), cell, goal_l, threadIdx.x, 256);
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
+int rollout_gso_observe_launch(const RolloutArgs& a, hipStream_t st) {
+    const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
+    if (occ > 64 * 1024) return -2;
+    size_t smem = occ + 2 * kMaxAgents * sizeof(int);
+    if (smem < (size_t)kGsoSmemBytes) smem = kGsoSmemBytes;
+    const int groups = (a.N + kObsAgentsPerWg - 1) / kObsAgentsPerWg;
+    hipLaunchKernelGGL(rollout_gso_observe_kernel, dim3(a.B * (groups + 1)), dim3(256), smem, st, a, groups);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int rollout_observe_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (occ > 64 * 1024) return -2;

@@ -111,6 +111,14 @@ class BatchedRollout:
         self._call(_native.lib().gnnpp_rollout_gso, 'gnnpp_rollout_gso')
         return self.S
 
+    def gso_observe(self):
+        """gso() (no radius growth: not for step 0) and observe() of the current positions as ONE launch
+        (gnnpp_rollout_gso_observe): the two are independent given the positions."""
+        self._r.grow = 0
+        self._call(_native.lib().gnnpp_rollout_gso_observe, 'gnnpp_rollout_gso_observe')
+        self._state_step = self.t
+        return self.obs, self.S
+
     def move(self, logits=None, actions=None, choices=None, currentstep=None):
         """Apply one joint action.  logits [N,B,5] (DecentralPlannerNet.forward_logits) or action
         ids [B,N] int32; `choices` [B,C] int16 only for tie_mode='replay'.  Returns flags [B,3]
@@ -181,9 +189,11 @@ class BatchedRollout:
         """One rollout step of all episodes: observe -> gso -> policy forward -> move.  From the
         second step on the observation and the GSO were already produced by the previous step's
         fused move kernel."""
-        if self._state_step != self.t or self.t == 0:        # step 0 may grow the radius
+        if self.t == 0:                                      # step 0 may grow the radius
             self.observe()
             self.gso()
+        elif self._state_step != self.t:                     # large teams: graph and observations side by side
+            self.gso_observe()
         if self._policy_step(model):                         # small teams: the whole step is one launch
             return self.flags
         model.addGSO(self.S)

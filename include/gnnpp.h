@@ -337,6 +337,10 @@ typedef struct gnnpp_rollout {
 int gnnpp_rollout_observe(const gnnpp_rollout* r, void* stream);
 int gnnpp_rollout_gso(const gnnpp_rollout* r, void* stream);
 int gnnpp_rollout_move(const gnnpp_rollout* r, void* stream);
+/* gnnpp_rollout_gso (grow = 0) and gnnpp_rollout_observe of the current positions in ONE launch: the two depend only
+ * on the positions, so their workgroups run side by side (large teams, where one workgroup per episode is too
+ * little for gnnpp_rollout_step).  Same results as the two calls. */
+int gnnpp_rollout_gso_observe(const gnnpp_rollout* r, void* stream);
 /* move -> gso (grow = 0) -> observe of the new positions in ONE launch: the simulator work between
  * two policy forwards of a rollout (the loop agents/decentralplannerlocal.py:560-599 runs move,
  * then getCurrentState + getGSO of the next iteration).  Same results as the three calls in

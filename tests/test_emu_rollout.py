@@ -42,11 +42,15 @@ def replay_case(lib, Struct, z, ci, m, fused=False):
     r.tie_mode, r.choice_count = 2, ccount.ctypes.data
     for t in range(T):
         assert (pos[0] == pos_all[t]).all(), (ci, t)
-        if not fused or t == 0:     # fused: the previous gnnpp_rollout_step already produced obs and S
+        pair = fused == 'pair' and t > 0       # gnnpp_rollout_gso_observe: graph + observations in one launch
+        if pair:
+            r.grow = 0
+            assert lib.gnnpp_rollout_gso_observe(ctypes.byref(r), None) == 0
+        if (not fused or t == 0) or (fused == 'pair' and not pair):   # fused step: already produced obs and S
             assert lib.gnnpp_rollout_observe(ctypes.byref(r), None) == 0
         assert (obs[0] == z['t%d_obs' % ci][t].astype(np.float32)).all(), (ci, t)
         r.grow = int(t == 0)
-        if not fused or t == 0:
+        if (not fused or t == 0) or (fused == 'pair' and not pair):
             assert lib.gnnpp_rollout_gso(ctypes.byref(r), None) == 0
         assert radius[0] == z['t%d_radius' % ci][t], (ci, t)
         assert (S[0] == z['t%d_gso' % ci][t].astype(np.float32)).all(), (ci, t)
@@ -60,7 +64,7 @@ def replay_case(lib, Struct, z, ci, m, fused=False):
         r.logits, r.actions, r.currentstep = logits.ctypes.data, None, t + 1
         r.choices, r.max_choices = ch.ctypes.data, ch.shape[1]
         r.grow = 0
-        assert (lib.gnnpp_rollout_step if fused else lib.gnnpp_rollout_move)(ctypes.byref(r), None) == 0
+        assert (lib.gnnpp_rollout_step if fused is True else lib.gnnpp_rollout_move)(ctypes.byref(r), None) == 0
         assert ccount[0] == nch, (ci, t, ccount[0], nch)
         assert list(flags[0]) == [int(v) for v in z['t%d_flags' % ci][t]], (ci, t)
         assert (reached[0] == z['t%d_reached' % ci][t]).all(), (ci, t)
@@ -86,6 +90,17 @@ def test_emu_rollout_traces_fused_step(rollout_golden):
     z, meta = rollout_golden
     for ci, m in enumerate(meta):
         replay_case(lib, RolloutStruct, z, ci, m, fused=True)
+
+
+def test_emu_rollout_traces_gso_observe_pair(rollout_golden):
+    """gnnpp_rollout_gso_observe (the graph's and the observations' workgroups in one launch, what large teams
+    run between two moves) replays the same traces."""
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    lib = emu_lib.load()
+    z, meta = rollout_golden
+    for ci, m in enumerate(meta):
+        replay_case(lib, RolloutStruct, z, ci, m, fused='pair')
 
 
 def test_emu_rollout_argument_checks():
