@@ -181,8 +181,8 @@ def rollout_bench():
         net.addGSO(env.S)
         lg = net.forward_logits(env.obs)
         row['move_us'] = round(timeit(lambda: env.move(logits=lg), reps=20), 2)
-        if N <= 32:
-            row['sim_step_us'] = round(timeit(lambda: env.move_and_observe(logits=lg), reps=20), 2)
+        row['sim_step_us'] = round(timeit(lambda: env.move_and_observe(logits=lg), reps=20), 2)   # one launch
+        row['move_then_pair_us'] = round(timeit(lambda: (env.move(logits=lg), env.gso_observe()), reps=20), 2)
         row['policy_us'] = round(timeit(lambda: (net.addGSO(env.S), net.forward_logits(env.obs)), reps=20), 2)
         row['step_us_one_per_call'] = round(timeit(lambda: env.step(net), reps=20), 2)
         t = timeit(lambda: env.steps(net, 8), reps=6) / 8       # eight steps enqueued per host call

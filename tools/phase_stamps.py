@@ -42,7 +42,7 @@ def report(tag, st, order):
     print(json.dumps(row), flush=True)
 
 
-for (N, B, W) in ((10, 512, 20), (16, 512, 20)):
+for (N, B, W) in ((10, 512, 20), (16, 512, 20), (100, 128, 100)):
     class Cfg:
         num_agents, nGraphFilterTaps, device = N, 3, dev
     rng = np.random.default_rng(N)
@@ -70,6 +70,8 @@ for (N, B, W) in ((10, 512, 20), (16, 512, 20)):
     report('rollout_step_kernel N=%d B=%d' % (N, B), stamps(min(B, 1024)),
            ['move:entry', 'move:state_loaded', 'move:proposed', 'move:pass1', 'move:passes', 'move:final_pass',
             'move:stored', 'sim:move_done', 'sim:gso_done', 'sim:observe_done'])
+    if N > 16:                                                # (the one-launch policy step is for N <= 16)
+        continue
     ptrs = net.policy_pointers()
     enc, taps, gb, aw, ab, K = ptrs
     M.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(_native.RolloutStruct)] + [ctypes.c_void_p] * 5 + \
