@@ -81,6 +81,10 @@ class BatchedRollout:
         self.seed = int(seed) & 0xffffffff
         self.t = 0                                            # steps taken so far
         self._state_step = -1                                 # step whose positions obs / S describe
+        # teams up to this size run move -> graph -> observations as ONE launch (gnnpp_rollout_step, one workgroup
+        # of 256 / 1024 threads per episode): measured faster than move + (graph || observations) at every size up
+        # to the 128-agent limit (N = 40: 108 vs 119 us per step, N = 100: 156 vs 160)
+        self.fused_sim_max_agents = 128
         self._logits = None                                   # [N,B,5] of the one-launch step
         r = _native.RolloutStruct()
         r.grid, r.grid_batched, r.goal, r.pos = _p(self.grid), self.grid_batched, _p(self.goal), _p(self.pos)
@@ -192,15 +196,15 @@ class BatchedRollout:
         if self.t == 0:                                      # step 0 may grow the radius
             self.observe()
             self.gso()
-        elif self._state_step != self.t:                     # large teams: graph and observations side by side
+        elif self._state_step != self.t:                     # stale state: graph and observations side by side
             self.gso_observe()
         if self._policy_step(model):                         # small teams: the whole step is one launch
             return self.flags
         model.addGSO(self.S)
         logits = model.forward_logits(self.obs)
-        # one workgroup per episode pays off while an episode's observations are small; large teams
-        # keep the three launches (16 agents per observation workgroup)
-        return self.move_and_observe(logits=logits) if self.N <= 32 else self.move(logits=logits)
+        # one launch for move -> graph -> observations (see fused_sim_max_agents); beyond it: move now, the
+        # graph and the observations side by side at the start of the next step
+        return self.move_and_observe(logits=logits) if self.N <= self.fused_sim_max_agents else self.move(logits=logits)
 
     def steps(self, model, n):
         """n rollout steps.  Small teams (the one-launch step): the launches of all n steps are enqueued by ONE
