@@ -231,6 +231,70 @@ __device__ __forceinline__ void gso_wave0(const RolloutArgs& p, const int* pos, 
     if (lane == 0) { *shared_r = r; *shared_flag = connected; }
 }
 
+// The same graph built by ALL waves of the workgroup (no radius growth): the N adjacency rows are independent,
+// so wave w computes rows w, w + nw, ... (every wave holds all positions: lane l = agents l and l + 64) and puts
+// them into adj; after a barrier wave 0 reads its agents' rows back (the relation is symmetric: row n is
+// also agent n's neighbour mask), runs the level-synchronous search and writes inv / flag / radius.  On one
+// wave the row loop is ~30 dependent instructions x N: 17 us at N = 100; split over 16 waves it is the search
+// that remains.  Contains TWO workgroup barriers: every thread of the workgroup must call it.
+__device__ __forceinline__ void gso_all_waves(const RolloutArgs& p, const int* pos, double r, char* smem, int tid,
+                                              int nt) {
+    unsigned long long* adj = reinterpret_cast<unsigned long long*>(smem);          // [N][2]
+    double* inv = reinterpret_cast<double*>(adj + 2 * kMaxAgents);                  // [N]
+    double* shared_r = inv + kMaxAgents;                                            // [1]
+    int* shared_flag = reinterpret_cast<int*>(shared_r + 1);                        // [1]
+    const int N = p.N, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const bool two = N > 64;
+    int px[2], py[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = lane + 64 * h;
+        live[h] = n < N;
+        px[h] = live[h] ? pos[2 * n] : -(1 << 20);
+        py[h] = live[h] ? pos[2 * n + 1] : -(1 << 20);
+    }
+    const long long T = dist2_threshold(r);
+    const int Ti = T > 0x7fffffffLL ? 0x7fffffff : (int)T;
+    for (int i = wave; i < N; i += nw) {
+        const int bx = lane_get(px, i), by = lane_get(py, i);
+        bool e[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int dx = px[h] - bx, dy = py[h] - by;
+            e[h] = live[h] && lane + 64 * h != i && dx * dx + dy * dy <= Ti;
+        }
+        const MaskPair row = ballot2(e[0], two && e[1]);
+        if (lane == 0) { adj[2 * i] = row.lo; adj[2 * i + 1] = row.hi; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long a0[2] = {0ull, 0ull}, a1[2] = {0ull, 0ull};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = lane + 64 * h;
+            if (live[h]) { a0[h] = adj[2 * n]; a1[h] = adj[2 * n + 1]; }
+        }
+        MaskPair R = {1ull, 0ull}, F = R;                              // reached set, frontier
+        while (F.lo | F.hi) {
+            const MaskPair nb = ballot2(live[0] && ((a0[0] & F.lo) | (a1[0] & F.hi)) != 0ull,
+                                        two && live[1] && ((a0[1] & F.lo) | (a1[1] & F.hi)) != 0ull);
+            F.lo = nb.lo & ~R.lo; F.hi = nb.hi & ~R.hi;
+            R.lo |= nb.lo; R.hi |= nb.hi;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = lane + 64 * h;
+            if (live[h]) {
+                const int deg = __popcll(a0[h]) + __popcll(a1[h]);
+                inv[n] = deg ? sqrt(1.0 / (double)deg) : 0.0;
+            }
+        }
+        if (lane == 0) { *shared_r = r; *shared_flag = __popcll(R.lo) + __popcll(R.hi) == N; }
+    }
+    __syncthreads();
+}
+
 // S = float(D^-1/2 A D^-1/2) to HBM by all threads, radius / connected by thread 0 (after a barrier)
 __device__ __forceinline__ void gso_store(const RolloutArgs& p, int b, const char* smem, int tid, int nt) {
     const unsigned long long* adj = reinterpret_cast<const unsigned long long*>(smem);
@@ -255,8 +319,12 @@ __device__ __forceinline__ void gso_store(const RolloutArgs& p, int b, const cha
 
 __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int* pos, bool grow,
                                          char* smem, int tid, int nt) {
-    if (tid < 64) gso_wave0(p, pos, grow, p.radius[b], smem, tid);
-    __syncthreads();
+    if (grow) {                                          // step 0: the radius search is a sequential loop
+        if (tid < 64) gso_wave0(p, pos, true, p.radius[b], smem, tid);
+        __syncthreads();
+    } else {
+        gso_all_waves(p, pos, p.radius[b], smem, tid, nt);
+    }
     gso_store(p, b, smem, tid, nt);
 }
 
@@ -270,6 +338,9 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
 // red [4 kMaxAgents] + spos [2 kMaxAgents] + goal_l [2 kMaxAgents] ints, gso_smem [kGsoSmemBytes],
 // occ [H*W] bytes of LDS.
 __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos);
+// kAllWavesGso (large teams, 16 waves): the graph's adjacency rows are spread over all waves (gso_all_waves)
+// after the cell marking, instead of wave 0 building the whole graph next to it.
+template <bool kAllWavesGso = false>
 __device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos, int* red, int* goal_l,
                                          char* gso_smem, unsigned char* occ, int tid, int nt) {
     const double radius = p.radius[b];                   // (in flight while wave 0 moves)
@@ -277,9 +348,14 @@ __device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos,
     else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);
     __syncthreads();
     GNNPP_STAMP(b, 7, tid == 0);
-    if (tid < 64) gso_wave0(p, spos, false, radius, gso_smem, tid);
-    else observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
-    __syncthreads();
+    if (kAllWavesGso) {
+        if (tid >= 64) observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
+        gso_all_waves(p, spos, radius, gso_smem, tid, nt);       // (ends with a barrier)
+    } else {
+        if (tid < 64) gso_wave0(p, spos, false, radius, gso_smem, tid);
+        else observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
+        __syncthreads();
+    }
     GNNPP_STAMP(b, 8, tid == 0);
     gso_store(p, b, gso_smem, tid, nt);
     observe_rows(p, b, spos, 0, p.N, occ, goal_l, tid, nt);
@@ -677,7 +753,8 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
     unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    sim_tail(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);
+    if (nt > 256) sim_tail<true>(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);      // (workgroup-uniform)
+    else sim_tail<false>(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);
 }
 
 // Communication GSO and observations of the CURRENT positions in one launch, for teams too large for one workgroup
