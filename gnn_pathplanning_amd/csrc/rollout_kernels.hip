@@ -337,25 +337,18 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
 //   everybody stores S, then the observation rows
 // red [4 kMaxAgents] + spos [2 kMaxAgents] + goal_l [2 kMaxAgents] ints, gso_smem [kGsoSmemBytes],
 // occ [H*W] bytes of LDS.
-__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos);
-// kAllWavesGso (large teams, 16 waves): the graph's adjacency rows are spread over all waves (gso_all_waves)
-// after the cell marking, instead of wave 0 building the whole graph next to it.
-template <bool kAllWavesGso = false>
+__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos, unsigned* cellcnt = nullptr);
 __device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos, int* red, int* goal_l,
-                                         char* gso_smem, unsigned char* occ, int tid, int nt) {
+                                         char* gso_smem, unsigned char* occ, int tid, int nt,
+                                         unsigned* cellcnt = nullptr) {
     const double radius = p.radius[b];                   // (in flight while wave 0 moves)
-    if (tid < 64) move_body(p, b, tid, red, spos);
+    if (tid < 64) move_body(p, b, tid, red, spos, cellcnt);
     else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);
     __syncthreads();
     GNNPP_STAMP(b, 7, tid == 0);
-    if (kAllWavesGso) {
-        if (tid >= 64) observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
-        gso_all_waves(p, spos, radius, gso_smem, tid, nt);       // (ends with a barrier)
-    } else {
-        if (tid < 64) gso_wave0(p, spos, false, radius, gso_smem, tid);
-        else observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
-        __syncthreads();
-    }
+    if (tid < 64) gso_wave0(p, spos, false, radius, gso_smem, tid);
+    else observe_prep(p, spos, occ, goal_l, tid - 64, nt - 64);
+    __syncthreads();
     GNNPP_STAMP(b, 8, tid == 0);
     gso_store(p, b, gso_smem, tid, nt);
     observe_rows(p, b, spos, 0, p.N, occ, goal_l, tid, nt);
@@ -474,18 +467,50 @@ __device__ __forceinline__ int lane_get_t(const int (&v)[2], int agent) {
 
 // two = lanes carry a second agent (N > 64): a compile-time switch, so that teams of up to 64 agents
 // run straight-line scalar code in the scan below
+// cellcnt (optional, large teams): an all-zero LDS map of one BYTE per grid cell (packed four to a word).  The
+// two candidate sets -- "somebody else plans my planned cell" and "somebody else plans the cell I stand on" --
+// are then three LDS operations per agent, all agents at once (count the plans per cell, read two counts, put
+// the zeros back), instead of the scan's N dependent broadcast-and-ballot steps (6 us per call at N = 100).
 template <bool two>
 __device__ bool inter_robot_collision_t(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
-                                        int& calls) {
+                                        int& calls, unsigned* cellcnt) {
     int ckey[2], nkey[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         ckey[h] = cell_key(r.curx[h], r.cury[h]);
         nkey[h] = cell_key(r.nxtx[h], r.nxty[h]);
     }
+    MaskPair todo = {0ull, 0ull}, todo2 = {0ull, 0ull};
+    if (cellcnt) {
+        int ni[2], ci[2];
+        bool lv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            lv[h] = lane + 64 * h < N;
+            ni[h] = lv[h] ? r.nxtx[h] * p.W + r.nxty[h] : 0;
+            ci[h] = lv[h] ? r.curx[h] * p.W + r.cury[h] : 0;
+            if (lv[h]) __hip_atomic_fetch_add(cellcnt + (ni[h] >> 2), 1u << (8 * (ni[h] & 3)), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // one wave: its LDS instructions complete in order, so every lane's increment precedes every lane's
+        // read below -- as long as the compiler keeps the instruction order (a relaxed atomic orders nothing)
+        __builtin_amdgcn_wave_barrier();
+        bool dup[2], stood[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned cn = lv[h] ? (cellcnt[ni[h] >> 2] >> (8 * (ni[h] & 3))) & 255u : 0u;
+            const unsigned cc = lv[h] ? (cellcnt[ci[h] >> 2] >> (8 * (ci[h] & 3))) & 255u : 0u;
+            dup[h] = cn > 1u;                                        // another agent plans my planned cell
+            stood[h] = cc > (ni[h] == ci[h] ? 1u : 0u);              // another agent plans the cell I stand on
+        }
+        todo = ballot2(dup[0], two && dup[1]);
+        todo2 = ballot2(stood[0], two && stood[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (lv[h]) cellcnt[ni[h] >> 2] = 0u;                     // the map is all zero again
+    } else {
     // ---- all-pairs scan, branch-free: agent j's planned cell is broadcast with readlane; one ballot
     // marks everybody else planning the same cell, one everybody standing on it ------------------------
-    MaskPair todo = {0ull, 0ull}, todo2 = {0ull, 0ull};
     const int n_lo = two ? 64 : N;
     for (int j = 0; j < n_lo; ++j) {
         const int nj = __builtin_amdgcn_readlane(nkey[0], j);
@@ -502,6 +527,7 @@ __device__ bool inter_robot_collision_t(const RolloutArgs& p, AgentRegs& r, int 
             todo.lo |= same.lo; todo.hi |= same.hi & self;
             todo2.lo |= stand.lo; todo2.hi |= stand.hi & self;
         }
+    }
     }
     if (!(todo.lo | todo.hi | todo2.lo | todo2.hi)) return false;
 
@@ -571,16 +597,16 @@ __device__ bool inter_robot_collision_t(const RolloutArgs& p, AgentRegs& r, int 
 }
 
 __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b, int N, int lane,
-                                      int& calls, int* __restrict__ xy) {
-    (void)xy;
-    return N > 64 ? inter_robot_collision_t<true>(p, r, b, N, lane, calls)
-                  : inter_robot_collision_t<false>(p, r, b, N, lane, calls);
+                                      int& calls, unsigned* cellcnt) {
+    return N > 64 ? inter_robot_collision_t<true>(p, r, b, N, lane, calls, cellcnt)
+                  : inter_robot_collision_t<false>(p, r, b, N, lane, calls, cellcnt);
 }
 
 // One episode's move by ONE wavefront (lane = threadIdx.x & 63; no workgroup barrier inside, so it can
 // run as wave 0 of a larger workgroup).  red = [4][kMaxAgents] ints of LDS (conflict test / statistics
 // scratch); spos (optional) receives the positions after the move ([N][2], LDS) for the fused step kernel.
-__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos) {
+// cellcnt: nullptr, or ceil(H*W / 4) words of LDS for inter_robot_collision's cell-count map (zeroed here).
+__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos, unsigned* cellcnt) {
     const int N = p.N;
     int* pos = p.pos + (size_t)b * N * 2;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * p.H * p.W : 0);
@@ -666,15 +692,19 @@ __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* 
         const MaskPair bm = ballot2(bumped[0], bumped[1]);
         predict_collision = (bm.lo | bm.hi) != 0;
         GNNPP_STAMP(b, 2, lane == 0);
-        bool detect = inter_robot_collision(p, r, b, N, lane, calls, red);
+        if (cellcnt) {
+            for (int i = lane; i < (p.H * p.W + 3) / 4; i += 64) cellcnt[i] = 0u;
+            __builtin_amdgcn_wave_barrier();                 // (all of the map is zero before the first count)
+        }
+        bool detect = inter_robot_collision(p, r, b, N, lane, calls, cellcnt);
         GNNPP_STAMP(b, 3, lane == 0);
         for (int it = 0; it < N; ++it) {
             if (!detect) break;
-            detect = inter_robot_collision(p, r, b, N, lane, calls, red);
+            detect = inter_robot_collision(p, r, b, N, lane, calls, cellcnt);
             predict_collision = true;
         }
         GNNPP_STAMP(b, 4, lane == 0);
-        move_collision = inter_robot_collision(p, r, b, N, lane, calls, red);
+        move_collision = inter_robot_collision(p, r, b, N, lane, calls, cellcnt);
         GNNPP_STAMP(b, 5, lane == 0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -736,9 +766,19 @@ __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* 
     }
 }
 
+// Teams above kCellMapMinAgents on maps of at most kCellMapMaxCells cells get the cell-count map of
+// inter_robot_collision_t (one byte per cell of LDS behind the other scratch); the launchers size the
+// allocation with the same rule.
+constexpr int kCellMapMinAgents = 24, kCellMapMaxCells = 32 * 1024;
+__host__ __device__ inline size_t cell_map_bytes(int N, int H, int W) {
+    return (N > kCellMapMinAgents && (long)H * W <= kCellMapMaxCells) ? (((size_t)H * W + 15) & ~(size_t)15) : 0;
+}
+
 __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    move_body(p, blockIdx.x, threadIdx.x, reinterpret_cast<int*>(gnnpp_smem), nullptr);
+    int* red = reinterpret_cast<int*>(gnnpp_smem);
+    unsigned* cellcnt = cell_map_bytes(p.N, p.H, p.W) ? reinterpret_cast<unsigned*>(red + 4 * kMaxAgents) : nullptr;
+    move_body(p, blockIdx.x, threadIdx.x, red, nullptr, cellcnt);
 }
 
 // Fused simulator step between two policy forwards: move (wave 0) -> communication GSO ->
@@ -753,8 +793,9 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
     unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (nt > 256) sim_tail<true>(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);      // (workgroup-uniform)
-    else sim_tail<false>(p, b, spos, red, goal_l, gso_smem, occ, tid, nt);
+    const size_t occ_bytes = ((size_t)p.H * p.W + 15) & ~(size_t)15;
+    unsigned* cellcnt = cell_map_bytes(p.N, p.H, p.W) ? reinterpret_cast<unsigned*>(occ + occ_bytes) : nullptr;
+    sim_tail(p, b, spos, red, goal_l, gso_smem, occ, tid, nt, cellcnt);
 }
 
 // Communication GSO and observations of the CURRENT positions in one launch, for teams too large for one workgroup
@@ -808,14 +849,15 @@ int rollout_gso_launch(const RolloutArgs& a, hipStream_t st) {
 }
 
 int rollout_move_launch(const RolloutArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(rollout_move_kernel, dim3(a.B), dim3(64), 4 * kMaxAgents * sizeof(int), st, a);
+    hipLaunchKernelGGL(rollout_move_kernel, dim3(a.B), dim3(64),
+                       4 * kMaxAgents * sizeof(int) + cell_map_bytes(a.N, a.H, a.W), st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int rollout_step_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (occ > 64 * 1024) return -2;
-    const size_t smem = 8 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ;
+    const size_t smem = 8 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ + cell_map_bytes(a.N, a.H, a.W);
     const int nt = a.N > 32 ? 1024 : 256;               // enough threads for N * 363 observation cells
     hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B), dim3(nt), smem, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -82,9 +82,10 @@ class BatchedRollout:
         self.t = 0                                            # steps taken so far
         self._state_step = -1                                 # step whose positions obs / S describe
         # teams up to this size run move -> graph -> observations as ONE launch (gnnpp_rollout_step, one workgroup
-        # of 256 / 1024 threads per episode): measured faster than move + (graph || observations) at every size up
-        # to the 128-agent limit (N = 40: 108 vs 119 us per step, N = 100: 156 vs 160)
-        self.fused_sim_max_agents = 128
+        # per episode); larger ones as move, then graph || observations in a second launch (gnnpp_rollout_gso_observe:
+        # more workgroups than episodes).  Measured per simulator step: N = 50 33.5 (one launch) vs 35.8 us,
+        # N = 100 53.5 vs 48.9
+        self.fused_sim_max_agents = 64
         self._logits = None                                   # [N,B,5] of the one-launch step
         r = _native.RolloutStruct()
         r.grid, r.grid_batched, r.goal, r.pos = _p(self.grid), self.grid_batched, _p(self.goal), _p(self.pos)
