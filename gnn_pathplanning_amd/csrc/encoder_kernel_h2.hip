@@ -826,22 +826,28 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         }
         if (a < pt.N && q < 2) {                          // lane holds node a, outputs 4 q + reg
             float* dst = pt.logits + ((size_t)a * pt.B + blockIdx.x) * 5;
+            // with the simulator tail: a copy [N][5] in LDS for this wave's move (red + 2 kMaxAgents, see below)
+            float* lds = reinterpret_cast<float*>(z0 + (KT + 1) * (16 * kZs)) + 4 * kMaxAgents + a * 5;
             if (q == 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dst[t] = d[t] + pt.act_b[t];
+                for (int t = 0; t < 4; ++t) {
+                    dst[t] = d[t] + pt.act_b[t];
+                    if (pt.with_sim) lds[t] = d[t] + pt.act_b[t];
+                }
             } else {
                 dst[4] = d[0] + pt.act_b[4];
+                if (pt.with_sim) lds[4] = d[0] + pt.act_b[4];
             }
         }
+        __builtin_amdgcn_wave_barrier();                  // (the LDS copy precedes this wave's reads in move_body)
     }
     if (!pt.with_sim) return;
 
     // ==== simulator step of this episode (same code as rollout_step_kernel) ===========================
-    // The logits go through memory (this workgroup wrote them, its own L2 serves them back); wave 0
-    // moves, then everybody builds the GSO and the observations of the new positions -- into the very
+    // Wave 0 goes from the head straight into the move (the logits wait for it in LDS); the other waves are
+    // already staging the map meanwhile -- no barrier between head and simulator: the simulator's LDS lies behind
+    // the z / y rows.  Then everybody builds the GSO and the observations of the new positions -- into the very
     // obs / S rows this workgroup consumed at its start, which nobody else reads.
-    __threadfence_block();
-    __syncthreads();
     {
         int* spos = reinterpret_cast<int*>(z0 + (KT + 1) * (16 * kZs));
         int* red = spos + 2 * kMaxAgents;
@@ -850,7 +856,12 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
         const int b = blockIdx.x;
         GNNPP_STAMP(b, 10, tid == 0);
-        sim_tail(pt.sim, b, spos, red, goal_l, gso_smem, occ, tid, kThreads);
+        // the collision passes' cell-count map (one more byte per grid cell) behind the occupancy grid, if it fits
+        const size_t occ_bytes = ((size_t)pt.sim.H * pt.sim.W + 15) & ~(size_t)15;
+        unsigned* cellcnt = 2 * occ_bytes <= policy_sim_occ_bytes(KT) ? reinterpret_cast<unsigned*>(occ + occ_bytes)
+                                                                      : nullptr;
+        sim_tail(pt.sim, b, spos, red, goal_l, gso_smem, occ, tid, kThreads, cellcnt,
+                 reinterpret_cast<const float*>(red + 2 * kMaxAgents));
     }
 }
 

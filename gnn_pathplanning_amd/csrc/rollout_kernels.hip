@@ -337,12 +337,13 @@ __device__ __forceinline__ void gso_body(const RolloutArgs& p, int b, const int*
 //   everybody stores S, then the observation rows
 // red [4 kMaxAgents] + spos [2 kMaxAgents] + goal_l [2 kMaxAgents] ints, gso_smem [kGsoSmemBytes],
 // occ [H*W] bytes of LDS.
-__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos, unsigned* cellcnt = nullptr);
+__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos, unsigned* cellcnt = nullptr,
+                          const float* lds_logits = nullptr);
 __device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos, int* red, int* goal_l,
                                          char* gso_smem, unsigned char* occ, int tid, int nt,
-                                         unsigned* cellcnt = nullptr) {
+                                         unsigned* cellcnt = nullptr, const float* lds_logits = nullptr) {
     const double radius = p.radius[b];                   // (in flight while wave 0 moves)
-    if (tid < 64) move_body(p, b, tid, red, spos, cellcnt);
+    if (tid < 64) move_body(p, b, tid, red, spos, cellcnt, lds_logits);
     else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);
     __syncthreads();
     GNNPP_STAMP(b, 7, tid == 0);
@@ -606,7 +607,10 @@ __device__ bool inter_robot_collision(const RolloutArgs& p, AgentRegs& r, int b,
 // run as wave 0 of a larger workgroup).  red = [4][kMaxAgents] ints of LDS (conflict test / statistics
 // scratch); spos (optional) receives the positions after the move ([N][2], LDS) for the fused step kernel.
 // cellcnt: nullptr, or ceil(H*W / 4) words of LDS for inter_robot_collision's cell-count map (zeroed here).
-__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos, unsigned* cellcnt) {
+// lds_logits: nullptr, or this episode's logits [N][5] left in LDS by THIS wave (the one-launch policy kernel's
+// head: no trip through memory, no workgroup barrier between head and move).
+__device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* spos, unsigned* cellcnt,
+                          const float* lds_logits) {
     const int N = p.N;
     int* pos = p.pos + (size_t)b * N * 2;
     const unsigned char* grid = p.grid + (p.grid_batched ? (size_t)b * p.H * p.W : 0);
@@ -628,8 +632,8 @@ __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* 
         r.curx[h] = r.cury[h] = r.nxtx[h] = r.nxty[h] = -1 - n;          // distinct dummies
         r.last[h] = 4;
         if (live[h]) {
-            if (p.logits) {         // argmax of the logits == argmax of LogSoftmax, first max wins
-                const float* l = p.logits + ((size_t)n * p.B + b) * 5;
+            if (lds_logits || p.logits) {   // argmax of the logits == argmax of LogSoftmax, first max wins
+                const float* l = lds_logits ? lds_logits + n * 5 : p.logits + ((size_t)n * p.B + b) * 5;
                 int kk = 0;
                 float best = l[0];
 #pragma unroll
@@ -766,12 +770,13 @@ __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* 
     }
 }
 
-// Teams above kCellMapMinAgents on maps of at most kCellMapMaxCells cells get the cell-count map of
-// inter_robot_collision_t (one byte per cell of LDS behind the other scratch); the launchers size the
-// allocation with the same rule.
-constexpr int kCellMapMinAgents = 24, kCellMapMaxCells = 32 * 1024;
+// Maps of at most kCellMapMaxCells cells get the cell-count map of inter_robot_collision_t (one byte per cell of
+// LDS behind the other scratch; it pays at every team size: N = 16 1.5 us per step, N = 100 18 us); the
+// launchers size the allocation with the same rule.
+constexpr int kCellMapMaxCells = 32 * 1024;
 __host__ __device__ inline size_t cell_map_bytes(int N, int H, int W) {
-    return (N > kCellMapMinAgents && (long)H * W <= kCellMapMaxCells) ? (((size_t)H * W + 15) & ~(size_t)15) : 0;
+    (void)N;
+    return (long)H * W <= kCellMapMaxCells ? (((size_t)H * W + 15) & ~(size_t)15) : 0;
 }
 
 __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
