@@ -60,6 +60,7 @@ __device__ __forceinline__ void projected_goal(int dx, int dy, int& px, int& py)
 }
 
 constexpr int kObsAgentsPerWg = 16;
+constexpr size_t kObsStageBytes = kObsAgentsPerWg * 363 * sizeof(float);   // LDS stage of a workgroup's output rows
 
 // Observation builder, in two parts so that the static half can run early (in the fused kernels the
 // waves that do not move stage it while wave 0 runs the collision shielding):
@@ -124,10 +125,14 @@ __device__ __forceinline__ void observe_prep(const RolloutArgs& p, const int* po
     }
 }
 
-// one thread per (agent, channel, row): 11 outputs sharing all their index arithmetic; LDS reads only
+// one thread per (agent, channel, row): 11 outputs sharing all their index arithmetic; LDS reads only.
+// stage (optional): (n1 - n0) * 363 floats of LDS that receive the rows instead of p.obs -- a thread's 11 floats
+// are 44 bytes apart from its neighbour's, so written straight to memory every store instruction scatters 4-byte
+// pieces; observe_flush() then moves the block out with consecutive lanes on consecutive floats.
 __device__ __forceinline__ void observe_rows(const RolloutArgs& p, int b, const int* pos, int n0, int n1,
-                                             const unsigned char* cell, const int* goal_l, int tid, int nt) {
-    float* out = p.obs + ((size_t)b * p.N + n0) * 363;
+                                             const unsigned char* cell, const int* goal_l, int tid, int nt,
+                                             float* stage = nullptr) {
+    float* out = stage ? stage : p.obs + ((size_t)b * p.N + n0) * 363;
     const int rows = (n1 - n0) * 33;                     // (agent, channel, row i) triples
     for (int row = tid; row < rows; row += nt) {
         const int na = row / 33, rr = row - na * 33;
@@ -156,9 +161,15 @@ __device__ __forceinline__ void observe_rows(const RolloutArgs& p, int b, const 
     }
 }
 
+__device__ __forceinline__ void observe_flush(const RolloutArgs& p, int b, int n0, int n1, const float* stage,
+                                              int tid, int nt) {
+    float* out = p.obs + ((size_t)b * p.N + n0) * 363;
+    for (int i = tid; i < (n1 - n0) * 363; i += nt) out[i] = stage[i];
+}
+
 // grid = (ceil(N / 16), B): a workgroup builds the episode's occupancy grid in LDS and writes the
 // observations of 16 agents.
-__global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs p) {
+__global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs p, int staged) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * kObsAgentsPerWg;
@@ -169,7 +180,14 @@ __global__ __launch_bounds__(256) void rollout_observe_kernel(const RolloutArgs 
     __syncthreads();
     observe_prep(p, pos, cell, goal_l, threadIdx.x, 256);
     __syncthreads();
-    observe_rows(p, b, pos, n0, min(p.N, n0 + kObsAgentsPerWg), cell, goal_l, threadIdx.x, 256);
+    const size_t occ_bytes = ((size_t)p.H * p.W + 15) & ~(size_t)15;
+    float* stage = staged ? reinterpret_cast<float*>(cell + occ_bytes) : nullptr;   // (maps too large for it: direct)
+    const int n1 = min(p.N, n0 + kObsAgentsPerWg);
+    observe_rows(p, b, pos, n0, n1, cell, goal_l, threadIdx.x, 256, stage);
+    if (stage) {                                         // (workgroup-uniform)
+        __syncthreads();
+        observe_flush(p, b, n0, n1, stage, threadIdx.x, 256);
+    }
 }
 
 // ---- communication GSO ---------------------------------------------------------------------------
@@ -370,7 +388,10 @@ __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* 
                           const float* lds_logits = nullptr);
 __device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos, int* red, int* goal_l,
                                          char* gso_smem, unsigned char* occ, int tid, int nt,
-                                         unsigned* cellcnt = nullptr, const float* lds_logits = nullptr) {
+                                         unsigned* cellcnt = nullptr, const float* lds_logits = nullptr,
+                                         float* obs_stage = nullptr) {
+    // obs_stage: nullptr, or N * 363 floats of LDS: the observation rows go there first and leave with consecutive
+    // lanes on consecutive floats (see observe_rows); one more barrier
     const double radius = p.radius[b];                   // (in flight while wave 0 moves)
     if (tid < 64) move_body(p, b, tid, red, spos, cellcnt, lds_logits);
     else observe_stage(p, b, occ, goal_l, tid - 64, nt - 64);
@@ -381,7 +402,11 @@ __device__ __forceinline__ void sim_tail(const RolloutArgs& p, int b, int* spos,
     __syncthreads();
     GNNPP_STAMP(b, 8, tid == 0);
     gso_store(p, b, gso_smem, tid, nt);
-    observe_rows(p, b, spos, 0, p.N, occ, goal_l, tid, nt);
+    observe_rows(p, b, spos, 0, p.N, occ, goal_l, tid, nt, obs_stage);
+    if (obs_stage) {                                     // (workgroup-uniform)
+        __syncthreads();
+        observe_flush(p, b, 0, p.N, obs_stage, tid, nt);
+    }
     GNNPP_STAMP(b, 9, tid == 0);
 }
 
@@ -819,7 +844,7 @@ __global__ __launch_bounds__(64) void rollout_move_kernel(const RolloutArgs p) {
 // observations of the NEW positions, one workgroup per episode, positions handed over in LDS.
 // Same results as the three kernels in sequence (gso never grows the radius here: that only
 // happens at step 0, which runs the separate kernels).
-__global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p) {
+__global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p, int staged) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     int* spos = reinterpret_cast<int*>(gnnpp_smem);                        // [N][2]
     int* red = spos + 2 * kMaxAgents;                                      // [4][kMaxAgents]
@@ -828,15 +853,17 @@ __global__ __launch_bounds__(1024) void rollout_step_kernel(const RolloutArgs p)
     unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const size_t occ_bytes = ((size_t)p.H * p.W + 15) & ~(size_t)15;
-    unsigned* cellcnt = cell_map_bytes(p.N, p.H, p.W) ? reinterpret_cast<unsigned*>(occ + occ_bytes) : nullptr;
-    sim_tail(p, b, spos, red, goal_l, gso_smem, occ, tid, nt, cellcnt);
+    const size_t map_bytes = cell_map_bytes(p.N, p.H, p.W);
+    unsigned* cellcnt = map_bytes ? reinterpret_cast<unsigned*>(occ + occ_bytes) : nullptr;
+    float* stage = staged ? reinterpret_cast<float*>(occ + occ_bytes + map_bytes) : nullptr;
+    sim_tail(p, b, spos, red, goal_l, gso_smem, occ, tid, nt, cellcnt, nullptr, stage);
 }
 
 // Communication GSO and observations of the CURRENT positions in one launch, for teams too large for one workgroup
 // per episode (rollout_step_kernel): both depend only on the positions, so their workgroups run side by side --
 // per episode `groups` observation workgroups (16 agents each) and one GSO workgroup.  The two kernels in
 // sequence leave most of the chip idle twice (B graph workgroups, then B * groups observation workgroups).
-__global__ __launch_bounds__(256) void rollout_gso_observe_kernel(const RolloutArgs p, int groups) {
+__global__ __launch_bounds__(256) void rollout_gso_observe_kernel(const RolloutArgs p, int groups, int staged) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     const int per = groups + 1;
     const int b = blockIdx.x / per, r = blockIdx.x - b * per;
@@ -852,7 +879,14 @@ __global__ __launch_bounds__(256) void rollout_gso_observe_kernel(const RolloutA
     __syncthreads();
     observe_prep(p, pos, cell, goal_l, threadIdx.x, 256);
     __syncthreads();
-    observe_rows(p, b, pos, n0, min(p.N, n0 + kObsAgentsPerWg), cell, goal_l, threadIdx.x, 256);
+    const size_t occ_bytes = ((size_t)p.H * p.W + 15) & ~(size_t)15;
+    float* stage = staged ? reinterpret_cast<float*>(cell + occ_bytes) : nullptr;   // (maps too large for it: direct)
+    const int n1 = min(p.N, n0 + kObsAgentsPerWg);
+    observe_rows(p, b, pos, n0, n1, cell, goal_l, threadIdx.x, 256, stage);
+    if (stage) {                                         // (workgroup-uniform)
+        __syncthreads();
+        observe_flush(p, b, n0, n1, stage, threadIdx.x, 256);
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -860,19 +894,23 @@ int rollout_gso_observe_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (occ > 64 * 1024) return -2;
     size_t smem = occ + 2 * kMaxAgents * sizeof(int);
+    const int staged = smem + kObsStageBytes <= 64 * 1024;      // the output stage, while the default LDS limit allows
+    if (staged) smem += kObsStageBytes;
     if (smem < (size_t)kGsoSmemBytes) smem = kGsoSmemBytes;
     const int groups = (a.N + kObsAgentsPerWg - 1) / kObsAgentsPerWg;
-    hipLaunchKernelGGL(rollout_gso_observe_kernel, dim3(a.B * (groups + 1)), dim3(256), smem, st, a, groups);
+    hipLaunchKernelGGL(rollout_gso_observe_kernel, dim3(a.B * (groups + 1)), dim3(256), smem, st, a, groups, staged);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int rollout_observe_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (occ > 64 * 1024) return -2;
-    const size_t smem = occ + 2 * kMaxAgents * sizeof(int);
+    size_t smem = occ + 2 * kMaxAgents * sizeof(int);
+    const int staged = smem + kObsStageBytes <= 64 * 1024;
+    if (staged) smem += kObsStageBytes;
     hipLaunchKernelGGL(rollout_observe_kernel,
                        dim3((a.N + kObsAgentsPerWg - 1) / kObsAgentsPerWg, a.B), dim3(256), smem, st,
-                       a);
+                       a, staged);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -891,9 +929,12 @@ int rollout_move_launch(const RolloutArgs& a, hipStream_t st) {
 int rollout_step_launch(const RolloutArgs& a, hipStream_t st) {
     const size_t occ = ((size_t)a.H * a.W + 15) & ~(size_t)15;
     if (occ > 64 * 1024) return -2;
-    const size_t smem = 8 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ + cell_map_bytes(a.N, a.H, a.W);
+    size_t smem = 8 * kMaxAgents * sizeof(int) + kGsoSmemBytes + occ + cell_map_bytes(a.N, a.H, a.W);
+    const size_t stage_bytes = (size_t)a.N * 363 * sizeof(float);
+    const int staged = smem + stage_bytes <= 64 * 1024;  // the observations' output stage, while the LDS limit allows
+    if (staged) smem += stage_bytes;
     const int nt = a.N > 32 ? 1024 : 256;               // enough threads for N * 363 observation cells
-    hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B), dim3(nt), smem, st, a);
+    hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B), dim3(nt), smem, st, a, staged);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -83,9 +83,9 @@ class BatchedRollout:
         self._state_step = -1                                 # step whose positions obs / S describe
         # teams up to this size run move -> graph -> observations as ONE launch (gnnpp_rollout_step, one workgroup
         # per episode); larger ones as move, then graph || observations in a second launch (gnnpp_rollout_gso_observe:
-        # more workgroups than episodes).  Measured per simulator step: N = 50 33.5 (one launch) vs 35.8 us,
-        # N = 100 53.5 vs 48.9
-        self.fused_sim_max_agents = 64
+        # more workgroups than episodes).  Measured per simulator step: N = 10 16.1 (one launch) vs 17.3 us,
+        # N = 50 33.2 vs 28.5, N = 100 52.4 vs 42.4
+        self.fused_sim_max_agents = 32
         self._logits = None                                   # [N,B,5] of the one-launch step
         r = _native.RolloutStruct()
         r.grid, r.grid_batched, r.goal, r.pos = _p(self.grid), self.grid_batched, _p(self.goal), _p(self.pos)
