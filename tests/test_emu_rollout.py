@@ -174,11 +174,17 @@ def test_emu_move_dense_conflicts_vs_oracle():
     from oracle import rollout_oracle as ro
     lib = emu_lib.load()
     rng = np.random.default_rng(21)
-    for (B, N, W) in ((24, 9, 4), (12, 14, 5), (6, 70, 10)):
+    # (the last case: a map of more than 32 768 cells has no LDS cell-count map -- the collision candidates come
+    # from the all-pairs scan; its agents start in one 5 x 5 corner so that they still collide)
+    for (B, N, W) in ((24, 9, 4), (12, 14, 5), (6, 70, 10), (3, 14, 182)):
         grids = (rng.random((B, W, W)) < 0.04).astype(np.uint8)
         starts = np.zeros((B, N, 2), np.int32); goals = np.zeros((B, N, 2), np.int32)
         for b in range(B):
+            if W > 100:
+                grids[b, :5, :5] = 0
             free = np.argwhere(grids[b] == 0)
+            if W > 100:
+                free = free[(free[:, 0] < 5) & (free[:, 1] < 5)]
             while len(free) < N:
                 grids[b] = 0
                 free = np.argwhere(grids[b] == 0)
