@@ -50,6 +50,30 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_enc_params_cache = {}
+
+
+def _encoder_params(ps, buffers, eps):
+    """struct gnnpp_encoder_params of the 20 parameter tensors (+ the 10 running-statistics buffers): filling a
+    ctypes struct costs more host time than a kernel launch, and the pointers of a model do not move from step to
+    step, so the struct is kept per pointer tuple."""
+    key = tuple(t.data_ptr() for t in ps) + (tuple(t.data_ptr() for t in buffers) if buffers is not None else ()) \
+        + (float(eps),)
+    p = _enc_params_cache.get(key)
+    if p is None:
+        if len(_enc_params_cache) > 64:
+            _enc_params_cache.clear()
+        p = _native.EncoderParams()
+        for i in range(5):
+            p.conv_w[i], p.conv_b[i] = ps[4 * i].data_ptr(), ps[4 * i + 1].data_ptr()
+            p.bn_w[i], p.bn_b[i] = ps[4 * i + 2].data_ptr(), ps[4 * i + 3].data_ptr()
+            if buffers is not None:
+                p.bn_mean[i], p.bn_var[i] = buffers[2 * i].data_ptr(), buffers[2 * i + 1].data_ptr()
+        p.bn_eps = float(eps)
+        _enc_params_cache[key] = p
+    return p
+
+
 class _EncoderTrainFunction(torch.autograd.Function):
     """Train-mode ConvLayers of ALL agents on the HIP kernels of csrc/train_encoder.hip.
 
@@ -64,14 +88,9 @@ class _EncoderTrainFunction(torch.autograd.Function):
         L = _native.lib()
         B, N = obs.shape[0], obs.shape[1]
         dev = obs.device
-        ps = [t.detach().contiguous().float() for t in tensors]
-        p = _native.EncoderParams()
-        for i in range(5):
-            p.conv_w[i], p.conv_b[i] = ps[4 * i].data_ptr(), ps[4 * i + 1].data_ptr()
-            p.bn_w[i], p.bn_b[i] = ps[4 * i + 2].data_ptr(), ps[4 * i + 3].data_ptr()
-            if buffers is not None:
-                p.bn_mean[i], p.bn_var[i] = buffers[2 * i].data_ptr(), buffers[2 * i + 1].data_ptr()
-        p.bn_eps = float(eps)
+        ps = [t.detach() if (t.dtype is torch.float32 and t.is_contiguous()) else t.detach().contiguous().float()
+              for t in tensors]
+        p = _encoder_params(ps, buffers, eps)
         ws = torch.empty(L.gnnpp_encoder_train_workspace_floats(N, B), dtype=torch.float32, device=dev)
         feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)     # sample-major: node-major rows
         with _native.device_guard(dev):
@@ -91,14 +110,11 @@ class _EncoderTrainFunction(torch.autograd.Function):
         ps = ctx.saved_tensors[2:]
         B, N = obs.shape[0], obs.shape[1]
         dev = obs.device
-        p, g = _native.EncoderParams(), _native.EncoderGrads()
+        p, g = _encoder_params(ps, None, ctx.eps), _native.EncoderGrads()
         grads = [torch.empty_like(t) for t in ps]
         for i in range(5):
-            p.conv_w[i], p.conv_b[i] = ps[4 * i].data_ptr(), ps[4 * i + 1].data_ptr()
-            p.bn_w[i], p.bn_b[i] = ps[4 * i + 2].data_ptr(), ps[4 * i + 3].data_ptr()
             g.conv_w[i], g.conv_b[i] = grads[4 * i].data_ptr(), grads[4 * i + 1].data_ptr()
             g.bn_w[i], g.bn_b[i] = grads[4 * i + 2].data_ptr(), grads[4 * i + 3].data_ptr()
-        p.bn_eps = ctx.eps
         d = dfeat.contiguous().float()
         with _native.device_guard(dev):
             _native.check(L.gnnpp_encoder_train_bwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(d), ctypes.byref(g),
