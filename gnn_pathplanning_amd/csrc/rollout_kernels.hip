@@ -750,8 +750,10 @@ __device__ void move_body(const RolloutArgs& p, int b, int lane, int* red, int* 
         const MaskPair bm = ballot2(bumped[0], bumped[1]);
         predict_collision = (bm.lo | bm.hi) != 0;
         GNNPP_STAMP(b, 2, lane == 0);
-        if (cellcnt) {
-            for (int i = lane; i < (p.H * p.W + 3) / 4; i += 64) cellcnt[i] = 0u;
+        if (cellcnt) {                                       // (the allocation is a multiple of 16 bytes)
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const v4u zero4 = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < (p.H * p.W + 15) / 16; i += 64) reinterpret_cast<v4u*>(cellcnt)[i] = zero4;
             __builtin_amdgcn_wave_barrier();                 // (all of the map is zero before the first count)
         }
         bool detect = inter_robot_collision(p, r, b, N, lane, calls, cellcnt);
