@@ -554,9 +554,22 @@ def main():
             with torch.no_grad():
                 t_roll1 = time_kernel(lambda: env.step(net), reps=40)
                 t_roll = time_kernel(lambda: env.steps(net, 8), reps=10) / 8
+            # the same episodes as two slices on two HIP streams (episodes are independent: one slice's kernel
+            # tail and launch gap overlap the other's kernel); reported beside the single-stream figure
+            from gnn_pathplanning_amd.rollout import GroupedRollout
+            genv = GroupedRollout(grids, starts, goals, 10 ** 6, dev, groups=2, tie_mode='hashed', seed=1337)
+
+            with torch.no_grad():
+                genv.steps(net, 8)
+                # (wall clock between device synchronisations: an event on one stream does not see the other)
+                t_roll2 = sorted(r[0] for r in timed_regions(lambda: genv.steps(net, 8, wait_caller=False), 20, 5,
+                                                             collective=False))[2] / 160
             result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
                                       'us_one_step_per_call': t_roll1 * 1e6,
-                                      'how': 'BatchedRollout.steps(model, 8): eight steps enqueued per host call',
+                                      'us_two_streams': t_roll2 * 1e6,
+                                      'agent_steps_per_s_two_streams': B * N / t_roll2,
+                                      'how': 'BatchedRollout.steps(model, 8): eight steps enqueued per host call; '
+                                             'two_streams: GroupedRollout(groups=2), wall clock over 160 steps',
                                       'what': 'observe + gso + policy forward + move (collision shielding), '
                                               'all on the device, %d episodes' % B}
 

@@ -221,6 +221,7 @@ class DecentralPlannerNet(nn.Module):
         self._enc_cache = _native.PackCache()
         self._head_cache = _native.PackCache()
         self._ws = None
+        self._ws_key = None
         # Range guard of the split-f16 schedules (include/gnnpp.h): a device int the kernels raise when
         # an activation leaves the f16 range.  'flag' (default): no synchronisation, the caller (or
         # BatchedRollout.run) polls check_range(); 'strict': every forward reads the flag back and
@@ -416,8 +417,16 @@ class DecentralPlannerNet(nn.Module):
             st = _native.stream_ptr(dev)
             if self.L == 1 and Ns == N and gl.F == 128:
                 # the planner of the reference's configs: ONE C call (one or two kernels)
-                if self._ws is None or self._ws.shape[0] != B * N or self._ws.device != dev:
-                    self._ws = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
+                # feature workspace between the two kernels: one per (size, stream) -- several batches of a rollout
+                # may be in flight on different streams (rollout.GroupedRollout)
+                wkey = (B * N, st.value)
+                if self._ws is None or self._ws_key != wkey or self._ws.device != dev:
+                    self._ws_all = getattr(self, '_ws_all', {})
+                    if wkey not in self._ws_all or self._ws_all[wkey].device != dev:
+                        if len(self._ws_all) > 16:
+                            self._ws_all.clear()
+                        self._ws_all[wkey] = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
+                    self._ws, self._ws_key = self._ws_all[wkey], wkey
                 logits = torch.empty(N, B, 5, dtype=torch.float32, device=dev)
                 rc = L.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc.data_ptr(),
                                         gl.packed_taps().data_ptr(), gb_p, aw_p, ab_p,

@@ -248,3 +248,79 @@ class BatchedRollout:
                 'makespan': self.stats[:, 0].cpu(), 'flowtime': self.stats[:, 1].cpu(),
                 'end_step': self.end_step.cpu(), 'start_step': self.start_step.cpu(),
                 'positions': self.pos.cpu(), 'radius': self.radius.cpu(), 'done': self.done.bool().cpu()}
+
+
+class GroupedRollout:
+    """The same batch of episodes as `groups` BatchedRollouts over contiguous slices, each on its OWN HIP stream.
+    Episodes are independent, so nothing orders one group's step t + 1 after another group's step t: the launch
+    gap and the tail of one group's kernel (workgroups finish at different times, the observation stores drain)
+    overlap with the other group's kernel.  Measured at C2 (512 episodes of 10 agents, one-launch steps): 44-49 us
+    per step of all 512 episodes with two groups against 52-55 us on one stream.
+
+    Same interface as BatchedRollout for what a rollout driver needs: steps(), run(), results().  tie_mode
+    'lowest' and 'mt19937' give exactly the single-batch results (episode b keeps its generator seed + b);
+    'hashed' hashes the episode's index inside its group, i.e. draws a different -- equally arbitrary -- stream."""
+
+    def __init__(self, grid, starts, goals, maxstep, device, groups=2, seed=0, **kw):
+        starts, goals = torch.as_tensor(starts), torch.as_tensor(goals)
+        g = torch.as_tensor(grid)
+        B = int(starts.shape[0])
+        ms = torch.as_tensor(maxstep)
+        groups = max(1, min(int(groups), B))
+        bounds = [round(i * B / groups) for i in range(groups + 1)]
+        self.envs, self.streams, self.slices = [], [], []
+        dev = torch.device(device)
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            sd = seed[lo:hi] if hasattr(seed, '__len__') else int(seed) + lo
+            self.envs.append(BatchedRollout(g[lo:hi] if g.dim() == 3 else g, starts[lo:hi], goals[lo:hi],
+                                            ms[lo:hi] if ms.dim() else ms, dev, seed=sd, **kw))
+            self.streams.append(torch.cuda.Stream(device=dev))
+            self.slices.append((lo, hi))
+        self.device, self.B, self.N = dev, B, self.envs[0].N
+
+    def _each(self, fn, wait_caller=True):
+        cur = torch.cuda.current_stream(self.device)
+        for env, st in zip(self.envs, self.streams):
+            if wait_caller:
+                st.wait_stream(cur)                          # whatever the caller's stream prepared (the episodes'
+            with torch.cuda.stream(st):                      # state, new weights) is visible to the group
+                fn(env)
+
+    def join(self):
+        """Make the caller's stream wait for every group's work."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def steps(self, model, n, wait_caller=True):
+        """n steps of every group.  wait_caller=False: the groups do not wait for the caller's stream first --
+        for back-to-back bursts with nothing in between (after a join() a wait would be a barrier across the
+        groups: the faster group would idle until the slower one has finished the previous burst)."""
+        self._each(lambda env: env.steps(model, n), wait_caller)
+
+    def run(self, model, max_steps=None, check_every=8):
+        limit = max(int(e.maxstep.max().item()) for e in self.envs) if max_steps is None else int(max_steps)
+        steps = 0
+        while steps < limit:
+            burst = min(check_every - steps % check_every, limit - steps)
+            self.steps(model, burst, wait_caller=steps == 0)
+            steps += burst
+            if steps % check_every == 0:
+                self.join()
+                if hasattr(model, 'check_range'):
+                    model.check_range()
+                if all(bool((e.done != 0).all().item()) for e in self.envs):
+                    break
+        self.join()
+        if hasattr(model, 'check_range'):
+            model.check_range()
+        return self.results()
+
+    def results(self):
+        self.join()
+        parts = [e.results() for e in self.envs]
+        out = {'steps': max(p['steps'] for p in parts)}
+        for k in parts[0]:
+            if k != 'steps':
+                out[k] = torch.cat([p[k] for p in parts], 0)
+        return out

@@ -207,6 +207,35 @@ def test_steps_burst_equals_single_steps(dev):
             assert torch.equal(a._logits, b._logits)
 
 
+@pytest.mark.parametrize('N,groups', [(10, 2), (10, 3), (24, 2)])
+def test_grouped_rollout_equals_one_batch(dev, N, groups):
+    """GroupedRollout (episode slices on their own HIP streams, overlapping one another) ends every episode in
+    exactly the state the single-stream BatchedRollout gives it.  N = 24 takes the two-kernel policy, whose
+    feature workspace is per stream."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.rollout import BatchedRollout, GroupedRollout
+    B, W = 50, 20
+    rng = np.random.default_rng(N + groups)
+    grids, starts, goals = random_episodes(rng, B, N, W, 0.08)
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(orc.init_state_dict(3, seed=13))
+    maxstep = rng.integers(10, 40, size=B)
+    for tie in ('lowest', 'mt19937'):
+        one = BatchedRollout(grids, starts, goals, maxstep, dev, tie_mode=tie, seed=3).run(net)
+        env = GroupedRollout(grids, starts, goals, maxstep, dev, groups=groups, tie_mode=tie, seed=3)
+        many = env.run(net)
+        assert [hi - lo for lo, hi in env.slices] and sum(hi - lo for lo, hi in env.slices) == B
+        assert set(one) == set(many)
+        for k in one:
+            if k == 'steps':
+                assert one[k] == many[k]
+            else:
+                assert torch.equal(one[k], many[k]), (tie, k)
+
+
 def test_closed_loop_rollout_with_policy(dev):
     """observe -> gso -> forward -> move on the GPU; every stage checked against the CPU oracles
     fed with the GPU's own state, so a near-tie in the logits cannot make the trajectories drift."""
