@@ -63,6 +63,7 @@ struct LsigfArgs {
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
     int* range_flag;       // optional device int: set to 1 when the split-f16 contraction saw |z| >= 65504
+    int pf_part_off;       // policy_filter_kernel.hip: LDS byte offset of the partial logits
     int ablate;            // GNNPP_MEASURE builds only (tools/ab_bench.py): bit 0 skip the shifts, bit 1
                            // skip the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         }
     };
     load_tap(Acur, 0);
+    GNNPP_STAMP(blockIdx.x, 0, tid == 0);
 
     // ---- zero what the staging does not overwrite ---------------------------------------------------
     {
@@ -490,10 +492,12 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             if (p.K > 2 || H2) stage_x(p, zbuf0, g0, ng, tid, NT, true);
         }
         __syncthreads();                               // z_0 (and Sl) visible
+        GNNPP_STAMP(blockIdx.x, 1, tid == 0);
         if (p.K > 1 && !GNNPP_ABLATE(p, 1)) {
             build_lists(p, Sl, idx, cnt, R, wave, NW, lane);
             __syncthreads();
         }
+        GNNPP_STAMP(blockIdx.x, 2, tid == 0);
 
         if (H2) {
             // order per tap: shift z_k -> z_{k+1} | convert z_k in place | contract z_k
@@ -514,8 +518,10 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                     }
                 }
                 __syncthreads();                         // every reader of the fp32 z_k is done
+                GNNPP_STAMP(blockIdx.x, 3 + 3 * k, tid == 0 && k < 3);      // shift k -> k+1 done
                 split_rows(zcur, row_lo, row_hi, zs, wave, NW, lane, bad);
                 __syncthreads();
+                GNNPP_STAMP(blockIdx.x, 4 + 3 * k, tid == 0 && k < 3);      // z_k split
                 if (has_mfma && !GNNPP_ABLATE(p, 2)) {
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
                 // the next tap's fragments fly during the next shift (no second register set)
                 if (tap + 1 < ntaps) load_tap(Acur, tap + 1);
                 if (k + 1 < p.K) __syncthreads();         // z_k's buffer is the target of the next shift
+                GNNPP_STAMP(blockIdx.x, 5 + 3 * k, tid == 0 && k < 3);      // tap k contracted
             }
         } else
         for (int k = 0; k < p.K; ++k, ++tap) {
@@ -597,6 +604,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     if (GNNPP_ABLATE(p, 8)) return;
     if (H2 && p.range_flag && bad) *p.range_flag = 1;
     __syncthreads();                                   // every wave is done reading z
+    GNNPP_STAMP(blockIdx.x, 12, tid == 0);
     float* ybuf = zbuf0;
     float* actw = zbuf1;                               // act_w staged here: [5][F]
     if (p.act_w)
@@ -626,6 +634,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         }
     }
     __syncthreads();
+    GNNPP_STAMP(blockIdx.x, 13, tid == 0);
 
     const int nrows = row_hi - row_lo;
     if (p.y) {
@@ -694,6 +703,7 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             }
         }
     }
+    GNNPP_STAMP(blockIdx.x, 14, tid == 0);
 }
 
 // logits [N,B,5] -> actions [B,N]; first maximum wins (torch.max semantics).
@@ -824,7 +834,11 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     return 0;
 }
 
+static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st);   // policy_filter_kernel.hip
+
 int lsigf_dispatch(const LsigfArgs& a, const LsigfPlan& plan, hipStream_t st) {
+    const int pf = policy_filter_dispatch(a, plan, st);               // the policy step's shape: its own kernel
+    if (pf <= 0) return pf;
     const hipError_t err = plan.nw == 16 ? launch_rtw<16>(plan.rtw, a, plan.grid, plan.smem, st)
                                          : launch_rtw<8>(plan.rtw, a, plan.grid, plan.smem, st);
     return err == hipSuccess ? 0 : -3;

@@ -1,0 +1,390 @@
+// Graph filter + ReLU + action head of the POLICY step for teams of 17 .. 100 agents (gfx950): the second
+// kernel of gnnpp_policy_fwd when a graph no longer fits the fused one-launch kernel.
+//
+//   logits[n, b, :] = act_b + act_w . relu(bias + sum_k W_k . z_k[b, n, :]),   z_0 = x,  z_k = S^T-gather of z_{k-1}
+//
+// Same arithmetic as lsigf_kernel<.., H2 = true> with the fused head (graphML.py:2273-2367 BatchLSIGF,
+// decentralplanner.py:301-315): exact fp32 shifts in ascending neighbour order, split-f16 contraction with the
+// taps accumulated in the order k = 0, 1, .., the cross terms in their own accumulator.  What differs is the
+// schedule.  lsigf_kernel is one kernel for every layout / precision / training dump the filter API has; one
+// workgroup's time there (19.5 us at 256 graphs of 50 nodes, profiles/r02_phase_stamps.jsonl) is a chain of
+// exposed latencies: a load -> store staging loop (one memory round trip per element: 4.5 us), the bias /
+// act_w / act_b fetched where they are used (two more round trips: 3.9 us of epilogue), one conversion pass
+// and one barrier per tap, a 32-MFMA dependent chain per row tile for the head, and register spills on the way
+// (128 VGPRs for 16 waves).  Here, for the one shape the policy has (E = 1, G = F = 128, node-major x, one
+// graph per workgroup):
+//   * every global load of the kernel is issued in the first instructions -- x (at most four 16-byte loads per
+//     thread), S (all of it in flight), the first tap's A fragments, and ONE float per thread of act_w / bias /
+//     act_b / the split scale, parked in LDS until the epilogue: one memory round trip in total;
+//   * a QUARTER wave gathers a node (8 features per lane, 4 neighbours per trip): 64 nodes in flight per pass,
+//     one pass for 50 nodes;
+//   * the last shift writes z_{K-1} directly as hi | lo halves: the last tap needs no conversion pass and no
+//     barrier between it and the tap before;
+//   * the head is applied to the accumulators where they are: after bias + ReLU a lane holds y[row, 4 features]
+//     -- exactly the B operand of the 16x16x4 MFMA against act_w's columns of its own 16-feature tile -- so every
+//     wave multiplies its tile (4 MFMAs per row tile) and the eight tiles' partial logits are summed through LDS
+//     in the fixed order mt = 0..7 (deterministic; the rounding differs from the one-chain head of lsigf_kernel
+//     in the last bit, tests/test_gpu_parity.py compares the two).  No y tile in LDS, no 32-MFMA chain.
+// Two workgroups per graph (nsplit = 2, as in lsigf_kernel) when at most 128 large graphs would leave half of
+// the CUs idle: both stage the graph and run the shifts k < K-1 on all rows; the last shift, the contraction
+// and the head run on the workgroup's own half of the row tiles.
+#include "gnnpp_common.h"
+
+namespace gnnpp {
+
+constexpr int kPfZs = 136;                 // LDS row stride of a z buffer in floats (128 + 8: see lsigf_kernel)
+constexpr int kPfConsts = 776;             // act_w [5][128] | bias [128] | act_b [5] | 1 / split scale | pad
+constexpr int kPfMaxNodes = 100;
+constexpr int kPfMinNodes = 17;
+
+// LDS bytes up to the constants (z buffers, S slab, neighbour lists, degrees)
+__host__ __device__ inline size_t pf_lds_base(int N, int Ns, int K) {
+    const size_t lists = K > 1 ? (size_t)N * Ns + ((N + 15) & ~15) : 0;
+    return (2 * (size_t)N * kPfZs * 4 + (K > 1 ? (size_t)N * Ns * 4 : 0) + lists + 15) & ~(size_t)15;
+}
+
+// z_{k+1}[r, :] = sum over the neighbours m of node r (ascending) of S[m, r] * z_k[m, :], rows [row_lo, row_hi):
+// a quarter wave per row; lane ql holds features [4 ql, 4 ql + 4) and [64 + 4 ql, 64 + 4 ql + 4).
+// split_out: the result is stored as f16 hi | lo halves (the layout split_rows produces) instead of fp32.
+__device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const unsigned char* __restrict__ idx,
+                                          const unsigned char* __restrict__ cnt, const float* __restrict__ zprev,
+                                          float* __restrict__ znxt, int Ns, int row_lo, int row_hi, int wave,
+                                          int lane, bool split_out, unsigned long long& bad) {
+    typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+    const int quarter = lane >> 4, ql = lane & 15;
+    for (int rb = row_lo + 4 * wave; rb < row_hi; rb += 64) {           // wave-uniform trip count
+        const int r = rb + quarter;
+        const bool rv = r < row_hi;
+        const int rr = rv ? r : rb;
+        const float* wl = Sl + rr * Ns;                                  // compacted weights of node rr
+        const unsigned char* il = idx + rr * Ns;
+        const int deg = rv ? (int)cnt[rr] : 0;
+        const float* zc = zprev + 4 * ql;
+        v4f acc0 = vzero(), acc1 = vzero();
+        for (int d = 0; __ballot(d < deg) != 0ull; d += 4) {             // until all four rows are done
+            // entries past the degree: weight 0 and a stale (but valid) row index
+            const unsigned pk = *reinterpret_cast<const unsigned*>(il + d);
+            const v4f w = *reinterpret_cast<const v4f*>(wl + d);
+            v4f za[4], zb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* zr = zc + __umul24((pk >> (8 * u)) & 255u, (unsigned)kPfZs);
+                za[u] = *reinterpret_cast<const v4f*>(zr);
+                zb[u] = *reinterpret_cast<const v4f*>(zr + 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc0[c] = fmaf(w[u], za[u][c], acc0[c]);
+                    acc1[c] = fmaf(w[u], zb[u][c], acc1[c]);
+                }
+            }
+        }
+        float* row = znxt + rr * kPfZs;
+        if (!split_out) {
+            if (rv) {
+                *reinterpret_cast<v4f*>(row + 4 * ql) = acc0;
+                *reinterpret_cast<v4f*>(row + 64 + 4 * ql) = acc1;
+            }
+        } else {
+            // |z| >= 65504 does not fit the hi half: range guard as in split_rows
+            float mx = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fmaxf(fabsf(acc0[c]), fabsf(acc1[c])));
+            bad |= __ballot(rv && mx >= 65504.f);
+            v4h h0, l0, h1, l1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                h0[c] = (_Float16)acc0[c]; l0[c] = (_Float16)(acc0[c] - (float)h0[c]);
+                h1[c] = (_Float16)acc1[c]; l1[c] = (_Float16)(acc1[c] - (float)h1[c]);
+            }
+            if (rv) {
+                *reinterpret_cast<v2f*>(row + 2 * ql) = __builtin_bit_cast(v2f, h0);          // features 4 ql ..
+                *reinterpret_cast<v2f*>(row + 32 + 2 * ql) = __builtin_bit_cast(v2f, h1);     // features 64 + 4 ql ..
+                *reinterpret_cast<v2f*>(row + 64 + 2 * ql) = __builtin_bit_cast(v2f, l0);
+                *reinterpret_cast<v2f*>(row + 96 + 2 * ql) = __builtin_bit_cast(v2f, l1);
+            }
+        }
+    }
+}
+
+// RTW = 16-row MFMA tiles per wave (waves 0..7 own the first RTW tiles of the workgroup's range, waves 8..15 the
+// next RTW; wave & 7 is the 16-feature output tile).
+template <int RTW>
+__global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    constexpr int NT = 1024, NW = 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 15;      // row inside a 16-row tile (MFMA j)
+    const int q = lane >> 4;      // MFMA k slot
+    const int N = p.N, Ns = p.Ns, K = p.K;
+
+    int gblk = blockIdx.x, part = 0;
+    if (p.nsplit == 2) {                               // blocks b and b + 8 of a group of 16: one graph (same XCD)
+        part = (gblk >> 3) & 1;
+        gblk = (gblk >> 4) * 8 + (gblk & 7);
+    }
+    if (gblk >= p.B) return;                           // padding block of a split grid (uniform)
+    const int mt = wave & 7;
+    const int rt_all = (N + 15) >> 4;
+    const int tile_lo = p.nsplit == 2 ? (part ? rt_all >> 1 : 0) : 0;
+    const int tile_hi = p.nsplit == 2 ? (part ? rt_all : rt_all >> 1) : rt_all;
+    const int row_lo = tile_lo * 16, row_hi = min(tile_hi * 16, N);
+    const int rt0 = tile_lo + (wave >> 3) * RTW;       // first row tile of this wave
+    const bool has_mfma = rt0 < tile_hi;
+
+    float* zbuf0 = reinterpret_cast<float*>(gnnpp_smem);
+    float* zbuf1 = zbuf0 + N * kPfZs;
+    float* Sl = zbuf1 + N * kPfZs;                     // [N][Ns]: row n = column n of the GSO, then its list
+    unsigned char* idx = reinterpret_cast<unsigned char*>(Sl + (K > 1 ? N * Ns : 0));
+    unsigned char* cnt = idx + (K > 1 ? N * Ns : 0);
+    float* cb = reinterpret_cast<float*>(gnnpp_smem + pf_lds_base(N, Ns, K));
+    float* part_sums = reinterpret_cast<float*>(gnnpp_smem + p.pf_part_off);      // [8][N][8]
+
+    GNNPP_STAMP(blockIdx.x, 0, tid == 0);
+    // ---- every global load of the kernel, issued now -------------------------------------------------------
+    // x: [N][128] contiguous, 32 N 16-byte pieces
+    const v4f* xs = reinterpret_cast<const v4f*>(p.x + (size_t)gblk * N * 128);
+    v4f xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + u * NT;
+        if (i < N * 32) xv[u] = xs[i];
+    }
+    // S: dense [N][N] slab, fp32 (16 bytes at a time when the slabs allow it) or fp64
+    const int NN = N * N;
+    const size_t sidx = (size_t)gblk * NN;
+    v4f s4[3];
+    float s1[10];
+    double sd[10];
+    if (K > 1) {
+        if (p.s_is_f64) {
+            const double* src = reinterpret_cast<const double*>(p.S) + sidx;
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int i = tid + u * NT;
+                if (i < NN) sd[u] = src[i];
+            }
+        } else if (p.s_vec4) {
+            const v4f* src = reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(p.S) + sidx);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = tid + u * NT;
+                if (i < (NN >> 2)) s4[u] = src[i];
+            }
+        } else {
+            const float* src = reinterpret_cast<const float*>(p.S) + sidx;
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int i = tid + u * NT;
+                if (i < NN) s1[u] = src[i];
+            }
+        }
+    }
+    // constants of the epilogue: one float per thread
+    float cpre = 0.f;
+    if (tid < 640) cpre = p.act_w[tid];
+    else if (tid < 768) cpre = p.bias ? p.bias[tid - 640] : 0.f;
+    else if (tid < 773) cpre = p.act_b[tid - 768];
+    else if (tid == 773) cpre = p.wpk_h[filter_packed_h2_floats(128, 128, K, 1) + 1];
+    // A fragments of the first tap (packed block (k, mt, gg): 64 lanes x 16 bytes = hi | lo of four k-steps)
+    constexpr size_t tap_stride = (size_t)8 * 8 * 256;
+    v4f Acur[8];
+    auto load_tap = [&](int tap) {
+        if (has_mfma) {
+            const float* wt = p.wpk_h + tap * tap_stride + ((size_t)mt * 8 * 64 + lane) * 4;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) Acur[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
+        }
+    };
+    load_tap(0);
+
+    // ---- LDS: zero the index lists, then the staged data ------------------------------------------------
+    if (K > 1) {                                       // stale list entries must be valid rows
+        unsigned* iz = reinterpret_cast<unsigned*>(idx);
+        for (int i = tid; i < (N * Ns) >> 2; i += NT) iz[i] = 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + u * NT;
+        if (i < N * 32) *reinterpret_cast<v4f*>(zbuf0 + (i >> 5) * kPfZs + 4 * (i & 31)) = xv[u];
+    }
+    if (K > 1) {
+        // element e = m * N + n of the slab goes to Sl[n][m]   (m = e / N exactly: (e + 0.5) / N is at least
+        // 0.5 / N away from an integer, the float error is < 1e-3 of that for e < 2^14)
+        const float inv_n = 1.0f / (float)N;
+        if (p.s_is_f64) {
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int e = tid + u * NT;
+                if (e < NN) {
+                    const int m = (int)(((float)e + 0.5f) * inv_n), n = e - m * N;
+                    Sl[n * Ns + m] = (float)sd[u];
+                }
+            }
+        } else if (p.s_vec4) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int e = 4 * (tid + u * NT);
+                if (e < NN) {
+                    int m = (int)(((float)e + 0.5f) * inv_n), n = e - m * N;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        Sl[n * Ns + m] = s4[u][c];
+                        if (++n == N) { n = 0; ++m; }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int e = tid + u * NT;
+                if (e < NN) {
+                    const int m = (int)(((float)e + 0.5f) * inv_n), n = e - m * N;
+                    Sl[n * Ns + m] = s1[u];
+                }
+            }
+        }
+    }
+    if (tid < 774) cb[tid] = cpre;
+    __syncthreads();                                   // z_0, S, constants visible
+    GNNPP_STAMP(blockIdx.x, 1, tid == 0);
+    if (K > 1) {
+        build_lists(p, Sl, idx, cnt, N, wave, NW, lane);
+        __syncthreads();
+    }
+    GNNPP_STAMP(blockIdx.x, 2, tid == 0);
+
+    unsigned long long bad = 0;                        // lanes that handed |z| >= 65504 to the f16 pipe
+    v4f acc[RTW], acc2[RTW];                           // hi.hi products | cross terms
+#pragma unroll
+    for (int t = 0; t < RTW; ++t) { acc[t] = vzero(); acc2[t] = vzero(); }
+    auto brow = [&](int t) { return min((rt0 + t) * 16 + a, N - 1); };     // (rows >= N: copies, never stored)
+
+    for (int k = 0; k < K; ++k) {
+        float* zcur = (k & 1) ? zbuf1 : zbuf0;
+        float* znxt = (k & 1) ? zbuf0 : zbuf1;
+        const bool presplit = k > 0 && k + 1 == K;     // z_{K-1} was written as hi | lo by the last shift
+        if (k + 1 < K) {
+            const bool last = k + 2 == K;              // only the LAST shift may be restricted to the own rows
+            pf_gather(Sl, idx, cnt, zcur, znxt, Ns, last ? row_lo : 0, last ? row_hi : N, wave, lane, last, bad);
+        }
+        if (!presplit) {
+            if (K > 1) __syncthreads();                // every reader of the fp32 z_k is done; z_{k+1} visible
+            GNNPP_STAMP(blockIdx.x, 3 + 3 * k, tid == 0 && k < 3);
+            split_rows(zcur, row_lo, row_hi, kPfZs, wave, NW, lane, bad);
+            __syncthreads();
+            GNNPP_STAMP(blockIdx.x, 4 + 3 * k, tid == 0 && k < 3);
+        }
+        if (has_mfma) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const v8h Ah = __builtin_bit_cast(v8h, Acur[2 * kb]);
+                const v8h Al = __builtin_bit_cast(v8h, Acur[2 * kb + 1]);
+#pragma unroll
+                for (int t = 0; t < RTW; ++t) {
+                    const float* zrow = zcur + brow(t) * kPfZs + q * 4;
+                    const v8h Bh = __builtin_bit_cast(v8h, *reinterpret_cast<const v4f*>(zrow + kb * 16));
+                    const v8h Bl = __builtin_bit_cast(v8h, *reinterpret_cast<const v4f*>(zrow + 64 + kb * 16));
+                    acc2[t] = mfma16h(Ah, Bl, acc2[t]);
+                    acc[t] = mfma16h(Ah, Bh, acc[t]);
+                    acc2[t] = mfma16h(Al, Bh, acc2[t]);
+                }
+            }
+        }
+        if (k + 1 < K) load_tap(k + 1);                // in flight during the next shift
+        // z_k's buffer is the target of the next shift -- unless that shift does not exist (k + 2 >= K: the
+        // next tap reads the other buffer, which the last shift completed two barriers ago)
+        if (k + 2 < K) __syncthreads();
+        GNNPP_STAMP(blockIdx.x, 5 + 3 * k, tid == 0 && k < 3);
+    }
+    if (p.range_flag && bad) *p.range_flag = 1;
+
+    // ---- epilogue: bias + ReLU in registers, this wave's 16 features of the head, partial logits to LDS ----
+    GNNPP_STAMP(blockIdx.x, 12, tid == 0);
+    if (has_mfma) {
+        const int f0 = mt * 16 + q * 4;
+        const float h2_inv = cb[773];
+        const v4f bv = *reinterpret_cast<const v4f*>(cb + 640 + f0);
+        v4f A5 = vzero();                              // act_w[a5 = a][f0 .. f0 + 4), rows a5 >= 5 zero
+        if (a < 5) A5 = *reinterpret_cast<const v4f*>(cb + a * 128 + f0);
+#pragma unroll
+        for (int t = 0; t < RTW; ++t) {
+            const int row = (rt0 + t) * 16 + a;
+            v4f v = (acc[t] + acc2[t]) * h2_inv + bv;
+            if (p.relu) v = vrelu(v);
+            const v4f d = mfma16x4(A5, v, vzero());    // d[r] = logit part a5 = 4 q + r of this lane's row
+            if (rt0 + t < tile_hi && row < N) {
+                float* ps = part_sums + (mt * N + row) * 8;
+                if (q == 0) *reinterpret_cast<v4f*>(ps) = d;
+                else if (q == 1) ps[4] = d[0];
+            }
+        }
+    }
+    __syncthreads();
+    GNNPP_STAMP(blockIdx.x, 13, tid == 0);
+    const int nout = (row_hi - row_lo) * 5;
+    for (int i = tid; i < nout; i += NT) {
+        const int row = row_lo + i / 5, a5 = i % 5;
+        float s = part_sums[row * 8 + a5];
+#pragma unroll
+        for (int m = 1; m < 8; ++m) s += part_sums[(m * N + row) * 8 + a5];
+        p.logits[((size_t)row * p.B + gblk) * 5 + a5] = s + cb[768 + a5];
+    }
+    GNNPP_STAMP(blockIdx.x, 14, tid == 0);
+}
+
+std::atomic<int> g_filter_policy_kernel{1};            // GNNPP_TUNE_FILTER_POLICY_KERNEL: 0 = lsigf_kernel everywhere
+
+// Does the planned filter launch have the policy step's shape?  (a is complete: lsigf_plan ran.)
+static bool policy_filter_applies(const LsigfArgs& a) {
+    return g_filter_policy_kernel.load(std::memory_order_relaxed) && a.act_w && a.act_b && a.logits && !a.y &&
+           !a.zs && a.E == 1 && a.G == 128 && a.F == 128 && a.F_all == 128 && a.x_node_major && a.Nin == a.N &&
+           !a.bias_per_node && !a.s_transposed && a.s_batched && a.gpw == 1 &&
+           g_filter_waves.load(std::memory_order_relaxed) != 8 &&
+           a.N >= kPfMinNodes && a.N <= kPfMaxNodes && g_filter_f16.load(std::memory_order_relaxed) &&
+           (reinterpret_cast<uintptr_t>(a.x) & 15) == 0
+#ifdef GNNPP_MEASURE
+           && a.ablate == 0
+#endif
+        ;
+}
+
+template <int RTW>
+static hipError_t policy_filter_launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
+    static LdsAttrOnce once;
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&policy_filter_kernel<RTW>), kLdsBytes);
+    hipLaunchKernelGGL((policy_filter_kernel<RTW>), dim3(grid), dim3(1024), smem, st, a);
+    return hipGetLastError();
+}
+
+// Launches the policy filter for a planned call; returns 1 when the shape is not the policy's (the caller runs
+// lsigf_kernel), 0 on success, -3 on a launch error.
+static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st) {
+    if (!policy_filter_applies(a)) return 1;
+    const size_t base = pf_lds_base(a.N, a.Ns, a.K) + kPfConsts * 4;
+    const size_t parts = (size_t)8 * a.N * 8 * 4;
+    size_t smem = base + parts;
+    a.pf_part_off = (int)base;
+    if (smem > (size_t)kLdsBytes) {
+        // large graphs: the partial logits reuse the S slab (dead after the last shift)
+        if (a.K < 2 || (size_t)a.N * a.Ns * 4 < parts || base > (size_t)kLdsBytes) return 1;
+        smem = base;
+        a.pf_part_off = 2 * a.N * kPfZs * 4;
+    }
+    const int tiles = a.nsplit == 2 ? a.rt_total - a.rt_total / 2 : a.rt_total;
+    hipError_t err;
+    switch ((tiles + 1) / 2) {
+        case 1: err = policy_filter_launch_one<1>(a, plan.grid, smem, st); break;
+        case 2: err = policy_filter_launch_one<2>(a, plan.grid, smem, st); break;
+        case 3: err = policy_filter_launch_one<3>(a, plan.grid, smem, st); break;
+        case 4: err = policy_filter_launch_one<4>(a, plan.grid, smem, st); break;
+        default: return 1;
+    }
+    return err == hipSuccess ? 0 : -3;
+}
+
+}  // namespace gnnpp

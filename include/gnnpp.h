@@ -67,6 +67,10 @@ const char* gnnpp_error_string(int code);
                                          encodes one graph's agents, then runs that graph's filter and
                                          action head on chip (identical logits); 0: always the encoder
                                          kernel followed by the filter kernel                        */
+#define GNNPP_TUNE_POLICY_FILTER    9  /* 1 (default): the filter + action head of gnnpp_policy_fwd / the rollout step
+                                         for teams of 17 .. 100 agents (one graph per workgroup, FILTER_F16 = 1,
+                                         FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
+                                         0: on the general filter kernel (same logits to the last bit or two) */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

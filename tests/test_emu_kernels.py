@@ -367,3 +367,49 @@ def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
         lib.gnnpp_set_tuning(7, 0)
         lib.gnnpp_set_tuning(1, 0)
     assert picked >= 4
+
+
+@pytest.mark.parametrize('N,K,f64,split,B', [(20, 3, 0, 1, 2), (37, 2, 1, 1, 2), (50, 3, 0, 2, 1), (33, 4, 1, 2, 2),
+                                             (18, 1, 0, 1, 1), (21, 3, 0, 1, 3)])
+def test_emu_policy_filter_kernel(emu, N, K, f64, split, B):
+    """policy_filter_kernel (filter + ReLU + action head of the policy step for 17..100 agents, one graph per
+    workgroup): the general filter kernel's logits to rounding (the head sums eight 16-feature partial products
+    instead of one 128-long chain), an fp64 restatement's within TOL; fp32 / fp64 and 16-byte / unaligned GSO slabs,
+    one and two workgroups per graph, K = 1..4."""
+    el, lib = emu
+    g = np.random.default_rng(100 * N + K)
+    h = (g.standard_normal((128, 1, K, 128)) / np.sqrt(128 * K)).astype(np.float32)
+    x = np.maximum(g.standard_normal((B, N, 128)), 0).astype(np.float32)
+    S = ((g.random((B, N, N)) < 0.2) * g.random((B, N, N))).astype(np.float64 if f64 else np.float32)
+    for b in range(B):
+        np.fill_diagonal(S[b], 0)
+    bias = (g.standard_normal(128) / 4).astype(np.float32)
+    aw = (g.standard_normal((5, 128)) / 8).astype(np.float32)
+    ab = g.standard_normal(5).astype(np.float32)
+    packed = el.pack_filter(lib, h)
+    outs = []
+    lib.gnnpp_set_tuning(0, -1); lib.gnnpp_set_tuning(5, 1); lib.gnnpp_set_tuning(2, 0)
+    try:
+        assert lib.gnnpp_set_tuning(7, split) == 0 and lib.gnnpp_set_tuning(1, 1) == 0
+        for mode in (1, 0):
+            assert lib.gnnpp_set_tuning(9, mode) == 0 and lib.gnnpp_get_tuning(9) == mode
+            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+            flag = np.zeros(1, np.int32)
+            assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
+                                             el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, el.ptr(flag),
+                                             None) == 0
+            assert flag[0] == 0
+            outs.append(logits)
+    finally:
+        lib.gnnpp_set_tuning(9, 1); lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0)
+    # fp64 restatement: z_k[b, n, :] = sum_m S[b, m, n] z_{k-1}[b, m, :]
+    z = x.astype(np.float64)
+    y = np.zeros((B, N, 128))
+    for k in range(K):
+        y += z @ h[:, 0, k, :].astype(np.float64).T
+        z = np.einsum('bmn,bmg->bng', S.astype(np.float32).astype(np.float64), z)
+    want = (np.maximum(y + bias, 0) @ aw.astype(np.float64).T + ab).transpose(1, 0, 2)
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(outs[0] - want).max() <= TOL * scale
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
+    assert lib.gnnpp_set_tuning(9, 2) == -1

@@ -475,3 +475,52 @@ def test_unseen_parameter_updates_and_invalidate_packed(dev):
     net64.addGSO(S)
     d = net64.forward_logits(obs)
     assert (d - a).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize('B,N,K,f64', [(256, 50, 3, 0), (128, 100, 3, 1), (128, 100, 2, 0), (7, 17, 3, 0), (300, 64, 4, 1),
+                                       (5, 89, 3, 0), (5, 90, 3, 1), (130, 97, 1, 0), (40, 33, 2, 0), (64, 100, 4, 0)])
+def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64):
+    """Filter + ReLU + head of the policy step for 17..100 agents: policy_filter_kernel (default) against the
+    general filter kernel on the same inputs -- equal to rounding (the head's eight partial sums instead of one
+    chain) -- and against an fp64 restatement within TOL.  Shapes on both sides of every switch: one / two
+    workgroups per graph (B <= 128 large graphs), partial logits in their own LDS / in the dead S slab (N >= 90),
+    1..4 row tiles per wave, K = 1..4, fp32 / fp64 GSO."""
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    g = torch.Generator().manual_seed(B * 131 + N * 7 + K)
+    h = torch.randn(128, 1, K, 128, generator=g) / (128 * K) ** 0.5
+    x = torch.relu(torch.randn(B, N, 128, generator=g))
+    S = ((torch.rand(B, N, N, generator=g) < 8.0 / N) * torch.rand(B, N, N, generator=g))
+    S = S * (1 - torch.eye(N))
+    S = S.double() if f64 else S.float()
+    bias, aw, ab = torch.randn(128, generator=g) / 4, torch.randn(5, 128, generator=g) / 8, torch.randn(5, generator=g)
+    packed = torch.empty(L.gnnpp_filter_packed_floats(128, 128, K, 1), dtype=torch.float32, device=dev)
+    hd = h.to(dev)
+    assert L.gnnpp_filter_pack(hd.data_ptr(), packed.data_ptr(), 128, 128, K, 1, None) == 0
+    xd, Sd, bd, awd, abd = x.to(dev), S.to(dev), bias.to(dev), aw.to(dev), ab.to(dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    outs = []
+    try:
+        for mode in (1, 0, 1):
+            assert L.gnnpp_set_tuning(9, mode) == 0
+            lg = torch.full((N, B, 5), float('nan'), device=dev)
+            assert L.gnnpp_filter_head_fwd(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(),
+                                           awd.data_ptr(), abd.data_ptr(), lg.data_ptr(), B, N, 128, 128, K, 1, f64,
+                                           flag.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            outs.append(lg.cpu())
+    finally:
+        L.gnnpp_set_tuning(9, 1)
+    assert flag.item() == 0
+    assert torch.equal(outs[0], outs[2])                                  # deterministic
+    z = x.double()
+    y = torch.zeros(B, N, 128, dtype=torch.float64)
+    Sf = S.float().double()
+    for k in range(K):
+        y += z @ h[:, 0, k, :].double().t()
+        z = torch.einsum('bmn,bmg->bng', Sf, z)
+    want = (torch.relu(y + bias.double()) @ aw.double().t() + ab.double()).permute(1, 0, 2)
+    scale = max(1.0, want.abs().max().item())
+    assert (outs[0].double() - want).abs().max().item() <= TOL * scale
+    assert (outs[0] - outs[1]).abs().max().item() <= 4e-6 * scale
+    assert not torch.equal(outs[0], outs[1]) or K == 0                    # (the new kernel did run)
