@@ -45,11 +45,14 @@ __host__ __device__ inline size_t pf_lds_base(int N, int Ns, int K) {
 
 // z_{k+1}[r, :] = sum over the neighbours m of node r (ascending) of S[m, r] * z_k[m, :], rows [row_lo, row_hi):
 // a quarter wave per row; lane ql holds features [4 ql, 4 ql + 4) and [64 + 4 ql, 64 + 4 ql + 4).
-// split_out: the result is stored as f16 hi | lo halves (the layout split_rows produces) instead of fp32.
+// znxt: fp32 result rows (may be null); zsplit: the same rows as f16 hi | lo halves, the layout split_rows
+// produces (may be null) -- the last shift writes only those.  (Writing both in a middle shift, into a third
+// buffer, to drop the conversion pass of the tap before the last was measured at N = 50: no gain -- the extra
+// stores cost the shift what the pass saved.)
 __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const unsigned char* __restrict__ idx,
                                           const unsigned char* __restrict__ cnt, const float* __restrict__ zprev,
-                                          float* __restrict__ znxt, int Ns, int row_lo, int row_hi, int wave,
-                                          int lane, bool split_out, unsigned long long& bad) {
+                                          float* __restrict__ znxt, float* __restrict__ zsplit, int Ns, int row_lo,
+                                          int row_hi, int wave, int lane, unsigned long long& bad) {
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     const int quarter = lane >> 4, ql = lane & 15;
     for (int rb = row_lo + 4 * wave; rb < row_hi; rb += 64) {           // wave-uniform trip count
@@ -62,32 +65,34 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
         const float* zc = zprev + 4 * ql;
         v4f acc0 = vzero(), acc1 = vzero();
         for (int d = 0; __ballot(d < deg) != 0ull; d += 4) {             // until all four rows are done
-            // entries past the degree: weight 0 and a stale (but valid) row index
+            // entries past the degree: weight 0 and a stale (but valid) row index.  (Masking those reads per
+            // lane was measured: the branches cost more than the LDS cycles they save, 1.72 -> 1.94 us per shift.)
             const unsigned pk = *reinterpret_cast<const unsigned*>(il + d);
             const v4f w = *reinterpret_cast<const v4f*>(wl + d);
+            const float* zr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) zr[u] = zc + __umul24((pk >> (8 * u)) & 255u, (unsigned)kPfZs);
             v4f za[4], zb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float* zr = zc + __umul24((pk >> (8 * u)) & 255u, (unsigned)kPfZs);
-                za[u] = *reinterpret_cast<const v4f*>(zr);
-                zb[u] = *reinterpret_cast<const v4f*>(zr + 64);
-            }
+            for (int u = 0; u < 4; ++u) za[u] = *reinterpret_cast<const v4f*>(zr[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u) zb[u] = *reinterpret_cast<const v4f*>(zr[u] + 64);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc0[c] = fmaf(w[u], za[u][c], acc0[c]);
-                    acc1[c] = fmaf(w[u], zb[u][c], acc1[c]);
-                }
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc0[c] = fmaf(w[u], za[u][c], acc0[c]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc1[c] = fmaf(w[u], zb[u][c], acc1[c]);
         }
-        float* row = znxt + rr * kPfZs;
-        if (!split_out) {
-            if (rv) {
-                *reinterpret_cast<v4f*>(row + 4 * ql) = acc0;
-                *reinterpret_cast<v4f*>(row + 64 + 4 * ql) = acc1;
-            }
-        } else {
+        if (znxt && rv) {
+            float* row = znxt + rr * kPfZs;
+            *reinterpret_cast<v4f*>(row + 4 * ql) = acc0;
+            *reinterpret_cast<v4f*>(row + 64 + 4 * ql) = acc1;
+        }
+        if (zsplit) {
+            float* row = zsplit + rr * kPfZs;
             // |z| >= 65504 does not fit the hi half: range guard as in split_rows
             float mx = 0.f;
 #pragma unroll
@@ -193,24 +198,41 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     // A fragments of the first tap (packed block (k, mt, gg): 64 lanes x 16 bytes = hi | lo of four k-steps)
     constexpr size_t tap_stride = (size_t)8 * 8 * 256;
     v4f Acur[8];
-    auto load_tap = [&](int tap) {
+    auto load_tap = [&](v4f (&A)[8], int tap) {
         if (has_mfma) {
             const float* wt = p.wpk_h + tap * tap_stride + ((size_t)mt * 8 * 64 + lane) * 4;
 #pragma unroll
-            for (int gg = 0; gg < 8; ++gg) Acur[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
+            for (int gg = 0; gg < 8; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
         }
     };
-    load_tap(0);
 
     // ---- LDS: zero the index lists, then the staged data ------------------------------------------------
     if (K > 1) {                                       // stale list entries must be valid rows
         unsigned* iz = reinterpret_cast<unsigned*>(idx);
         for (int i = tid; i < (N * Ns) >> 2; i += NT) iz[i] = 0u;
     }
+    // z_0 twice: fp32 in the first buffer (the first shift reads it) and as f16 hi | lo halves in the second
+    // (the first tap's MFMA operand, layout of split_rows) -- tap 0 then needs no conversion pass of its own
+    unsigned long long bad = 0;                        // lanes that handed |z| >= 65504 to the f16 pipe
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+        typedef _Float16 v4h __attribute__((ext_vector_type(4)));
         const int i = tid + u * NT;
-        if (i < N * 32) *reinterpret_cast<v4f*>(zbuf0 + (i >> 5) * kPfZs + 4 * (i & 31)) = xv[u];
+        const bool ok = i < N * 32;
+        const v4f v = ok ? xv[u] : vzero();
+        bad |= __ballot(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= 65504.f);
+        v4h hh, ll;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            hh[c] = (_Float16)v[c];
+            ll[c] = (_Float16)(v[c] - (float)hh[c]);
+        }
+        if (ok) {
+            const int r = i >> 5, c4 = i & 31;
+            *reinterpret_cast<v4f*>(zbuf0 + r * kPfZs + 4 * c4) = v;
+            *reinterpret_cast<v2f*>(zbuf1 + r * kPfZs + 2 * c4) = __builtin_bit_cast(v2f, hh);
+            *reinterpret_cast<v2f*>(zbuf1 + r * kPfZs + 64 + 2 * c4) = __builtin_bit_cast(v2f, ll);
+        }
     }
     if (K > 1) {
         // element e = m * N + n of the slab goes to Sl[n][m]   (m = e / N exactly: (e + 0.5) / N is at least
@@ -250,43 +272,27 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
         }
     }
     if (tid < 774) cb[tid] = cpre;
-    __syncthreads();                                   // z_0, S, constants visible
+    // The first tap's fragments (8 KB per wave, 128 KB per workgroup) are requested only now, behind the staged
+    // data: ahead of it they would queue in front of the later waves' x / S loads.  They arrive during the
+    // barrier and the list building.
+    load_tap(Acur, 0);
+    __syncthreads();                                   // z_0 (both forms), S, constants visible
     GNNPP_STAMP(blockIdx.x, 1, tid == 0);
-    if (K > 1) {
-        build_lists(p, Sl, idx, cnt, N, wave, NW, lane);
-        __syncthreads();
-    }
-    GNNPP_STAMP(blockIdx.x, 2, tid == 0);
 
-    unsigned long long bad = 0;                        // lanes that handed |z| >= 65504 to the f16 pipe
     v4f acc[RTW], acc2[RTW];                           // hi.hi products | cross terms
 #pragma unroll
     for (int t = 0; t < RTW; ++t) { acc[t] = vzero(); acc2[t] = vzero(); }
     auto brow = [&](int t) { return min((rt0 + t) * 16 + a, N - 1); };     // (rows >= N: copies, never stored)
-
-    for (int k = 0; k < K; ++k) {
-        float* zcur = (k & 1) ? zbuf1 : zbuf0;
-        float* znxt = (k & 1) ? zbuf0 : zbuf1;
-        const bool presplit = k > 0 && k + 1 == K;     // z_{K-1} was written as hi | lo by the last shift
-        if (k + 1 < K) {
-            const bool last = k + 2 == K;              // only the LAST shift may be restricted to the own rows
-            pf_gather(Sl, idx, cnt, zcur, znxt, Ns, last ? row_lo : 0, last ? row_hi : N, wave, lane, last, bad);
-        }
-        if (!presplit) {
-            if (K > 1) __syncthreads();                // every reader of the fp32 z_k is done; z_{k+1} visible
-            GNNPP_STAMP(blockIdx.x, 3 + 3 * k, tid == 0 && k < 3);
-            split_rows(zcur, row_lo, row_hi, kPfZs, wave, NW, lane, bad);
-            __syncthreads();
-            GNNPP_STAMP(blockIdx.x, 4 + 3 * k, tid == 0 && k < 3);
-        }
+    // contraction of one tap: D[f, row] += W_k[f, g] z_k[row, g], z_k as hi | lo halves in `zsplit`
+    auto contract = [&](const float* zsplit, const v4f (&A)[8]) {
         if (has_mfma) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const v8h Ah = __builtin_bit_cast(v8h, Acur[2 * kb]);
-                const v8h Al = __builtin_bit_cast(v8h, Acur[2 * kb + 1]);
+                const v8h Ah = __builtin_bit_cast(v8h, A[2 * kb]);
+                const v8h Al = __builtin_bit_cast(v8h, A[2 * kb + 1]);
 #pragma unroll
                 for (int t = 0; t < RTW; ++t) {
-                    const float* zrow = zcur + brow(t) * kPfZs + q * 4;
+                    const float* zrow = zsplit + brow(t) * kPfZs + q * 4;
                     const v8h Bh = __builtin_bit_cast(v8h, *reinterpret_cast<const v4f*>(zrow + kb * 16));
                     const v8h Bl = __builtin_bit_cast(v8h, *reinterpret_cast<const v4f*>(zrow + 64 + kb * 16));
                     acc2[t] = mfma16h(Ah, Bl, acc2[t]);
@@ -295,11 +301,56 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
                 }
             }
         }
-        if (k + 1 < K) load_tap(k + 1);                // in flight during the next shift
-        // z_k's buffer is the target of the next shift -- unless that shift does not exist (k + 2 >= K: the
-        // next tap reads the other buffer, which the last shift completed two barriers ago)
-        if (k + 2 < K) __syncthreads();
-        GNNPP_STAMP(blockIdx.x, 5 + 3 * k, tid == 0 && k < 3);
+    };
+
+    // Schedule (taps accumulate in the order 0, 1, ..):
+    //   lists || tap 0 (from the staged hi | lo z_0: the list building is ballot / latency work, the tap is
+    //   LDS-bandwidth work -- different waves are in different phases and fill each other's gaps)
+    //   shift k = 1 .. K-1: z_{k-1} (fp32, buffer (k-1) & 1) -> z_k (buffer k & 1; the LAST shift writes hi | lo);
+    //   once shift k has read the fp32 z_{k-1}, that is converted in place and contracted (k >= 2);
+    //   the last tap follows the one before without a barrier.
+    if (K > 1) build_lists(p, Sl, idx, cnt, N, wave, NW, lane);
+    GNNPP_STAMP(blockIdx.x, 2, tid == 0);
+    contract(zbuf1, Acur);
+    if (K > 1) load_tap(Acur, 1);                      // in flight during the shift(s)
+    GNNPP_STAMP(blockIdx.x, 3, tid == 0);
+    for (int k = 1; k + 1 < K; ++k) {                  // the shifts before the last one: all rows, fp32 out
+        float* zsrc = (k & 1) ? zbuf0 : zbuf1;         // z_{k-1}, fp32
+        float* zdst = (k & 1) ? zbuf1 : zbuf0;
+        __syncthreads();                               // lists visible / tap k-2 is done with zdst
+        GNNPP_STAMP(blockIdx.x, 4, tid == 0 && k == 1);
+        pf_gather(Sl, idx, cnt, zsrc, zdst, nullptr, Ns, 0, N, wave, lane, bad);
+        GNNPP_STAMP(blockIdx.x, 5, tid == 0 && k == 1);
+        if (k >= 2) {
+            __syncthreads();                           // every reader of the fp32 z_{k-1} is done
+            split_rows(zsrc, row_lo, row_hi, kPfZs, wave, NW, lane, bad);
+            __syncthreads();
+            contract(zsrc, Acur);                      // tap k-1
+            load_tap(Acur, k);
+        }
+    }
+    if (K > 1) {                                       // the last shift: own rows only, written as hi | lo
+        const int k = K - 1;
+        float* zsrc = (k & 1) ? zbuf0 : zbuf1;
+        float* zdst = (k & 1) ? zbuf1 : zbuf0;
+        __syncthreads();
+        GNNPP_STAMP(blockIdx.x, k == 1 ? 4 : 6, tid == 0);
+        pf_gather(Sl, idx, cnt, zsrc, nullptr, zdst, Ns, row_lo, row_hi, wave, lane, bad);
+        __syncthreads();                               // z_{K-1} visible; every reader of the fp32 z_{K-2} is done
+        GNNPP_STAMP(blockIdx.x, 7, tid == 0);
+        if (k >= 2) {
+            // (A second register set for the last tap's fragments, requested before this conversion pass, was
+            // measured: the conversion pass took 1.2 instead of 0.5 us and the kernel 16.1 instead of 14.9 us.)
+            split_rows(zsrc, row_lo, row_hi, kPfZs, wave, NW, lane, bad);
+            __syncthreads();
+            GNNPP_STAMP(blockIdx.x, 8, tid == 0);
+            contract(zsrc, Acur);                      // tap K-2
+            load_tap(Acur, k);
+            GNNPP_STAMP(blockIdx.x, 9, tid == 0);
+            contract(zdst, Acur);                      // tap K-1, no barrier in between
+        } else {
+            contract(zdst, Acur);                      // K == 2: tap 1 (tap 0 ran beside the list building)
+        }
     }
     if (p.range_flag && bad) *p.range_flag = 1;
 

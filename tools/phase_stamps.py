@@ -135,9 +135,13 @@ for (N, B) in ((50, 256), (100, 128)):
         assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
                                   B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
         torch.cuda.synchronize()
+    SLOTS.update({'pf:entry': 0, 'pf:staged': 1, 'pf:lists(wave0)': 2, 'pf:tap0(wave0)': 3, 'pf:barrier1': 4,
+                  'pf:shift1(wave0)': 5, 'pf:barrier2': 6, 'pf:shift2': 7, 'pf:split1': 8, 'pf:tap1(wave0)': 9,
+                  'pf:tap2(wave0)': 12, 'pf:partial_logits': 13, 'pf:stored': 14})   # (K = 3)
     report('policy_filter_kernel inside the policy step (B=%d, N=%d)' % (B, N), stamps(B),
-           ['f:entry', 'f:staged', 'f:lists', 'f:shift1', 'f:split0', 'f:tap0', 'f:shift2', 'f:split1', 'f:tap1',
-            'f:tap2', 'f:contracted', 'f:y_in_lds', 'f:stored'])      # (y_in_lds: the partial logits are)
+           ['pf:entry', 'pf:staged', 'pf:lists(wave0)', 'pf:tap0(wave0)', 'pf:barrier1', 'pf:shift1(wave0)',
+            'pf:barrier2', 'pf:shift2', 'pf:split1', 'pf:tap1(wave0)', 'pf:tap2(wave0)', 'pf:partial_logits',
+            'pf:stored'])
     assert M.gnnpp_set_tuning(9, 0) == 0
     for _ in range(5):
         assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
