@@ -383,6 +383,20 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         ssv[i] = pk[EncLayout::kHss + min(tid + i * kThreads, EncLayout::kHssFloats - 1)];
     float* const sstab = bufObs + 16 * 256;                          // Y holds <= 16 fragments
     float* const Ssm = sstab + EncLayout::kHssFloats;                // FUSED: GSO, [16][17], zero padded
+    // FUSED: what the epilogue of the filter reads -- act_w [5][128] | bias [128] | act_b [5] | 1 / split scale --
+    // takes the same road (774 floats, four per thread): no load is left behind the weight ring
+    float* const hconst = Ssm + 16 * 17;
+    float hcv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FUSED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * kThreads;
+            if (c < 640) hcv[i] = pt.act_w[c];
+            else if (c < 768) hcv[i] = pt.gf_bias ? pt.gf_bias[c - 640] : 0.f;
+            else if (c < 773) hcv[i] = pt.act_b[c - 768];
+            else if (c == 773) hcv[i] = pt.filt_h2[filter_packed_h2_floats(128, 128, KT, 1) + 1];
+        }
+    }
     float sval = 0.f;
     if (FUSED) {
         const int m = tid >> 4, n = tid & 15;                        // one GSO entry per thread
@@ -555,6 +569,9 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // (first read after L1's mid-layer barrier)
     if (FUSED) {
         Ssm[(tid >> 4) * 17 + (tid & 15)] = sval;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (tid + i * kThreads < 774) hconst[tid + i * kThreads] = hcv[i];
     }
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
@@ -796,34 +813,30 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
     GNNPP_STAMP(blockIdx.x, 14, tid == 0);
     if (range_flag && bad) *range_flag = 1;               // (every split of this kernel is behind us)
-    // bias + ReLU -> y rows (behind the z buffers), then the 128 -> 5 action head on the fp32 MFMA.
-    // Wave 0 fetches its A fragments of actionsMLP.0.weight [5,128] now (the weight ring is empty, so a
-    // compiler-issued load no longer interferes); they land while the y rows are written.
-    float* const yb = z0 + KT * (16 * kZs);
-    v4f headA[8];
-    if (wave == 0) {
-#pragma unroll
-        for (int gg = 0; gg < 8; ++gg)
-            headA[gg] = a < 5 ? *reinterpret_cast<const v4f*>(pt.act_w + a * 128 + gg * 16 + 4 * q) : vzero();
-    }
+    // bias + ReLU in registers, then the 128 -> 5 action head on the fp32 MFMA where the accumulators are: a lane
+    // holds y[node a, 4 features of its channel tile] -- the B operand of the 16x16x4 MFMA against act_w's
+    // columns of that tile -- so each wave multiplies its two tiles (one chain of 8 MFMAs from zero) and the four
+    // waves' partial logits meet in LDS, summed in wave order (lsigf_kernel's head pairs the tiles the same
+    // way: identical logits).  Every constant comes from LDS (parked there before the ring started).
+    float* const yb = z0 + KT * (16 * kZs);              // [4 waves][16 nodes][8]: partial logits
     {
-        const float finv = pt.filt_h2[filter_packed_h2_floats(128, 128, KT, 1) + 1];
+        const float finv = hconst[773];
+        v4f d = vzero();
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int f0 = (2 * wave + m) * 16 + 4 * q;
-            v4f bv = vzero();
-            if (pt.gf_bias) bv = *reinterpret_cast<const v4f*>(pt.gf_bias + f0);
-            *reinterpret_cast<v4f*>(yb + a * kZs + f0) = vrelu((fa[m] + fc[m]) * finv + bv);
+            const v4f bv = *reinterpret_cast<const v4f*>(hconst + 640 + f0);
+            const v4f A5 = a < 5 ? *reinterpret_cast<const v4f*>(hconst + a * 128 + f0) : vzero();
+            d = mfma16x4(A5, vrelu((fa[m] + fc[m]) * finv + bv), d);
         }
+        if (q < 2) *reinterpret_cast<v4f*>(yb + (wave * 16 + a) * 8 + 4 * q) = d;   // outputs 4 q + reg of node a
     }
     __syncthreads();
     if (wave == 0) {
-        v4f d = vzero();
+        v4f d = *reinterpret_cast<const v4f*>(yb + a * 8 + 4 * (q & 1));
 #pragma unroll
-        for (int gg = 0; gg < 8; ++gg) {
-            const int f0 = gg * 16 + 4 * q;
-            d = mfma16x4(headA[gg], *reinterpret_cast<const v4f*>(yb + a * kZs + f0), d);
-        }
+        for (int w = 1; w < kWaves; ++w) d += *reinterpret_cast<const v4f*>(yb + (w * 16 + a) * 8 + 4 * (q & 1));
+        const v4f ab4 = *reinterpret_cast<const v4f*>(hconst + 768 + 4 * (q & 1));   // act_b[0..3] | act_b[4], .
         if (a < pt.N && q < 2) {                          // lane holds node a, outputs 4 q + reg
             float* dst = pt.logits + ((size_t)a * pt.B + blockIdx.x) * 5;
             // with the simulator tail: a copy [N][5] in LDS for this wave's move (red + 2 kMaxAgents, see below)
@@ -831,12 +844,12 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             if (q == 0) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    dst[t] = d[t] + pt.act_b[t];
-                    if (pt.with_sim) lds[t] = d[t] + pt.act_b[t];
+                    dst[t] = d[t] + ab4[t];
+                    if (pt.with_sim) lds[t] = d[t] + ab4[t];
                 }
             } else {
-                dst[4] = d[0] + pt.act_b[4];
-                if (pt.with_sim) lds[4] = d[0] + pt.act_b[4];
+                dst[4] = d[0] + ab4[0];
+                if (pt.with_sim) lds[4] = d[0] + ab4[0];
             }
         }
         __builtin_amdgcn_wave_barrier();                  // (the LDS copy precedes this wave's reads in move_body)

@@ -677,19 +677,25 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
         // staged act_w (rows >= 5 are zero), B fragment from the staged y tile.
         const int i5 = lane & 15;
         for (int rt = tile_lo + wave; rt < tile_hi; rt += NW) {
+            // Term order of the fused policy kernel (encoder_kernel_h2.hip), whose four waves each chain their
+            // two 16-feature tiles from zero and add the partial logits in wave order: identical results.
             v4f d = vzero();
             const int r = rt * 16 + a;                  // this lane's row; it holds a5 = 4*q + reg
             const float* yrow = ybuf + min(r, R - 1) * zs;
-            for (int gg = 0; gg < p.MT; ++gg) {
-                const int f0 = gg * 16 + q * 4;
-                v4f A = vzero();
-                if (i5 < 5) {
+            for (int g2 = 0; g2 < p.MT; g2 += 2) {
+                v4f dp = vzero();
+                for (int gg = g2; gg < min(g2 + 2, p.MT); ++gg) {
+                    const int f0 = gg * 16 + q * 4;
+                    v4f A = vzero();
+                    if (i5 < 5) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        if (f0 + s < p.F) A[s] = actw[i5 * p.F + f0 + s];
+                        for (int s = 0; s < 4; ++s)
+                            if (f0 + s < p.F) A[s] = actw[i5 * p.F + f0 + s];
+                    }
+                    const v4f Bv = *reinterpret_cast<const v4f*>(yrow + f0);
+                    dp = mfma16x4(A, Bv, dp);
                 }
-                const v4f Bv = *reinterpret_cast<const v4f*>(yrow + f0);
-                d = mfma16x4(A, Bv, d);
+                d = g2 == 0 ? dp : d + dp;
             }
             if (r < R && q < 2) {
                 const int j = r / N, n = r - j * N;
