@@ -401,6 +401,11 @@ def main():
         y = torch.empty(M, 128, device=dev)
         t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(y), B, N, N,
                                                      128, 128, K, 1, 0, 1, 1, 1, 1, 0, None, st))
+        # the filter launch of the policy step itself: features -> logits (filter + ReLU + action head; for teams
+        # of 17..100 agents that is policy_filter_kernel, else lsigf_kernel with the fused head)
+        lg_fh = torch.empty(N, B, 5, device=dev)
+        t_fh = time_kernel(lambda: L.gnnpp_filter_head_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(aw), vp(ab),
+                                                           vp(lg_fh), B, N, 128, 128, K, 1, 0, None, st))
         enc_flops = 2.0 * ENC_MACS_PER_AGENT * M
         pol_flops = policy_flops_per_agent(K, mean_deg) * M
         if fused:
@@ -468,7 +473,13 @@ def main():
         result['step_breakdown_us'] = {
             'whole_step_wall': 1e6 * elapsed / args.steps, 'whole_step_device': 1e6 * dev_elapsed / args.steps,
             'encoder_kernel_alone': t_enc * 1e6, 'filter_kernel_alone': t_gf * 1e6,
-            'one_kernel_step': bool(fused)}
+            'filter_and_head_alone': t_fh * 1e6, 'one_kernel_step': bool(fused)}
+        result['policy_filter'] = {
+            'kernel': ('gnnpp::policy_filter_kernel' if 17 <= N <= 100 and L.gnnpp_get_tuning(9) == 1 else
+                       'gnnpp::lsigf_kernel') + ' (features -> logits: filter + bias + ReLU + action head, the second '
+                      'launch of the two-kernel policy step)',
+            'avg_launch_us': t_fh * 1e6, 'agent_steps_per_s': M / t_fh,
+            'algorithmic_GBps': (gf_bytes - 512.0 * M + 20.0 * M) / t_fh / 1e9}
         result['filter_kernel'] = {
             'kernel': 'gnnpp::lsigf_kernel (node-major features in, bias + ReLU fused)', 'avg_launch_us': t_gf * 1e6,
             'agent_steps_per_s': M / t_gf, 'algorithmic_GBps': gf_bytes / t_gf / 1e9,

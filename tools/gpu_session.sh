@@ -41,7 +41,7 @@ if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path 
 if has filterab; then stamp "filter kernel A/B"
   timeout 400 python tools/filter_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_ab.jsonl; fi
 if has stamps; then stamp "phase stamps of the rollout kernels"
-  timeout 300 python tools/phase_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tail -8 | tee $OUT/phase_stamps.jsonl; fi
+  timeout 300 python tools/phase_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tail -14 | tee $OUT/phase_stamps.jsonl; fi
 if has fablate; then stamp "filter ablation"
   timeout 300 python tools/ab_bench.py filter_ablation 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_ablation.jsonl; fi
 if has pipelined; then stamp "pipelined steps"
