@@ -32,7 +32,10 @@
 
 namespace gnnpp {
 
-constexpr int kPfZs = 136;                 // LDS row stride of a z buffer in floats (128 + 8: see lsigf_kernel)
+constexpr int kPfZs = 136;                 // LDS row stride of a z buffer in floats (128 + 8, as lsigf_kernel).  Measured
+                                           // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE per C3 launch, filter time): 136:
+                                           // 0.60 M / 2.73 M, 14.8 us; 132: 1.31 M / 3.44 M, 15.4 us; 140: 1.21 M / 3.34 M,
+                                           // 15.2 us; wider strides do not fit 100 nodes.
 constexpr int kPfConsts = 776;             // act_w [5][128] | bias [128] | act_b [5] | 1 / split scale | pad
 constexpr int kPfMaxNodes = 100;
 constexpr int kPfMinNodes = 17;
