@@ -14,8 +14,10 @@
 // (128 VGPRs for 16 waves).  Here, for the one shape the policy has (E = 1, G = F = 128, node-major x, one
 // graph per workgroup):
 //   * every global load of the kernel is issued in the first instructions -- x (at most four 16-byte loads per
-//     thread), S (all of it in flight), the first tap's A fragments, and ONE float per thread of act_w / bias /
-//     act_b / the split scale, parked in LDS until the epilogue: one memory round trip in total;
+//     thread), S (all of it in flight), ONE float per thread of act_w / bias / act_b / the split scale (parked in
+//     LDS until the epilogue), then the first tap's A fragments: one memory round trip in total;
+//   * z_0 goes to LDS twice while it is in registers, as fp32 (the first shift reads it) and as hi | lo halves:
+//     tap 0 is contracted beside the list building and needs no conversion pass;
 //   * a QUARTER wave gathers a node (8 features per lane, 4 neighbours per trip): 64 nodes in flight per pass,
 //     one pass for 50 nodes;
 //   * the last shift writes z_{K-1} directly as hi | lo halves: the last tap needs no conversion pass and no
@@ -23,7 +25,7 @@
 //   * the head is applied to the accumulators where they are: after bias + ReLU a lane holds y[row, 4 features]
 //     -- exactly the B operand of the 16x16x4 MFMA against act_w's columns of its own 16-feature tile -- so every
 //     wave multiplies its tile (4 MFMAs per row tile) and the eight tiles' partial logits are summed through LDS
-//     in the fixed order mt = 0..7 (deterministic; the rounding differs from the one-chain head of lsigf_kernel
+//     in the fixed order mt = 0..7 (deterministic; the rounding differs from the pair-chain head of lsigf_kernel
 //     in the last bit, tests/test_gpu_parity.py compares the two).  No y tile in LDS, no 32-MFMA chain.
 // Two workgroups per graph (nsplit = 2, as in lsigf_kernel) when at most 128 large graphs would leave half of
 // the CUs idle: both stage the graph and run the shifts k < K-1 on all rows; the last shift, the contraction
