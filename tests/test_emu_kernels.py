@@ -370,12 +370,13 @@ def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
 
 
 @pytest.mark.parametrize('N,K,f64,split,B', [(20, 3, 0, 1, 2), (37, 2, 1, 1, 2), (50, 3, 0, 2, 1), (33, 4, 1, 2, 2),
-                                             (18, 1, 0, 1, 1), (21, 3, 0, 1, 3)])
+                                             (18, 1, 0, 1, 1), (21, 3, 0, 1, 3), (92, 2, 0, 1, 1), (100, 3, 1, 1, 1)])
 def test_emu_policy_filter_kernel(emu, N, K, f64, split, B):
     """policy_filter_kernel (filter + ReLU + action head of the policy step for 17..100 agents, one graph per
     workgroup): the general filter kernel's logits to rounding (the head sums eight 16-feature partial products
     instead of one 128-long chain), an fp64 restatement's within TOL; fp32 / fp64 and 16-byte / unaligned GSO slabs,
-    one and two workgroups per graph, K = 1..4."""
+    one and two workgroups per graph, K = 1..4; 92 / 100 nodes: three / four row tiles per wave, the partial logits
+    in the dead S slab (the LDS is full)."""
     el, lib = emu
     g = np.random.default_rng(100 * N + K)
     h = (g.standard_normal((128, 1, K, 128)) / np.sqrt(128 * K)).astype(np.float32)
