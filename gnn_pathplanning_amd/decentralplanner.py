@@ -222,6 +222,7 @@ class DecentralPlannerNet(nn.Module):
         self._head_cache = _native.PackCache()
         self._ws = None
         self._ws_key = None
+        self._ws_all = {}                          # feature workspaces by (rows, stream)
         # Range guard of the split-f16 schedules (include/gnnpp.h): a device int the kernels raise when
         # an activation leaves the f16 range.  'flag' (default): no synchronisation, the caller (or
         # BatchedRollout.run) polls check_range(); 'strict': every forward reads the flag back and
@@ -421,7 +422,6 @@ class DecentralPlannerNet(nn.Module):
                 # may be in flight on different streams (rollout.GroupedRollout)
                 wkey = (B * N, st.value)
                 if self._ws is None or self._ws_key != wkey or self._ws.device != dev:
-                    self._ws_all = getattr(self, '_ws_all', {})
                     if wkey not in self._ws_all or self._ws_all[wkey].device != dev:
                         if len(self._ws_all) > 16:
                             self._ws_all.clear()

@@ -286,6 +286,10 @@ class GroupedRollout:
             with torch.cuda.stream(st):                      # state, new weights) is visible to the group
                 fn(env)
 
+    @property
+    def t(self):
+        return self.envs[0].t                                # (all groups step together)
+
     def join(self):
         """Make the caller's stream wait for every group's work."""
         cur = torch.cuda.current_stream(self.device)
