@@ -11,6 +11,8 @@ Outputs
   tests/golden/policy_model.npz   DecentralPlannerNet parameters (reference init + randomised BN
                                   running stats) and forward I/O for several (N, K, B)
   tests/golden/policy_multilayer.npz  planners with L = 2 graph-filter layers and / or E = 2
+  tests/golden/policy_large.npz   forward I/O of teams of 50 / 64 / 100 agents (parameters of policy_model.npz);
+                                  `python oracle/gen_golden.py large` writes only this file
   tests/golden/training_grads.npz train-mode forward/backward, standalone filter gradients
 Every random draw is seeded (module constructors included): re-running reproduces the files bit for bit.
 """
@@ -176,6 +178,41 @@ def gen_policy(DecentralPlannerNet):
     print('policy_model: %d cases' % len(meta))
 
 
+def gen_policy_large(DecentralPlannerNet):
+    """Large teams (the shapes of BASELINE configs 3 and 5): the reference's forward with the parameters stored in
+    policy_model.npz -> policy_large.npz (inputs, logits; the features are not kept: the encoder is per agent and
+    covered by policy_model.npz)."""
+    from oracle.policy_oracle import synth_gso_geometric, synth_gso_sparse, synth_obs
+    z = np.load(os.path.join(OUT, 'policy_model.npz'))
+    sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith('sd/')}
+    store, meta = {}, []
+    for (N, K, B, gso, W) in ((50, 3, 2, 'geo64', 50), (100, 2, 1, 'sparse32', 0), (100, 4, 2, 'geo64', 100),
+                              (64, 3, 3, 'geo32', 40), (100, 3, 1, 'geo64', 100)):
+        net = DecentralPlannerNet(Cfg(N, K)).eval()
+        sdk = dict(sd)
+        if K != 3:
+            sdk['GFL.0.weight'] = torch.from_numpy(np.array(z['gfl_w_K%d' % K]))
+        net.load_state_dict(sdk)
+        obs = synth_obs(B, N, seed=N * 100 + K)
+        if gso == 'sparse32':
+            S = synth_gso_sparse(B, N, 6.0, seed=N * 5 + K)
+        else:
+            S = torch.from_numpy(synth_gso_geometric(B, N, W, seed=N * 7 + K))
+            if gso == 'geo32':
+                S = S.float()
+        with torch.no_grad():
+            net.addGSO(S)
+            out = net(obs)
+        i = len(meta)
+        store['q%d_obs' % i] = obs.numpy()
+        store['q%d_S' % i] = S.numpy()
+        store['q%d_logits' % i] = torch.stack(out, dim=1).numpy()      # [B,N,5]
+        meta.append({'N': N, 'K': K, 'B': B, 'gso': gso})
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'policy_large.npz'), **store)
+    print('policy_large: %d cases' % len(meta))
+
+
 def gen_multilayer(DecentralPlannerNet, gml):
     """Planners with SEVERAL graph-filter layers and E > 1 edge features -> policy_multilayer.npz.
     The reference builds / runs L layers and E features generically (decentralplanner.py:205-224,
@@ -334,7 +371,11 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'training':
         gen_training(Net, gml)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'large':
+        gen_policy_large(Net)
+        sys.exit(0)
     gen_lsigf(gml)
     gen_policy(Net)
+    gen_policy_large(Net)
     gen_multilayer(Net, gml)
     gen_training(Net, gml)

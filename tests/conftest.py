@@ -31,6 +31,13 @@ def policy_golden():
     return _load('policy_model.npz')
 
 
+@pytest.fixture(scope='session')
+def policy_large_golden():
+    """Teams of 50 / 64 / 100 agents through the REAL reference (oracle/gen_golden.py large); parameters are
+    policy_model.npz's."""
+    return _load('policy_large.npz')
+
+
 def golden_state_dict(z, K=3):
     import torch
     sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith('sd/')}

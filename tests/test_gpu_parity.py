@@ -92,6 +92,31 @@ def test_policy_golden(dev, policy_golden, enc_variant):
         assert (acts == want.argmax(-1)).all()
 
 
+def test_policy_large_teams_golden(dev, policy_golden, policy_large_golden, enc_variant):
+    """Teams of 50 / 64 / 100 agents against logits computed by the REFERENCE (tests/golden/policy_large.npz): the
+    two-kernel policy step with policy_filter_kernel (default) and with the general filter kernel."""
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    zp, _ = policy_golden
+    z, meta = policy_large_golden
+    try:
+        for i, m in enumerate(meta):
+            net = _net(m['N'], m['K'], dev, golden_state_dict(zp, m['K']))
+            obs = torch.from_numpy(z['q%d_obs' % i]).to(dev)
+            S = torch.from_numpy(z['q%d_S' % i]).to(dev)
+            want = z['q%d_logits' % i]
+            net.addGSO(S)
+            for mode in (1, 0):
+                assert L.gnnpp_set_tuning(9, mode) == 0
+                got = torch.stack(net(obs), 1).cpu().numpy()
+                assert np.abs(got - want).max() <= TOL, (i, m, mode, np.abs(got - want).max())
+                srt = np.sort(want, -1)
+                clear = srt[..., -1] - srt[..., -2] > 1e-5
+                assert (got.argmax(-1)[clear] == want.argmax(-1)[clear]).all()
+    finally:
+        L.gnnpp_set_tuning(9, 1)
+
+
 @pytest.mark.parametrize('B,N,K,W', [(1, 10, 3, 20), (512, 10, 3, 20), (256, 50, 3, 50),
                                      (128, 100, 2, 100), (128, 100, 3, 100), (128, 100, 4, 100),
                                      (37, 7, 3, 12), (5, 64, 3, 40)])

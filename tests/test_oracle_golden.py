@@ -63,6 +63,26 @@ def test_policy_matches_reference(policy_golden):
         assert torch.equal(orc.decode_actions(out), want)
 
 
+def test_policy_large_teams_match_reference(policy_golden, policy_large_golden):
+    """BASELINE configs 3 / 5 shapes (50, 64, 100 agents; K = 2, 3, 4; fp64 / fp32 / sparse asymmetric GSOs):
+    the oracle against logits computed by the reference itself."""
+    zp, _ = policy_golden
+    z, meta = policy_large_golden
+    assert {m['N'] for m in meta} == {50, 64, 100} and {m['K'] for m in meta} == {2, 3, 4}
+    for i, m in enumerate(meta):
+        sd = golden_state_dict(zp, m['K'])
+        obs = torch.from_numpy(z['q%d_obs' % i])
+        S = torch.from_numpy(z['q%d_S' % i])
+        with torch.no_grad():
+            out = orc.policy_forward(sd, S, obs)
+        logits = torch.stack(out, dim=1).numpy()
+        assert logits.shape == (m['B'], m['N'], 5)
+        assert np.abs(logits - z['q%d_logits' % i]).max() <= TOL, (i, m)
+        clear = orc.top2_margin(out) > 1e-5
+        want = torch.from_numpy(z['q%d_logits' % i]).argmax(-1)
+        assert torch.equal(orc.decode_actions(out)[clear], want[clear])
+
+
 def test_state_dict_contract(policy_golden):
     z, _ = policy_golden
     sd = golden_state_dict(z)
