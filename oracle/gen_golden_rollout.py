@@ -1,7 +1,8 @@
 """Record rollout traces from the REAL reference simulator (utils/multirobotsim_dcenlocal.py) into
 tests/golden/rollout_traces.npz.  Build-container only (needs /root/reference); only data is stored.
 
-    python oracle/gen_golden_rollout.py
+    python oracle/gen_golden_rollout.py          # rollout_traces.npz (+ the .mat / checkpoint fixtures)
+    python oracle/gen_golden_rollout.py large    # rollout_traces_large.npz: teams of 50 and 100 agents
 
 Every case is a hand-made MAPF instance (random obstacle map, distinct start/goal cells) driven
 through setup / getCurrentState / getGSO / move exactly like agents/decentralplannerlocal.py:534-592.
@@ -132,6 +133,43 @@ def run_case(simmod, net, cfg, grid, starts, goals, makespan, policy, rng, noise
     return rec, fin
 
 
+def pack_case(store, meta, ci, cfg, grid, goals, rec, fin, policy):
+    T = len(rec['obs'])
+    store['t%d_grid' % ci] = grid.astype(np.uint8)
+    store['t%d_goal' % ci] = goals.astype(np.int16)
+    store['t%d_pos' % ci] = np.stack(rec['pos'])                 # [T+1,N,2]
+    store['t%d_obs' % ci] = np.stack(rec['obs'])                 # [T,N,3,11,11] uint8
+    store['t%d_gso' % ci] = np.stack(rec['gso'])                 # [T,N,N] float64
+    store['t%d_radius' % ci] = np.array(rec['radius'])
+    store['t%d_logits' % ci] = np.stack(rec['logits'])
+    store['t%d_actions' % ci] = np.stack(rec['actions'])
+    store['t%d_flags' % ci] = np.array(rec['flags'], dtype=np.uint8)
+    store['t%d_reached' % ci] = np.stack(rec['reached'])
+    store['t%d_choices' % ci] = np.array(rec['choices'], dtype=np.int16)
+    store['t%d_nchoices' % ci] = np.array(rec['nchoices'], dtype=np.int16)
+    m = {'N': cfg.num_agents, 'W': int(grid.shape[0]), 'policy': policy, 'T': T, 'commR': cfg.commR,
+         'collisions': int(sum(rec['nchoices']))}
+    m.update(fin)
+    meta.append(m)
+    print(m)
+
+
+def main_large():
+    """Teams of 50 and 100 agents on 50 x 50 / 100 x 100 maps (the rollouts of BASELINE configs 3 and 5) through the
+    reference simulator, scripted noisy-greedy policy -> rollout_traces_large.npz."""
+    simmod, _ = import_reference()
+    rng = np.random.default_rng(20260927)
+    random.seed(4242)
+    store, meta = {}, []
+    for ci, (N, W, dens, mk, noise) in enumerate(((50, 50, 0.05, 10, 0.2), (100, 100, 0.03, 8, 0.2))):
+        cfg = Cfg(N)
+        grid, starts, goals = make_case(rng, N, W, dens)
+        rec, fin = run_case(simmod, None, cfg, grid, starts, goals, mk, 'greedy', rng, noise)
+        pack_case(store, meta, ci, cfg, grid, goals, rec, fin, 'greedy')
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'rollout_traces_large.npz'), **store)
+
+
 def main():
     simmod, Net = import_reference()
     z = np.load(os.path.join(OUT, 'policy_model.npz'))
@@ -208,4 +246,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'large':
+        main_large()
+    else:
+        main()

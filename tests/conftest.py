@@ -52,6 +52,13 @@ def rollout_golden():
 
 
 @pytest.fixture(scope='session')
+def rollout_large_golden():
+    """Teams of 50 / 100 agents on 50 x 50 / 100 x 100 maps through the REAL reference simulator
+    (oracle/gen_golden_rollout.py large)."""
+    return _load('rollout_traces_large.npz')
+
+
+@pytest.fixture(scope='session')
 def training_golden():
     return _load('training_grads.npz')
 

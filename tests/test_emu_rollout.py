@@ -103,6 +103,19 @@ def test_emu_rollout_traces_gso_observe_pair(rollout_golden):
         replay_case(lib, RolloutStruct, z, ci, m, fused='pair')
 
 
+def test_emu_rollout_traces_large_teams(rollout_large_golden):
+    """The reference simulator's traces for 50 agents / 50 x 50 and 100 agents / 100 x 100 maps through the HIP
+    kernels (separate launches and the graph + observations pair large teams run): two-word agent masks, the
+    cell-count map on big grids, goal offsets up to 99."""
+    import emu_lib
+    from gnn_pathplanning_amd._native import RolloutStruct
+    lib = emu_lib.load()
+    z, meta = rollout_large_golden
+    for ci, m in enumerate(meta):
+        replay_case(lib, RolloutStruct, z, ci, m)
+        replay_case(lib, RolloutStruct, z, ci, m, fused='pair')
+
+
 def test_emu_rollout_argument_checks():
     import emu_lib
     from gnn_pathplanning_amd._native import RolloutStruct

@@ -30,8 +30,19 @@ def random_episodes(rng, B, N, W, density):
 
 
 def test_replay_simulator_traces(dev, rollout_golden):
+    _replay_traces(dev, *rollout_golden)
+
+
+def test_replay_simulator_traces_large_teams(dev, rollout_large_golden):
+    """The reference simulator's own traces for 50 agents / 50 x 50 and 100 agents / 100 x 100 (the rollouts of
+    BASELINE configs 3 and 5): observations, GSO, radius, collision shielding, statistics -- bit for bit."""
+    z, meta = rollout_large_golden
+    assert [m['N'] for m in meta] == [50, 100]
+    _replay_traces(dev, z, meta)
+
+
+def _replay_traces(dev, z, meta):
     from gnn_pathplanning_amd.rollout import BatchedRollout
-    z, meta = rollout_golden
     for ci, m in enumerate(meta):
         pos_all = z['t%d_pos' % ci].astype(np.int64)
         env = BatchedRollout(z['t%d_grid' % ci], pos_all[0][None], z['t%d_goal' % ci][None],

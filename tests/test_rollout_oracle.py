@@ -21,6 +21,17 @@ class Replay:
 def test_rollout_traces_replay_bit_exact(rollout_golden):
     z, meta = rollout_golden
     assert sum(m['collisions'] for m in meta) >= 30          # the traces do exercise the shielding
+    _replay(z, meta)
+
+
+def test_rollout_traces_large_teams_replay_bit_exact(rollout_large_golden):
+    """50 agents on a 50 x 50 map, 100 agents on a 100 x 100 map (the rollouts of BASELINE configs 3 and 5)."""
+    z, meta = rollout_large_golden
+    assert [m['N'] for m in meta] == [50, 100] and sum(m['collisions'] for m in meta) >= 20
+    _replay(z, meta)
+
+
+def _replay(z, meta):
     for ci, m in enumerate(meta):
         grid, goal = z['t%d_grid' % ci], z['t%d_goal' % ci]
         pos, T = z['t%d_pos' % ci], m['T']
