@@ -382,6 +382,8 @@ def test_emu_policy_filter_kernel(emu, N, K, f64, split, B):
     h = (g.standard_normal((128, 1, K, 128)) / np.sqrt(128 * K)).astype(np.float32)
     x = np.maximum(g.standard_normal((B, N, 128)), 0).astype(np.float32)
     S = ((g.random((B, N, N)) < 0.2) * g.random((B, N, N))).astype(np.float64 if f64 else np.float32)
+    S[0, :, N // 2] = g.random(N)                            # a hub: node N/2 gathers from everybody (whole-wave path)
+    S[-1, :, 0] = (g.random(N) < 0.5) * g.random(N)          # and a half-hub at the start of the row range
     for b in range(B):
         np.fill_diagonal(S[b], 0)
     bias = (g.standard_normal(128) / 4).astype(np.float32)

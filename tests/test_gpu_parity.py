@@ -516,6 +516,9 @@ def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64):
     h = torch.randn(128, 1, K, 128, generator=g) / (128 * K) ** 0.5
     x = torch.relu(torch.randn(B, N, 128, generator=g))
     S = ((torch.rand(B, N, N, generator=g) < 8.0 / N) * torch.rand(B, N, N, generator=g))
+    S[0, :, N // 2] = torch.rand(N, generator=g)                           # hubs: nodes that gather from (almost)
+    S[B // 2, :, N - 1] = torch.rand(N, generator=g)                       # everybody take the whole-wave path
+    S[-1, :, 0] = (torch.rand(N, generator=g) < 0.5) * torch.rand(N, generator=g)
     S = S * (1 - torch.eye(N))
     S = S.double() if f64 else S.float()
     bias, aw, ab = torch.randn(128, generator=g) / 4, torch.randn(5, 128, generator=g) / 8, torch.randn(5, generator=g)
