@@ -50,12 +50,14 @@ __host__ __device__ inline size_t pf_lds_base(int N, int Ns, int K) {
 
 // z_{k+1}[r, :] = sum over the neighbours m of node r (ascending) of S[m, r] * z_k[m, :], rows [row_lo, row_hi):
 // a quarter wave per row; lane ql holds features [4 ql, 4 ql + 4) and [64 + 4 ql, 64 + 4 ql + 4).
-// The loop runs to the largest degree among a wave's four nodes, and a launch waits for its slowest workgroup: the
-// time follows the batch's heaviest node (geometric graphs of 100 agents: mean degree 8, single nodes of 30 .. 50).
+// A shift reads 512 bytes of LDS per edge, and a launch waits for its slowest workgroup: the time follows the
+// DENSEST graph of the batch (geometric graphs of 100 agents: mean degree 8, but a crowded corner is a near-clique
+// of 30 .. 50 nodes; per-workgroup stamps at C5: median 16.4 us, slowest 19.9 / 25.9 us for a batch whose densest
+// graph has a node of degree 30 / 52, correlation of a workgroup's time with its graph's largest degree 0.9).
 // Measured and dropped: fetching the next trip's indices / weights one trip ahead (no change: the compiler's
 // schedule already overlaps them), and a whole-wave path for nodes of more than 16 neighbours (two features per
-// lane, 16 neighbours per trip, every wave picking its share of the heavy nodes with two ballots: C3 14.4 -> 18.6 us,
-// C5 24.0 -> 32.5 us on the same inputs -- the extra pass costs every workgroup more than the rare long loop).
+// lane, 16 neighbours per trip: C3 14.4 -> 18.6 us, C5 24.0 -> 32.5 us on the same inputs -- the work is edges,
+// not a long loop on one node).
 // znxt: fp32 result rows (may be null); zsplit: the same rows as f16 hi | lo halves, the layout split_rows
 // produces (may be null) -- the last shift writes only those.  (Writing both in a middle shift, into a third
 // buffer, to drop the conversion pass of the tap before the last was measured at N = 50: no gain -- the extra
