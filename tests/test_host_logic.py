@@ -151,3 +151,33 @@ def test_prepowered_gso_api_surface():
     assert SK.shape == (2, 2, 3, 5, 5) and torch.allclose(SK[:, :, 2], S @ S, atol=1e-6)
     m.addGSO(S)
     assert m.N == 5 and m.B == 2 and 'number_nodes=5' in m.extra_repr()
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The bench lines committed under profiles/ (copied from GPU sessions) carry every field of the driver's
+    contract, with consistent arithmetic: value = batch x agents / ms_per_step, roofline.frac = achieved / peak."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r02_bench_c*.json')))
+    assert len(files) >= 3
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                    'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+            assert key in d, (f, key)
+        assert d['unit'] == 'agent-steps/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
+        assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config']
+        cfg = d['config']
+        per_step = cfg['batch_per_gpu'] * cfg['agents'] * d['n_gpus']
+        assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+        rl = d['roofline']
+        for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert key in rl, (f, key)
+        assert rl['bound'] in ('hbm', 'mfma') and abs(rl['frac'] - rl['achieved'] / rl['peak']) <= 1e-6
+        assert rl['traffic'] is None or rl['traffic'] > 0
+        cb = d['cpu_baseline']
+        for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert key in cb, (f, key)
+        assert cb['kind'] in ('port', 'reference') and cb['value'] > 0
+        assert d['parity']['max_abs_dlogit'] <= d['parity']['tolerance']
