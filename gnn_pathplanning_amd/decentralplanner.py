@@ -233,22 +233,24 @@ class DecentralPlannerNet(nn.Module):
     # ------------------------------------------------------------------------------------
     def addGSO(self, S):
         # B x N x N, or B x E x N x N when E > 1 (decentralplanner.py:266-276)
+        # (a plain attribute: written through __dict__, nn.Module.__setattr__ costs ~2.5 us per call)
         if self.E == 1:
             assert len(S.shape) == 3
-            self.S = S.unsqueeze(1)
+            self.__dict__['S'] = S.unsqueeze(1)
         else:
             assert len(S.shape) == 4
             assert S.shape[1] == self.E
-            self.S = S
+            self.__dict__['S'] = S
 
     def _encoder_tensors(self):
         """The 32 tensors the packed encoder depends on.  Walking nn.Sequential / __getattr__ costs
         ~40 us per call, so the list is memoised; _apply() (.to/.cuda/.float), load_state_dict(),
         train()/eval() transitions and invalidate_packed() drop it; a periodic refresh catches a
         Parameter OBJECT replaced by hand after at most 64 forwards."""
-        self._calls = getattr(self, '_calls', 0) + 1
-        t = getattr(self, '_enc_tensors', None)
-        if t is None or (self._calls & 63) == 0:
+        d = self.__dict__
+        calls = d['_calls'] = d.get('_calls', 0) + 1
+        t = d.get('_enc_tensors')
+        if t is None or (calls & 63) == 0:
             t = []
             for ci, bi in zip(_CONV_IDX, _BN_IDX):
                 conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
