@@ -86,6 +86,15 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the group dicts and every state tensor: the cached raw-pointer tables die here."""
+        self.__dict__.pop('_gnnpp_tables', None)
+        return super().load_state_dict(state_dict)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.pop('_gnnpp_tables', None)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -93,26 +102,37 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _native.lib()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group['params'] if p.grad is not None]
             if not ps:
                 continue
             dev = _native.require_gpu(*ps)
-            st = self.state.setdefault('gnnpp_%d' % id(group), {})
+            # The device-side step counter is optimizer STATE: keyed by the group's INDEX (load_state_dict()
+            # rebuilds the group dicts, so id(group) does not survive a checkpoint round trip) and therefore saved
+            # and restored by state_dict() / load_state_dict() next to the moments.
+            st = self.state.setdefault('gnnpp_group_%d' % gi, {})
             if 'counter' not in st:
                 st['counter'] = torch.zeros(3, dtype=torch.float32, device=dev)
+            elif st['counter'].device != dev or st['counter'].dtype is not torch.float32:
+                st['counter'] = st['counter'].to(device=dev, dtype=torch.float32)      # (loaded with map_location)
             for p in ps:
                 s = self.state[p]
                 if 'exp_avg' not in s:
                     assert p.dtype is torch.float32 and p.is_contiguous()
                     s['exp_avg'] = torch.zeros_like(p)
                     s['exp_avg_sq'] = torch.zeros_like(p)
+                elif not s['exp_avg'].is_contiguous() or not s['exp_avg_sq'].is_contiguous():
+                    s['exp_avg'], s['exp_avg_sq'] = s['exp_avg'].contiguous(), s['exp_avg_sq'].contiguous()
             b1, b2 = group['betas']
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             # the pointer tables are rebuilt only when a pointer moved (the caching allocator hands the
-            # gradients the same blocks step after step; filling a ctypes struct costs more than the launch)
-            key = tuple(p.data_ptr() for p in ps) + tuple(g.data_ptr() for g in grads)
-            cache = self.__dict__.setdefault('_gnnpp_tables', {}).setdefault(id(group), {})   # (not optimizer state)
+            # gradients the same blocks step after step; filling a ctypes struct costs more than the launch);
+            # the key covers EVERY pointer a table holds -- parameters, gradients and both moments (a
+            # load_state_dict() replaces the moment tensors)
+            key = tuple(p.data_ptr() for p in ps) + tuple(g.data_ptr() for g in grads) + \
+                tuple(self.state[p]['exp_avg'].data_ptr() for p in ps) + \
+                tuple(self.state[p]['exp_avg_sq'].data_ptr() for p in ps)
+            cache = self.__dict__.setdefault('_gnnpp_tables', {}).setdefault(gi, {})   # (not optimizer state)
             if cache.get('key') != key:
                 tables = []
                 for i0 in range(0, len(ps), 32):
