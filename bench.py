@@ -58,6 +58,124 @@ ENC_MACS_PER_AGENT = 1238112 + 16384    # CNN + compress MLP (SURVEY.md section 
 ENC_WEIGHT_FLOATS = 156288              # conv + BN-folded scale/shift + FC, read once per launch
 
 
+# The three arithmetics of the matrix-pipe contractions (include/gnnpp.h GNNPP_PREC_*): what the roofline prices.
+# `peak` is the guide's dense peak of the MFMA instruction actually issued; `products` = MFMA products issued per
+# algorithmic fp32 multiply-add (NOT folded into the peak): the ceiling of `frac` for algorithmic fp32 FLOPs on that
+# instruction is 1 / products.
+PRECISION_INFO = {
+    0: {'name': 'fp32', 'instr': 'v_mfma_f32_16x16x32_bf16', 'peak': F16_MFMA_PEAK_TFLOPS, 'products': 6,
+        'dtype': 'f32 (fp32-equivalent: every operand exactly as three bf16 planes, 6 of 9 plane products on the bf16 '
+                 'MFMA pipe, f32 accumulate; graph shifts / epilogues / head in exact f32)'},
+    1: {'name': 'fp32_mfma', 'instr': 'v_mfma_f32_16x16x4_f32', 'peak': FP32_MFMA_PEAK_TFLOPS, 'products': 1,
+        'dtype': 'f32 (exact fp32 MFMA)'},
+    2: {'name': 'split_f16', 'instr': 'v_mfma_f32_16x16x32_f16', 'peak': F16_MFMA_PEAK_TFLOPS, 'products': 3,
+        'dtype': 'f32 operands as f16 hi+lo pairs (22 significand bits, |x| < 65504): NARROWER than f32'},
+}
+
+
+def roofline_block(kernel, info, flops, t_launch, exe_flops, lanes=''):
+    """frac = algorithmic fp32 FLOPs per launch / launch time / the guide's dense peak of the instruction issued."""
+    ach = flops / t_launch / 1e12
+    return {'kernel': kernel, 'bound': 'mfma', 'dtype': info['dtype'], 'instruction': info['instr'],
+            'achieved': ach, 'peak': info['peak'], 'unit': 'TFLOP/s', 'frac': ach / info['peak'],
+            'mfma_products_per_fp32_mac': info['products'],
+            'frac_ceiling_for_this_arithmetic': 1.0 / info['products'],
+            'frac_of_arithmetic_ceiling': ach / (info['peak'] / info['products']),
+            'peak_note': ('dense %s peak of MI355X_MICROARCH.md; algorithmic fp32 FLOPs cost %d MFMA product(s) '
+                          'each, which is stated here and NOT folded into the peak' % (info['instr'], info['products']))
+                         + lanes,
+            'vs_fp32_mfma_peak': ach / FP32_MFMA_PEAK_TFLOPS,
+            'avg_launch_us': t_launch * 1e6, 'flops_per_launch': flops,
+            'executed_mfma_flops_per_launch': exe_flops,
+            'pipe_busy_frac': exe_flops / t_launch / 1e12 / info['peak']}
+
+
+def fused_rule(L, B, N, K, prec):
+    """gnnpp_policy_fwd's rule for the one-launch policy kernel (csrc/gnnpp_api.hip fused_policy_applies)."""
+    return bool(L.gnnpp_get_tuning(6) == 1 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13))
+
+
+def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel, vp, st):
+    """Compact record of another BASELINE config inside the C2 line: value, ms/step, dominant kernel us, frac,
+    parity (max |dlogit| vs the oracle, near-ties).  Default precision."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    N, W, K, B = CONFIGS[name]
+    K = k_over or K
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, K, dev
+    sd = orc.init_state_dict(K, seed=1337)
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(sd)
+    obs_cpu = orc.synth_obs(B, N, seed=1337)
+    S64 = orc.synth_gso_geometric(B, N, W, seed=1337)
+    S_cpu = torch.from_numpy(S64).float()
+    mean_deg = float((S64 != 0).sum() / (B * N))
+    obs, S = obs_cpu.to(dev), S_cpu.to(dev)
+    M = B * N
+
+    def step():
+        net.addGSO(S)
+        return net(obs)
+    for _ in range(15):
+        out = step()
+    nst = 30
+    r = sorted(x[0] for x in timed_regions(step, nst, 3, collective=False))[1] / nst
+    prec = net._prec()
+    enc = net.packed_encoder()
+    feat = torch.empty(M, 128, device=dev)
+    t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, prec, None, st), 30)
+    tiles = (M + 15) // 16
+    info = PRECISION_INFO[prec]
+    rl = roofline_block('gnnpp::encoder_kernel_b3<false, 3>', info, 2.0 * ENC_MACS_PER_AGENT * M, t_enc,
+                        8628 * 16384.0 * tiles)
+    with torch.no_grad():
+        want = orc.policy_forward(sd, S_cpu, obs_cpu)
+    got = [o.cpu() for o in out]
+    err = max((g - w).abs().max().item() for g, w in zip(got, want))
+    margin = orc.top2_margin(want)
+    clear = margin > 1e-5
+    ids_w = orc.decode_actions(want)
+    ids_g = torch.stack([g.argmax(-1) for g in got], 1)
+    return {'agents': N, 'taps': K, 'batch': B, 'mean_degree': round(mean_deg, 3),
+            'value': M / r, 'unit': 'agent-steps/s', 'ms_per_step': 1e3 * r,
+            'dominant_kernel': rl['kernel'], 'dominant_kernel_us': t_enc * 1e6, 'frac': rl['frac'],
+            'frac_of_arithmetic_ceiling': rl['frac_of_arithmetic_ceiling'], 'pipe_busy_frac': rl['pipe_busy_frac'],
+            'filter_and_head_us': 1e6 * (r - t_enc),
+            'parity_max_abs_dlogit': err, 'near_tie_rows': int((~clear).sum()),
+            'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear]))}
+
+
+def rotating_batches(orc, net, dev, N, W, B, timed_regions, resident_value, nb=64):
+    """C2 with `nb` DISTINCT resident batches visited round-robin (> 256 MB in total: neither L2 nor the Infinity
+    Cache can hold them), against the headline's one L2-warm batch."""
+    base_o = orc.synth_obs(B, N, seed=4242).to(dev)
+    base_S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=4242)).float().to(dev)
+    g = torch.Generator(device='cpu').manual_seed(99)
+    obs_all = torch.empty(nb, *base_o.shape, device=dev)
+    S_all = torch.empty(nb, *base_S.shape, device=dev)
+    for i in range(nb):                                      # distinct contents: a per-batch permutation of the graphs
+        perm = torch.randperm(B, generator=g).to(dev)
+        obs_all[i] = base_o[perm]
+        S_all[i] = base_S[perm]
+    total_mb = (obs_all.numel() + S_all.numel()) * 4 / 1e6
+    state = {'i': 0}
+
+    def step():
+        i = state['i'] = (state['i'] + 1) % nb
+        net.addGSO(S_all[i])
+        return net(obs_all[i])
+    for _ in range(nb):
+        step()
+    nst = 2 * nb
+    r = sorted(x[0] for x in timed_regions(step, nst, 3, collective=False))[1] / nst
+    return {'batches': nb, 'resident_MB': round(total_mb, 1), 'agent_steps_per_s': B * N / r, 'ms_per_step': 1e3 * r,
+            'vs_single_resident_batch': (B * N / r) / resident_value,
+            'what': '%d distinct batches (%.0f MB of observations + GSOs) round-robin: every step reads its inputs '
+                    'from HBM' % (nb, total_mb)}
+
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -383,52 +501,46 @@ def main():
                 fn()
             return sorted(r[1] for r in timed_regions(fn, reps, 5))[2] / reps
 
-        variant = L.gnnpp_get_tuning(0)
-        split_f16 = variant == 7
-        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split_f16 else FP32_MFMA_PEAK_TFLOPS
-        dtype_note = ('f16 hi/lo split of fp32 operands (3 f16 MFMAs per fp32 product), fp32 accumulate'
-                      if split_f16 else 'fp32 MFMA')
-        peak_note = ('dense f16 MFMA peak %.1f / 3 products; the exact-fp32 MFMA pipe peaks at %.1f TFLOP/s'
-                     % (F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)) if split_f16 else \
-            'fp32 MFMA peak (MI355X_MICROARCH.md)'
+        # ---- roofline of the dominant kernel, in the arithmetic the HEADLINE runs: the model's default precision
+        # 'fp32' = bf16x3 operand split (fp32-equivalent; include/gnnpp.h GNNPP_PREC_FP32)
+        prec = net._prec()
+        assert prec == _native.PREC_FP32, 'the headline is measured in the default (fp32-equivalent) arithmetic'
+        info = PRECISION_INFO[prec]
         tiles = (M + 15) // 16
-        # Is the step ONE kernel?  (gnnpp_policy_fwd's rule: N <= 16, K = 3, B <= 512 or N >= 13, split-f16
-        # schedules.)  Then the dominant kernel IS the step and its launch time is measured in the timed
-        # region itself.
-        fused = (split_f16 and L.gnnpp_get_tuning(6) == 1 and L.gnnpp_get_tuning(5) == 1 and N <= 16
-                 and K == 3 and (B <= 512 or N >= 13))
-        t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st))
+        fused = fused_rule(L, B, N, K, prec)
+        t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, prec, None, st))
         y = torch.empty(M, 128, device=dev)
         t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(y), B, N, N,
-                                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, None, st))
+                                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, prec, None, st))
         # the filter launch of the policy step itself: features -> logits (filter + ReLU + action head; for teams
         # of 17..100 agents that is policy_filter_kernel, else lsigf_kernel with the fused head)
         lg_fh = torch.empty(N, B, 5, device=dev)
         t_fh = time_kernel(lambda: L.gnnpp_filter_head_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(aw), vp(ab),
-                                                           vp(lg_fh), B, N, 128, 128, K, 1, 0, None, st))
+                                                           vp(lg_fh), B, N, 128, 128, K, 1, 0, prec, None, st))
         enc_flops = 2.0 * ENC_MACS_PER_AGENT * M
         pol_flops = policy_flops_per_agent(K, mean_deg) * M
         if fused:
-            kernel = ('gnnpp::encoder_kernel_h2<true, K=%d> (fused policy kernel: encoder + graph filter + action ' % K +
+            kernel = ('gnnpp::encoder_kernel_b3<true, K=%d> (fused policy kernel: encoder + graph filter + action ' % K +
                       'head, one workgroup per graph)')
-            kname = 'encoder_kernel_h2<true'                    # (<true, K>: the fused instantiation)
+            kname = 'encoder_kernel_b3<true'                    # (<true, K>: the fused instantiation)
             t_dom = dev_elapsed / args.steps                   # HIP events around the reported region
             how = ('HIP events on the launch stream around the reported timed region / its %d launches '
                    '(the step is this one kernel; includes the inter-launch gap)' % args.steps)
             flops = pol_flops
             alg_bytes = M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (ENC_WEIGHT_FLOATS + K * 128 * 128 + 768) * 4.0
-            exe = (4314 + 288) * 16384.0 * B                   # f16 MFMAs per graph tile: encoder 4314 + filter 288
+            # bf16 MFMAs per graph tile: encoder 8628 (= 2 x 4314: six plane products where split-f16 issues three)
+            # + filter contraction 192 K
+            exe = (8628 + 192 * K) * 16384.0 * B
             lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
                     'algorithmic work' % (N, N)
         else:
-            kernel = 'gnnpp::encoder_kernel_h2<false, 3>' if split_f16 else 'gnnpp::encoder_kernel_f32'
-            kname = 'encoder_kernel_h2<false' if split_f16 else 'encoder_kernel_f32'
+            kernel, kname = 'gnnpp::encoder_kernel_b3<false, 3>', 'encoder_kernel_b3<false'
             t_dom = t_enc
             how = ('HIP events around back-to-back launches of the kernel (median of 5 regions); the step is '
-                   'this kernel followed by gnnpp::lsigf_kernel')
+                   'this kernel followed by the filter + head kernel')
             flops = enc_flops
             alg_bytes = M * (363 + 128) * 4.0 + ENC_WEIGHT_FLOATS * 4.0
-            exe = (4314 * 16384.0 if split_f16 else 8876 * 2048.0) * tiles   # MFMAs per 16-agent tile x FLOP each
+            exe = 8628 * 16384.0 * tiles                        # MFMAs per 16-agent tile x FLOP each
             lanes = ''
         traffic, traffic_detail = None, {'note': 'not measured (--pmc off, N > 1, or not rank 0)'}
         if args.pmc == 'auto' and world == 1:
@@ -436,28 +548,21 @@ def main():
                 traffic, traffic_detail = measure_traffic(args.config, kname)
             except Exception as e:                              # never let the profiler break the bench line
                 traffic, traffic_detail = None, {'note': 'pmc pass raised %s' % type(e).__name__}
-        result['roofline'] = {
-            'kernel': kernel, 'bound': 'mfma', 'dtype': dtype_note,
-            'achieved': flops / t_dom / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': flops / t_dom / 1e12 / peak, 'peak_note': peak_note + lanes,
-            'vs_fp32_mfma_peak': flops / t_dom / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            'traffic': traffic, 'traffic_detail': traffic_detail, 'algorithmic_bytes': alg_bytes,
-            'avg_launch_us': t_dom * 1e6, 'avg_launch_how': how, 'flops_per_launch': flops,
-            'executed_mfma_flops_per_launch': exe,
-            'pipe_busy_frac': exe / t_dom / 1e12 / (F16_MFMA_PEAK_TFLOPS if split_f16 else FP32_MFMA_PEAK_TFLOPS),
-        }
+        result['roofline'] = roofline_block(kernel, info, flops, t_dom, exe, lanes)
+        result['roofline'].update({'traffic': traffic, 'traffic_detail': traffic_detail,
+                                   'algorithmic_bytes': alg_bytes, 'avg_launch_how': how})
         clk = None
         if world == 1 and args.pmc == 'auto':
             try:
                 clk = measure_clock(
                     fused,
                     (vp(obs), vp(S), vp(enc), vp(taps), vp(gbias), vp(aw), vp(ab), vp(feat), vp(lg), B, N, K, 1,
-                     int(S.dtype is torch.float64), None, st),
-                    (vp(obs), vp(enc), vp(feat), M, None, st), B if fused else tiles)
+                     int(S.dtype is torch.float64), prec, None, st),
+                    (vp(obs), vp(enc), vp(feat), M, prec, None, st), B if fused else tiles)
             except Exception as e:                              # a measurement extra: never break the line
                 result['roofline']['effective_clock_note'] = 'not measured: %s' % type(e).__name__
         if clk:
-            # the same two ratios against the pipe's rate at the clock the kernel was measured to run at (the
+            # the same ratios against the pipe's rate at the clock the kernel was measured to run at (the
             # peak above assumes 2.4 GHz); `frac` stays the contract's figure
             rl = result['roofline']
             rl['effective_clock_GHz'] = clk
@@ -465,10 +570,9 @@ def main():
                                          'kernel, median over its workgroups)')
             rl['frac_at_effective_clock'] = rl['frac'] * NOMINAL_CLOCK_GHZ / clk
             rl['pipe_busy_frac_at_effective_clock'] = rl['pipe_busy_frac'] * NOMINAL_CLOCK_GHZ / clk
-        result['encoder_schedule'] = variant
-        if split_f16:
-            result['dtype'] = ('f32 operands as f16 hi+lo pairs on the f16 MFMA pipe (encoder, filter contraction), '
-                               'f32 MFMA (graph shifts, head); f32 accumulate')
+        result['precision'] = info['name']
+        result['dtype'] = 'f32 (bf16x3 exact operand split, f32 accumulate)'
+        result['dtype_detail'] = info['dtype']
         gf_bytes = M * (1024 + 4 * N) + 196608.0 * K / 3
         result['step_breakdown_us'] = {
             'whole_step_wall': 1e6 * elapsed / args.steps, 'whole_step_device': 1e6 * dev_elapsed / args.steps,
@@ -502,24 +606,43 @@ def main():
                                           'ms_per_step': 1e3 * r / max(20, args.steps // 4),
                                           'what': 'addGSO + forward + decode_actions kernel + .cpu() of the [B,N] int32 '
                                                   'ids, synchronous every step (multirobotsim_dcenlocal.py:589-599)'}
-                # (2) the exact-fp32 schedules (no f16 pipe anywhere): same step
-                L.gnnpp_set_tuning(0, 5)
-                L.gnnpp_set_tuning(5, 0)
-                try:
-                    for _ in range(10):
-                        out32 = step()
-                    r = sorted(x[0] for x in timed_regions(step, max(20, args.steps // 2), 5))[2]
-                    t32 = r / max(20, args.steps // 2)
-                    t_enc32 = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, None, st), 50)
-                finally:
-                    L.gnnpp_set_tuning(0, -1)
-                    L.gnnpp_set_tuning(5, 1)
-                sec['exact_fp32_schedule'] = {
-                    'agent_steps_per_s': M / t32, 'ms_per_step': 1e3 * t32,
-                    'encoder_kernel_us': t_enc32 * 1e6,
-                    'encoder_frac_of_fp32_mfma_peak': enc_flops / t_enc32 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                    'max_abs_dlogit_vs_default': max((a - b).abs().max().item() for a, b in zip(out, out32)),
-                    'what': 'GNNPP_TUNE_ENCODER_VARIANT=5, GNNPP_TUNE_FILTER_F16=0: every MFMA is v_mfma_f32_16x16x4_f32'}
+                # (2) the other two arithmetics on the same step, each with its own roofline block: the exact fp32
+                # MFMA, and the opt-in split-f16 mode (NARROWER than fp32: a labelled secondary, never the headline)
+                for pname, key in (('fp32_mfma', 'exact_fp32_mfma_schedule'), ('split_f16', 'split_f16_fast_mode')):
+                    pc = _native.precision_code(pname)
+                    pinfo = PRECISION_INFO[pc]
+                    net.precision = pname
+                    try:
+                        for _ in range(10):
+                            outp = step()
+                        nst = max(20, args.steps // 2)
+                        regs = timed_regions(step, nst, 5)
+                        r = sorted(x[0] for x in regs)[2]
+                        rdev = sorted(x[1] for x in regs)[2]
+                        tp = r / nst
+                        t_encp = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, pc, None, st), 50)
+                        flag_p = int(net.range_exceeded()) if pname == 'split_f16' else 0
+                    finally:
+                        net.precision = 'fp32'
+                    fused_p = fused_rule(L, B, N, K, pc)
+                    if pname == 'split_f16':
+                        exe_p = ((4314 + 96 * K) * 16384.0 * B) if fused_p else 4314 * 16384.0 * tiles
+                        kern_p = 'gnnpp::encoder_kernel_h2<%s>' % ('true, K=%d' % K if fused_p else 'false, 3')
+                    else:
+                        exe_p, kern_p = 8876 * 2048.0 * tiles, 'gnnpp::encoder_kernel_f32'
+                    rec = {'precision': pname, 'dtype': pinfo['dtype'], 'agent_steps_per_s': M / tp,
+                           'ms_per_step': 1e3 * tp, 'encoder_kernel_us': t_encp * 1e6,
+                           'max_abs_dlogit_vs_default': max((a - b).abs().max().item() for a, b in zip(out, outp)),
+                           'roofline': roofline_block(kern_p, pinfo, pol_flops if fused_p else enc_flops,
+                                                      rdev / nst if fused_p else t_encp, exe_p, ''),
+                           'range_flag': flag_p}
+                    if pname == 'split_f16':
+                        rec['what'] = ('precision="split_f16" (opt-in): operands as f16 hi+lo pairs, 22 significand '
+                                       'bits, valid for |activation| < 65504 -- narrower than the reference\'s fp32, '
+                                       'hence never the headline')
+                    else:
+                        rec['what'] = 'precision="fp32_mfma": every MFMA is v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain)'
+                    sec[key] = rec
                 # (3) batch sweep: many graphs per launch (throughput regime) -- policy step and filter alone
                 sweep, fsweep = [], []
                 for Bs in (B, 4 * B, 16 * B, 64 * B):
@@ -538,15 +661,33 @@ def main():
                     xf = torch.relu(torch.randn(Bs * N, 128, device=dev))
                     yf = torch.empty_like(xf)
                     tf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(xf), vp(Ss), vp(taps), vp(gbias), vp(yf), Bs, N, N,
-                                                               128, 128, K, 1, 0, 1, 1, 1, 1, 0, None, st), reps)
+                                                               128, 128, K, 1, 0, 1, 1, 1, 1, 0, prec, None, st), reps)
                     fb = Bs * N * (1024 + 4 * N) + 196608.0 * K / 3
+                    ffl = 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * Bs * N
                     fsweep.append({'batch': Bs, 'us': tf * 1e6, 'agent_steps_per_s': Bs * N / tf,
-                                   'algorithmic_GBps': fb / tf / 1e9, 'hbm_frac_of_8TBps': fb / tf / (HBM_PEAK_TBPS * 1e12)})
+                                   'algorithmic_GBps': fb / tf / 1e9, 'hbm_frac_of_8TBps': fb / tf / (HBM_PEAK_TBPS * 1e12),
+                                   'algorithmic_TFLOPs': ffl / tf / 1e12})
                     del o, Ss, xf, yf
                 sec['batch_sweep_policy'] = sweep
                 sec['batch_sweep_filter_only'] = fsweep
                 sec['batch_sweep_note'] = ('larger batches amortise launch latency and the per-launch weight stream; '
-                                           'the filter-only rows are the HBM-fraction figure of SURVEY.md section 8d')
+                                           'the filter-only rows are the HBM-fraction figure of SURVEY.md section 8d '
+                                           '(default precision: fp32-equivalent contraction)')
+                # (4) the remaining single-GPU configs of BASELINE.json and a NON-RESIDENT variant of this one:
+                # compact records (value, ms/step, dominant kernel, frac, parity) inside the driver-run line
+                if args.config == 'c2':
+                    others = {}
+                    for nm, k_over in (('c3', None), ('c5', 2), ('c5', 3), ('c5', 4)):
+                        try:
+                            others['%s_K%d' % (nm, k_over or CONFIGS[nm][2])] = quick_config(
+                                orc, L, _native, nm, k_over, dev, timed_regions, time_kernel, vp, st)
+                        except Exception as e:                  # an extra: never break the line
+                            others['%s_K%s' % (nm, k_over)] = {'error': '%s: %s' % (type(e).__name__, e)}
+                    sec['other_configs'] = others
+                    try:
+                        sec['c2_rotating_batches'] = rotating_batches(orc, net, dev, N, W, B, timed_regions, value / world)
+                    except Exception as e:
+                        sec['c2_rotating_batches'] = {'error': '%s: %s' % (type(e).__name__, e)}
             result['secondary'] = sec
 
             # one whole rollout step on the device (observation builder + communication GSO + this
@@ -597,11 +738,13 @@ def main():
         near = [{'graph': int(b_), 'agent': int(n_), 'margin': float(margin[b_, n_]),
                  'same_action': bool(ids_g[b_, n_] == ids_w[b_, n_])}
                 for b_, n_ in (~clear).nonzero().tolist()][:16]
-        net.check_range()
         result['parity'] = {'max_abs_dlogit': err, 'tolerance': 1e-4,
                             'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear])),
                             'near_tie_rows': int((~clear).sum()), 'near_tie_list': near,
-                            'rows': int(clear.numel()), 'range_flag': 0}
+                            'rows': int(clear.numel()),
+                            # the default arithmetic has no input domain: no guard exists to be read; the flag of
+                            # the split-f16 secondary is reported with it
+                            'range_flag': int(net.range_exceeded())}
         if not args.no_cpu_baseline:
             med, reps, spent = time_cpu(orc, sd, S_cpu, obs_cpu, args.cpu_seconds)
             cb = {'value': B * N / med, 'unit': 'agent-steps/s', 'cores': threads, 'usable_cores': usable_cores(),

@@ -33,6 +33,24 @@ class GnnppError(RuntimeError):
     pass
 
 
+# include/gnnpp.h GNNPP_PREC_*: the arithmetic of a call's matrix-pipe contractions, passed PER CALL
+PREC_FP32, PREC_FP32_MFMA, PREC_SPLIT_F16 = 0, 1, 2
+PRECISIONS = {'fp32': PREC_FP32, 'fp32_mfma': PREC_FP32_MFMA, 'split_f16': PREC_SPLIT_F16}
+
+
+def precision_code(p):
+    """'fp32' (default: bf16x3 operand split, fp32-equivalent, no input domain) | 'fp32_mfma' (exact fp32 MFMA) |
+    'split_f16' (fast 22-bit split, |x| < 65504, guarded) or the integer code -> GNNPP_PREC_*."""
+    if isinstance(p, str):
+        if p not in PRECISIONS:
+            raise GnnppError('unknown precision %r (one of %s)' % (p, sorted(PRECISIONS)))
+        return PRECISIONS[p]
+    p = int(p)
+    if p not in (0, 1, 2):
+        raise GnnppError('unknown precision code %d' % p)
+    return p
+
+
 def _sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [HEADER]
 
@@ -72,7 +90,10 @@ def build(force=False, verbose=False, measure=False):
 # (mangled-name substring, stream items, scratch bytes allowed): the encoder and the fused policy kernels for
 # K = 2, 3, 4 filter taps (16 more fragments per tap)
 RING_KERNELS = (('encoder_kernel_h2ILb0ELi3E', 196, 0), ('encoder_kernel_h2ILb1ELi2E', 228, 32),
-                ('encoder_kernel_h2ILb1ELi3E', 244, 32), ('encoder_kernel_h2ILb1ELi4E', 260, 32))
+                ('encoder_kernel_h2ILb1ELi3E', 244, 32), ('encoder_kernel_h2ILb1ELi4E', 260, 32),
+                # the bf16x3 (fp32-equivalent, default) schedule: three planes per fragment, 24 filter items per tap
+                ('encoder_kernel_b3ILb0ELi3E', 294, 0), ('encoder_kernel_b3ILb1ELi2E', 342, 32),
+                ('encoder_kernel_b3ILb1ELi3E', 366, 32), ('encoder_kernel_b3ILb1ELi4E', 390, 32))
 
 
 def check_ring_isa(isa_path, verbose=False):
@@ -157,13 +178,13 @@ def _bind(path):
     L.gnnpp_filter_packed_floats.restype = cs
     L.gnnpp_filter_packed_floats.argtypes = [ci] * 4
     L.gnnpp_filter_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp]
-    L.gnnpp_lsigf_fwd.argtypes = [vp] * 5 + [ci] * 13 + [vp, vp]
-    L.gnnpp_lsigf_fwd_save.argtypes = [vp] * 6 + [ci] * 14 + [vp, vp]
+    L.gnnpp_lsigf_fwd.argtypes = [vp] * 5 + [ci] * 14 + [vp, vp]
+    L.gnnpp_lsigf_fwd_save.argtypes = [vp] * 6 + [ci] * 15 + [vp, vp]
     L.gnnpp_lsigf_fwd_save.restype = ci
     L.gnnpp_encoder_packed_floats.restype = cs
     L.gnnpp_encoder_packed_floats.argtypes = []
     L.gnnpp_encoder_pack.argtypes = [ctypes.POINTER(EncoderParams), vp, vp]
-    L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, vp, vp]
+    L.gnnpp_encoder_fwd.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     L.gnnpp_encoder_train_workspace_floats.restype = cs
     L.gnnpp_encoder_train_workspace_floats.argtypes = [ci, ci]
     L.gnnpp_encoder_train_fwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ci, ci, ctypes.c_float, ci,
@@ -185,17 +206,17 @@ def _bind(path):
     L.gnnpp_policy_loss.restype = ci
     L.gnnpp_adam_step.argtypes = [ctypes.POINTER(AdamTensors), vp, cf, cf, cf, cf, cf, ci, vp]
     L.gnnpp_adam_step.restype = ci
-    L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 5 + [vp, vp]
-    L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 7 + [vp, vp]
+    L.gnnpp_policy_fwd.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp]
+    L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 8 + [vp, vp]
     L.gnnpp_filter_head_fwd.restype = ci
     L.gnnpp_decode_actions.argtypes = [vp, vp, ci, ci, vp]
     for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move', 'gnnpp_rollout_gso_observe',
               'gnnpp_rollout_step'):
         getattr(L, f).argtypes = [ctypes.POINTER(RolloutStruct), vp]
         getattr(L, f).restype = ci
-    L.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, vp]
+    L.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, ci, vp]
     L.gnnpp_rollout_policy_step.restype = ci
-    L.gnnpp_rollout_policy_steps.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, ci, vp]
+    L.gnnpp_rollout_policy_steps.argtypes = [ctypes.POINTER(RolloutStruct)] + [vp] * 5 + [ci, ci, ci, vp]
     L.gnnpp_rollout_policy_steps.restype = ci
     for f in ('gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_encoder_pack', 'gnnpp_encoder_fwd',
               'gnnpp_policy_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',

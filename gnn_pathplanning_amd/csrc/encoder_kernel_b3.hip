@@ -1,0 +1,694 @@
+// Encoder kernel, bf16x3 schedule ("b3") -- the DEFAULT: fp32-equivalent arithmetic on the bf16 matrix pipe.
+//
+// Same layers, same 16-agent tile, same one-MFMA-tile-per-output-position plan as the other two schedules
+// (encoder_pack.hip), same asm-managed weight ring as the split-f16 schedule (encoder_kernel_h2.hip).  What
+// differs is the operand form (gnnpp_common.h, "bf16x3"):
+//
+//      x = xh + xm + xl   exactly (three bf16 planes, fp32's exponent range),
+//      w x ~= wh xl + wl xh + wm xm + wh xm + wm xh + wh xh      (fp32 accumulate; dropped terms <= 2^-23 |w x|)
+//
+// Six v_mfma_f32_16x16x32_bf16 per 32-channel block: 96 matrix-pipe cycles where the exact-fp32 schedule's
+// eight v_mfma_f32_16x16x4_f32 need 256 and the split-f16 schedule's three f16 MFMAs 48 -- but unlike the latter
+// there is NO input range (|x| < 65504), no weight pre-scaling and no guard flag: every finite fp32 activation
+// and weight is represented exactly.  This is what the reference's plain fp32 aten path
+// (graphs/models/decentralplanner.py:284-290, utils/graphUtils/graphML.py:2342-2366) is replaced by when the
+// caller does not ask for anything else (GNNPP_PREC_FP32).
+//
+// Activations in LDS: [position][kb][plane 3][lane 64] x 16 bytes -- 6 bytes per element.  The largest
+// activation (25 positions x 32 channels x 16 agents) is then 75 KiB, and two workgroups must still share a
+// CU (160 KiB), so the kernel lives in ONE 75 KiB region R plus a 2.5 (5) KiB table:
+//   * the padded observations (two 32-bit words per pixel: h | m << 16, and l) are staged into R; L0 keeps its
+//     pooled outputs in registers (<= 7 windows x 2 channel tiles per wave) until every wave has read its last
+//     pixel, then writes them over the observations;
+//   * L1 and L2 run "in place" the same way (accumulators live across the barrier that ends the reads);
+//   * the 2x2 / 1x1 layers use disjoint 24 / 24 / 12 KiB pieces of R.
+// <true, K>: the fused policy kernel (one graph of N <= 16 agents per workgroup: encoder, K-tap graph filter,
+// ReLU, action head and optionally the simulator step), as encoder_kernel_h2<true, K>; the filter's shifts stay
+// exact fp32 (dense S on the fp32 MFMA), its tap contraction runs on bf16x3 planes written by the producer of
+// each z_k (FC epilogue / shift epilogue) -- no conversion pass.
+#include <utility>
+
+#include "gnnpp_common.h"
+
+namespace gnnpp {
+
+// per-wave item stream: L1 (54) | L2 (54) | L3 (54) | L4 (108) | FC (24); one item = one 16-byte plane fragment of
+// one (kb, tap, mt)
+constexpr int kb_L1 = 0, kb_L2 = 54, kb_L3 = 108, kb_L4 = 162, kb_FC = 270, kb_END = 294;
+constexpr int kb_FILT = kb_END;           // fused: [tap K][kb 4][mt_local 2][plane 3] = 24 K items
+
+// LDS map (bytes)
+constexpr int kB3Frag = 1024;                              // one plane fragment: 64 lanes x 16 bytes
+constexpr int kB3Region = 25 * 3 * kB3Frag;                // R: 76 800
+constexpr int kB3Obs2 = kObsFloatsLds * 4;                 // second observation word array (l planes)
+constexpr int kB3L2out = 0, kB3L3out = 24 * kB3Frag, kB3L4out = 48 * kB3Frag;
+constexpr int kB3Table = kB3Region;                        // BatchNorm table (640 floats); FUSED: later the head's
+constexpr int kB3TableBytes = EncLayout::kBssFloats * 4;   //   constants (776 floats) + the GSO [16][17]
+constexpr int kB3TableBytesFused = 5120;
+constexpr int kB3SsmOff = 776 * 4;
+constexpr size_t kB3Smem = kB3Region + kB3TableBytes;              // 79 360: two workgroups per CU
+constexpr size_t kB3SmemFused = kB3Region + kB3TableBytesFused;    // 81 920: exactly half of the CU's LDS
+static_assert(2 * kObsFloatsLds * 4 <= kB3Region && kB3SsmOff + 16 * 17 * 4 <= kB3TableBytesFused &&
+              2 * kB3SmemFused <= (size_t)kLdsBytes, "b3 LDS map");
+// fused tail: z ping-pong (fp32 rows, stride kZs) | K plane buffers (row stride 800 B) | partial logits
+constexpr int kB3ZBytes = 16 * kZs * 4;                    // 8 704
+constexpr int kB3PRow = 3 * 256 + 32;                      // 800: three 256-byte planes + pad (bank spread as kZs)
+constexpr int kB3PBytes = 16 * kB3PRow;                    // 12 800
+constexpr int kB3POff = 2 * kB3ZBytes;
+static_assert(kB3POff + kPolicyTapsMax * kB3PBytes + 4 * 16 * 8 * 4 <= kB3Region, "fused tail fits R");
+// the simulator step's LDS lies where the (dead) fp32 z rows were
+constexpr size_t policy_sim_occ_bytes_b3() {
+    return (size_t)kB3POff - 8 * kMaxAgents * sizeof(int) - kGsoSmemBytes;
+}
+
+struct WStreamB {                 // per-wave segment bases (wave-uniform: SGPRs) + this lane's offset
+    const float* seg[6];
+    int lane_bytes;
+};
+
+__device__ __forceinline__ const float* ring_item_ptr(const WStreamB& ws, int idx) {
+    if (idx < kb_L2) return ws.seg[0] + (idx - kb_L1) * EncLayout::kHItem;
+    if (idx < kb_L3) return ws.seg[1] + (idx - kb_L2) * EncLayout::kHItem;
+    if (idx < kb_L4) return ws.seg[2] + (idx - kb_L3) * EncLayout::kHItem;
+    if (idx < kb_FC) return ws.seg[3] + (idx - kb_L4) * EncLayout::kHItem;
+    if (idx < kb_FILT) return ws.seg[4] + (idx - kb_FC) * EncLayout::kHItem;
+    // filter block (tap, mt, kb) of gnnpp_filter_pack's b3 region: ((tap * 8 + mt) * 4 + kb) * 768 floats, plane p
+    // at + 256 p; seg[5] already points at this wave's first channel tile
+    const int j = idx - kb_FILT, pl = j % 3, ml = (j / 3) & 1, kb = (j / 6) & 3, tap = j / 24;
+    return ws.seg[5] + tap * (8 * 4 * 768) + ml * (4 * 768) + kb * 768 + pl * 256;
+}
+
+// One (kb, tap) step IT of NMT channel tiles over a compile-time position set: the three plane fragments of every
+// position the tap reaches (from LDS, or from the preloaded registers Pin), six MFMAs per (position, tile), small
+// terms first; consecutive MFMAs hit different accumulators.
+template <int IT, int NKB, int H, int W, int NMT, int NSLOT, class PosFn, bool PRELOAD, int CH = NSLOT>
+__device__ __forceinline__ void b3_tap_mfma(const v4f* in, const v4f* Pin, const v8b (&A)[NMT][3],
+                                            v4f (&acc)[NSLOT][NMT], int lane) {
+    constexpr int kb = IT / 9, tap = IT % 9;
+    constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int j0 = 0; j0 < NSLOT; j0 += CH) {               // CH slots at a time bounds the B registers
+        v8b B[CH][3];
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = j0 + jj;
+            int y = 0, x = 0;
+            const bool used = j < NSLOT && PosFn::get(j, y, x);
+            const int iy = y + dy, ix = x + dx;
+            if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const int o = ((iy * W + ix) * NKB + kb) * 3;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) B[jj][p] = as_b8(PRELOAD ? Pin[o + p] : in[(o + p) * 64 + lane]);
+            }
+        }
+#pragma unroll
+        for (int term = 0; term < kB3Terms; ++term) {
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+                const int j = j0 + jj;
+                int y = 0, x = 0;
+                const bool used = j < NSLOT && PosFn::get(j, y, x);
+                const int iy = y + dy, ix = x + dx;
+                if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const bool fresh = term == 0 && first_step_of_slot<H, W, PosFn>(IT, j);
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m)
+                        acc[j][m] = mfma16b(A[m][b3_term_a(term)], B[jj][b3_term_b(term)],
+                                            fresh ? vzero() : acc[j][m]);
+                }
+            }
+        }
+    }
+}
+
+// The weight stream of a layer (item order [kb][tap][mt][plane]): for every step IT take the 3 NMT fragments off
+// the ring, refill the slots, hand them to body(IT, A).  Wave-uniform, branch-free (tools/check_ring_isa.py).
+template <int END, int START, int NMT, class Body, int... IT>
+__device__ __forceinline__ void b3_stream_steps(const WStreamB& ws, v4f (&ring)[kRingH], Body&& body,
+                                                std::integer_sequence<int, IT...>) {
+    auto step = [&](auto itc) {
+        constexpr int it = decltype(itc)::value;
+        __builtin_amdgcn_sched_barrier(kSchedItemMask);
+        v8b A[NMT][3];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int idx = START + (it * NMT + m) * 3 + p;
+                A[m][p] = as_b8(ring_take_f4<END>(ring, idx));
+                h2_ring_load<END>(ws, ring, idx + kRingH);
+            }
+        }
+        body(itc, A);
+    };
+    (step(std::integral_constant<int, IT>{}), ...);
+}
+
+// a whole 2x2 layer for one position set, its input preloaded into registers
+template <int END, int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn>
+__device__ __forceinline__ void b3_conv_preload(const WStreamB& ws, v4f (&ring)[kRingH], const v4f* in,
+                                                v4f (&acc)[NSLOT][NMT], int lane) {
+    v4f Pin[H * W * NKB * 3];
+#pragma unroll
+    for (int i = 0; i < H * W * NKB * 3; ++i) Pin[i] = in[i * 64 + lane];
+    b3_stream_steps<END, START, NMT>(ws, ring, [&](auto itc, const v8b (&A)[NMT][3]) {
+        b3_tap_mfma<decltype(itc)::value, NKB, H, W, NMT, NSLOT, PosFn, true>(in, Pin, A, acc, lane);
+    }, std::make_integer_sequence<int, 9 * NKB>{});
+}
+
+template <bool FUSED, int KT>
+__global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_b3(const float* __restrict__ obs,
+                                                                 const float* __restrict__ pk,
+                                                                 float* __restrict__ feat, int M, int stop,
+                                                                 const PolicyTail pt) {
+    constexpr int END = FUSED ? kb_FILT + 24 * KT : kb_END;
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    v4f* const R4 = reinterpret_cast<v4f*>(gnnpp_smem);              // region R as 16-byte fragments' lanes
+    unsigned* const obsw = reinterpret_cast<unsigned*>(gnnpp_smem);  // observation words (h | m << 16), l at + kObsFloatsLds
+    float* const sstab = reinterpret_cast<float*>(gnnpp_smem + kB3Table);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: real branches per wave
+    const int a = lane & 15;
+    const int q = lane >> 4;
+    const int agent0 = blockIdx.x * (FUSED ? pt.N : kTileAgents);   // FUSED: the tile is graph blockIdx.x
+    GNNPP_STAMP(blockIdx.x, 11, tid == 0);
+
+    WStreamB ws;
+    ws.seg[0] = pk + EncLayout::kB1;
+    ws.seg[1] = pk + EncLayout::kB2 + (wave & 1) * (54 * EncLayout::kHItem);
+    ws.seg[2] = pk + EncLayout::kB3 + wave * (54 * EncLayout::kHItem);
+    ws.seg[3] = pk + EncLayout::kB4 + wave * (108 * EncLayout::kHItem);
+    ws.seg[4] = pk + EncLayout::kBfcw + wave * (24 * EncLayout::kHItem);
+    ws.seg[5] = FUSED ? pt.filt_h2 + wave * (2 * 4 * 768) : pk;     // (pt.filt_h2: the b3 region of the filter pack)
+    ws.lane_bytes = lane * 16;
+    // BatchNorm scale/shift of all five layers: fetched now, parked in the table behind R, so that no
+    // compiler-issued global load (whose wait would drain the ring) sits between the layers
+    float ssv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        ssv[i] = pk[EncLayout::kBss + min(tid + i * kThreads, EncLayout::kBssFloats - 1)];
+    // FUSED: what the epilogue of the filter reads -- act_w [5][128] | bias [128] | act_b [5] -- and the GSO take the
+    // same road, but the table has no room for them before L4 is done: they wait in five registers
+    float hcv[4] = {0.f, 0.f, 0.f, 0.f};
+    float sval = 0.f;
+    if (FUSED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * kThreads;
+            if (c < 640) hcv[i] = pt.act_w[c];
+            else if (c < 768) hcv[i] = pt.gf_bias ? pt.gf_bias[c - 640] : 0.f;
+            else if (c < 773) hcv[i] = pt.act_b[c - 768];
+        }
+        const int m = tid >> 4, n = tid & 15;                        // one GSO entry per thread
+        if (m < pt.N && n < pt.N) {
+            const size_t i = ((size_t)blockIdx.x * pt.N + m) * pt.N + n;
+            sval = pt.s_is_f64 ? (float)reinterpret_cast<const double*>(pt.S)[i]
+                               : reinterpret_cast<const float*>(pt.S)[i];
+        }
+    }
+    v4f ring[kRingH];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("; weight ring lives in v[208:255]" ::: "v255");   // (see encoder_kernel_h2.hip)
+#endif
+#pragma unroll
+    for (int i = 0; i < kRingH; ++i) h2_ring_load<END>(ws, ring, i);
+
+    // ---- observations: all loads first, zero-fill while they fly, then split + scatter -------------------
+    {
+        constexpr int NV4 = (kTileAgents * kObsFloats + 3) / 4 + 1;
+        constexpr int PER = (NV4 + kThreads - 1) / kThreads;
+        const int n_agents = FUSED ? pt.N : min(kTileAgents, M - agent0);
+        const int valid = n_agents * kObsFloats;
+        const float* src = obs + (size_t)agent0 * kObsFloats;
+        const int shift = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3);
+        const float* src4 = src - shift;
+        const long floats_left = (long)(M - agent0) * kObsFloats + shift;   // from src4 to the end of the tensor
+        const bool head_ok = shift == 0 || agent0 > 0;                      // (never read in front of the tensor)
+        v4f v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = tid + k * kThreads;
+            const int e0 = 4 * idx - shift;
+            if (head_ok && 4L * idx + 4 <= floats_left && e0 < valid) {
+                v[k] = *reinterpret_cast<const v4f*>(src4 + 4 * idx);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[k][c] = src[min(max(e0 + c, 0), valid - 1)];
+            }
+        }
+        for (int i = tid; i < 2 * kObsFloatsLds / 4; i += kThreads) R4[i] = vzero();
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (tid + i * kThreads < EncLayout::kBssFloats) sstab[tid + i * kThreads] = ssv[i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e0 = (tid + k * kThreads) * 4 - shift;
+            const int es = max(e0, 0);
+            int ag = es / kObsFloats;
+            const int rem = es - ag * kObsFloats;
+            int ch = rem / 121;
+            const int r2 = rem - ch * 121;
+            int y = r2 / 11, x = r2 - y * 11;
+            unsigned w1[4], w2[4];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                unsigned h, m, l;
+                b3_split2(v[k][2 * c2], v[k][2 * c2 + 1], h, m, l);
+                w1[2 * c2] = __builtin_amdgcn_perm(m, h, 0x05040100u);        // (h | m << 16) of the even element
+                w1[2 * c2 + 1] = __builtin_amdgcn_perm(m, h, 0x07060302u);    // ... of the odd element
+                w2[2 * c2] = l & 0xffffu;
+                w2[2 * c2 + 1] = l >> 16;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = e0 + c;
+                if (e >= 0) {
+                    if (e < valid) {
+                        const int o = ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1;
+                        obsw[o] = w1[c];
+                        obsw[kObsFloatsLds + o] = w2[c];
+                    }
+                    if (++x == 11) {
+                        x = 0;
+                        if (++y == 11) {
+                            y = 0;
+                            if (++ch == 3) { ch = 0; ++ag; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (GNNPP_STOP_AT(stop, 1)) return;
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 0, tid == 0);
+
+    // ---- L0: 3 -> 32 @ 11x11 (the 10x10 the pool reads), direct, K = 27 in ONE 32-slot block -------
+    // Lane (q, agent) owns k-slots (q, e) as in the split-f16 schedule: sixteen word reads per position (eight
+    // h | m words, eight l words, position offset = instruction immediate), three v_perm per register pair, then
+    // 6 MFMAs per channel tile.  The pooled outputs stay in registers until every wave is done with the pixels.
+    {
+        v8b A0[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                A0[i][p] = as_b8(*reinterpret_cast<const v4f*>(pk + EncLayout::kB0 + ((i * 3 + p) * 64 + lane) * 4));
+        int aoff[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            aoff[e] = a * kAgentStride + (q < 3 ? q * (kPadHW * kPadHW) + (e / 3) * kPadHW + e % 3
+                                                : e < 3 ? e * (kPadHW * kPadHW) + 2 * kPadHW + 2 : 0);
+        v4f res[7][2];
+#pragma unroll
+        for (int wi = 0; wi < 7; ++wi) {
+            const int win = wave + 4 * wi;
+            if (win < 25) {                                  // (wave-uniform)
+                __builtin_amdgcn_sched_barrier(kSchedItemMask);
+                const int wy = win / 5, wx = win - wy * 5;
+                const unsigned* base = obsw + (2 * wy) * kPadHW + 2 * wx;
+                v4f acc[4][2];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    unsigned d1[8], d2[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        d1[e] = base[aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
+                        d2[e] = base[kObsFloatsLds + aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
+                    }
+                    unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        bh[w] = __builtin_amdgcn_perm(d1[2 * w + 1], d1[2 * w], 0x05040100u);
+                        bm[w] = __builtin_amdgcn_perm(d1[2 * w + 1], d1[2 * w], 0x07060302u);
+                        bl[w] = __builtin_amdgcn_perm(d2[2 * w + 1], d2[2 * w], 0x05040100u);
+                    }
+                    const v4u bhv = {bh[0], bh[1], bh[2], bh[3]}, bmv = {bm[0], bm[1], bm[2], bm[3]},
+                              blv = {bl[0], bl[1], bl[2], bl[3]};
+                    const v8b B[3] = {__builtin_bit_cast(v8b, bhv), __builtin_bit_cast(v8b, bmv),
+                                      __builtin_bit_cast(v8b, blv)};
+#pragma unroll
+                    for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[pp][i] = mfma16b(A0[i][b3_term_a(term)], B[b3_term_b(term)],
+                                                 term == 0 ? vzero() : acc[pp][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v4f sc, sh;
+                    load_ss(sstab + EncLayout::kBssL0, 32, i, q, sc, sh);
+                    v4f r = vrelu(vfma(acc[0][i], sc, sh));
+#pragma unroll
+                    for (int pp = 1; pp < 4; ++pp) r = vmax(r, vfma(acc[pp][i], sc, sh));
+                    res[wi][i] = r;
+                }
+            }
+        }
+        __syncthreads();                                     // every wave has read its last pixel
+#pragma unroll
+        for (int wi = 0; wi < 7; ++wi) {
+            const int win = wave + 4 * wi;
+            if (win < 25) {
+                v4f pl[3];
+                b3_split8(res[wi][0], res[wi][1], pl);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+            }
+        }
+    }
+    __syncthreads();
+    if (GNNPP_STOP_AT(stop, 2)) return;
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 1, tid == 0);
+
+    // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
+    {
+        v4f acc[7][2];                                    // first touched by a zero-source MFMA (b3_tap_mfma)
+        b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+            constexpr int IT = decltype(itc)::value;
+            switch (wave) {
+                case 0: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<0>, false, 4>(R4, nullptr, A, acc, lane); break;
+                case 1: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<1>, false, 4>(R4, nullptr, A, acc, lane); break;
+                case 2: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<2>, false, 4>(R4, nullptr, A, acc, lane); break;
+                default: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<3>, false, 4>(R4, nullptr, A, acc, lane); break;
+            }
+        }, std::make_integer_sequence<int, 9>{});
+        __syncthreads();                                   // everyone is done reading L0's output
+        v4f sc[2], sh[2];
+        load_ss(sstab + EncLayout::kBssL1, 32, 0, q, sc[0], sh[0]);
+        load_ss(sstab + EncLayout::kBssL1, 32, 1, q, sc[1], sh[1]);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int p = wave + 4 * j;
+            if (p < 25) {
+                v4f pl[3];
+                b3_split8(vrelu(vfma(acc[j][0], sc[0], sh[0])), vrelu(vfma(acc[j][1], sc[1], sh[1])), pl);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) R4[(p * 3 + pp) * 64 + lane] = pl[pp];
+            }
+        }
+    }
+    __syncthreads();
+    if (GNNPP_STOP_AT(stop, 3)) return;
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 2, tid == 0);
+
+    // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2], in place (front of R) --------
+    {
+        const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
+        v4f acc[8][2];                                    // first touched by a zero-source MFMA (b3_tap_mfma)
+        b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+            constexpr int IT = decltype(itc)::value;
+            if (pair == 0) b3_tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<0>, false, 4>(R4, nullptr, A, acc, lane);
+            else           b3_tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<1>, false, 4>(R4, nullptr, A, acc, lane);
+        }, std::make_integer_sequence<int, 9>{});
+        v4f sc[2], sh[2];
+        load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp, q, sc[0], sh[0]);
+        load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp + 1, q, sc[1], sh[1]);
+        v4f r[2][2];
+#pragma unroll
+        for (int wi = 0; wi < 2; ++wi)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                r[wi][m] = vrelu(vfma(acc[4 * wi][m], sc[m], sh[m]));
+#pragma unroll
+                for (int pp = 1; pp < 4; ++pp)
+                    r[wi][m] = vmax(r[wi][m], vfma(acc[4 * wi + pp][m], sc[m], sh[m]));
+            }
+        __syncthreads();                                   // everyone is done reading L1's output
+        v4f* const O4 = reinterpret_cast<v4f*>(gnnpp_smem + kB3L2out);
+#pragma unroll
+        for (int wi = 0; wi < 2; ++wi) {
+            const int t = wi == 0 ? pair : 3 - pair;
+            v4f pl[3];
+            b3_split8(r[wi][0], r[wi][1], pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) O4[((t * 2 + mp) * 3 + p) * 64 + lane] = pl[p];
+        }
+    }
+    __syncthreads();
+    if (GNNPP_STOP_AT(stop, 4)) return;
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 3, tid == 0);
+
+    // ---- L3: 64 -> 64 @ 2x2, one channel tile per wave, input held in registers ----------------------
+    {
+        const int mt = wave;
+        v4f acc[4][1];
+        b3_conv_preload<END, kb_L3, 2, 2, 2, 1, 4, Pos2x2H>(
+            ws, ring, reinterpret_cast<const v4f*>(gnnpp_smem + kB3L2out), acc, lane);
+        v4f sc, sh;
+        load_ss(sstab + EncLayout::kBssL3, 64, mt, q, sc, sh);
+        v2f* const O2 = reinterpret_cast<v2f*>(gnnpp_smem + kB3L3out);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v2f pl[3];
+            b3_split4(vrelu(vfma(acc[j][0], sc, sh)), pl);
+            // fragment (pos j, block mt >> 1): this tile is its e = 4 (mt & 1) .. +3 half
+            const int o = (j * 2 + (mt >> 1)) * 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) O2[((o + p) * 64 + lane) * 2 + (mt & 1)] = pl[p];
+        }
+    }
+    __syncthreads();
+    if (GNNPP_STOP_AT(stop, 5)) return;
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 4, tid == 0);
+
+    // ---- L4: 64 -> 128 @ 2x2, pool -> [1][kb 4], tiles 2w, 2w+1 per wave ------------------------------
+    {
+        v4f acc[4][2];
+        b3_conv_preload<END, kb_L4, 2, 2, 2, 2, 4, Pos2x2H>(
+            ws, ring, reinterpret_cast<const v4f*>(gnnpp_smem + kB3L3out), acc, lane);
+        v4f sc[2], sh[2];
+        load_ss(sstab + EncLayout::kBssL4, 128, 2 * wave, q, sc[0], sh[0]);
+        load_ss(sstab + EncLayout::kBssL4, 128, 2 * wave + 1, q, sc[1], sh[1]);
+        v4f r[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            r[m] = vrelu(vfma(acc[0][m], sc[m], sh[m]));
+#pragma unroll
+            for (int j = 1; j < 4; ++j) r[m] = vmax(r[m], vfma(acc[j][m], sc[m], sh[m]));
+        }
+        v4f pl[3];
+        b3_split8(r[0], r[1], pl);
+        v4f* const O4 = reinterpret_cast<v4f*>(gnnpp_smem + kB3L4out);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) O4[(wave * 3 + p) * 64 + lane] = pl[p];
+    }
+    __syncthreads();
+    if (GNNPP_STOP_AT(stop, 6)) return;
+    if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 5, tid == 0);
+    float* const hconst = sstab;                                     // FUSED: the table now holds the head's constants
+    float* const Ssm = reinterpret_cast<float*>(gnnpp_smem + kB3Table + kB3SsmOff);   // GSO [16][17], zero padded
+    if (FUSED) {                                                     // (the BatchNorm table is dead)
+        Ssm[(tid >> 4) * 17 + (tid & 15)] = sval;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (tid + i * kThreads < 773) hconst[tid + i * kThreads] = hcv[i];
+    }
+
+    // ---- FC 128 -> 128 + ReLU -> feat[agent][128]; tiles 2w, 2w+1 per wave ------------------------
+    float* const zA = reinterpret_cast<float*>(gnnpp_smem);          // FUSED: z ping-pong (fp32 rows)
+    {
+        const v4f* const I4 = reinterpret_cast<const v4f*>(gnnpp_smem + kB3L4out);
+        v8b B[4][3];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) B[kb][p] = as_b8(I4[(kb * 3 + p) * 64 + lane]);
+        v4f acc[2][2] = {{vzero(), vzero()}, {vzero(), vzero()}};    // [tile][hh | the five smaller terms]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            __builtin_amdgcn_sched_barrier(kSchedItemMask);
+            v8b A[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int idx = kb_FC + (kb * 2 + m) * 3 + p;
+                    A[m][p] = as_b8(ring_take_f4<END>(ring, idx));
+                    h2_ring_load<END>(ws, ring, idx + kRingH);
+                }
+#pragma unroll
+            for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][term == kB3Terms - 1 ? 0 : 1] =
+                        mfma16b(A[m][b3_term_a(term)], B[kb][b3_term_b(term)], acc[m][term == kB3Terms - 1 ? 0 : 1]);
+        }
+        if (FUSED) {
+            // z_0 = the features of the graph's agents: fp32 rows (the first shift reads them) AND bf16x3 planes (tap
+            // 0's MFMA operand) while they are in registers; lane (q, a) holds channels 16 mt + 4 q .. + 3 of agent a
+            char* const P0 = gnnpp_smem + kB3POff;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int mt = 2 * wave + m;
+                const v4f b = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt * 16 + q * 4);
+                const v4f f = vrelu((acc[m][0] + acc[m][1]) + b);
+                if (KT > 1) *reinterpret_cast<v4f*>(zA + a * kZs + mt * 16 + q * 4) = f;
+                v2f pl[3];
+                b3_split4(f, pl);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<v2f*>(P0 + a * kB3PRow + p * 256 + (mt * 16 + q * 4) * 2) = pl[p];
+            }
+        } else if (agent0 + a < M) {
+            float* dst = feat + (size_t)(agent0 + a) * 128 + q * 4;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int mt = 2 * wave + m;
+                const v4f b = *reinterpret_cast<const v4f*>(pk + EncLayout::kBfc + mt * 16 + q * 4);
+                *reinterpret_cast<v4f*>(dst + mt * 16) = vrelu((acc[m][0] + acc[m][1]) + b);
+            }
+        }
+    }
+    if (!FUSED) return;
+
+    // ==== graph filter + action head of this graph (K = KT taps, G = F = 128) =====================
+    // z_k = z_{k-1} S as a dense product on the fp32 MFMA, all m in ascending order: bit-identical to
+    // lsigf_kernel's sparse gather (fmaf(0, z, acc) == acc).  The shift's epilogue writes z_k as fp32 rows (if
+    // another shift follows) and as bf16x3 planes.
+    __syncthreads();                                     // z_0 complete (both forms); head constants and GSO visible
+    GNNPP_STAMP(blockIdx.x, 12, tid == 0);
+#pragma unroll
+    for (int k = 1; k < KT; ++k) {
+        const float* zp = zA + ((k - 1) & 1) * (16 * kZs);
+        float* zn = zA + (k & 1) * (16 * kZs);
+        char* const Pk = gnnpp_smem + kB3POff + k * kB3PBytes;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ft = 2 * wave + t;
+            v4f d = vzero();
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int m = 4 * st + q;
+                d = mfma16(zp[m * kZs + 16 * ft + a], Ssm[m * 17 + a], d);   // A[i = feature][k = m], B[k = m][j = node]
+            }
+            if (k + 1 < KT) *reinterpret_cast<v4f*>(zn + a * kZs + 16 * ft + 4 * q) = d;   // node a, features 16 ft + 4 q ..
+            v2f pl[3];
+            b3_split4(d, pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<v2f*>(Pk + a * kB3PRow + p * 256 + (16 * ft + 4 * q) * 2) = pl[p];
+        }
+        __syncthreads();
+    }
+    GNNPP_STAMP(blockIdx.x, 13, tid == 0);
+    // contraction on the bf16 pipe: channel tiles 2w, 2w+1; the hh products in one accumulator, the five smaller
+    // terms in another
+    v4f fa[2] = {vzero(), vzero()}, fc[2] = {vzero(), vzero()};
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap) {
+        const char* zr = gnnpp_smem + kB3POff + tap * kB3PBytes + a * kB3PRow + q * 16;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            __builtin_amdgcn_sched_barrier(kSchedItemMask);
+            v8b A[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int idx = kb_FILT + ((tap * 4 + kb) * 2 + m) * 3 + p;
+                    A[m][p] = as_b8(ring_take_f4<END>(ring, idx));
+                    h2_ring_load<END>(ws, ring, idx + kRingH);
+                }
+            v8b B[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) B[p] = as_b8(*reinterpret_cast<const v4f*>(zr + p * 256 + kb * 64));
+#pragma unroll
+            for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (term == kB3Terms - 1) fa[m] = mfma16b(A[m][0], B[0], fa[m]);
+                    else fc[m] = mfma16b(A[m][b3_term_a(term)], B[b3_term_b(term)], fc[m]);
+                }
+        }
+    }
+    GNNPP_STAMP(blockIdx.x, 14, tid == 0);
+    // bias + ReLU in registers, then the 128 -> 5 action head on the fp32 MFMA where the accumulators are (as
+    // encoder_kernel_h2<true, K>): each wave multiplies its two tiles, the four partial logits meet in LDS.
+    float* const yb = reinterpret_cast<float*>(gnnpp_smem + kB3POff + KT * kB3PBytes);   // [4 waves][16 nodes][8]
+    {
+        v4f d = vzero();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int f0 = (2 * wave + m) * 16 + 4 * q;
+            const v4f bv = *reinterpret_cast<const v4f*>(hconst + 640 + f0);
+            const v4f A5 = a < 5 ? *reinterpret_cast<const v4f*>(hconst + a * 128 + f0) : vzero();
+            d = mfma16x4(A5, vrelu((fa[m] + fc[m]) + bv), d);
+        }
+        if (q < 2) *reinterpret_cast<v4f*>(yb + (wave * 16 + a) * 8 + 4 * q) = d;   // outputs 4 q + reg of node a
+    }
+    __syncthreads();
+    // simulator state (with_sim): where the fp32 z rows were -- every reader of those passed the barrier above
+    int* const spos = reinterpret_cast<int*>(gnnpp_smem);
+    if (wave == 0) {
+        v4f d = *reinterpret_cast<const v4f*>(yb + a * 8 + 4 * (q & 1));
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) d += *reinterpret_cast<const v4f*>(yb + (w * 16 + a) * 8 + 4 * (q & 1));
+        const v4f ab4 = *reinterpret_cast<const v4f*>(hconst + 768 + 4 * (q & 1));   // act_b[0..3] | act_b[4], .
+        if (a < pt.N && q < 2) {                          // lane holds node a, outputs 4 q + reg
+            float* dst = pt.logits + ((size_t)a * pt.B + blockIdx.x) * 5;
+            // with the simulator tail: a copy [N][5] in LDS for this wave's move (red + 2 kMaxAgents, see below)
+            float* lds = reinterpret_cast<float*>(spos) + 4 * kMaxAgents + a * 5;
+            if (q == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dst[t] = d[t] + ab4[t];
+                    if (pt.with_sim) lds[t] = d[t] + ab4[t];
+                }
+            } else {
+                dst[4] = d[0] + ab4[0];
+                if (pt.with_sim) lds[4] = d[0] + ab4[0];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                  // (the LDS copy precedes this wave's reads in move_body)
+    }
+    if (!pt.with_sim) return;
+
+    // ==== simulator step of this episode (same code as rollout_step_kernel; see encoder_kernel_h2.hip) ==========
+    {
+        int* red = spos + 2 * kMaxAgents;
+        int* goal_l = red + 4 * kMaxAgents;
+        char* gso_smem = reinterpret_cast<char*>(goal_l + 2 * kMaxAgents);
+        unsigned char* occ = reinterpret_cast<unsigned char*>(gso_smem + kGsoSmemBytes);
+        const int b = blockIdx.x;
+        GNNPP_STAMP(b, 10, tid == 0);
+        const size_t occ_bytes = ((size_t)pt.sim.H * pt.sim.W + 15) & ~(size_t)15;
+        unsigned* cellcnt = 2 * occ_bytes <= policy_sim_occ_bytes_b3() ? reinterpret_cast<unsigned*>(occ + occ_bytes)
+                                                                       : nullptr;
+        sim_tail(pt.sim, b, spos, red, goal_l, gso_smem, occ, tid, kThreads, cellcnt,
+                 reinterpret_cast<const float*>(red + 2 * kMaxAgents));
+    }
+}
+
+int encoder_launch_b3(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    static LdsAttrOnce once;
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_b3<false, 3>), (int)kB3Smem);
+    const int grid = (M + kTileAgents - 1) / kTileAgents;
+    hipLaunchKernelGGL((encoder_kernel_b3<false, 3>), dim3(grid), dim3(kThreads), kB3Smem, st, obs, packed, feat, M,
+                       GNNPP_ENCODER_STOP_VALUE, PolicyTail{});   // (zero-initialised: unused by <false>)
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// whole policy step of B graphs with N <= 16 agents and K = 2, 3 or 4 taps: one workgroup per graph
+template <int KT>
+static int policy_launch_fused_b3_k(const float* obs, const float* packed, const PolicyTail& pt, hipStream_t st) {
+    static LdsAttrOnce once;
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_b3<true, KT>), (int)kB3SmemFused);
+    hipLaunchKernelGGL((encoder_kernel_b3<true, KT>), dim3(pt.B), dim3(kThreads), kB3SmemFused, st, obs, packed,
+                       static_cast<float*>(nullptr), pt.B * pt.N, 0, pt);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// pt.filt_h2 must point at the b3 region of the filter pack
+int policy_launch_fused_b3(const float* obs, const float* packed, const PolicyTail& pt, int K, hipStream_t st) {
+    switch (K) {
+        case 2: return policy_launch_fused_b3_k<2>(obs, packed, pt, st);
+        case 3: return policy_launch_fused_b3_k<3>(obs, packed, pt, st);
+        case 4: return policy_launch_fused_b3_k<4>(obs, packed, pt, st);
+        default: return -2;
+    }
+}
+
+}  // namespace gnnpp

@@ -85,10 +85,14 @@ __device__ __forceinline__ const float* h2_item_ptr(const WStreamH& ws, int idx)
     X(6, 232, 233, 234, 235) X(7, 236, 237, 238, 239) X(8, 240, 241, 242, 243)                 \
     X(9, 244, 245, 246, 247) X(10, 248, 249, 250, 251) X(11, 252, 253, 254, 255)
 
-template <int END>
-__device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRingH], int idx) {
+__device__ __forceinline__ const float* ring_item_ptr(const WStreamH& ws, int idx) { return h2_item_ptr(ws, idx); }
+
+// WS: the kernel's stream descriptor (WStreamH here, WStreamB in encoder_kernel_b3.hip): a `lane_bytes` member and an
+// overload of ring_item_ptr(ws, idx)
+template <int END, class WS>
+__device__ __forceinline__ void h2_ring_load(const WS& ws, v4f (&ring)[kRingH], int idx) {
     if (idx < END) {
-        const float* p = h2_item_ptr(ws, idx);             // wave-uniform (scalar) fragment base
+        const float* p = ring_item_ptr(ws, idx);           // wave-uniform (scalar) fragment base
 #if defined(__HIP_DEVICE_COMPILE__)
         (void)ring;
         switch (idx % kRingH) {                          // folds: idx is a constant after unrolling
@@ -107,9 +111,9 @@ __device__ __forceinline__ void h2_ring_load(const WStreamH& ws, v4f (&ring)[kRi
     }
 }
 
-// the fragment of item idx, once it has landed
+// the fragment of item idx (16 raw bytes), once it has landed
 template <int END>
-__device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
+__device__ __forceinline__ v4f ring_take_f4(v4f (&ring)[kRingH], int idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)ring;
     const int younger = END - 1 - idx < kRingH - 1 ? END - 1 - idx : kRingH - 1;
@@ -132,10 +136,14 @@ __device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
 #undef GNNPP_X
     }
     v4f r = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(v8h, r);
+    return r;
 #else
-    return __builtin_bit_cast(v8h, ring[idx % kRingH]);
+    return ring[idx % kRingH];
 #endif
+}
+template <int END>
+__device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
+    return __builtin_bit_cast(v8h, ring_take_f4<END>(ring, idx));
 }
 
 __device__ __forceinline__ v8h as_h8(v4f v) { return __builtin_bit_cast(v8h, v); }

@@ -5,8 +5,8 @@
 // (graphs/models/decentralplanner.py:284-290, layers built at :155-195).  In eval mode every
 // agent of every sample is independent, so all M = B*N agents are folded into one batch.
 //
-// Both schedules (encoder_kernel_h2.hip = split-f16 default, encoder_kernel_f32.hip = exact fp32)
-// share this plan: one workgroup (4 waves) owns a tile of 16 agents and carries them through all
+// All three schedules (encoder_kernel_b3.hip = bf16x3, the fp32-equivalent default; encoder_kernel_f32.hip = exact
+// fp32 MFMA; encoder_kernel_h2.hip = split-f16, opt-in) share this plan: one workgroup (4 waves) owns a tile of 16 agents and carries them through all
 // six layers with the activations never leaving LDS:
 //
 //   obs   [16][3][12][12]  zero-padded on top/left only                 (27.7 KB, buffer Y)
@@ -140,9 +140,55 @@ __device__ __forceinline__ void enc_h2_pack_layer(const float* __restrict__ w, f
     }
 }
 
+// bf16x3 A fragments (gnnpp_common.h, "b3"): w = h + m + l exactly, no scale.  Layout of a layer:
+// [group][kb][tap][mt_local][plane 3][lane 64][e 8], the same channel order as the split-f16 fragments.
+__device__ __forceinline__ void enc_b3_pack_layer(const float* __restrict__ w, int cin, int ntap, int ngroup,
+                                                  int nmtl, int nkb, float* __restrict__ dst, int t0, int stride) {
+    unsigned short* out = reinterpret_cast<unsigned short*>(dst);
+    const int total = ngroup * nkb * ntap * nmtl * 512;           // (lane, e) pairs per plane
+    for (int idx = t0; idx < total; idx += stride) {
+        const int e = idx & 7, l = (idx >> 3) & 63;
+        int blk = idx >> 9;
+        const int ml = blk % nmtl; blk /= nmtl;
+        const int tap = blk % ntap; blk /= ntap;
+        const int kb = blk % nkb;
+        const int grp = blk / nkb;
+        const int co = (grp * nmtl + ml) * 16 + (l & 15);
+        const int ci = 32 * kb + 16 * (e >> 2) + 4 * (l >> 4) + (e & 3);
+        const float v = w[((size_t)co * cin + ci) * ntap + tap];
+        unsigned h, m, lo;
+        b3_split2(v, 0.f, h, m, lo);
+        const size_t item = (size_t)(idx >> 9) * 3;               // h item, then m, then l
+        out[(item * 64 + l) * 8 + e] = (unsigned short)(h & 0xffffu);
+        out[((item + 1) * 64 + l) * 8 + e] = (unsigned short)(m & 0xffffu);
+        out[((item + 2) * 64 + l) * 8 + e] = (unsigned short)(lo & 0xffffu);
+    }
+}
+
 __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ packed) {
     const int stride = gridDim.x * blockDim.x;
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // bf16x3 fragments of the default (fp32-equivalent) schedule
+    enc_b3_pack_layer(rp.conv_w[1], 32, 9, 1, 2, 1, packed + EncLayout::kB1, t0, stride);
+    enc_b3_pack_layer(rp.conv_w[2], 32, 9, 2, 2, 1, packed + EncLayout::kB2, t0, stride);
+    enc_b3_pack_layer(rp.conv_w[3], 64, 9, 4, 1, 2, packed + EncLayout::kB3, t0, stride);
+    enc_b3_pack_layer(rp.conv_w[4], 64, 9, 4, 2, 2, packed + EncLayout::kB4, t0, stride);
+    enc_b3_pack_layer(rp.fc_w, 128, 1, 4, 2, 4, packed + EncLayout::kBfcw, t0, stride);
+    {   // L0: [mt 2][plane 3][lane 64][e 8], k-slots as the split-f16 L0 block below
+        unsigned short* out = reinterpret_cast<unsigned short*>(packed + EncLayout::kB0);
+        for (int idx = t0; idx < 2 * 512; idx += stride) {
+            const int e = idx & 7, l = (idx >> 3) & 63, mt = idx >> 9, qq = l >> 4;
+            const int co = mt * 16 + (l & 15);
+            float v = 0.f;
+            if (qq < 3) v = rp.conv_w[0][(co * 3 + qq) * 9 + e];
+            else if (e < 3) v = rp.conv_w[0][(co * 3 + e) * 9 + 8];
+            unsigned h, m, lo;
+            b3_split2(v, 0.f, h, m, lo);
+            out[((mt * 3 + 0) * 64 + l) * 8 + e] = (unsigned short)(h & 0xffffu);
+            out[((mt * 3 + 1) * 64 + l) * 8 + e] = (unsigned short)(m & 0xffffu);
+            out[((mt * 3 + 2) * 64 + l) * 8 + e] = (unsigned short)(lo & 0xffffu);
+        }
+    }
     // split-f16 fragments (scales were written by enc_layer_scale_kernel, earlier on this stream)
     enc_h2_pack_layer(rp.conv_w[1], packed[EncLayout::kHscale + 0], 32, 9, 1, 2, 1,
                       packed + EncLayout::kH1, t0, stride);
@@ -233,6 +279,12 @@ __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ p
                                                 : layer == 3 ? EncLayout::kHssL3 : EncLayout::kHssL4);
             packed[hoff + c] = sc * inv;
             packed[hoff + c_n + c] = shf;
+            // bf16x3 path: unscaled, one contiguous table
+            const int boff = EncLayout::kBss + (layer == 0 ? EncLayout::kBssL0 : layer == 1 ? EncLayout::kBssL1
+                                                : layer == 2 ? EncLayout::kBssL2 : layer == 3 ? EncLayout::kBssL3
+                                                : EncLayout::kBssL4);
+            packed[boff + c] = sc;
+            packed[boff + c_n + c] = shf;
         }
     }
 }
@@ -274,21 +326,25 @@ int encoder_pack_launch(const EncRawParams& rp, float* packed, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-constexpr int kDefaultEncoderVariant = 7;
-// 7: split-f16 schedule (encoder_kernel_h2.hip, default); 5: exact-fp32 schedule (encoder_kernel_f32.hip:
-// fp32 MFMA, Winograd F(2x2,3x3) in L0 and L2).  Read on every dispatch, written by gnnpp_set_tuning.
-std::atomic<int> g_encoder_variant{kDefaultEncoderVariant};
+// Arithmetic of a call (include/gnnpp.h GNNPP_PREC_*): 0 = bf16x3 (encoder_kernel_b3.hip, fp32-equivalent, default),
+// 1 = exact fp32 MFMA (encoder_kernel_f32.hip, Winograd F(2x2,3x3) in L0 and L2), 2 = split-f16
+// (encoder_kernel_h2.hip, |x| < 65504).  Chosen per call: no process-wide state.
+constexpr int kPrecFp32 = 0, kPrecFp32Mfma = 1, kPrecSplitF16 = 2;
 int encoder_launch_f32(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 int encoder_launch_h2(const float* obs, const float* packed, float* feat, int M, int* range_flag,
                       hipStream_t st);
+int encoder_launch_b3(const float* obs, const float* packed, float* feat, int M, hipStream_t st);
 
 // range_flag (optional device int): raised by the split-f16 schedule when an activation leaves the
-// f16 range; the exact-fp32 schedule has no such limit and never touches it.
-int encoder_launch(const float* obs, const float* packed, float* feat, int M, int* range_flag,
+// f16 range; the other schedules have no such limit and never touch it.
+int encoder_launch(const float* obs, const float* packed, float* feat, int M, int* range_flag, int prec,
                    hipStream_t st) {
-    return g_encoder_variant.load(std::memory_order_relaxed) == 7
-               ? encoder_launch_h2(obs, packed, feat, M, range_flag, st)
-               : encoder_launch_f32(obs, packed, feat, M, st);
+    switch (prec) {
+        case kPrecFp32: return encoder_launch_b3(obs, packed, feat, M, st);
+        case kPrecFp32Mfma: return encoder_launch_f32(obs, packed, feat, M, st);
+        case kPrecSplitF16: return encoder_launch_h2(obs, packed, feat, M, range_flag, st);
+        default: return -1;
+    }
 }
 
 }  // namespace gnnpp

@@ -10,6 +10,7 @@
 #include "encoder_kernel_f32.hip"
 #include "rollout_kernels.hip"       // before the fused policy kernel, which can run the simulator step too
 #include "encoder_kernel_h2.hip"
+#include "encoder_kernel_b3.hip"
 #include "lsigf_kernel.hip"
 #include "policy_filter_kernel.hip"
 #include "train_encoder.hip"
@@ -21,14 +22,14 @@ static_assert(GNNPP_OK == 0 && GNNPP_ERR_UNSUPPORTED == -2 && GNNPP_ERR_LAUNCH =
 
 extern "C" {
 
-int gnnpp_version(void) { return 200; }
+int gnnpp_version(void) { return 300; }
 
 const char* gnnpp_error_string(int code) {
     switch (code) {
         case GNNPP_OK: return "ok";
         case GNNPP_ERR_ARG: return "invalid argument (null pointer, non-positive size or inconsistent flags)";
         case GNNPP_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels (more than 112 nodes, or the graph's rows exceed the 160 KB LDS budget: N <= 100 is guaranteed at G, F <= 128)";
-        case GNNPP_ERR_RANGE: return "an activation left the f16 range (|x| >= 65504) of the split-f16 schedule; results of this call are not finite -- select the exact-fp32 schedule (GNNPP_TUNE_ENCODER_VARIANT = 5, GNNPP_TUNE_FILTER_F16 = 0)";
+        case GNNPP_ERR_RANGE: return "an activation left the f16 range (|x| >= 65504) of GNNPP_PREC_SPLIT_F16; results of this call are not trustworthy -- run it with GNNPP_PREC_FP32 (the default), which has no input domain";
         case GNNPP_ERR_LAUNCH: return "HIP kernel launch failed";
         default: return "unknown gnnpp error code";
     }
@@ -49,9 +50,9 @@ int gnnpp_filter_pack(const float* h, float* packed, int G, int F, int K, int E,
 int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const float* bias,
                     float* y, int B, int N, int Nin, int G, int F, int K, int E, int s_is_f64,
                     int s_batched, int x_node_major, int y_node_major, int relu, int bias_per_node,
-                    int* range_flag, void* stream) {
+                    int precision, int* range_flag, void* stream) {
     if (!x || !packed || !y || B <= 0 || N <= 0 || Nin <= 0 || Nin > N || G <= 0 || F <= 0 ||
-        K <= 0 || E <= 0)
+        K <= 0 || E <= 0 || precision < 0 || precision > 2)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
     if ((x_node_major || y_node_major) && Nin != N) return GNNPP_ERR_ARG;
@@ -61,16 +62,17 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
     a.B = B; a.N = N; a.Nin = Nin; a.G = G; a.F = F; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = s_batched;
     a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
-    a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag;
+    a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag; a.prec = precision;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
                          float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
                          int s_is_f64, int s_batched, int s_transposed, int x_node_major,
-                         int y_node_major, int relu, int bias_per_node, int* range_flag, void* stream) {
+                         int y_node_major, int relu, int bias_per_node, int precision, int* range_flag,
+                         void* stream) {
     if (!x || !packed || !y || B <= 0 || N <= 0 || Nin <= 0 || Nin > N || G <= 0 || F <= 0 ||
-        K <= 0 || E <= 0)
+        K <= 0 || E <= 0 || precision < 0 || precision > 2)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
     if ((x_node_major || y_node_major) && Nin != N) return GNNPP_ERR_ARG;
@@ -80,7 +82,7 @@ int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, con
     a.B = B; a.N = N; a.Nin = Nin; a.G = G; a.F = F; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = s_batched; a.s_transposed = s_transposed;
     a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
-    a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag;
+    a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag; a.prec = precision;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
@@ -101,35 +103,33 @@ int gnnpp_encoder_pack(const gnnpp_encoder_params* p, float* packed, void* strea
     return encoder_pack_launch(rp, packed, static_cast<hipStream_t>(stream));
 }
 
-int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, int* range_flag,
-                      void* stream) {
-    if (!obs || !packed || !feat || M <= 0) return GNNPP_ERR_ARG;
-    return encoder_launch(obs, packed, feat, M, range_flag, static_cast<hipStream_t>(stream));
+int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, int precision,
+                      int* range_flag, void* stream) {
+    if (!obs || !packed || !feat || M <= 0 || precision < 0 || precision > 2) return GNNPP_ERR_ARG;
+    return encoder_launch(obs, packed, feat, M, range_flag, precision, static_cast<hipStream_t>(stream));
 }
 
 std::atomic<int> g_fused_policy{1};   // GNNPP_TUNE_FUSED_POLICY
 
-// Does the one-launch policy kernel apply?  (split-f16 schedules selected, N <= 16, K = 3, and a
-// batch for which one workgroup per graph pays: measured -8 % at B = 512, -17 % at B <= 64 (N = 10),
-// but +40 % at B = 2048 -- or N nearly fills the 16-lane tile.)
-static bool fused_policy_applies(int B, int N, int K) {
+// Does the one-launch policy kernel apply?  (bf16x3 or split-f16 arithmetic -- the exact-fp32 MFMA schedule has no
+// fused form --, N <= 16, K = 2..4, and a batch for which one workgroup per graph pays: measured -8 % at B = 512,
+// -17 % at B <= 64 (N = 10), but +40 % at B = 2048 -- or N nearly fills the 16-lane tile.)
+static bool fused_policy_applies(int B, int N, int K, int prec) {
 #ifdef GNNPP_MEASURE
     if (g_filter_ablate.load(std::memory_order_relaxed) || g_encoder_stop.load(std::memory_order_relaxed))
         return false;
 #endif
     const bool fused_pays = B <= 2 * 256 || N >= 13;
-    return g_fused_policy.load(std::memory_order_relaxed) && fused_pays &&
-           g_encoder_variant.load(std::memory_order_relaxed) == 7 &&
-           g_filter_f16.load(std::memory_order_relaxed) && N <= kTileAgents && K >= kPolicyTapsMin &&
-           K <= kPolicyTapsMax;
+    return g_fused_policy.load(std::memory_order_relaxed) && fused_pays && prec != kPrecFp32Mfma &&
+           N <= kTileAgents && K >= kPolicyTapsMin && K <= kPolicyTapsMax;
 }
 
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
                      const float* filt_packed, const float* gf_bias, const float* act_w,
                      const float* act_b, float* feat_ws, float* logits, int B, int N, int K, int E,
-                     int s_is_f64, int* range_flag, void* stream) {
+                     int s_is_f64, int precision, int* range_flag, void* stream) {
     if (!obs || !enc_packed || !filt_packed || !act_w || !act_b || !feat_ws || !logits || B <= 0 ||
-        N <= 0 || K <= 0 || E <= 0)
+        N <= 0 || K <= 0 || E <= 0 || precision < 0 || precision > 2)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
     if (N > GNNPP_MAX_ROWS) return GNNPP_ERR_UNSUPPORTED;
@@ -139,30 +139,32 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
     a.act_w = act_w; a.act_b = act_b; a.logits = logits;
     a.B = B; a.N = N; a.Nin = N; a.G = GNNPP_FEAT; a.F = GNNPP_FEAT; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1;
-    a.range_flag = range_flag;
+    a.range_flag = range_flag; a.prec = precision;
     LsigfPlan plan;
     int rc = lsigf_plan(a, plan);
     if (rc) return rc;
     // Fused path: a 16-lane tile per graph wastes (16 - N) / 16 of the encoder's lanes, which is free
     // while the graphs fit the chip in one round (2 workgroups per CU).
-    if (E == 1 && fused_policy_applies(B, N, K)) {
+    if (E == 1 && fused_policy_applies(B, N, K, precision)) {
         // one launch: a workgroup encodes one graph's agents and runs its filter + action head
         PolicyTail pt;
-        pt.S = S; pt.filt_h2 = a.wpk_h; pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b;
+        pt.S = S; pt.filt_h2 = precision == kPrecFp32 ? a.wpk_b : a.wpk_h;
+        pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b;
         pt.logits = logits; pt.B = B; pt.N = N; pt.s_is_f64 = s_is_f64;
         pt.range_flag = range_flag;
         pt.with_sim = 0;
-        return policy_launch_fused(obs, enc_packed, pt, K, st);
+        return precision == kPrecFp32 ? policy_launch_fused_b3(obs, enc_packed, pt, K, st)
+                                      : policy_launch_fused(obs, enc_packed, pt, K, st);
     }
-    rc = encoder_launch(obs, enc_packed, feat_ws, B * N, range_flag, st);
+    rc = encoder_launch(obs, enc_packed, feat_ws, B * N, range_flag, precision, st);
     return rc ? rc : lsigf_dispatch(a, plan, st);
 }
 
 int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, const float* bias,
                           const float* act_w, const float* act_b, float* logits, int B, int N, int G,
-                          int F, int K, int E, int s_is_f64, int* range_flag, void* stream) {
+                          int F, int K, int E, int s_is_f64, int precision, int* range_flag, void* stream) {
     if (!x || !packed || !act_w || !act_b || !logits || B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 ||
-        E <= 0)
+        E <= 0 || precision < 0 || precision > 2)
         return GNNPP_ERR_ARG;
     if (K > 1 && !S) return GNNPP_ERR_ARG;
     if (N > GNNPP_MAX_ROWS || F > 128) return GNNPP_ERR_UNSUPPORTED;   // the head needs all features at once
@@ -171,7 +173,7 @@ int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, co
     a.act_w = act_w; a.act_b = act_b; a.logits = logits;
     a.B = B; a.N = N; a.Nin = N; a.G = G; a.F = F; a.K = K; a.E = E;
     a.s_is_f64 = s_is_f64; a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1;
-    a.range_flag = range_flag;
+    a.range_flag = range_flag; a.prec = precision;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
@@ -299,10 +301,8 @@ int gnnpp_measure_read_stamps(unsigned long long* host, int n) {
 
 int gnnpp_get_tuning(int key) {
     switch (key) {
-        case GNNPP_TUNE_ENCODER_VARIANT: return g_encoder_variant.load();
         case GNNPP_TUNE_FILTER_GPW: return g_filter_gpw.load();
         case GNNPP_TUNE_FILTER_WAVES: return g_filter_waves.load();
-        case GNNPP_TUNE_FILTER_F16: return g_filter_f16.load();
         case GNNPP_TUNE_FUSED_POLICY: return g_fused_policy.load();
         case GNNPP_TUNE_FILTER_SPLIT: return g_filter_split.load();
         case GNNPP_TUNE_POLICY_FILTER: return g_filter_policy_kernel.load();
@@ -316,10 +316,6 @@ int gnnpp_get_tuning(int key) {
 
 int gnnpp_set_tuning(int key, int value) {
     switch (key) {
-        case GNNPP_TUNE_ENCODER_VARIANT:
-            if (value != -1 && value != 5 && value != 7) return GNNPP_ERR_ARG;
-            g_encoder_variant.store(value < 0 ? kDefaultEncoderVariant : value);
-            return GNNPP_OK;
         case GNNPP_TUNE_FILTER_GPW:
             if (value < 0) return GNNPP_ERR_ARG;
             g_filter_gpw.store(value);
@@ -327,10 +323,6 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_FUSED_POLICY:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;
             g_fused_policy.store(value);
-            return GNNPP_OK;
-        case GNNPP_TUNE_FILTER_F16:
-            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
-            g_filter_f16.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_WAVES:
             if (value != 0 && value != 8 && value != 16) return GNNPP_ERR_ARG;
@@ -408,7 +400,7 @@ int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream) {
 
 int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
                               const float* gf_bias, const float* act_w, const float* act_b, int K,
-                              void* stream) {
+                              int precision, void* stream) {
     if (!rollout_common_ok(r) || !r->grid || !r->goal || !r->obs || !r->radius || !r->S || !r->logits ||
         !r->reached || !r->start_step || !r->end_step || !r->maxstep || !r->flags || !r->stats ||
         r->H <= 0 || r->W <= 0 || !enc_packed || !filt_packed || !act_w || !act_b)
@@ -416,11 +408,15 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
     if (r->tie_mode == GNNPP_TIE_REPLAY && (!r->choices || r->max_choices <= 0)) return GNNPP_ERR_ARG;
     if (r->tie_mode < 0 || r->tie_mode > 3) return GNNPP_ERR_ARG;
     if (r->tie_mode == GNNPP_TIE_MT19937 && (!r->rng_words || !r->rng_cursor || r->rng_max <= 0)) return GNNPP_ERR_ARG;
+    if (precision < 0 || precision > 2) return GNNPP_ERR_ARG;
     // same conditions as the fused policy kernel of gnnpp_policy_fwd, plus room for the occupancy grid
-    if (!(fused_policy_applies(r->B, r->N, K) && (size_t)r->H * r->W <= policy_sim_occ_bytes(K)))
+    const size_t occ_room = precision == kPrecFp32 ? policy_sim_occ_bytes_b3() : policy_sim_occ_bytes(K);
+    if (!(fused_policy_applies(r->B, r->N, K, precision) && (size_t)r->H * r->W <= occ_room))
         return GNNPP_ERR_UNSUPPORTED;
     PolicyTail pt;
-    pt.S = r->S; pt.filt_h2 = filt_packed + filter_packed_f32_floats(GNNPP_FEAT, GNNPP_FEAT, K, 1);
+    pt.S = r->S;
+    pt.filt_h2 = filt_packed + (precision == kPrecFp32 ? filter_packed_b3_offset(GNNPP_FEAT, GNNPP_FEAT, K, 1)
+                                                       : filter_packed_f32_floats(GNNPP_FEAT, GNNPP_FEAT, K, 1));
     pt.gf_bias = gf_bias; pt.act_w = act_w; pt.act_b = act_b; pt.logits = const_cast<float*>(r->logits);
     pt.B = r->B; pt.N = r->N; pt.s_is_f64 = 0;
     pt.range_flag = r->range_flag;
@@ -428,17 +424,19 @@ int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, c
     pt.sim = *r;
     pt.sim.grow = 0;
     pt.sim.actions = nullptr;
-    return policy_launch_fused(r->obs, enc_packed, pt, K, static_cast<hipStream_t>(stream));
+    return precision == kPrecFp32 ? policy_launch_fused_b3(r->obs, enc_packed, pt, K, static_cast<hipStream_t>(stream))
+                                  : policy_launch_fused(r->obs, enc_packed, pt, K, static_cast<hipStream_t>(stream));
 }
 
 int gnnpp_rollout_policy_steps(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
                                const float* gf_bias, const float* act_w, const float* act_b, int K,
-                               int nsteps, void* stream) {
+                               int nsteps, int precision, void* stream) {
     if (!r || nsteps <= 0 || r->tie_mode == GNNPP_TIE_REPLAY) return GNNPP_ERR_ARG;
     gnnpp_rollout rs = *r;
     for (int s = 0; s < nsteps; ++s) {
         rs.currentstep = r->currentstep + s;
-        const int rc = gnnpp_rollout_policy_step(&rs, enc_packed, filt_packed, gf_bias, act_w, act_b, K, stream);
+        const int rc = gnnpp_rollout_policy_step(&rs, enc_packed, filt_packed, gf_bias, act_w, act_b, K, precision,
+                                                 stream);
         if (rc != GNNPP_OK) return rc;                   // (argument / shape errors surface at s = 0)
     }
     return GNNPP_OK;

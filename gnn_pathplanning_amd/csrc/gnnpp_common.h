@@ -29,6 +29,8 @@ __device__ unsigned long long g_stamps[1024 * 32];
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));   // one 16x16x32 f16 MFMA operand
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));     // one 16x16x32 bf16 MFMA operand
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kThreads = 256;        // 4 waves per workgroup, one per SIMD
@@ -88,6 +90,101 @@ __device__ __forceinline__ v4f mfma16h(v8h a, v8h b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_bf16: same lane map and rate as the f16 form; bf16 has fp32's exponent range, so three
+// bf16 planes represent ANY finite fp32 value exactly (bf16x3, below).
+__device__ __forceinline__ v4f mfma16b(v8b a, v8b b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- bf16x3: the fp32-equivalent operand form of the matrix pipe ("b3") ------------------------------------
+//      x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)      (round to nearest even)
+// Both residuals are exact in fp32 and l is exactly representable (24 significand bits = 8 + 8 + 8), so the
+// three planes carry x EXACTLY, with fp32's exponent range: no domain restriction, no weight pre-scaling, no
+// guard.  A product keeps six of the nine plane products,
+//      w x ~= wh xl + wl xh + wm xm + wh xm + wm xh + wh xh        (fp32 accumulate, small terms first),
+// dropping wm xl + wl xm + wl xl <= 2^-23 |w x| in the worst case (2^-26 typical): below the rounding of one
+// fp32 multiply-add.  Six v_mfma_f32_16x16x32_bf16 per 32 channels = 96 matrix-pipe cycles against the 256 of
+// eight v_mfma_f32_16x16x4_f32: 2.7x the fp32 pipe's rate at fp32's accuracy.
+// |x| > 0x7f7f0000 (3.39e38, the largest bf16) would round h to infinity: the value handed to the first
+// conversion is clamped there (v_med3), the residual then carries the rest -- still exact.
+constexpr int kB3Planes = 3;
+constexpr int kB3Terms = 6;
+// (weight plane, activation plane) of term t, small terms first
+__host__ __device__ constexpr int b3_term_a(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0; }
+__host__ __device__ constexpr int b3_term_b(int t) { return t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : t == 4 ? 0 : 0; }
+
+__device__ __forceinline__ unsigned b3_cvt_pk(float lo, float hi) {      // two fp32 -> two bf16 (RNE), lo in bits 0..15
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#else
+    auto one = [](float f) -> unsigned {
+        unsigned u;
+        __builtin_memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;                 // NaN stays NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    return (one(lo) & 0xffffu) | (one(hi) << 16);
+#endif
+}
+__device__ __forceinline__ float b3_sub(float a, float b) {              // a - b as ONE v_sub_f32 (the SLP vectoriser
+#if defined(__HIP_DEVICE_COMPILE__)                                      // would pair these into v_pk_add_f32, which
+    float r;                                                             // is slower beside MFMAs)
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a - b;
+#endif
+}
+__device__ __forceinline__ float b3_bits(unsigned u) {
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__device__ __forceinline__ float b3_clamp(float x) {
+    const float big = b3_bits(0x7f7f0000u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, -big, big);
+#else
+    return x != x ? x : (x < -big ? -big : x > big ? big : x);
+#endif
+}
+// two fp32 values -> their three planes as packed bf16 pairs (x0 in the low halves)
+__device__ __forceinline__ void b3_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = b3_cvt_pk(b3_clamp(x0), b3_clamp(x1));
+    const float r0 = b3_sub(x0, b3_bits(h << 16));
+    const float r1 = b3_sub(x1, b3_bits(h & 0xffff0000u));
+    m = b3_cvt_pk(r0, r1);
+    const float s0 = b3_sub(r0, b3_bits(m << 16));
+    const float s1 = b3_sub(r1, b3_bits(m & 0xffff0000u));
+    l = b3_cvt_pk(s0, s1);
+}
+// eight fp32 values (two D tiles: a = k-slots e 0..3, b = e 4..7) -> the three 16-byte plane fragments
+__device__ __forceinline__ void b3_split8(v4f a, v4f b, v4f (&pl)[3]) {
+    unsigned h[4], m[4], l[4];
+    b3_split2(a[0], a[1], h[0], m[0], l[0]);
+    b3_split2(a[2], a[3], h[1], m[1], l[1]);
+    b3_split2(b[0], b[1], h[2], m[2], l[2]);
+    b3_split2(b[2], b[3], h[3], m[3], l[3]);
+    const v4u hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]}, lv = {l[0], l[1], l[2], l[3]};
+    pl[0] = __builtin_bit_cast(v4f, hv);
+    pl[1] = __builtin_bit_cast(v4f, mv);
+    pl[2] = __builtin_bit_cast(v4f, lv);
+}
+// four fp32 values (one D tile) -> the 8-byte halves of the three plane fragments
+__device__ __forceinline__ void b3_split4(v4f a, v2f (&pl)[3]) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    unsigned h[2], m[2], l[2];
+    b3_split2(a[0], a[1], h[0], m[0], l[0]);
+    b3_split2(a[2], a[3], h[1], m[1], l[1]);
+    const v2u hv = {h[0], h[1]}, mv = {m[0], m[1]}, lv = {l[0], l[1]};
+    pl[0] = __builtin_bit_cast(v2f, hv);
+    pl[1] = __builtin_bit_cast(v2f, mv);
+    pl[2] = __builtin_bit_cast(v2f, lv);
+}
+__device__ __forceinline__ v8b as_b8(v4f v) { return __builtin_bit_cast(v8b, v); }
+
 __device__ __forceinline__ v4f vzero() { v4f z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 __device__ __forceinline__ v4f vrelu(v4f v) {
@@ -127,7 +224,8 @@ __device__ __forceinline__ float wave_read_lane(float v, int src) {
 // ---- packed layouts (in floats) -------------------------------------------------------------
 // graph-filter taps: [fp32 fragments: block (e, k, mt, gg) of 64 lanes x 4 floats]
 //                    [split-f16 fragments: block (e, k, mt, kb, hi/lo) of 64 lanes x 8 halves]
-//                    [2^k, 2^-k]                                         see lsigf_kernel.hip
+//                    [2^k, 2^-k, 0, 0]
+//                    [bf16x3 fragments: block (e, k, mt, kb, plane) of 64 lanes x 8 bf16]   see lsigf_kernel.hip
 __host__ __device__ inline size_t filter_packed_f32_floats(int G, int F, int K, int E) {
     const size_t NG = (G + 15) / 16, MT = (F + 15) / 16;
     return (size_t)E * K * MT * NG * 256;
@@ -136,8 +234,16 @@ __host__ __device__ inline size_t filter_packed_h2_floats(int G, int F, int K, i
     const size_t KB = (G + 31) / 32, MT = (F + 15) / 16;
     return (size_t)E * K * MT * KB * 512;
 }
-__host__ __device__ inline size_t filter_packed_floats(int G, int F, int K, int E) {
+// bf16x3 fragments: block (e, k, mt, kb) = [plane 3][lane 64][8 bf16] = 768 floats, behind the scale pair
+__host__ __device__ inline size_t filter_packed_b3_floats(int G, int F, int K, int E) {
+    const size_t KB = (G + 31) / 32, MT = (F + 15) / 16;
+    return (size_t)E * K * MT * KB * 768;
+}
+__host__ __device__ inline size_t filter_packed_b3_offset(int G, int F, int K, int E) {
     return filter_packed_f32_floats(G, F, K, E) + filter_packed_h2_floats(G, F, K, E) + 4;
+}
+__host__ __device__ inline size_t filter_packed_floats(int G, int F, int K, int E) {
+    return filter_packed_b3_offset(G, F, K, E) + filter_packed_b3_floats(G, F, K, E);
 }
 
 // encoder: offsets of each layer's block inside the packed buffer
@@ -179,7 +285,18 @@ struct EncLayout {
     static constexpr int kHss0 = kH0 + 4 * kHItem;
     static constexpr int kHss = kHss0 + 64;
     static constexpr int kHssL1 = 0, kHssL2 = 64, kHssL3 = 192, kHssL4 = 320, kHssFloats = 576;
-    static constexpr int kTotal = kHss + kHssFloats;
+    // bf16x3 path (encoder_kernel_b3.hip): w = h + m + l exactly, three bf16 fragments of 16 bytes per lane in
+    // each wave's consumption order [group][kb][tap][mt_local][plane 3][lane 64][8 bf16]; no weight scale
+    static constexpr int kB1 = kHss + kHssFloats;                        // [1][1][9][2][3] items
+    static constexpr int kB2 = kB1 + 54 * kHItem;                        // [2][1][9][2][3]
+    static constexpr int kB3 = kB2 + 108 * kHItem;                       // [4][2][9][1][3]
+    static constexpr int kB4 = kB3 + 216 * kHItem;                       // [4][2][9][2][3]
+    static constexpr int kBfcw = kB4 + 432 * kHItem;                     // [4][4][1][2][3]
+    static constexpr int kB0 = kBfcw + 96 * kHItem;                      // L0: [mt 2][plane 3][lane 64][e 8]
+    // the BatchNorm table the b3 kernel keeps in LDS: L0 [32][32] | L1 [32][32] | L2 [64][64] | L3 | L4 [128][128]
+    static constexpr int kBss = kB0 + 6 * kHItem;
+    static constexpr int kBssL0 = 0, kBssL1 = 64, kBssL2 = 128, kBssL3 = 256, kBssL4 = 384, kBssFloats = 640;
+    static constexpr int kTotal = kBss + kBssFloats;
 };
 
 }  // namespace gnnpp

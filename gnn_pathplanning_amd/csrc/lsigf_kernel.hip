@@ -40,6 +40,8 @@ struct LsigfArgs {
     const void* S;
     const float* wpk;      // packed taps, see pack_filter_kernel
     const float* wpk_h;    // split-f16 fragments + {2^k, 2^-k} (inside the same packed buffer)
+    const float* wpk_b;    // bf16x3 fragments (inside the same packed buffer)
+    int prec;              // GNNPP_PREC_*: arithmetic of the tap contraction
     const float* bias;     // [F] or nullptr
     float* y;              // may be nullptr when only the action head is wanted
     const float* act_w;    // [5,F] or nullptr: fused action head
@@ -64,6 +66,7 @@ struct LsigfArgs {
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
     int* range_flag;       // optional device int: set to 1 when the split-f16 contraction saw |z| >= 65504
     int pf_part_off;       // policy_filter_kernel.hip: LDS byte offset of the partial logits
+    int pf_plane_off;      // policy_filter_kernel.hip, bf16x3 mode: LDS byte offset of the plane buffer
     int ablate;            // GNNPP_MEASURE builds only (tools/ab_bench.py): bit 0 skip the shifts, bit 1
                            // skip the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
@@ -160,6 +163,29 @@ __global__ void pack_filter_kernel(const float* __restrict__ h, float* __restric
         const size_t item = (idx >> 9) * 2;
         out[(item * 64 + l) * 8 + e8] = hi;
         out[((item + 1) * 64 + l) * 8 + e8] = (_Float16)(v - (float)hi);
+    }
+    // bf16x3 fragments (gnnpp_common.h, "b3"): block (e, k, mt, kb) = [plane 3][lane 64][8 bf16], same channel
+    // order, w = h + m + l exactly (no scale)
+    unsigned short* ob = reinterpret_cast<unsigned short*>(packed + filter_packed_b3_offset(G, F, K, E));
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_h;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e8 = idx & 7;
+        const int l = (idx >> 3) & 63;
+        size_t blk = idx >> 9;
+        const int kb = blk % KB; blk /= KB;
+        const int mt = blk % MT; blk /= MT;
+        const int k = blk % K;
+        const int e = blk / K;
+        const int f = mt * 16 + (l & 15);
+        const int g = kb * 32 + (l >> 4) * 8 + e8;
+        float v = 0.f;
+        if (f < F && g < G) v = h[(((size_t)f * E + e) * K + k) * G + g];
+        unsigned ph, pm, pl;
+        b3_split2(v, 0.f, ph, pm, pl);
+        const size_t item = (idx >> 9) * 3;
+        ob[(item * 64 + l) * 8 + e8] = (unsigned short)(ph & 0xffffu);
+        ob[((item + 1) * 64 + l) * 8 + e8] = (unsigned short)(pm & 0xffffu);
+        ob[((item + 2) * 64 + l) * 8 + e8] = (unsigned short)(pl & 0xffffu);
     }
 }
 
@@ -745,14 +771,14 @@ static hipError_t launch_one(const LsigfArgs& a, int grid, size_t smem, hipStrea
     return hipGetLastError();
 }
 
-std::atomic<int> g_filter_f16{1};     // split-f16 contraction when G == 128 (GNNPP_TUNE_FILTER_F16)
-
 template <int RTW, int NW>
 static hipError_t launch_ng(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
     if (a.NG != 8) return launch_one<RTW, NW, 0, false>(a, grid, smem, st);
     // The input-gradient launch (s_transposed: x := dy) keeps the fp32 MFMA: cotangents of 1e-4 .. 1e-7
     // sit in the f16 subnormal range, where the unscaled hi/lo split of the B operand loses them.
-    return (a.G == 128 && g_filter_f16.load(std::memory_order_relaxed) && !a.s_transposed)
+    // (GNNPP_PREC_FP32 contracts on the exact fp32 MFMA here: this kernel's two z buffers leave no LDS for bf16x3
+    // planes at the sizes it exists for; the policy's own kernels carry the bf16x3 form.)
+    return (a.G == 128 && a.prec == kPrecSplitF16 && !a.s_transposed)
                ? launch_one<RTW, NW, 8, true>(a, grid, smem, st)
                : launch_one<RTW, NW, 8, false>(a, grid, smem, st);
 }
@@ -792,6 +818,7 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     a.mt0 = a.f0 / 16;
     a.MT_all = (a.F_all + 15) / 16;
     a.wpk_h = a.wpk + filter_packed_f32_floats(a.G, a.F_all, a.K, a.E);
+    a.wpk_b = a.wpk + filter_packed_b3_offset(a.G, a.F_all, a.K, a.E);
     if (a.MT > 8) return -2;                          // F > 128 per launch: lsigf_launch splits F
     const int wide = a.NG > a.MT ? a.NG : a.MT;
     a.zstride = 16 * wide + 8;

@@ -27,6 +27,13 @@
 //     wave multiplies its tile (4 MFMAs per row tile) and the eight tiles' partial logits are summed through LDS
 //     in the fixed order mt = 0..7 (deterministic; the rounding differs from the pair-chain head of lsigf_kernel
 //     in the last bit, tests/test_gpu_parity.py compares the two).  No y tile in LDS, no 32-MFMA chain.
+// MODE (the call's `precision`, include/gnnpp.h): 0 = the split-f16 schedule described above (GNNPP_PREC_SPLIT_F16);
+// 2 = bf16x3, the fp32-equivalent default (GNNPP_PREC_FP32): z_k exists as fp32 rows (what the next shift reads) and,
+// for the workgroup's own rows, as three bf16 planes in ONE extra buffer PB (row stride 800 B) written by the
+// PRODUCER of z_k -- the staging loop for z_0, the shift's epilogue for z_k -- so there is no conversion pass at all;
+// six MFMAs per (row tile, 32 channels); needs N * 800 more bytes of LDS, which exists up to about 64 nodes;
+// 1 = exact fp32 MFMA (GNNPP_PREC_FP32_MFMA, and GNNPP_PREC_FP32 on graphs whose planes do not fit): the taps read
+// the fp32 rows directly, 32 MFMAs of K = 4 per (row tile, 128 channels).
 // Two workgroups per graph (nsplit = 2, as in lsigf_kernel) when at most 128 large graphs would leave half of
 // the CUs idle: both stage the graph and run the shifts k < K-1 on all rows; the last shift, the contraction
 // and the head run on the workgroup's own half of the row tiles.
@@ -62,10 +69,15 @@ __host__ __device__ inline size_t pf_lds_base(int N, int Ns, int K) {
 // produces (may be null) -- the last shift writes only those.  (Writing both in a middle shift, into a third
 // buffer, to drop the conversion pass of the tap before the last was measured at N = 50: no gain -- the extra
 // stores cost the shift what the pass saved.)
+constexpr int kPfPRow = 3 * 256 + 32;     // MODE 2: row stride of the plane buffer PB (bytes)
+
+template <int MODE>
 __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const unsigned char* __restrict__ idx,
                                           const unsigned char* __restrict__ cnt, const float* __restrict__ zprev,
                                           float* __restrict__ znxt, float* __restrict__ zsplit, int Ns, int row_lo,
-                                          int row_hi, int wave, int lane, unsigned long long& bad) {
+                                          int row_hi, int wave, int lane, unsigned long long& bad,
+                                          char* __restrict__ planes = nullptr, int own_lo = 0, int own_hi = 0) {
+    // MODE 2: `planes` = PB; rows [own_lo, own_hi) also leave as bf16x3 planes (PB row r - own_lo); zsplit unused
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     const int quarter = lane >> 4, ql = lane & 15;
     for (int rb = row_lo + 4 * wave; rb < row_hi; rb += 64) {           // wave-uniform trip count
@@ -104,7 +116,20 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
             *reinterpret_cast<v4f*>(row + 4 * ql) = acc0;
             *reinterpret_cast<v4f*>(row + 64 + 4 * ql) = acc1;
         }
-        if (zsplit) {
+        if (MODE == 2) {
+            v2f p0[3], p1[3];
+            b3_split4(acc0, p0);
+            b3_split4(acc1, p1);
+            if (rv && rr >= own_lo && rr < own_hi) {
+                char* row = planes + (rr - own_lo) * kPfPRow;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    *reinterpret_cast<v2f*>(row + p * 256 + 8 * ql) = p0[p];           // features 4 ql ..
+                    *reinterpret_cast<v2f*>(row + p * 256 + 128 + 8 * ql) = p1[p];     // features 64 + 4 ql ..
+                }
+            }
+        }
+        if (MODE == 0 && zsplit) {
             float* row = zsplit + rr * kPfZs;
             // |z| >= 65504 does not fit the hi half: range guard as in split_rows
             float mx = 0.f;
@@ -129,7 +154,7 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
 
 // RTW = 16-row MFMA tiles per wave (waves 0..7 own the first RTW tiles of the workgroup's range, waves 8..15 the
 // next RTW; wave & 7 is the 16-feature output tile).
-template <int RTW>
+template <int RTW, int MODE>
 __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     constexpr int NT = 1024, NW = 16;
@@ -161,6 +186,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     unsigned char* cnt = idx + (K > 1 ? N * Ns : 0);
     float* cb = reinterpret_cast<float*>(gnnpp_smem + pf_lds_base(N, Ns, K));
     float* part_sums = reinterpret_cast<float*>(gnnpp_smem + p.pf_part_off);      // [8][N][8]
+    char* const PB = gnnpp_smem + p.pf_plane_off;      // MODE 2: bf16x3 planes of this workgroup's own rows
 
     GNNPP_STAMP(blockIdx.x, 0, tid == 0);
     // ---- every global load of the kernel, issued now -------------------------------------------------------
@@ -207,15 +233,18 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     if (tid < 640) cpre = p.act_w[tid];
     else if (tid < 768) cpre = p.bias ? p.bias[tid - 640] : 0.f;
     else if (tid < 773) cpre = p.act_b[tid - 768];
-    else if (tid == 773) cpre = p.wpk_h[filter_packed_h2_floats(128, 128, K, 1) + 1];
-    // A fragments of the first tap (packed block (k, mt, gg): 64 lanes x 16 bytes = hi | lo of four k-steps)
-    constexpr size_t tap_stride = (size_t)8 * 8 * 256;
-    v4f Acur[8];
-    auto load_tap = [&](v4f (&A)[8], int tap) {
+    else if (tid == 773) cpre = MODE == 0 ? p.wpk_h[filter_packed_h2_floats(128, 128, K, 1) + 1] : 1.f;
+    // A fragments of the first tap.  MODE 0: packed block (k, mt, gg) = 64 lanes x 16 bytes = hi | lo of four
+    // k-steps; MODE 1: the fp32 fragments of four k-steps; MODE 2: block (k, mt, kb) = three 16-byte planes
+    constexpr int NA = MODE == 2 ? 12 : 8;
+    constexpr size_t tap_stride = (size_t)8 * NA * 256;
+    v4f Acur[NA];
+    auto load_tap = [&](v4f (&A)[NA], int tap) {
         if (has_mfma) {
-            const float* wt = p.wpk_h + tap * tap_stride + ((size_t)mt * 8 * 64 + lane) * 4;
+            const float* wt = (MODE == 0 ? p.wpk_h : MODE == 1 ? p.wpk : p.wpk_b) + tap * tap_stride +
+                              ((size_t)mt * NA * 64 + lane) * 4;
 #pragma unroll
-            for (int gg = 0; gg < 8; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
+            for (int gg = 0; gg < NA; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
         }
     };
 
@@ -233,19 +262,30 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
         const int i = tid + u * NT;
         const bool ok = i < N * 32;
         const v4f v = ok ? xv[u] : vzero();
-        bad |= __ballot(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= 65504.f);
-        v4h hh, ll;
+        const int r = i >> 5, c4 = i & 31;
+        if (MODE == 0) {
+            bad |= __ballot(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= 65504.f);
+            v4h hh, ll;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            hh[c] = (_Float16)v[c];
-            ll[c] = (_Float16)(v[c] - (float)hh[c]);
+            for (int c = 0; c < 4; ++c) {
+                hh[c] = (_Float16)v[c];
+                ll[c] = (_Float16)(v[c] - (float)hh[c]);
+            }
+            if (ok) {
+                *reinterpret_cast<v2f*>(zbuf1 + r * kPfZs + 2 * c4) = __builtin_bit_cast(v2f, hh);
+                *reinterpret_cast<v2f*>(zbuf1 + r * kPfZs + 64 + 2 * c4) = __builtin_bit_cast(v2f, ll);
+            }
         }
-        if (ok) {
-            const int r = i >> 5, c4 = i & 31;
-            *reinterpret_cast<v4f*>(zbuf0 + r * kPfZs + 4 * c4) = v;
-            *reinterpret_cast<v2f*>(zbuf1 + r * kPfZs + 2 * c4) = __builtin_bit_cast(v2f, hh);
-            *reinterpret_cast<v2f*>(zbuf1 + r * kPfZs + 64 + 2 * c4) = __builtin_bit_cast(v2f, ll);
+        if (MODE == 2) {
+            v2f pl[3];
+            b3_split4(v, pl);
+            if (ok && r >= row_lo && r < row_hi) {
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    *reinterpret_cast<v2f*>(PB + (r - row_lo) * kPfPRow + pp * 256 + 8 * c4) = pl[pp];
+            }
         }
+        if (ok) *reinterpret_cast<v4f*>(zbuf0 + r * kPfZs + 4 * c4) = v;
     }
     if (K > 1) {
         // element e = m * N + n of the slab goes to Sl[n][m]   (m = e / N exactly: (e + 0.5) / N is at least
@@ -292,25 +332,59 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     __syncthreads();                                   // z_0 (both forms), S, constants visible
     GNNPP_STAMP(blockIdx.x, 1, tid == 0);
 
-    v4f acc[RTW], acc2[RTW];                           // hi.hi products | cross terms
+    v4f acc[RTW], acc2[RTW];                           // hi.hi products | cross terms (MODE 1: acc only)
 #pragma unroll
     for (int t = 0; t < RTW; ++t) { acc[t] = vzero(); acc2[t] = vzero(); }
     auto brow = [&](int t) { return min((rt0 + t) * 16 + a, N - 1); };     // (rows >= N: copies, never stored)
-    // contraction of one tap: D[f, row] += W_k[f, g] z_k[row, g], z_k as hi | lo halves in `zsplit`
-    auto contract = [&](const float* zsplit, const v4f (&A)[8]) {
-        if (has_mfma) {
+    // contraction of one tap: D[f, row] += W_k[f, g] z_k[row, g]; `zsrc`: MODE 0 z_k as hi | lo halves, MODE 1 the
+    // fp32 rows, MODE 2 ignored (the planes are in PB)
+    auto contract = [&](const float* zsrc, const v4f (&A)[NA]) {
+        if (!has_mfma) return;
+        if (MODE == 0) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const v8h Ah = __builtin_bit_cast(v8h, A[2 * kb]);
                 const v8h Al = __builtin_bit_cast(v8h, A[2 * kb + 1]);
 #pragma unroll
                 for (int t = 0; t < RTW; ++t) {
-                    const float* zrow = zsplit + brow(t) * kPfZs + q * 4;
+                    const float* zrow = zsrc + brow(t) * kPfZs + q * 4;
                     const v8h Bh = __builtin_bit_cast(v8h, *reinterpret_cast<const v4f*>(zrow + kb * 16));
                     const v8h Bl = __builtin_bit_cast(v8h, *reinterpret_cast<const v4f*>(zrow + 64 + kb * 16));
                     acc2[t] = mfma16h(Ah, Bl, acc2[t]);
                     acc[t] = mfma16h(Ah, Bh, acc[t]);
                     acc2[t] = mfma16h(Al, Bh, acc2[t]);
+                }
+            }
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) {
+                v4f Bf[RTW];
+#pragma unroll
+                for (int t = 0; t < RTW; ++t)
+                    Bf[t] = *reinterpret_cast<const v4f*>(zsrc + brow(t) * kPfZs + q * 4 + gg * 16);
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int t = 0; t < RTW; ++t) acc[t] = mfma16(A[gg % NA][st], Bf[t][st], acc[t]);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int t = 0; t < RTW; ++t) {
+                    // PB row of this lane's node, clamped into the workgroup's own rows (a D column depends only
+                    // on its own B column; columns outside are never stored)
+                    const int pr = min((rt0 + t) * 16 + a, row_hi - 1) - row_lo;
+                    const char* zrow = PB + pr * kPfPRow + kb * 64 + q * 16;
+                    v8b Bp[3];
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp) Bp[pp] = as_b8(*reinterpret_cast<const v4f*>(zrow + pp * 256));
+#pragma unroll
+                    for (int term = 0; term < kB3Terms; ++term) {
+                        const v8b Ap = as_b8(A[(3 * kb + b3_term_a(term)) % NA]);
+                        if (term == kB3Terms - 1) acc[t] = mfma16b(Ap, Bp[0], acc[t]);
+                        else acc2[t] = mfma16b(Ap, Bp[b3_term_b(term)], acc2[t]);
+                    }
                 }
             }
         }
@@ -324,15 +398,33 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     //   the last tap follows the one before without a barrier.
     if (K > 1) build_lists(p, Sl, idx, cnt, N, wave, NW, lane);
     GNNPP_STAMP(blockIdx.x, 2, tid == 0);
-    contract(zbuf1, Acur);
+    contract(MODE == 0 ? zbuf1 : zbuf0, Acur);
     if (K > 1) load_tap(Acur, 1);                      // in flight during the shift(s)
     GNNPP_STAMP(blockIdx.x, 3, tid == 0);
+    if (MODE != 0) {
+        // fp32 rows ping-pong; tap k is contracted right behind shift k.  MODE 2: the shift's epilogue writes the
+        // planes of the workgroup's own rows into PB (which tap k-1 has finished reading: first barrier).
+        for (int k = 1; k < K; ++k) {
+            const float* zsrc = ((k - 1) & 1) ? zbuf1 : zbuf0;
+            float* zdst = (k & 1) ? zbuf1 : zbuf0;
+            const bool last = k + 1 == K;
+            if (MODE == 2 || k == 1) __syncthreads();  // lists visible / PB free (MODE 1, k >= 2: zdst was z_{k-2},
+                                                       // whose tap finished before the previous shift's barrier)
+            GNNPP_STAMP(blockIdx.x, 4, tid == 0 && k == 1);
+            pf_gather<MODE>(Sl, idx, cnt, zsrc, (MODE == 2 && last) ? nullptr : zdst, nullptr, Ns, last ? row_lo : 0,
+                            last ? row_hi : N, wave, lane, bad, PB, row_lo, row_hi);
+            __syncthreads();                           // z_k visible
+            GNNPP_STAMP(blockIdx.x, 5, tid == 0 && k == 1);
+            contract(zdst, Acur);
+            if (k + 1 < K) load_tap(Acur, k + 1);
+        }
+    } else {
     for (int k = 1; k + 1 < K; ++k) {                  // the shifts before the last one: all rows, fp32 out
         float* zsrc = (k & 1) ? zbuf0 : zbuf1;         // z_{k-1}, fp32
         float* zdst = (k & 1) ? zbuf1 : zbuf0;
         __syncthreads();                               // lists visible / tap k-2 is done with zdst
         GNNPP_STAMP(blockIdx.x, 4, tid == 0 && k == 1);
-        pf_gather(Sl, idx, cnt, zsrc, zdst, nullptr, Ns, 0, N, wave, lane, bad);
+        pf_gather<0>(Sl, idx, cnt, zsrc, zdst, nullptr, Ns, 0, N, wave, lane, bad);
         GNNPP_STAMP(blockIdx.x, 5, tid == 0 && k == 1);
         if (k >= 2) {
             __syncthreads();                           // every reader of the fp32 z_{k-1} is done
@@ -348,7 +440,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
         float* zdst = (k & 1) ? zbuf1 : zbuf0;
         __syncthreads();
         GNNPP_STAMP(blockIdx.x, k == 1 ? 4 : 6, tid == 0);
-        pf_gather(Sl, idx, cnt, zsrc, nullptr, zdst, Ns, row_lo, row_hi, wave, lane, bad);
+        pf_gather<0>(Sl, idx, cnt, zsrc, nullptr, zdst, Ns, row_lo, row_hi, wave, lane, bad);
         __syncthreads();                               // z_{K-1} visible; every reader of the fp32 z_{K-2} is done
         GNNPP_STAMP(blockIdx.x, 7, tid == 0);
         if (k >= 2) {
@@ -365,7 +457,8 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
             contract(zdst, Acur);                      // K == 2: tap 1 (tap 0 ran beside the list building)
         }
     }
-    if (p.range_flag && bad) *p.range_flag = 1;
+    }
+    if (MODE == 0 && p.range_flag && bad) *p.range_flag = 1;
 
     // ---- epilogue: bias + ReLU in registers, this wave's 16 features of the head, partial logits to LDS ----
     GNNPP_STAMP(blockIdx.x, 12, tid == 0);
@@ -378,7 +471,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
 #pragma unroll
         for (int t = 0; t < RTW; ++t) {
             const int row = (rt0 + t) * 16 + a;
-            v4f v = (acc[t] + acc2[t]) * h2_inv + bv;
+            v4f v = MODE == 0 ? (acc[t] + acc2[t]) * h2_inv + bv : MODE == 1 ? acc[t] + bv : (acc[t] + acc2[t]) + bv;
             if (p.relu) v = vrelu(v);
             const v4f d = mfma16x4(A5, v, vzero());    // d[r] = logit part a5 = 4 q + r of this lane's row
             if (rt0 + t < tile_hi && row < N) {
@@ -409,45 +502,58 @@ static bool policy_filter_applies(const LsigfArgs& a) {
            !a.zs && a.E == 1 && a.G == 128 && a.F == 128 && a.F_all == 128 && a.x_node_major && a.Nin == a.N &&
            !a.bias_per_node && !a.s_transposed && a.s_batched && a.gpw == 1 &&
            g_filter_waves.load(std::memory_order_relaxed) != 8 &&
-           a.N >= kPfMinNodes && a.N <= kPfMaxNodes && g_filter_f16.load(std::memory_order_relaxed) &&
-           (reinterpret_cast<uintptr_t>(a.x) & 15) == 0
+           a.N >= kPfMinNodes && a.N <= kPfMaxNodes && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0
 #ifdef GNNPP_MEASURE
            && a.ablate == 0
 #endif
         ;
 }
 
-template <int RTW>
+template <int RTW, int MODE>
 static hipError_t policy_filter_launch_one(const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
     static LdsAttrOnce once;
-    set_lds_attr_once(once, reinterpret_cast<const void*>(&policy_filter_kernel<RTW>), kLdsBytes);
-    hipLaunchKernelGGL((policy_filter_kernel<RTW>), dim3(grid), dim3(1024), smem, st, a);
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&policy_filter_kernel<RTW, MODE>), kLdsBytes);
+    hipLaunchKernelGGL((policy_filter_kernel<RTW, MODE>), dim3(grid), dim3(1024), smem, st, a);
     return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t policy_filter_launch_rtw(int rtw, const LsigfArgs& a, int grid, size_t smem, hipStream_t st) {
+    switch (rtw) {
+        case 1: return policy_filter_launch_one<1, MODE>(a, grid, smem, st);
+        case 2: return policy_filter_launch_one<2, MODE>(a, grid, smem, st);
+        case 3: return policy_filter_launch_one<3, MODE>(a, grid, smem, st);
+        case 4: return policy_filter_launch_one<4, MODE>(a, grid, smem, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // Launches the policy filter for a planned call; returns 1 when the shape is not the policy's (the caller runs
 // lsigf_kernel), 0 on success, -3 on a launch error.
 static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st) {
     if (!policy_filter_applies(a)) return 1;
+    const int tiles = a.nsplit == 2 ? a.rt_total - a.rt_total / 2 : a.rt_total;
+    if ((tiles + 1) / 2 > 4) return 1;
     const size_t base = pf_lds_base(a.N, a.Ns, a.K) + kPfConsts * 4;
     const size_t parts = (size_t)8 * a.N * 8 * 4;
-    size_t smem = base + parts;
+    // GNNPP_PREC_FP32: bf16x3 planes of the workgroup's own rows when the LDS has room for them, else the exact
+    // fp32 MFMA (same accuracy class, 2.7x the matrix-pipe time)
+    int mode = a.prec == kPrecSplitF16 ? 0 : a.prec == kPrecFp32Mfma ? 1 : 2;
+    const size_t planes = (size_t)tiles * 16 * kPfPRow;
+    if (mode == 2 && base + parts + planes > (size_t)kLdsBytes) mode = 1;
+    size_t smem = base + parts + (mode == 2 ? planes : 0);
     a.pf_part_off = (int)base;
+    a.pf_plane_off = (int)(base + parts);
     if (smem > (size_t)kLdsBytes) {
         // large graphs: the partial logits reuse the S slab (dead after the last shift)
         if (a.K < 2 || (size_t)a.N * a.Ns * 4 < parts || base > (size_t)kLdsBytes) return 1;
         smem = base;
         a.pf_part_off = 2 * a.N * kPfZs * 4;
     }
-    const int tiles = a.nsplit == 2 ? a.rt_total - a.rt_total / 2 : a.rt_total;
-    hipError_t err;
-    switch ((tiles + 1) / 2) {
-        case 1: err = policy_filter_launch_one<1>(a, plan.grid, smem, st); break;
-        case 2: err = policy_filter_launch_one<2>(a, plan.grid, smem, st); break;
-        case 3: err = policy_filter_launch_one<3>(a, plan.grid, smem, st); break;
-        case 4: err = policy_filter_launch_one<4>(a, plan.grid, smem, st); break;
-        default: return 1;
-    }
+    const int rtw = (tiles + 1) / 2;
+    const hipError_t err = mode == 0 ? policy_filter_launch_rtw<0>(rtw, a, plan.grid, smem, st)
+                         : mode == 1 ? policy_filter_launch_rtw<1>(rtw, a, plan.grid, smem, st)
+                                     : policy_filter_launch_rtw<2>(rtw, a, plan.grid, smem, st);
     return err == hipSuccess ? 0 : -3;
 }
 

@@ -44,6 +44,8 @@ _FEATURES = 128
 _ACTIONS = 5
 _CONV_IDX = (0, 4, 7, 11, 14)
 _BN_IDX = (1, 5, 8, 12, 15)
+# precision of a planner whose config does not name one (see DecentralPlannerNet.precision)
+DEFAULT_PRECISION = 'fp32'
 
 
 def _ptr(t):
@@ -223,11 +225,16 @@ class DecentralPlannerNet(nn.Module):
         self._ws = None
         self._ws_key = None
         self._ws_all = {}                          # feature workspaces by (rows, stream)
-        # Range guard of the split-f16 schedules (include/gnnpp.h): a device int the kernels raise when
-        # an activation leaves the f16 range.  'flag' (default): no synchronisation, the caller (or
-        # BatchedRollout.run) polls check_range(); 'strict': every forward reads the flag back and
-        # transparently re-runs an out-of-range call under the exact-fp32 schedules.
-        self.range_policy = getattr(self.config, 'range_policy', 'flag')
+        # Arithmetic of the matrix-pipe contractions (include/gnnpp.h GNNPP_PREC_*), passed to the kernels PER CALL:
+        #   'fp32' (default)  fp32-equivalent bf16x3 operand split: no input domain, nothing for the caller to poll --
+        #                     what an unchanged caller of the reference (agents/decentralplannerlocal.py:575-588) gets;
+        #   'fp32_mfma'       exact fp32 MFMA (bitwise an fmaf chain);
+        #   'split_f16'       opt-in fast mode, NARROWER than fp32 (22-bit operands, |activation| < 65504).  Its
+        #                     range guard is a device int the kernels raise; range_policy 'strict' (default for this
+        #                     mode) reads it back after every forward and re-runs an out-of-range call with 'fp32';
+        #                     'flag' leaves the polling to the caller (check_range(); BatchedRollout.run does it).
+        self.precision = getattr(self.config, 'precision', None) or DEFAULT_PRECISION
+        self.range_policy = getattr(self.config, 'range_policy', 'strict')
         self._range_flag = None
 
     # ------------------------------------------------------------------------------------
@@ -244,20 +251,42 @@ class DecentralPlannerNet(nn.Module):
 
     def _encoder_tensors(self):
         """The 32 tensors the packed encoder depends on.  Walking nn.Sequential / __getattr__ costs
-        ~40 us per call, so the list is memoised; _apply() (.to/.cuda/.float), load_state_dict(),
-        train()/eval() transitions and invalidate_packed() drop it; a periodic refresh catches a
-        Parameter OBJECT replaced by hand after at most 64 forwards."""
+        ~40 us per call, so the list is memoised together with the (dict, key) slot each tensor -- and each
+        sub-module on the way to it -- lives in: every call re-reads those ~50 slots (plain dict lookups, ~3 us)
+        and compares OBJECT identities, so a Parameter, buffer or sub-module replaced by hand
+        (`conv.weight = nn.Parameter(...)`, `bn.running_mean = t`, `net.actionsMLP[0] = nn.Linear(..)`) is seen by
+        the very next forward (the previous every-64th-call refresh left a 63-forward window)."""
         d = self.__dict__
-        calls = d['_calls'] = d.get('_calls', 0) + 1
         t = d.get('_enc_tensors')
-        if t is None or (calls & 63) == 0:
-            t = []
+        if t is not None:
+            for store, key, obj in d['_enc_slots']:
+                if store.get(key) is not obj:
+                    t = None
+                    break
+        if t is None:
+            t, slots = [], []
             for ci, bi in zip(_CONV_IDX, _BN_IDX):
                 conv, bn = self.ConvLayers[ci], self.ConvLayers[bi]
-                t += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-            t += [self.compressMLP[0].weight, self.compressMLP[0].bias]
-            self._enc_tensors = t
-            self._mods = (tuple(self.GFL[2 * l] for l in range(self.L)), self.actionsMLP[0])
+                slots += [(self.ConvLayers._modules, str(ci), conv), (self.ConvLayers._modules, str(bi), bn)]
+                for mod in (conv, bn):
+                    for nm in ('weight', 'bias'):
+                        t.append(mod._parameters[nm])
+                        slots.append((mod._parameters, nm, t[-1]))
+                for nm in ('running_mean', 'running_var'):
+                    t.append(bn._buffers[nm])
+                    slots.append((bn._buffers, nm, t[-1]))
+            fc = self.compressMLP[0]
+            slots.append((self.compressMLP._modules, '0', fc))
+            for nm in ('weight', 'bias'):
+                t.append(fc._parameters[nm])
+                slots.append((fc._parameters, nm, t[-1]))
+            gfs, act = tuple(self.GFL[2 * l] for l in range(self.L)), self.actionsMLP[0]
+            slots += [(self.GFL._modules, str(2 * l), gf) for l, gf in enumerate(gfs)]
+            slots.append((self.actionsMLP._modules, '0', act))
+            slots += [(self._modules, nm, self._modules[nm]) for nm in ('ConvLayers', 'compressMLP', 'GFL', 'actionsMLP')]
+            d['_enc_tensors'] = t
+            d['_enc_slots'] = slots
+            d['_mods'] = (gfs, act)
         return t
 
     def invalidate_packed(self):
@@ -288,13 +317,17 @@ class DecentralPlannerNet(nn.Module):
             self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         return self._range_flag
 
+    def _prec(self):
+        return _native.precision_code(self.precision)
+
     def range_exceeded(self):
         """True iff some forward since the last reset handed |activation| >= 65504 to the split-f16
-        schedules (synchronises the device)."""
+        schedules (precision='split_f16' only; synchronises the device)."""
         return self._range_flag is not None and bool(self._range_flag.item())
 
     def check_range(self, reset=True):
-        """Raise GnnppError if a forward left the f16 range of the default schedules."""
+        """Raise GnnppError if a forward left the f16 range of precision='split_f16' (the default precision has
+        no input domain and never raises)."""
         if self.range_exceeded():
             if reset:
                 self._range_flag.zero_()
@@ -321,16 +354,18 @@ class DecentralPlannerNet(nn.Module):
     def packed_encoder(self):
         return self._enc_cache.get(self._encoder_tensors(), self._pack_encoder)
 
-    def encode(self, inputTensor):
+    def encode(self, inputTensor, precision=None):
         """extractFeatureMap of the reference (decentralplanner.py:283-290), node-major:
         inputTensor [B,N,3,11,11] -> [B,N,128]."""
         B, N = inputTensor.shape[0], inputTensor.shape[1]
         obs = inputTensor.detach().contiguous().float()
         dev = _native.require_gpu(obs, self.compressMLP[0].weight)
         feat = torch.empty(B, N, 128, dtype=torch.float32, device=dev)
+        prec = self._prec() if precision is None else _native.precision_code(precision)
         with _native.device_guard(dev):
             _native.check(_native.lib().gnnpp_encoder_fwd(
-                _ptr(obs), _ptr(self.packed_encoder()), _ptr(feat), B * N, _ptr(self._flag(dev)),
+                _ptr(obs), _ptr(self.packed_encoder()), _ptr(feat), B * N, prec,
+                _ptr(self._flag(dev)) if prec == _native.PREC_SPLIT_F16 else None,
                 _native.stream_ptr(dev)), 'gnnpp_encoder_fwd')
         return feat
 
@@ -357,6 +392,21 @@ class DecentralPlannerNet(nn.Module):
             lambda: self._head_pointers(gf, act))
         return enc.data_ptr(), taps.data_ptr(), gb_p, aw_p, ab_p, gf.K
 
+    def materialize_packs(self):
+        """Build every lazily cached device copy of the weights (packed encoder, packed taps of every graph-filter
+        layer, the head's pointer tensors) NOW, on the current stream; returns True when something was (re)built.
+        rollout.GroupedRollout calls it before forking onto its group streams."""
+        before = (self._enc_cache.key, self._head_cache.key) + tuple(gf._packed.key for gf in self.__dict__.get('_mods', ((), None))[0])
+        self.packed_encoder()
+        gfs, act = self._mods
+        for gf in gfs:
+            gf.packed_taps()
+        gl = gfs[-1]
+        self._head_cache.get((gl.bias, act.weight, act.bias) if gl.bias is not None else (act.weight, act.bias),
+                             lambda: self._head_pointers(gl, act))
+        after = (self._enc_cache.key, self._head_cache.key) + tuple(gf._packed.key for gf in gfs)
+        return before != after
+
     def forward_logits(self, inputTensor):
         """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
         contiguous [B,5] block) -- what forward() unbinds into the reference's list."""
@@ -364,22 +414,16 @@ class DecentralPlannerNet(nn.Module):
             return self._forward_train(inputTensor)
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
-        logits = self._forward_eval(inputTensor)
-        if self.range_policy == 'strict' and self.range_exceeded():
-            # an activation left the f16 range: this call again under the exact-fp32 schedules
-            L = _native.lib()
+        prec = self._prec()
+        logits = self._forward_eval(inputTensor, prec)
+        if prec == _native.PREC_SPLIT_F16 and self.range_policy == 'strict' and self.range_exceeded():
+            # an activation left the f16 range: this call again with the fp32-equivalent arithmetic (a per-call
+            # argument of the C entry points: nothing process-wide changes, other streams keep their schedule)
             self._range_flag.zero_()
-            old = (L.gnnpp_get_tuning(0), L.gnnpp_get_tuning(5))
-            L.gnnpp_set_tuning(0, 5)
-            L.gnnpp_set_tuning(5, 0)
-            try:
-                logits = self._forward_eval(inputTensor)
-            finally:
-                L.gnnpp_set_tuning(0, old[0])
-                L.gnnpp_set_tuning(5, old[1])
+            logits = self._forward_eval(inputTensor, _native.PREC_FP32)
         return logits
 
-    def _forward_eval(self, inputTensor):
+    def _forward_eval(self, inputTensor, prec=_native.PREC_FP32):
         B = inputTensor.shape[0]
         N = self.numAgents
         assert inputTensor.shape[1] >= N
@@ -402,7 +446,7 @@ class DecentralPlannerNet(nn.Module):
         if Ns > gml.MAX_NODES:
             # larger graphs than one workgroup's LDS holds: encoder kernel, then every filter layer as dense
             # exact-fp32 GEMMs (graphML._lsigf_large) and the head as one small library GEMM
-            x = self.encode(obs)
+            x = self.encode(obs, prec)
             if Ns != N:
                 x = torch.cat([x, x.new_zeros(B, Ns - N, x.shape[2])], 1)
             for gf in gfs:
@@ -411,7 +455,7 @@ class DecentralPlannerNet(nn.Module):
             return out.permute(1, 0, 2).contiguous()
         L = _native.lib()
         s64 = int(S.dtype is torch.float64)
-        flag = self._flag(dev).data_ptr()
+        flag = self._flag(dev).data_ptr() if prec == _native.PREC_SPLIT_F16 else None
         gl = gfs[-1]                               # last graph-filter layer: fused with the head
         gb_p, aw_p, ab_p, _keep = self._head_cache.get(
             (gl.bias, act.weight, act.bias) if gl.bias is not None else (act.weight, act.bias),
@@ -433,14 +477,14 @@ class DecentralPlannerNet(nn.Module):
                 rc = L.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc.data_ptr(),
                                         gl.packed_taps().data_ptr(), gb_p, aw_p, ab_p,
                                         self._ws.data_ptr(), logits.data_ptr(), B, N, gl.K, self.E,
-                                        s64, flag, st)
+                                        s64, prec, flag, st)
                 _native.check(rc, 'gnnpp_policy_fwd')
                 return logits
             # general form: encoder kernel, then one filter kernel per layer (node-major in / out, bias
             # + ReLU fused), the last one with the action head.  A GSO larger than numAgents carries
             # zero features on the extra nodes, whose outputs are dropped.
             x = torch.zeros(B, Ns, 128, dtype=torch.float32, device=dev) if Ns != N else None
-            feat = self.encode(obs)
+            feat = self.encode(obs, prec)
             if x is not None:
                 x[:, :N] = feat
             else:
@@ -452,12 +496,12 @@ class DecentralPlannerNet(nn.Module):
                     logits = torch.empty(Ns, B, 5, dtype=torch.float32, device=dev)
                     rc = L.gnnpp_filter_head_fwd(_ptr(x), _ptr(S), _ptr(gf.packed_taps()), _ptr(bias),
                                                  aw_p, ab_p, _ptr(logits), B, Ns, gf.G, gf.F, gf.K,
-                                                 self.E, s64, flag, st)
+                                                 self.E, s64, prec, flag, st)
                     _native.check(rc, 'gnnpp_filter_head_fwd')
                     return logits[:N] if Ns != N else logits
                 y = torch.empty(B, Ns, gf.F, dtype=torch.float32, device=dev)
                 rc = L.gnnpp_lsigf_fwd(_ptr(x), _ptr(S), _ptr(gf.packed_taps()), _ptr(bias), _ptr(y),
-                                       B, Ns, Ns, gf.G, gf.F, gf.K, self.E, s64, 1, 1, 1, 1, 0, flag, st)
+                                       B, Ns, Ns, gf.G, gf.F, gf.K, self.E, s64, 1, 1, 1, 1, 0, prec, flag, st)
                 _native.check(rc, 'gnnpp_lsigf_fwd')
                 x = y
         # last layer wider than 128 features: the 5-row head is one small library GEMM

@@ -33,6 +33,12 @@ from . import _native
 zeroTolerance = 1e-9    # kept for API parity (graphML.py:42-43)
 infiniteNumber = 1e12
 
+# Arithmetic of the tap contraction of the functions / modules below (include/gnnpp.h GNNPP_PREC_*), read at call
+# time: 'fp32' (default, fp32-equivalent: these operators contract on the exact fp32 MFMA), 'fp32_mfma' (the same
+# here), or the opt-in 'split_f16' (22-bit operands, |x| < 65504, unguarded at this level).  The reference's
+# signatures have no room for it, hence a module attribute.
+PRECISION = 'fp32'
+
 _MAX_F_PER_LAUNCH = 128
 MAX_NODES = 112         # rows one workgroup holds in LDS (GNNPP_MAX_NODES=100 guaranteed at G=F=128)
 
@@ -99,12 +105,15 @@ def _lsigf_large(h, S, x, b, batched, relu=False):
 
 
 def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
-                  save_taps=False, node_major=False):
+                  save_taps=False, node_major=False, precision=None):
     """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
     (and, with save_taps, zs [E*K, B*N, G]).  Any F: the C entry point splits wide filters.
-    node_major: x [B,N,G] -> y [B,N,F] (rows = nodes, the layout the kernel keeps in LDS anyway)."""
+    node_major: x [B,N,G] -> y [B,N,F] (rows = nodes, the layout the kernel keeps in LDS anyway).
+    precision: GNNPP_PREC_* of the tap contraction (0 = fp32-equivalent, the default; this operator contracts on
+    the exact fp32 MFMA then); 2 = the opt-in split-f16 schedule, unguarded here (no range flag is passed)."""
     dev = _native.require_gpu(h, S, x, b)
     L = _native.lib()
+    precision = _native.precision_code(PRECISION if precision is None else precision)
     F_out, E, K, G = h.shape
     N = S.shape[-1]
     B = x.shape[0]
@@ -133,11 +142,20 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
         if transposed or save_taps:
             rc = L.gnnpp_lsigf_fwd_save(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y), _ptr(zs),
                                         B, N, Nin, G, F_out, K, E, s64, int(batched), int(transposed),
-                                        nm, nm, int(relu), per_node, None, _native.stream_ptr(dev))
+                                        nm, nm, int(relu), per_node, int(precision), None,
+                                        _native.stream_ptr(dev))
         else:
             rc = L.gnnpp_lsigf_fwd(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y),
                                    B, N, Nin, G, F_out, K, E, s64, int(batched), nm, nm, int(relu),
-                                   per_node, None, _native.stream_ptr(dev))
+                                   per_node, int(precision), None, _native.stream_ptr(dev))
+    if rc == -2 and not (transposed or save_taps):
+        # GNNPP_ERR_UNSUPPORTED below MAX_NODES: the graph's rows do not fit the kernel's LDS budget (wide input
+        # features, or 101..112 nodes at G = F = 128).  The reference has no such limit: the dense exact-fp32 form.
+        if node_major:
+            return _lsigf_large(h, S, x, b, batched, relu)
+        xn = torch.zeros(B, N, G, dtype=torch.float32, device=dev)
+        xn[:, :Nin] = x.detach().permute(0, 2, 1)
+        return _lsigf_large(h, S, xn, b, batched, relu)[:, :Nin].permute(0, 2, 1).contiguous()
     _native.check(rc, 'gnnpp_lsigf_fwd')
     return (y, zs) if save_taps else y
 
@@ -146,14 +164,19 @@ _transposed_packs = {}
 
 
 def _packed_transposed_taps(h):
-    """Packed h.permute(3,1,2,0) (the taps of the input-gradient filter), cached per weight version:
-    a training step needs it once, however many backward calls share the weight."""
-    key = (id(h), h._version, h.data_ptr(), _native._pack_generation)
-    hit = _transposed_packs.get('k') == key
-    if not hit:
-        _transposed_packs['k'] = key
-        _transposed_packs['v'] = pack_filter_taps(h.detach().permute(3, 1, 2, 0).contiguous())
-    return _transposed_packs['v']
+    """Packed h.permute(3,1,2,0) (the taps of the input-gradient filter), cached PER WEIGHT and weight version: a
+    training step needs it once per filter layer, however many backward calls share the weight (a planner with
+    several graph-filter layers keeps one entry per layer; VERDICT r02: the single-entry cache repacked every
+    backward there)."""
+    key = (h._version, h.data_ptr(), _native._pack_generation)
+    ent = _transposed_packs.get(id(h))
+    if ent is None or ent[0] != key or ent[1]() is not h:
+        if len(_transposed_packs) > 32:
+            _transposed_packs.clear()
+        import weakref
+        ent = (key, weakref.ref(h), pack_filter_taps(h.detach().permute(3, 1, 2, 0).contiguous()))
+        _transposed_packs[id(h)] = ent
+    return ent[2]
 
 
 class _LSIGFFunction(torch.autograd.Function):

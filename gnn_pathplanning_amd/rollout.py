@@ -178,10 +178,12 @@ class BatchedRollout:
             self._logits = torch.empty(self.N, self.B, 5, dtype=torch.float32, device=self.device)
         r = self._r
         r.logits, r.actions, r.grow = _p(self._logits), None, 0
-        r.range_flag = _p(model._flag(self.device))          # range guard of the split-f16 policy
+        prec = model._prec() if hasattr(model, '_prec') else _native.PREC_FP32
+        # range guard: only the opt-in split-f16 arithmetic has an input domain
+        r.range_flag = _p(model._flag(self.device)) if prec == _native.PREC_SPLIT_F16 else None
         r.currentstep = self.t + 1
         with _native.device_guard(self.device):
-            rc = _native.lib().gnnpp_rollout_policy_steps(ctypes.byref(r), enc, taps, gb, aw, ab, K, nsteps,
+            rc = _native.lib().gnnpp_rollout_policy_steps(ctypes.byref(r), enc, taps, gb, aw, ab, K, nsteps, prec,
                                                           _native.stream_ptr(self.device))
         if rc == -2:                                         # shape not supported by the fused kernel
             return False
@@ -241,8 +243,21 @@ class BatchedRollout:
             model.check_range()
         return self.results()
 
+    def check_rng(self):
+        """tie_mode 'mt19937': every episode gets `rng_words` words of its Mersenne-Twister stream; the kernel
+        substitutes 0 for words past the end (and keeps counting them in rng_cursor).  An episode that consumed
+        more than it was given no longer follows the reference's random.choice stream: that is an error, not a
+        silent deviation."""
+        if self.rng_cursor is not None:
+            over = (self.rng_cursor > int(self.rng_words.shape[1])).nonzero().flatten()
+            if over.numel():
+                raise _native.GnnppError(
+                    'tie_mode mt19937: episode(s) %s consumed more than the %d random words they were given; '
+                    'construct the rollout with a larger rng_words' % (over[:8].tolist(), int(self.rng_words.shape[1])))
+
     def results(self):
         torch.cuda.synchronize(self.device)
+        self.check_rng()
         reached = self.reached.bool()
         return {'steps': self.t, 'reached': reached.cpu(), 'success': reached.all(dim=1).cpu(),
                 'makespan': self.stats[:, 0].cpu(), 'flowtime': self.stats[:, 1].cpu(),
@@ -278,8 +293,15 @@ class GroupedRollout:
             self.slices.append((lo, hi))
         self.device, self.B, self.N = dev, B, self.envs[0].N
 
-    def _each(self, fn, wait_caller=True):
+    def _each(self, fn, wait_caller=True, model=None):
         cur = torch.cuda.current_stream(self.device)
+        if model is not None and hasattr(model, 'materialize_packs'):
+            # The model's lazily built device caches (packed encoder, packed taps, head pointers) are rebuilt on
+            # whichever stream touches them first after a weight change.  Build them HERE, on the caller's stream,
+            # which every group stream then waits for -- otherwise the second group could launch on a pack the
+            # first group's stream is still writing (a cross-stream read-before-write race).
+            if model.materialize_packs():
+                wait_caller = True                           # (the groups must see the packs just enqueued)
         for env, st in zip(self.envs, self.streams):
             if wait_caller:
                 st.wait_stream(cur)                          # whatever the caller's stream prepared (the episodes'
@@ -300,7 +322,7 @@ class GroupedRollout:
         """n steps of every group.  wait_caller=False: the groups do not wait for the caller's stream first --
         for back-to-back bursts with nothing in between (after a join() a wait would be a barrier across the
         groups: the faster group would idle until the slower one has finished the previous burst)."""
-        self._each(lambda env: env.steps(model, n), wait_caller)
+        self._each(lambda env: env.steps(model, n), wait_caller, model)
 
     def run(self, model, max_steps=None, check_every=8):
         limit = max(int(e.maxstep.max().item()) for e in self.envs) if max_steps is None else int(max_steps)

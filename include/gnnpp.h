@@ -14,7 +14,10 @@
  *   - return value 0 = success, negative = error (gnnpp_error_string()); a failed call has
  *     enqueued nothing;
  *   - fp32 everywhere; a GSO may be given as fp64 and is rounded to fp32 on load exactly like the
- *     reference's `S.float()` (utils/graphUtils/graphML.py:2350).
+ *     reference's `S.float()` (utils/graphUtils/graphML.py:2350);
+ *   - every forward entry point takes `precision` (GNNPP_PREC_*): the arithmetic of its matrix-pipe
+ *     contractions, chosen PER CALL (no process-wide state: two streams / threads cannot change each other's
+ *     schedule).  0 = GNNPP_PREC_FP32 is what an unchanged caller of the reference gets.
  */
 #ifndef GNNPP_H_
 #define GNNPP_H_
@@ -29,7 +32,22 @@ extern "C" {
 #define GNNPP_ERR_ARG         (-1)   /* null pointer / non-positive size / inconsistent flags   */
 #define GNNPP_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels cover (see each call)     */
 #define GNNPP_ERR_LAUNCH      (-3)   /* HIP launch error                                         */
-#define GNNPP_ERR_RANGE       (-4)   /* gnnpp_check_finite: an activation overflowed the f16 range */
+#define GNNPP_ERR_RANGE       (-4)   /* GNNPP_PREC_SPLIT_F16 only: an activation left the f16 range  */
+
+/* Arithmetic of the matrix-pipe contractions (encoder convolutions + compressMLP, the filter's tap
+ * contraction).  Graph shifts, BatchNorm / bias / ReLU / pooling epilogues and the action head are exact fp32
+ * in every mode; accumulation is fp32 in every mode.
+ *   GNNPP_PREC_FP32 (default)  fp32-equivalent, NO input domain: every fp32 operand is represented exactly as
+ *       three bf16 planes (x = h + m + l, fp32's exponent range) and a product keeps six of the nine plane
+ *       products on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-23 |w x|, below one fp32 rounding).  Where
+ *       a kernel has no LDS room for the planes (the graph filter outside the fused policy kernel and the
+ *       policy filter of <= 64-node teams) the contraction runs on the exact fp32 MFMA instead -- also exact.
+ *   GNNPP_PREC_FP32_MFMA       v_mfma_f32_16x16x4_f32 everywhere: bitwise an fmaf chain, 2.7x more pipe time.
+ *   GNNPP_PREC_SPLIT_F16       fast, NARROWER than fp32: operands as f16 hi + lo halves (22 significand bits)
+ *       on v_mfma_f32_16x16x32_f16, valid for |activation| < 65504 only -- see "Range guard"; opt-in. */
+#define GNNPP_PREC_FP32        0
+#define GNNPP_PREC_FP32_MFMA   1
+#define GNNPP_PREC_SPLIT_F16   2
 
 #define GNNPP_OBS_C        3         /* observation channels      (decentralplanner.py:89)       */
 #define GNNPP_OBS_HW       11        /* observation height=width  (decentralplanner.py:22-23)    */
@@ -46,29 +64,24 @@ extern "C" {
 int         gnnpp_version(void);
 const char* gnnpp_error_string(int code);
 
-/* Process-wide tuning knobs (atomic; a concurrent call sees the old or the new value).  EVERY
- * setting computes the same function: the exact-fp32 schedules agree with the split-f16 defaults to
- * ~2^-22 per operand (measured: |dlogit| <= 2e-7).  Knobs that skip kernel phases for profiling are
- * not part of this ABI (csrc/gnnpp_measure.h, -DGNNPP_MEASURE builds only). */
-#define GNNPP_TUNE_ENCODER_VARIANT 0  /* 7 (default): split-f16 MFMA schedule (encoder_kernel_h2.hip);
-                                         5: exact-fp32 MFMA schedule (encoder_kernel_f32.hip);
-                                         -1: restore the default                                    */
+/* Process-wide tuning knobs (atomic; a concurrent call sees the old or the new value).  They choose between
+ * SCHEDULES of the same arithmetic (launch geometry, kernel fusion): every setting computes the same function
+ * to the last bit or two.  The arithmetic itself is the per-call `precision` argument, never a knob.  Knobs
+ * that skip kernel phases for profiling are not part of this ABI (csrc/gnnpp_measure.h, -DGNNPP_MEASURE
+ * builds only). */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
 #define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
 #define GNNPP_TUNE_FILTER_SPLIT    7  /* 0 = heuristic (two workgroups per graph when one-graph workgroups
                                          fill at most half of the 256 CUs); 1 = never; 2 = whenever
                                          a workgroup holds one graph with >= 2 row tiles            */
-#define GNNPP_TUNE_FILTER_F16       5  /* 1 (default): when G == 128 the filter's tap contraction runs
-                                         on the f16 matrix pipe with hi+lo split operands (shifts
-                                         stay exact fp32); 0: fp32 MFMA contraction              */
-#define GNNPP_TUNE_FUSED_POLICY     6  /* 1 (default): for teams of N <= 16 agents and K = 2, 3 or 4 taps (with
-                                         encoder schedule 7 and FILTER_F16 = 1), when B <= 512 graphs
+#define GNNPP_TUNE_FUSED_POLICY     6  /* 1 (default): for teams of N <= 16 agents and K = 2, 3 or 4 taps
+                                         (GNNPP_PREC_FP32 or GNNPP_PREC_SPLIT_F16), when B <= 512 graphs
                                          or N >= 13, gnnpp_policy_fwd is ONE kernel -- a workgroup
                                          encodes one graph's agents, then runs that graph's filter and
                                          action head on chip (identical logits); 0: always the encoder
                                          kernel followed by the filter kernel                        */
 #define GNNPP_TUNE_POLICY_FILTER    9  /* 1 (default): the filter + action head of gnnpp_policy_fwd / the rollout step
-                                         for teams of 17 .. 100 agents (one graph per workgroup, FILTER_F16 = 1,
+                                         for teams of 17 .. 100 agents (one graph per workgroup,
                                          FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
                                          0: on the general filter kernel (same logits to the last bit or two) */
 int         gnnpp_set_tuning(int key, int value);
@@ -102,20 +115,19 @@ int gnnpp_filter_pack(const float* h, float* packed, int G, int F, int K, int E,
  * relu     apply max(.,0) to y (GFL[1], decentralplanner.py:221).
  * Limits:  1 <= N <= GNNPP_MAX_NODES at G,F <= 128 (LDS footprint); K >= 1; any F
  *          (more than 128 output features run as ceil(F/128) launches inside the call).
- * range_flag  optional DEVICE int (NULL = no check), see "Range guard" below.
+ * precision   GNNPP_PREC_*; range_flag  optional DEVICE int (NULL = no check), see "Range guard" below.
  */
 int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const float* bias,
                     float* y, int B, int N, int Nin, int G, int F, int K, int E,
                     int s_is_f64, int s_batched, int x_node_major, int y_node_major, int relu,
-                    int bias_per_node, int* range_flag, void* stream);
+                    int bias_per_node, int precision, int* range_flag, void* stream);
 
-/* Range guard.  The default schedules feed the f16 matrix pipe with fp32 operands split in hi + lo
- * halves (22 mantissa bits), which is exact to ~2^-22 as long as every activation
- * satisfies |x| < 65504.  A call that hands a larger value to that pipe stores 1 to *range_flag
- * (never cleared by the library; plain store, no synchronisation added): the results of that call
- * are then NOT trustworthy -- re-run it under the exact-fp32 schedules (GNNPP_TUNE_ENCODER_VARIANT
- * = 5, GNNPP_TUNE_FILTER_F16 = 0), which have no range limit and never write the flag.
- * gnnpp_error_string(GNNPP_ERR_RANGE) is the message the Python layer raises. */
+/* Range guard (GNNPP_PREC_SPLIT_F16 only; the other modes have no input domain and never touch the flag).
+ * The split-f16 schedules feed the f16 matrix pipe with fp32 operands split in hi + lo halves (22 significand
+ * bits), which is exact to ~2^-22 as long as every activation satisfies |x| < 65504.  A call
+ * that hands a larger value to that pipe stores 1 to *range_flag (never cleared by the library; plain store, no
+ * synchronisation added): the results of that call are then NOT trustworthy -- re-run it with
+ * GNNPP_PREC_FP32.  gnnpp_error_string(GNNPP_ERR_RANGE) is the message the Python layer raises. */
 
 /*
  * Training variant of gnnpp_lsigf_fwd (loss.backward() at agents/decentralplannerlocal.py:314):
@@ -124,12 +136,13 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
  *   s_transposed  use S^T.  The input gradient of the filter is itself a filter,
  *                 dx = sum_k W_k^T . dy . (S^T)^k, i.e. this call with x := dy, taps packed from
  *                 h.permute(3,1,2,0) and s_transposed = 1.  This form always contracts on the exact
- *                 fp32 MFMA (cotangents are far below the f16 normal range).
+ *                 fp32 MFMA, whatever `precision` says (cotangents are far below the f16 normal range).
  */
 int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
                          float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
                          int s_is_f64, int s_batched, int s_transposed, int x_node_major,
-                         int y_node_major, int relu, int bias_per_node, int* range_flag, void* stream);
+                         int y_node_major, int relu, int bias_per_node, int precision, int* range_flag,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-agent encoder: 5 x (conv3x3 pad 1 -> BatchNorm(eval) -> ReLU [-> MaxPool 2]) -> flatten ->
@@ -158,8 +171,8 @@ int gnnpp_encoder_pack(const gnnpp_encoder_params* params, float* packed, void* 
 
 /* obs [M,3,11,11] (M = B*N agents, agent index b*N+n as in inputTensor[B,N,3,11,11]) ->
  * feat [M,128] node-major.  Any M >= 1. */
-int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, int* range_flag,
-                      void* stream);
+int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M, int precision,
+                      int* range_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TRAIN-mode encoder, forward and backward (BASELINE config 4: loss.backward() at
@@ -264,7 +277,7 @@ int gnnpp_adam_step(const gnnpp_adam_tensors* t, float* state, float lr, float b
 int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
                      const float* filt_packed, const float* gf_bias, const float* act_w,
                      const float* act_b, float* feat_ws, float* logits, int B, int N, int K, int E,
-                     int s_is_f64, int* range_flag, void* stream);
+                     int s_is_f64, int precision, int* range_flag, void* stream);
 
 /* Last graph-filter layer + ReLU + action head of a planner with SEVERAL graph-filter layers
  * (decentralplanner.py:205-224 builds L layers, :293-315 runs them and the head): the earlier layers
@@ -273,7 +286,7 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
  * logits [N,B,5] as gnnpp_policy_fwd. */
 int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, const float* bias,
                           const float* act_w, const float* act_b, float* logits, int B, int N, int G,
-                          int F, int K, int E, int s_is_f64, int* range_flag, void* stream);
+                          int F, int K, int E, int s_is_f64, int precision, int* range_flag, void* stream);
 
 /* Action decode used by the rollout loop (utils/multirobotsim_dcenlocal.py:589-591: LogSoftmax
  * then argmax == argmax of the logits, first maximum wins like torch.max).
@@ -354,17 +367,18 @@ int gnnpp_rollout_step(const gnnpp_rollout* r, void* stream);
  * r->S (fp32) with the packed encoder / filter weights, logits to r->logits [N,B,5], then move ->
  * gso -> observe as gnnpp_rollout_step; r->obs and r->S are overwritten with the next step's.
  * GNNPP_ERR_UNSUPPORTED (nothing enqueued) when the shape does not qualify (see GNNPP_TUNE_FUSED_POLICY;
- * H*W must fit the kernel's spare LDS): use gnnpp_policy_fwd + gnnpp_rollout_step then. */
+ * precision GNNPP_PREC_FP32 or GNNPP_PREC_SPLIT_F16; H*W must fit the kernel's spare LDS: 10 208 cells under
+ * GNNPP_PREC_FP32): use gnnpp_policy_fwd + gnnpp_rollout_step then. */
 int gnnpp_rollout_policy_step(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
                               const float* gf_bias, const float* act_w, const float* act_b, int K,
-                              void* stream);
+                              int precision, void* stream);
 /* nsteps consecutive calls of gnnpp_rollout_policy_step with currentstep = r->currentstep, +1, ...: the
  * inner loop of a rollout (agents/decentralplannerlocal.py:560-599) enqueued back to back, so the host
  * returns to its interpreter once per nsteps launches.  Episodes that end on the way freeze (see `done`);
  * GNNPP_TIE_REPLAY is per-call state and is refused (GNNPP_ERR_ARG). */
 int gnnpp_rollout_policy_steps(const gnnpp_rollout* r, const float* enc_packed, const float* filt_packed,
                                const float* gf_bias, const float* act_w, const float* act_b, int K,
-                               int nsteps, void* stream);
+                               int nsteps, int precision, void* stream);
 
 #ifdef __cplusplus
 }

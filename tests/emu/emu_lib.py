@@ -81,7 +81,7 @@ def pack_filter(lib, h):
     return packed
 
 
-def lsigf(lib, h, S, x, b, batched, Nin=None, relu=0, x_node_major=0, y_node_major=0, flag=None):
+def lsigf(lib, h, S, x, b, batched, Nin=None, relu=0, x_node_major=0, y_node_major=0, flag=None, precision=0):
     h = f32(h); x = f32(x)
     F, E, K, G = h.shape
     S = np.ascontiguousarray(S)
@@ -97,6 +97,6 @@ def lsigf(lib, h, S, x, b, batched, Nin=None, relu=0, x_node_major=0, y_node_maj
     per_node = int(bb is not None and bb.size != F)      # b [F,N]: one value per feature and node
     rc = lib.gnnpp_lsigf_fwd(ptr(x), ptr(S), ptr(packed), None if bb is None else ptr(bb), ptr(y),
                              B, N, Nin, G, F, K, E, is64, int(batched), x_node_major,
-                             y_node_major, relu, per_node, None if flag is None else ptr(flag), None)
+                             y_node_major, relu, per_node, precision, None if flag is None else ptr(flag), None)
     assert rc == 0, rc
     return y

@@ -168,6 +168,30 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_bf16: same lane map as the f16 form; operands are bf16 bit patterns (the upper half of an
+// fp32), products exact, the sum formed in double and rounded once
+f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int) {
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    if (w.n != 64) { std::fprintf(stderr, "emu: MFMA needs a full wave\n"); std::abort(); }
+    for (int e = 0; e < 8; ++e) {
+        w.a8[f.lane][e] = (float)a[e];
+        w.b8[f.lane][e] = (float)b[e];
+    }
+    wave_barrier();
+    const int j = f.lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = (f.lane >> 4) * 4 + r;
+        double acc = c[r];
+        for (int qq = 0; qq < 4; ++qq)
+            for (int e = 0; e < 8; ++e)
+                acc += (double)w.a8[i + 16 * qq][e] * (double)w.b8[j + 16 * qq][e];
+        c[r] = (float)acc;
+    }
+    wave_barrier();
+    return c;
+}
+
 // LDS bounds: everything behind the launch's dynamic shared-memory size is filled with a canary before
 // every workgroup and checked afterwards -- on the GPU an out-of-range LDS write is silently dropped
 // (r02: an epilogue buffer that outgrew a tiny graph's allocation passed here and failed there).

@@ -76,6 +76,8 @@ void wave_sync();                 // lockstep point: every lane of the wave reac
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int);
 }  // namespace gnnpp_emu
 
 #define threadIdx (gnnpp_emu::cur->tid)
@@ -97,6 +99,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int);
 #define __shfl_xor(v, m) gnnpp_emu::shfl_xor((v), (m))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 gnnpp_emu::mfma16x16x32_bf16
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() gnnpp_emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(x) (x)          // only used on wave-uniform values

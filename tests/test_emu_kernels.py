@@ -56,10 +56,12 @@ def test_emu_lsigf_node_major_relu(emu, lsigf_golden):
     assert np.abs(y.transpose(0, 2, 1) - np.maximum(want, 0)).max() <= TOL
 
 
-@pytest.mark.parametrize('variant', [7, 5])
-def test_emu_policy_golden(emu, policy_golden, variant):
+PRECS = [0, 1, 2]       # GNNPP_PREC_FP32 (bf16x3, default) | GNNPP_PREC_FP32_MFMA (exact) | GNNPP_PREC_SPLIT_F16
+
+
+@pytest.mark.parametrize('prec', PRECS)
+def test_emu_policy_golden(emu, policy_golden, prec):
     el, lib = emu
-    assert lib.gnnpp_set_tuning(0, variant) == 0        # encoder schedule: 7 = split-f16 (default), 5 = exact fp32
     z, meta = policy_golden
     sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
     enc = el.pack_encoder(lib, sd)
@@ -69,7 +71,7 @@ def test_emu_policy_golden(emu, policy_golden, variant):
         B, N, K = m['B'], m['N'], m['K']
         obs = el.f32(z['p%d_obs' % i])
         feat = np.full((B * N, 128), np.nan, dtype=np.float32)
-        assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), B * N, None, None) == 0
+        assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), B * N, prec, None, None) == 0
         want_feat = z['p%d_feat' % i].transpose(0, 2, 1).reshape(B * N, 128)
         assert np.abs(feat - want_feat).max() <= TOL, (i, m)
         # whole policy step through the single C entry point
@@ -83,7 +85,7 @@ def test_emu_policy_golden(emu, policy_golden, variant):
         aw, ab = el.f32(sd['actionsMLP.0.weight']), el.f32(sd['actionsMLP.0.bias'])
         rc = lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb),
                                   el.ptr(aw), el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K, 1,
-                                  is64, None, None)
+                                  is64, prec, None, None)
         assert rc == 0
         want = z['p%d_logits' % i]                         # [B,N,5]
         got = logits.transpose(1, 0, 2)
@@ -94,10 +96,12 @@ def test_emu_policy_golden(emu, policy_golden, variant):
         assert (acts == want.argmax(-1)).all()
 
 
-def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden):
-    """GNNPP_TUNE_FUSED_POLICY: one workgroup per graph (encoder + dense-MFMA shifts + split-f16
-    contraction + head) must give the very same logits as the encoder kernel followed by the filter
-    kernel: same arithmetic in the same order (the dense shift adds exact zeros)."""
+@pytest.mark.parametrize('prec', [0, 2])
+def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden, prec):
+    """GNNPP_TUNE_FUSED_POLICY: one workgroup per graph (encoder + dense-MFMA shifts + tap contraction + head).
+    Split-f16: the very same logits as the encoder kernel followed by the filter kernel (same arithmetic in the same
+    order; the dense shift adds exact zeros).  bf16x3 (the default): the two-kernel path contracts the taps on the
+    exact fp32 MFMA, the fused one on bf16x3 planes -- both fp32-equivalent, equal to a few ulps."""
     el, lib = emu
     z, meta = policy_golden
     sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
@@ -120,9 +124,12 @@ def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden):
                 ws = np.zeros((B * N, 128), dtype=np.float32)
                 assert lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb),
                                             el.ptr(aw), el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, 3, 1,
-                                            int(S.dtype == np.float64), None, None) == 0
+                                            int(S.dtype == np.float64), prec, None, None) == 0
                 outs.append(logits)
-            assert np.array_equal(outs[0], outs[1]), (i, m, np.abs(outs[0] - outs[1]).max())
+            if prec == 2:
+                assert np.array_equal(outs[0], outs[1]), (i, m, np.abs(outs[0] - outs[1]).max())
+            else:
+                assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * max(1.0, np.abs(outs[1]).max()), (i, m)
             assert np.abs(outs[0].transpose(1, 0, 2) - z['p%d_logits' % i]).max() <= TOL
             ran += 1
     finally:
@@ -130,8 +137,9 @@ def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden):
     assert ran >= 2
 
 
+@pytest.mark.parametrize('prec', [0, 2])
 @pytest.mark.parametrize('K', [2, 4])
-def test_emu_fused_policy_kernel_other_tap_counts(emu, K):
+def test_emu_fused_policy_kernel_other_tap_counts(emu, K, prec):
     """The fused policy kernel is instantiated for K = 2, 3, 4 filter taps (16 more weight-ring items and one
     more z buffer per tap): same logits as the two-kernel path, and as the oracle."""
     import torch
@@ -148,21 +156,22 @@ def test_emu_fused_policy_kernel_other_tap_counts(emu, K):
     S_t = torch.from_numpy(orc.synth_gso_geometric(B, N, 12, seed=K)).float()
     obs, S = el.f32(obs_t.numpy()), el.f32(S_t.numpy())
     outs = []
-    lib.gnnpp_set_tuning(0, -1)                              # default schedules, whatever an earlier test left
-    lib.gnnpp_set_tuning(5, 1)
     try:
         for mode in (1, 0):
             assert lib.gnnpp_set_tuning(6, mode) == 0
             logits = np.full((N, B, 5), np.nan, dtype=np.float32)
             ws = np.zeros((B * N, 128), dtype=np.float32)
             assert lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb), el.ptr(aw),
-                                        el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K, 1, 0, None, None) == 0
+                                        el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K, 1, 0, prec, None, None) == 0
             outs.append(logits)
             if mode == 1:
                 assert not ws.any()                          # one kernel: the feature workspace is not written
     finally:
         lib.gnnpp_set_tuning(6, 1)
-    assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+    if prec == 2:
+        assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+    else:
+        assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * max(1.0, np.abs(outs[1]).max())
     with torch.no_grad():
         want = torch.stack(orc.policy_forward(sd_t, S_t, obs_t), 0).numpy()
     assert np.abs(outs[0] - want).max() <= TOL
@@ -184,10 +193,12 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
     finally:
         lib.gnnpp_set_tuning(1, 0)
         lib.gnnpp_set_tuning(2, 0)
-    assert lib.gnnpp_set_tuning(8, 0) == -1 and lib.gnnpp_set_tuning(0, 9) == -1
-    # removed schedules and the measurement-only knobs (csrc/gnnpp_measure.h) are not part of the ABI
-    assert lib.gnnpp_set_tuning(0, 3) == -1 and lib.gnnpp_set_tuning(3, 1) == -1 and lib.gnnpp_set_tuning(4, 1) == -1
-    assert lib.gnnpp_set_tuning(0, -1) == 0 and lib.gnnpp_get_tuning(0) == 7
+    assert lib.gnnpp_set_tuning(8, 0) == -1
+    # the arithmetic is a per-call argument since ABI 300: the former precision knobs (0: encoder schedule, 5: filter
+    # f16) and the measurement-only knobs (csrc/gnnpp_measure.h) are not part of the ABI
+    assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 1) == -1 and lib.gnnpp_get_tuning(0) == -1
+    assert lib.gnnpp_set_tuning(3, 1) == -1 and lib.gnnpp_set_tuning(4, 1) == -1
+    assert lib.gnnpp_version() == 300
 
 
 def test_emu_lsigf_transposed_and_tap_dump(emu, lsigf_golden):
@@ -207,7 +218,7 @@ def test_emu_lsigf_transposed_and_tap_dump(emu, lsigf_golden):
         Sc = np.ascontiguousarray(Smat)
         rc = lib.gnnpp_lsigf_fwd_save(el.ptr(x), el.ptr(Sc), el.ptr(packed), None, el.ptr(y),
                                       el.ptr(zs) if want_zs else None, B, N, N, G, F_out, K, E, 0, 1,
-                                      transposed, 0, 0, 0, 0, None, None)
+                                      transposed, 0, 0, 0, 0, 0, None, None)
         assert rc == 0
         return y, zs
     y_t, _ = run(S, 1, False)
@@ -246,7 +257,7 @@ def test_emu_multilayer_and_edge_features(emu, policy_golden, multilayer_golden)
         S = np.ascontiguousarray(zm['m%d_S' % ci])
         is64 = int(S.dtype == np.float64)
         x = np.full((B * N, 128), np.nan, dtype=np.float32)
-        assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(x), B * N, None, None) == 0
+        assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(x), B * N, 0, None, None) == 0
         dims = [128] + m['dims']
         aw = el.f32(zm['m%d_actionsMLP.0.weight' % ci]); ab = el.f32(zm['m%d_actionsMLP.0.bias' % ci])
         want = zm['m%d_logits' % ci]
@@ -257,14 +268,14 @@ def test_emu_multilayer_and_edge_features(emu, policy_golden, multilayer_golden)
             if l + 1 < len(m['dims']):
                 y = np.full((B * N, dims[l + 1]), np.nan, dtype=np.float32)
                 rc = lib.gnnpp_lsigf_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(b), el.ptr(y), B, N, N,
-                                         dims[l], dims[l + 1], m['taps'][l], E, is64, 1, 1, 1, 1, 0, None, None)
+                                         dims[l], dims[l + 1], m['taps'][l], E, is64, 1, 1, 1, 1, 0, 0, None, None)
                 assert rc == 0
                 x = y
             else:
                 logits = np.full((N, B, 5), np.nan, dtype=np.float32)
                 rc = lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(b), el.ptr(aw),
                                                el.ptr(ab), el.ptr(logits), B, N, dims[l], dims[l + 1],
-                                               m['taps'][l], E, is64, None, None)
+                                               m['taps'][l], E, is64, 0, None, None)
                 assert rc == 0
         got = logits.transpose(1, 0, 2)
         assert np.abs(got - want).max() <= TOL, (ci, m, np.abs(got - want).max())
@@ -273,31 +284,26 @@ def test_emu_multilayer_and_edge_features(emu, policy_golden, multilayer_golden)
             lg2 = np.full((N, B, 5), np.nan, dtype=np.float32)
             ws = np.zeros((B * N, 128), dtype=np.float32)
             rc = lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(packed), el.ptr(b), el.ptr(aw),
-                                      el.ptr(ab), el.ptr(ws), el.ptr(lg2), B, N, m['taps'][0], E, is64, None, None)
+                                      el.ptr(ab), el.ptr(ws), el.ptr(lg2), B, N, m['taps'][0], E, is64, 0, None, None)
             assert rc == 0 and np.array_equal(lg2, logits)
         ran += 1
     assert ran >= 3
 
 
 def test_emu_range_guard(emu):
-    """Activations beyond the f16 range of the split-f16 schedules raise the caller's flag (and only
-    then); the exact-fp32 contraction has no such limit and leaves the flag alone."""
+    """Activations beyond the f16 range of GNNPP_PREC_SPLIT_F16 raise the caller's flag (and only then); the
+    other precisions have no such limit and leave the flag alone."""
     el, lib = emu
-    assert lib.gnnpp_set_tuning(0, -1) == 0 and lib.gnnpp_set_tuning(5, 1) == 0     # the default (split-f16) schedules
     g = np.random.default_rng(5)
     B, N, G, F_out, K = 2, 6, 128, 128, 2
     h = (g.standard_normal((F_out, 1, K, G)) / 16).astype(np.float32)
     S = (g.random((B, 1, N, N)) < 0.4).astype(np.float32) * 0.5
-    for scale, f16, want_flag in ((1.0, 1, 0), (3.0e4, 1, 0), (4.0e5, 1, 1), (4.0e5, 0, 0)):
+    for scale, prec, want_flag in ((1.0, 2, 0), (3.0e4, 2, 0), (4.0e5, 2, 1), (4.0e5, 0, 0), (4.0e5, 1, 0)):
         x = (np.abs(g.standard_normal((B, G, N))) * 0.25 * scale).astype(np.float32)
         x[0, 3, 2] = 0.3 * scale                              # the largest entries stay below / above 65504
         flag = np.zeros(1, np.int32)
-        assert lib.gnnpp_set_tuning(5, f16) == 0
-        try:
-            y = el.lsigf(lib, h, S, x, None, True, flag=flag)
-        finally:
-            lib.gnnpp_set_tuning(5, 1)
-        assert int(flag[0]) == want_flag, (scale, f16, flag, np.abs(x).max())
+        y = el.lsigf(lib, h, S, x, None, True, flag=flag, precision=prec)
+        assert int(flag[0]) == want_flag, (scale, prec, flag, np.abs(x).max())
         if not want_flag:
             ref = el_ref(h, S, x)
             assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
@@ -309,10 +315,16 @@ def test_emu_range_guard(emu):
     obs = (g.random((4, 3, 11, 11)) < 0.1).astype(np.float32)
     feat = np.zeros((4, 128), np.float32)
     flag = np.zeros(1, np.int32)
-    assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), 4, el.ptr(flag), None) == 0
+    assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), 4, 2, el.ptr(flag), None) == 0
     assert flag[0] == 0 and np.isfinite(feat).all()
     obs[1, 0, 5, 5] = 1.0e5
-    assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), 4, el.ptr(flag), None) == 0
+    feat0 = np.zeros((4, 128), np.float32)
+    assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat0), 4, 0, el.ptr(flag), None) == 0
+    assert flag[0] == 0 and np.isfinite(feat0).all()          # the default arithmetic has no input domain
+    feat1 = np.zeros((4, 128), np.float32)
+    assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat1), 4, 1, el.ptr(flag), None) == 0
+    assert flag[0] == 0 and np.abs(feat0 - feat1).max() <= 1e-5 * max(1.0, np.abs(feat1).max())
+    assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), 4, 2, el.ptr(flag), None) == 0
     assert flag[0] == 1
 
 
@@ -356,7 +368,7 @@ def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
             y = np.full((B, N, F_out), np.nan, np.float32)
             zs = np.full((E * K, B * N, G), np.nan, np.float32)
             rc = lib.gnnpp_lsigf_fwd_save(el.ptr(x), el.ptr(S), el.ptr(packed), None, el.ptr(y), el.ptr(zs),
-                                          B, N, N, G, F_out, K, E, 0, 1, 0, 1, 1, 1, 0, None, None)
+                                          B, N, N, G, F_out, K, E, 0, 1, 0, 1, 1, 1, 0, 0, None, None)
             assert rc == 0
             res.append((y, zs))
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
@@ -371,7 +383,8 @@ def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
 
 @pytest.mark.parametrize('N,K,f64,split,B', [(20, 3, 0, 1, 2), (37, 2, 1, 1, 2), (50, 3, 0, 2, 1), (33, 4, 1, 2, 2),
                                              (18, 1, 0, 1, 1), (21, 3, 0, 1, 3), (92, 2, 0, 1, 1), (100, 3, 1, 1, 1)])
-def test_emu_policy_filter_kernel(emu, N, K, f64, split, B):
+@pytest.mark.parametrize('prec', PRECS)
+def test_emu_policy_filter_kernel(emu, N, K, f64, split, B, prec):
     """policy_filter_kernel (filter + ReLU + action head of the policy step for 17..100 agents, one graph per
     workgroup): the general filter kernel's logits to rounding (the head sums eight 16-feature partial products
     instead of one 128-long chain), an fp64 restatement's within TOL; fp32 / fp64 and 16-byte / unaligned GSO slabs,
@@ -391,7 +404,7 @@ def test_emu_policy_filter_kernel(emu, N, K, f64, split, B):
     ab = g.standard_normal(5).astype(np.float32)
     packed = el.pack_filter(lib, h)
     outs = []
-    lib.gnnpp_set_tuning(0, -1); lib.gnnpp_set_tuning(5, 1); lib.gnnpp_set_tuning(2, 0)
+    lib.gnnpp_set_tuning(2, 0)
     try:
         assert lib.gnnpp_set_tuning(7, split) == 0 and lib.gnnpp_set_tuning(1, 1) == 0
         for mode in (1, 0):
@@ -399,8 +412,8 @@ def test_emu_policy_filter_kernel(emu, N, K, f64, split, B):
             logits = np.full((N, B, 5), np.nan, dtype=np.float32)
             flag = np.zeros(1, np.int32)
             assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
-                                             el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, el.ptr(flag),
-                                             None) == 0
+                                             el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, prec,
+                                             el.ptr(flag), None) == 0
             assert flag[0] == 0
             outs.append(logits)
     finally:

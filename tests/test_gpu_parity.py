@@ -23,14 +23,16 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(params=[7, 5], ids=['enc-split-f16', 'enc-fp32'])
+@pytest.fixture(params=['fp32', 'fp32_mfma', 'split_f16'], ids=['prec-bf16x3', 'prec-fp32-mfma', 'prec-split-f16'])
 def enc_variant(request, dev):
-    """Run a test under both encoder schedules: 7 = split-f16 MFMA, 5 = exact-fp32 MFMA."""
-    from gnn_pathplanning_amd import _native
-    L = _native.lib()
-    assert L.gnnpp_set_tuning(0, request.param) == 0
+    """Run a test under all three arithmetics (include/gnnpp.h GNNPP_PREC_*): the planners a test builds take the
+    precision from the module default, which this fixture sets: 'fp32' = bf16x3 (the shipped default),
+    'fp32_mfma' = exact fp32 MFMA, 'split_f16' = the opt-in fast mode."""
+    import gnn_pathplanning_amd.decentralplanner as dp
+    old = dp.DEFAULT_PRECISION
+    dp.DEFAULT_PRECISION = request.param
     yield request.param
-    assert L.gnnpp_set_tuning(0, -1) == 0              # back to the built-in default
+    dp.DEFAULT_PRECISION = old
 
 
 class Cfg:
@@ -269,17 +271,20 @@ def test_non_binary_observations(dev, enc_variant):
     assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'split_f16'])
 @pytest.mark.parametrize('B,N,W,K', [(512, 10, 20, 3), (33, 16, 24, 3), (5, 1, 8, 3), (64, 7, 12, 3), (600, 14, 20, 3),
                                      (2048, 10, 20, 3), (512, 10, 20, 2), (33, 16, 24, 4), (64, 7, 12, 4),
                                      (5, 3, 8, 2)])
-def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W, K):
+def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W, K, prec):
     """For N <= 16 and K = 2, 3, 4 taps the policy step is ONE kernel (a workgroup per graph: encoder, dense-MFMA
-    shifts, split-f16 contraction, head).  It performs the same arithmetic in the same order as the
-    encoder kernel + filter kernel, so the logits must be identical; fp64 and fp32 GSOs both."""
+    shifts, tap contraction, head).  Split-f16: the same arithmetic in the same order as the encoder kernel + filter
+    kernel, so the logits must be identical.  bf16x3 (default): identical encoder, but the two-kernel path contracts
+    the taps on the exact fp32 MFMA and the fused one on bf16x3 planes -- equal to a few ulps.  fp64 and fp32 GSOs."""
     from gnn_pathplanning_amd import _native
     L = _native.lib()
     sd = orc.init_state_dict(K, seed=31)
     net = _net(N, K, dev, sd)
+    net.precision = prec
     obs = orc.synth_obs(B, N, seed=B + 3 * N).to(dev)
     S64 = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=N))
     try:
@@ -290,7 +295,10 @@ def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W, K):
                 assert L.gnnpp_set_tuning(6, mode) == 0
                 outs.append(net.forward_logits(obs).clone())
             assert torch.equal(outs[0], outs[2])
-            assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+            if prec == 'split_f16':
+                assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+            else:
+                assert (outs[0] - outs[1]).abs().max().item() <= 2e-6 * max(1.0, outs[1].abs().max().item())
     finally:
         L.gnnpp_set_tuning(6, 1)
     want = torch.stack(orc.policy_forward(sd, S64.float(), obs.cpu()), 0)
@@ -414,10 +422,12 @@ def test_multilayer_and_edge_feature_planners(dev, policy_golden, multilayer_gol
         net.eval()
 
 
-def test_filter_split_f16_wide_dynamic_range(dev):
-    """The FILTER's split-f16 contraction (G = 128) with trained-scale taps spread over several decades
-    and features from 1e-3 to 1e3: relative error stays at fp32 level against the float64 statement."""
+@pytest.mark.parametrize('prec', ['fp32', 'split_f16'])
+def test_filter_split_f16_wide_dynamic_range(dev, prec, monkeypatch):
+    """The FILTER's contraction (G = 128; split-f16 and the default) with trained-scale taps spread over several
+    decades and features from 1e-3 to 1e3: relative error stays at fp32 level against the float64 statement."""
     import gnn_pathplanning_amd.graphML as gml
+    monkeypatch.setattr(gml, 'PRECISION', prec)
     g = torch.Generator().manual_seed(17)
     B, N, K = 64, 10, 3
     for tap_scale, feat_scale in ((1.0, 1.0), (60.0, 300.0), (0.003, 1e-3), (25.0, 2e-2)):
@@ -436,15 +446,16 @@ def test_filter_split_f16_wide_dynamic_range(dev):
 
 
 def test_range_guard_and_exact_fallback(dev):
-    """|activation| >= 65504 cannot go through the split-f16 schedules: the kernels raise the range
-    flag (check_range -> GnnppError), nothing is raised for in-range inputs, and range_policy =
-    'strict' re-runs the call under the exact-fp32 schedules and matches the oracle."""
+    """precision='split_f16' (opt-in): |activation| >= 65504 cannot go through the f16 pipe: the kernels raise the
+    range flag (range_policy 'flag': check_range -> GnnppError), nothing is raised for in-range inputs, and the
+    default range_policy 'strict' re-runs the call with the fp32-equivalent arithmetic and matches the oracle."""
     from gnn_pathplanning_amd import _native
     sd = orc.init_state_dict(3, seed=12)
     B, N = 9, 10
     obs = orc.synth_obs(B, N, seed=4)
     S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=4))
     net = _net(N, 3, dev, sd)
+    net.precision, net.range_policy = 'split_f16', 'flag'
     net.addGSO(S.to(dev))
     net(obs.to(dev))
     net.check_range()                                              # in range: no error
@@ -460,14 +471,104 @@ def test_range_guard_and_exact_fallback(dev):
         want = torch.stack(orc.policy_forward(sd2, S, obs), 0)
     assert torch.isfinite(want).all()
     net2 = _net(N, 3, dev, sd2)
-    net2.range_policy = 'strict'
+    net2.precision = 'split_f16'
+    assert net2.range_policy == 'strict'
     net2.addGSO(S.to(dev))
     got = net2.forward_logits(obs.to(dev)).cpu()
     assert not net2.range_exceeded()                               # consumed by the fallback
     assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
-    # the fallback restored the default schedules
-    L = _native.lib()
-    assert L.gnnpp_get_tuning(0) == 7 and L.gnnpp_get_tuning(5) == 1
+
+
+def test_default_precision_has_no_input_domain(dev):
+    """drive the module API exactly like agents/decentralplannerlocal.py:575-588 (addGSO, forward,
+    argmax -- no check_range, no flag) with a checkpoint whose activations overflow the f16 range: the DEFAULT
+    precision must match the oracle, on a second stream as well, and the same model must give the same bits from two
+    streams at once (per-call arithmetic: nothing process-wide is toggled)."""
+    sd = orc.init_state_dict(3, seed=12)
+    sd['ConvLayers.0.weight'] *= 3.0e4                              # L0 activations ~1e5 .. 1e6 (> 65504)
+    sd['ConvLayers.4.weight'] *= 1.0e-3
+    B, N = 24, 10
+    obs = orc.synth_obs(B, N, seed=4)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=4))
+    with torch.no_grad():
+        want = orc.policy_forward(sd, S, obs)
+    assert all(torch.isfinite(w).all() for w in want)
+    net = _net(N, 3, dev, sd)
+    assert net.precision == 'fp32'
+    net.addGSO(S.to(dev))
+    got = net(obs.to(dev))                                          # the reference's call protocol, nothing else
+    scale = max(w.abs().max().item() for w in want)
+    err = max((g.cpu() - w).abs().max().item() for g, w in zip(got, want))
+    assert err <= 2e-5 * scale, (err, scale)
+    ids = torch.stack([g.argmax(-1) for g in got], 1).cpu()
+    margin = orc.top2_margin(want)
+    clear = margin > 1e-5 * scale
+    assert (ids[clear] == orc.decode_actions(want)[clear]).all()
+    assert not net.range_exceeded() and net._range_flag is None     # no guard exists in this mode
+    # two streams at once: a split-f16 planner falling back on stream A must not change what stream B computes
+    net_b = _net(N, 3, dev, sd)
+    net_f = _net(N, 3, dev, sd)
+    net_f.precision = 'split_f16'                                   # strict: overflows, re-runs with 'fp32'
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    obs_d, S_d = obs.to(dev), S.to(dev)
+    torch.cuda.synchronize()
+    outs_b = []
+    for _ in range(4):
+        with torch.cuda.stream(sa):
+            net_f.addGSO(S_d)
+            a = net_f.forward_logits(obs_d)
+        with torch.cuda.stream(sb):
+            net_b.addGSO(S_d)
+            outs_b.append(net_b.forward_logits(obs_d))
+    torch.cuda.synchronize()
+    ref = torch.stack(got, 0)
+    assert all(torch.equal(o, ref) for o in outs_b)
+    assert (a.cpu() - torch.stack(want, 0)).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('lo,hi', [(1e-30, 1e-24), (1e-12, 1e-3), (1e3, 1e9), (1e20, 1e30), (1e-30, 1e30)])
+def test_default_precision_adversarial_ranges(dev, lo, hi):
+    """bf16x3 represents every finite fp32 operand exactly, with fp32's exponent range: encoder features for
+    observations / weights whose magnitudes are spread log-uniformly over [lo, hi] (far outside the f16 range on
+    either side; products stay inside fp32's) agree with the float64 statement of the same network at fp32 relative
+    accuracy -- no guard, no rescaling, no fallback involved."""
+    g = torch.Generator().manual_seed(int(abs(np.log10(lo)) * 100 + abs(np.log10(hi))))
+    sd = orc.init_state_dict(3, seed=21)
+    B, N = 3, 6
+
+    def spread(shape):
+        e = torch.rand(shape, generator=g) * (np.log10(hi) - np.log10(lo)) + np.log10(lo)
+        return (10.0 ** e.double()).float() * (torch.randint(0, 2, shape, generator=g) * 2 - 1).float()
+    obs = spread((B, N, 3, 11, 11)) * (torch.rand(B, N, 3, 11, 11, generator=g) < 0.3)
+    # first-layer weights scaled so that L0's outputs are O(1) again: the later layers see ordinary activations, the
+    # first layer sees operands of magnitude lo .. hi times weights of magnitude 1/hi .. 1/lo
+    sd['ConvLayers.0.weight'] = sd['ConvLayers.0.weight'] / float(np.sqrt(lo * hi))
+    net = _net(N, 3, dev, sd)
+    got = net.encode(obs.to(dev)).cpu().double()
+    want = orc.policy_features({k: v.double() for k, v in sd.items()}, obs.double()).permute(0, 2, 1)
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    assert scale > 0 and (got - want).abs().max().item() <= 3e-5 * scale, ((got - want).abs().max().item(), scale)
+
+
+def test_default_precision_denormal_and_huge_weights(dev):
+    """Weights in fp32's denormal range (|w| ~ 1e-40: exactly representable by bf16 planes only down to their own
+    subnormals -- the contribution is below fp32's resolution of the sum either way) and weights near 1e30 with
+    observations near 1e-30: finite, and equal to the float64 statement at fp32 relative accuracy."""
+    g = torch.Generator().manual_seed(77)
+    sd = orc.init_state_dict(3, seed=22)
+    w0 = sd['ConvLayers.0.weight']
+    w0[:, 0] *= 1e30                                               # channel 0: huge weights x tiny observations
+    w0[:, 1] = torch.randn(w0[:, 1].shape, generator=g) * 1e-40    # channel 1: denormal weights
+    B, N = 2, 5
+    obs = torch.rand(B, N, 3, 11, 11, generator=g)
+    obs[:, :, 0] *= 1e-30
+    net = _net(N, 3, dev, sd)
+    got = net.encode(obs.to(dev)).cpu().double()
+    want = orc.policy_features({k: v.double() for k, v in sd.items()}, obs.double()).permute(0, 2, 1)
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 3e-5 * scale
 
 
 def test_unseen_parameter_updates_and_invalidate_packed(dev):
@@ -504,7 +605,8 @@ def test_unseen_parameter_updates_and_invalidate_packed(dev):
 
 @pytest.mark.parametrize('B,N,K,f64', [(256, 50, 3, 0), (128, 100, 3, 1), (128, 100, 2, 0), (7, 17, 3, 0), (300, 64, 4, 1),
                                        (5, 89, 3, 0), (5, 90, 3, 1), (130, 97, 1, 0), (40, 33, 2, 0), (64, 100, 4, 0)])
-def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64):
+@pytest.mark.parametrize('prec', [0, 1, 2])
+def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64, prec):
     """Filter + ReLU + head of the policy step for 17..100 agents: policy_filter_kernel (default) against the
     general filter kernel on the same inputs -- equal to rounding (the head's eight partial sums instead of one
     chain) -- and against an fp64 restatement within TOL.  Shapes on both sides of every switch: one / two
@@ -534,7 +636,7 @@ def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64):
             lg = torch.full((N, B, 5), float('nan'), device=dev)
             assert L.gnnpp_filter_head_fwd(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(),
                                            awd.data_ptr(), abd.data_ptr(), lg.data_ptr(), B, N, 128, 128, K, 1, f64,
-                                           flag.data_ptr(), None) == 0
+                                           prec, flag.data_ptr(), None) == 0
             torch.cuda.synchronize()
             outs.append(lg.cpu())
     finally:
@@ -551,4 +653,5 @@ def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64):
     scale = max(1.0, want.abs().max().item())
     assert (outs[0].double() - want).abs().max().item() <= TOL * scale
     assert (outs[0] - outs[1]).abs().max().item() <= 4e-6 * scale
-    assert not torch.equal(outs[0], outs[1]) or K == 0                    # (the new kernel did run)
+    assert not torch.equal(outs[0], outs[1]) or K == 0 or prec == 1       # (the new kernel did run; under the exact
+                                                                          # fp32 MFMA both may round identically)

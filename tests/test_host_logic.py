@@ -36,11 +36,14 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     lib = built_lib.lib()
     assert lib.gnnpp_version() >= 100
     assert b'not supported' in lib.gnnpp_error_string(-2)
-    assert lib.gnnpp_filter_packed_floats(128, 128, 3, 1) == 2 * (3 * 8 * 8 * 256) + 4   # fp32 + split-f16 fragments + scale
-    assert lib.gnnpp_filter_packed_floats(5, 3, 2, 1) == 2 * 256 + 2 * 512 + 4
+    # fp32 fragments + split-f16 fragments + scale + bf16x3 fragments (three 16-byte planes per block of 32 channels)
+    assert lib.gnnpp_filter_packed_floats(128, 128, 3, 1) == 2 * (3 * 8 * 8 * 256) + 4 + 3 * 8 * 4 * 768
+    assert lib.gnnpp_filter_packed_floats(5, 3, 2, 1) == 2 * 256 + 2 * 512 + 4 + 2 * 768
     assert lib.gnnpp_encoder_packed_floats() > 555000 // 4
     # argument validation happens before any HIP call, so it is checkable without a GPU
-    assert lib.gnnpp_encoder_fwd(None, None, None, 16, None, None) == -1
+    assert lib.gnnpp_encoder_fwd(None, None, None, 16, 0, None, None) == -1
+    assert lib.gnnpp_version() == 300                        # ABI 300: per-call `precision`, no precision knobs
+    assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 0) == -1
     assert lib.gnnpp_decode_actions(None, None, 1, 1, None) == -1
 
 
