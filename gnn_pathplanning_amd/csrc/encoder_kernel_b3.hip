@@ -542,7 +542,10 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
     }
-    if (!FUSED) return;
+    if (!FUSED) {
+        GNNPP_STAMP(blockIdx.x, 6, tid == 0);
+        return;
+    }
 
     // ==== graph filter + action head of this graph (K = KT taps, G = F = 128) =====================
     // z_k = z_{k-1} S as a dense product on the fp32 MFMA, all m in ascending order: bit-identical to

@@ -350,7 +350,9 @@ def test_fused_adam_and_loss_match_torch(dev):
             loss = lossf(out, tgt)
             loss.backward()
             losses.append(loss.item())
-        assert abs(losses[0] - losses[1]) <= 2e-6 * max(1.0, abs(losses[0])), (it, losses)
+        # identical weights at it = 0; afterwards the two optimizers' last bits differ and the (inert, see below) conv
+        # biases walk apart by +-lr per step, which fp32 rounding turns into ~1e-5 of loss
+        assert abs(losses[0] - losses[1]) <= (2e-6 if it == 0 else 1e-4) * max(1.0, abs(losses[0])), (it, losses)
         if it == 0:                                      # identical weights: gradients comparable one to one
             for (k, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
                 assert (pa.grad - pb.grad).abs().max().item() <= 1e-6 + 1e-5 * pa.grad.abs().max().item(), k
