@@ -121,6 +121,81 @@ __device__ __forceinline__ void b3_tap_mfma(const v4f* in, const v4f* Pin, const
     }
 }
 
+// ---- software-pipelined form of the same step, for the layers whose input sits in LDS (L1, L2) ----------------
+// hipcc schedules b3_tap_mfma as  [LDS reads of a chunk] [wait] [its MFMAs] [next chunk's reads] [wait] ...: with one
+// workgroup on a CU (and for the YOUNGER of two, which only gets the issue slots the older one leaves: measured,
+// profiles/r03a_wg_spread.jsonl) every chunk pays the LDS latency with the matrix pipe idle -- a lone workgroup ran
+// L1 / L2 at 47 / 63 % of the pipe's rate.  Here the plane fragments of chunk c + 1 are REQUESTED before the MFMAs of
+// chunk c are issued (two register sets, alternating), across step boundaries too; sched_barrier(0) pins the order,
+// the compiler's s_waitcnt lgkmcnt(n) then waits only for the older set (LDS returns in order).
+template <int IT, int CHI, int NKB, int H, int W, int NSLOT, int CH, class PosFn>
+__device__ __forceinline__ void b3_load_chunk(const v4f* in, v4f (&B)[CH][3], int lane) {
+    constexpr int kb = IT / 9, tap = IT % 9;
+    constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int jj = 0; jj < CH; ++jj) {
+        const int j = CHI * CH + jj;
+        int y = 0, x = 0;
+        const bool used = j < NSLOT && PosFn::get(j, y, x);
+        const int iy = y + dy, ix = x + dx;
+        if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const int o = ((iy * W + ix) * NKB + kb) * 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) B[jj][p] = in[(o + p) * 64 + lane];
+        }
+    }
+}
+
+template <int IT, int CHI, int NKB, int H, int W, int NMT, int NSLOT, int CH, class PosFn>
+__device__ __forceinline__ void b3_mfma_chunk(const v4f (&B)[CH][3], const v8b (&A)[NMT][3],
+                                              v4f (&acc)[NSLOT][NMT]) {
+    constexpr int tap = IT % 9;
+    constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int term = 0; term < kB3Terms; ++term) {
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = CHI * CH + jj;
+            int y = 0, x = 0;
+            const bool used = j < NSLOT && PosFn::get(j, y, x);
+            const int iy = y + dy, ix = x + dx;
+            if (used && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const bool fresh = term == 0 && first_step_of_slot<H, W, PosFn>(IT, j);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m)
+                    acc[j][m] = mfma16b(A[m][b3_term_a(term)], as_b8(B[jj][b3_term_b(term)]),
+                                        fresh ? vzero() : acc[j][m]);
+            }
+        }
+    }
+}
+
+// step IT of NIT: for each of its chunks, request the NEXT chunk's planes (next chunk of this step, or the first
+// chunk of step IT + 1), then issue this chunk's MFMAs.  Bb[(linear chunk index) & 1] holds a chunk's planes;
+// the layer's prologue loads chunk (0, 0) into Bb[0].
+template <int IT, int NIT, int NKB, int H, int W, int NMT, int NSLOT, int CH, class PosFn, int... CHS>
+__device__ __forceinline__ void b3_step_pipelined_impl(const v4f* in, v4f (&Bb)[2][CH][3], const v8b (&A)[NMT][3],
+                                                       v4f (&acc)[NSLOT][NMT], int lane,
+                                                       std::integer_sequence<int, CHS...>) {
+    constexpr int NCH = (NSLOT + CH - 1) / CH;
+    auto chunk = [&](auto chc) {
+        constexpr int ch = decltype(chc)::value;
+        constexpr int L = IT * NCH + ch;
+        if constexpr (ch + 1 < NCH) b3_load_chunk<IT, ch + 1, NKB, H, W, NSLOT, CH, PosFn>(in, Bb[(L + 1) & 1], lane);
+        else if constexpr (IT + 1 < NIT) b3_load_chunk<IT + 1, 0, NKB, H, W, NSLOT, CH, PosFn>(in, Bb[(L + 1) & 1], lane);
+        __builtin_amdgcn_sched_barrier(0);
+        b3_mfma_chunk<IT, ch, NKB, H, W, NMT, NSLOT, CH, PosFn>(Bb[L & 1], A, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    (chunk(std::integral_constant<int, CHS>{}), ...);
+}
+template <int IT, int NIT, int NKB, int H, int W, int NMT, int NSLOT, int CH, class PosFn>
+__device__ __forceinline__ void b3_step_pipelined(const v4f* in, v4f (&Bb)[2][CH][3], const v8b (&A)[NMT][3],
+                                                  v4f (&acc)[NSLOT][NMT], int lane) {
+    b3_step_pipelined_impl<IT, NIT, NKB, H, W, NMT, NSLOT, CH, PosFn>(
+        in, Bb, A, acc, lane, std::make_integer_sequence<int, (NSLOT + CH - 1) / CH>{});
+}
+
 // The weight stream of a layer (item order [kb][tap][mt][plane]): for every step IT take the 3 NMT fragments off
 // the ring, refill the slots, hand them to body(IT, A).  Wave-uniform, branch-free (tools/check_ring_isa.py).
 template <int END, int START, int NMT, class Body, int... IT>
@@ -365,16 +440,27 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
     {
-        v4f acc[7][2];                                    // first touched by a zero-source MFMA (b3_tap_mfma)
-        b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
-            constexpr int IT = decltype(itc)::value;
-            switch (wave) {
-                case 0: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<0>, false, 4>(R4, nullptr, A, acc, lane); break;
-                case 1: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<1>, false, 4>(R4, nullptr, A, acc, lane); break;
-                case 2: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<2>, false, 4>(R4, nullptr, A, acc, lane); break;
-                default: b3_tap_mfma<IT, 1, 5, 5, 2, 7, PosL1H<3>, false, 4>(R4, nullptr, A, acc, lane); break;
-            }
-        }, std::make_integer_sequence<int, 9>{});
+        v4f acc[7][2];                                    // first touched by a zero-source MFMA (b3_mfma_chunk)
+        constexpr int CH1 = 2;                            // slots per chunk: 6 LDS reads in flight beside <= 24 MFMAs
+        v4f Bb[2][CH1][3];
+        // The per-wave position sets are compile-time types, and the whole layer (ring traffic included) sits inside
+        // the wave's case: one straight-line region per wave, accumulators updated in place.  (A branch per STEP,
+        // as in the split-f16 kernel, made every accumulator and both plane sets a phi at every step's join; next to
+        // the ring's 48 reserved registers the allocator answered with spills.)  Every case performs the same ring
+        // sequence, which tools/check_ring_isa.py verifies path by path.
+        auto layer1 = [&](auto wc) {
+            using P = PosL1H<decltype(wc)::value>;
+            b3_load_chunk<0, 0, 1, 5, 5, 7, CH1, P>(R4, Bb[0], lane);
+            b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+                b3_step_pipelined<decltype(itc)::value, 9, 1, 5, 5, 2, 7, CH1, P>(R4, Bb, A, acc, lane);
+            }, std::make_integer_sequence<int, 9>{});
+        };
+        switch (wave) {
+            case 0: layer1(std::integral_constant<int, 0>{}); break;
+            case 1: layer1(std::integral_constant<int, 1>{}); break;
+            case 2: layer1(std::integral_constant<int, 2>{}); break;
+            default: layer1(std::integral_constant<int, 3>{}); break;
+        }
         __syncthreads();                                   // everyone is done reading L0's output
         v4f sc[2], sh[2];
         load_ss(sstab + EncLayout::kBssL1, 32, 0, q, sc[0], sh[0]);
@@ -397,12 +483,20 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2], in place (front of R) --------
     {
         const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
-        v4f acc[8][2];                                    // first touched by a zero-source MFMA (b3_tap_mfma)
-        b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
-            constexpr int IT = decltype(itc)::value;
-            if (pair == 0) b3_tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<0>, false, 4>(R4, nullptr, A, acc, lane);
-            else           b3_tap_mfma<IT, 1, 5, 5, 2, 8, PosL2H<1>, false, 4>(R4, nullptr, A, acc, lane);
-        }, std::make_integer_sequence<int, 9>{});
+        v4f acc[8][2];                                    // first touched by a zero-source MFMA (b3_mfma_chunk)
+        constexpr int CH2 = 2;
+        v4f Bb[2][CH2][3];
+        auto layer2 = [&](auto pc) {
+            using P = PosL2H<decltype(pc)::value>;
+            b3_load_chunk<0, 0, 1, 5, 5, 8, CH2, P>(R4, Bb[0], lane);
+            b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+                b3_step_pipelined<decltype(itc)::value, 9, 1, 5, 5, 2, 8, CH2, P>(R4, Bb, A, acc, lane);
+            }, std::make_integer_sequence<int, 9>{});
+        };
+        switch (pair) {
+            case 0: layer2(std::integral_constant<int, 0>{}); break;
+            default: layer2(std::integral_constant<int, 1>{}); break;
+        }
         v4f sc[2], sh[2];
         load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp, q, sc[0], sh[0]);
         load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp + 1, q, sc[1], sh[1]);

@@ -96,23 +96,35 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
         elif not last.startswith('s_endpgm') and i + 1 < len(blocks):
             s.append(i + 1)
         succ.append(s)
-    # state per slot: age = ring loads issued after this slot's load (None = slot empty / taken)
+    # PATH-SENSITIVE walk of the control-flow graph.  A state = (age of every ring slot: ring loads issued after that
+    # slot's load, EMPTY = slot empty / taken; ring loads and fragments taken along the path; an over-estimate of the
+    # EXEC narrowing depth; SGPR pairs known to hold 0 / -1; what is known about vcc).  States are NOT merged at
+    # joins: a block is re-walked for every distinct state that reaches it (a few per block -- the arms of a
+    # per-wave switch each carry their own copy of a layer's ring traffic and must leave identical states behind).
     EMPTY = -1
-    entry = [None] * len(blocks)
-    entry[0] = tuple([EMPTY] * NSLOT)
-    work, reported = [0], set()
+    start = (tuple([EMPTY] * NSLOT), 0, 0, 0, frozenset(), None)
+    seen = [set() for _ in blocks]
+    seen[0].add(start)
+    work, reported = [(0, start)], set()
     stats = {'loads': 0, 'takes': 0}
-    counted = set()
+    exits = set()
 
     def err(i, k, msg):
         if (i, k) not in reported:
             reported.add((i, k))
             errors.append('block %d: %s' % (i, msg))
 
+    steps = 0
     while work:
-        i = work.pop()
-        age = list(entry[i])
+        i, st0 = work.pop()
+        steps += 1
+        if steps > 200000:
+            errors.append('analysis did not converge (ring traffic inside a loop?)')
+            break
+        age, nl, nt, depth = list(st0[0]), st0[1], st0[2], st0[3]
+        consts, vcc = dict(st0[4]), st0[5]
         last_wait = None
+        exec_written = False
         for k, t in enumerate(blocks[i]['ins']):
             code = t.split(';')[0]
             if 'RINGLOAD' in t:
@@ -123,8 +135,7 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
                     err(i, k, 'slot %d reloaded before it was taken: %s' % (s, t))
                 age = [a + 1 if a != EMPTY else a for a in age]
                 age[s] = 0
-                if (i, k) not in counted:
-                    counted.add((i, k)); stats['loads'] += 1
+                nl += 1
             elif 'RINGWAIT' in t:
                 last_wait = int(re.search(r'vmcnt\((\d+)\)', code).group(1))
             elif 'RINGTAKE' in t:
@@ -138,35 +149,84 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
                         % (s, last_wait, age[s], t))
                 if blocks[i]['ins'][k - 1].endswith('RINGTAKE %d' % s):
                     age[s] = EMPTY                      # second half of the fragment: slot is free
-                    if (i, k) not in counted:
-                        counted.add((i, k)); stats['takes'] += 1
+                    nt += 1
             else:
+                # EXEC narrowing: `depth` over-estimates how many exec-narrowing writes are unmatched on this path
+                # (capped, so loops converge); `exec_written` = this block wrote EXEC before its terminator
+                if re.match(r'^(s_and_saveexec_b64|s_andn2_saveexec_b64|s_and_b64\s+exec|s_andn2_b64\s+exec|'
+                            r's_xor_b64\s+exec|v_cmpx_)', code):
+                    depth = min(depth + 1, 4)
+                    exec_written = True
+                elif re.match(r'^(s_or_b64\s+exec,\s*exec,|s_mov_b64\s+exec,)', code):
+                    depth = max(0, depth - 1)
+                    exec_written = True
+                elif re.match(r'^s_or_saveexec_b64', code):
+                    exec_written = True
+                elif code.startswith('s_barrier'):
+                    depth = 0                              # __syncthreads() is only ever reached with every lane
+                                                           # active (workgroup-uniform code): the estimate restarts
+                # The structuriser lowers a wave-uniform if / else as a flag in an SGPR pair (s_mov_b64 sN, 0 | -1) and
+                # `s_and[n2]_b64 vcc, exec, sN; s_cbranch_vcc[n]z`: follow the flag, so that the two arms are not
+                # strung into one (infeasible) path.  Anything else that writes the pair or vcc forgets it.
+                cs = code.strip()
+                mm = re.match(r'^s_mov_b64\s+s\[(\d+):(\d+)\],\s*(0|-1)\s*$', cs)
+                ma = re.match(r'^s_(and|andn2)_b64\s+vcc,\s*exec,\s*s\[(\d+):(\d+)\]\s*$', cs)
+                first = re.match(r'^[sv]_\w+\s+(vcc|s\[(\d+):(\d+)\]|s(\d+))', cs)
+                if mm:
+                    consts[(int(mm.group(1)), int(mm.group(2)))] = int(mm.group(3))
+                elif ma and (int(ma.group(2)), int(ma.group(3))) in consts and depth == 0:
+                    c = consts[(int(ma.group(2)), int(ma.group(3)))]
+                    vcc = ('nz' if c == -1 else 'z') if ma.group(1) == 'and' else ('z' if c == -1 else 'nz')
+                elif first and not cs.startswith(('s_cmp', 's_cbranch', 's_branch', 's_waitcnt', 's_nop', 's_barrier',
+                                                  's_endpgm')):
+                    if first.group(1) == 'vcc':
+                        vcc = None
+                    else:
+                        lo = int(first.group(2) if first.group(2) is not None else first.group(4))
+                        hi = int(first.group(3) if first.group(3) is not None else first.group(4))
+                        for key in [k2 for k2 in consts if not (k2[1] < lo or k2[0] > hi)]:
+                            del consts[key]
                 bad = [r for r in regs_of(code) if r >= RING_LO]
                 if bad:
                     err(i, k, 'compiler code touches ring registers v%s: %s' % (sorted(bad), t))
-                if not code.startswith(('v_', 'ds_', 's_nop', 's_mov', 's_add', 's_lshl', 's_and', 's_cmp',
-                                        's_mul', 's_sub', 's_or', 's_cselect')):
-                    if code.startswith('s_waitcnt') and 'vmcnt' in code:
-                        m = re.search(r'vmcnt\((\d+)\)', code)
-                        last_wait = min(last_wait, int(m.group(1))) if last_wait is not None else int(m.group(1))
-                    elif code.startswith(('s_barrier', 's_cbranch', 's_branch', 's_endpgm', 's_waitcnt',
-                                          's_load', 'global_', 'buffer_', 'scratch_', 's_')):
-                        pass
-        out = tuple(age)
-        for j in succ[i]:
-            if entry[j] is None:
-                new = out
-            else:       # merge: a slot must agree on being empty; keep the smaller age (stricter)
-                new = tuple(EMPTY if (a == EMPTY and b == EMPTY) else
-                            (min(a, b) if a != EMPTY and b != EMPTY else -2) for a, b in zip(entry[j], out))
-                exit_only = any(t.startswith('s_endpgm') for t in blocks[j]['ins']) and \
-                    not any('RING' in t for t in blocks[j]['ins'])
-                if -2 in new and not exit_only:      # (early returns may leave loads pending)
-                    err(j, -1, 'paths disagree on which ring slots are pending at block %d' % j)
-                    new = tuple(EMPTY if x == -2 else x for x in new)
-            if new != entry[j]:
-                entry[j] = new
-                work.append(j)
+                if cs.startswith('s_waitcnt') and 'vmcnt' in cs:
+                    m = re.search(r'vmcnt\((\d+)\)', cs)
+                    last_wait = min(last_wait, int(m.group(1))) if last_wait is not None else int(m.group(1))
+        last_ins = blocks[i]['ins'][-1] if blocks[i]['ins'] else ''
+        if last_ins.startswith('s_endpgm'):
+            exits.add((nl, nt))
+        # With every lane active (depth 0: the kernels run full 64-lane waves and the ring traffic sits in
+        # wave-uniform code) EXEC is not zero, so `s_cbranch_execnz` -- which hipcc emits as the jump out of a
+        # uniform switch's case -- is always taken and `s_cbranch_execz` never: following their other edge would
+        # string several cases of a per-wave switch into one (infeasible) path.
+        nexts = succ[i]
+        if depth == 0 and not exec_written and last_ins.startswith('s_cbranch_execnz'):
+            nexts = succ[i][:1]
+        elif depth == 0 and not exec_written and last_ins.startswith('s_cbranch_execz'):
+            nexts = succ[i][1:]
+        elif last_ins.startswith('s_cbranch_vccnz') and vcc is not None:
+            nexts = succ[i][:1] if vcc == 'nz' else succ[i][1:]
+        elif last_ins.startswith('s_cbranch_vccz') and vcc is not None:
+            nexts = succ[i][:1] if vcc == 'z' else succ[i][1:]
+        if all(a == EMPTY for a in age):
+            # no ring load in flight (before the prologue / behind the last take: the simulator tail's divergent code):
+            # what is known about EXEC and the flags cannot matter to the ring any more -- collapse the states
+            depth, consts, vcc = 4, {}, None
+        out = (tuple(age), nl, nt, depth, frozenset(consts.items()), vcc)
+        for j in nexts:
+            if out not in seen[j]:
+                if len(seen[j]) > 64:
+                    err(j, -1, 'more than 64 distinct ring states reach block %d' % j)
+                    continue
+                seen[j].add(out)
+                work.append((j, out))
+    # every path to the end of the kernel that consumed the whole stream did it exactly once; early exits (the
+    # measurement build's phase stops, nothing in the product) may leave loads pending
+    if exits:
+        stats['loads'], stats['takes'] = max(e[0] for e in exits), max(e[1] for e in exits)
+        full = {e for e in exits if e[1] == stats['takes']}
+        if len(full) != 1:
+            errors.append('paths through the whole stream disagree on the ring traffic: %r' % sorted(exits))
     return errors, stats, meta
 
 
