@@ -43,7 +43,7 @@ constexpr int kB3Region = 25 * 3 * kB3Frag;                // R: 76 800
 constexpr int kB3Obs2 = kObsFloatsLds * 4;                 // second observation word array (l planes)
 constexpr int kB3L2out = 0, kB3L3out = 24 * kB3Frag, kB3L4out = 48 * kB3Frag;
 constexpr int kB3Table = kB3Region;                        // BatchNorm table (640 floats); FUSED: later the head's
-constexpr int kB3TableBytes = EncLayout::kBssFloats * 4;   //   constants (776 floats) + the GSO [16][17]
+constexpr int kB3TableBytes = EncLayout::kBssFloats * 4 + 16;   // (+ 4 plane-skipping flags)  constants (776 floats) + the GSO [16][17]
 constexpr int kB3TableBytesFused = 5120;
 constexpr int kB3SsmOff = 776 * 4;
 constexpr size_t kB3Smem = kB3Region + kB3TableBytes;              // 79 360: two workgroups per CU
@@ -231,6 +231,212 @@ __device__ __forceinline__ void b3_conv_preload(const WStreamB& ws, v4f (&ring)[
     }, std::make_integer_sequence<int, 9 * NKB>{});
 }
 
+// L0 for observations that need all three planes (anything but exact bf16 values): window by window, sixteen word
+// reads per position (eight h | m words, eight l words, position offset = instruction immediate), three v_perm per
+// register pair, 6 MFMAs per channel tile; the pooled outputs of all of a wave's windows stay in registers until
+// every wave is done with the pixels.  (Scheduling left to the compiler: this is the rare path -- the simulator's
+// observations take b3_l0_stream<true> -- and the explicit stream's two word sets do not fit beside 56 held outputs.)
+__device__ __forceinline__ void b3_l0_generic(const float* __restrict__ pk, const unsigned* obsw, const float* sstab,
+                                              v4f* R4, int wave, int lane) {
+    const int a = lane & 15, q = lane >> 4;
+    v8b A0[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            A0[i][p] = as_b8(*reinterpret_cast<const v4f*>(pk + EncLayout::kB0 + ((i * 3 + p) * 64 + lane) * 4));
+    int aoff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        aoff[e] = a * kAgentStride + (q < 3 ? q * (kPadHW * kPadHW) + (e / 3) * kPadHW + e % 3
+                                            : e < 3 ? e * (kPadHW * kPadHW) + 2 * kPadHW + 2 : 0);
+    v4f res[7][2];
+#pragma unroll
+    for (int wi = 0; wi < 7; ++wi) {
+        const int win = wave + 4 * wi;
+        if (win < 25) {                                  // (wave-uniform)
+            __builtin_amdgcn_sched_barrier(kSchedItemMask);
+            const int wy = win / 5, wx = win - wy * 5;
+            const unsigned* base = obsw + (2 * wy) * kPadHW + 2 * wx;
+            v4f acc[4][2];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                unsigned d1[8], d2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    d1[e] = base[aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
+                    d2[e] = base[kObsFloatsLds + aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
+                }
+                unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    bh[w] = __builtin_amdgcn_perm(d1[2 * w + 1], d1[2 * w], 0x05040100u);
+                    bm[w] = __builtin_amdgcn_perm(d1[2 * w + 1], d1[2 * w], 0x07060302u);
+                    bl[w] = __builtin_amdgcn_perm(d2[2 * w + 1], d2[2 * w], 0x05040100u);
+                }
+                const v4u bhv = {bh[0], bh[1], bh[2], bh[3]}, bmv = {bm[0], bm[1], bm[2], bm[3]},
+                          blv = {bl[0], bl[1], bl[2], bl[3]};
+                const v8b B[3] = {__builtin_bit_cast(v8b, bhv), __builtin_bit_cast(v8b, bmv),
+                                  __builtin_bit_cast(v8b, blv)};
+#pragma unroll
+                for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[pp][i] = mfma16b(A0[i][b3_term_a(term)], B[b3_term_b(term)],
+                                             term == 0 ? vzero() : acc[pp][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v4f sc, sh;
+                load_ss(sstab + EncLayout::kBssL0, 32, i, q, sc, sh);
+                v4f r = vrelu(vfma(acc[0][i], sc, sh));
+#pragma unroll
+                for (int pp = 1; pp < 4; ++pp) r = vmax(r, vfma(acc[pp][i], sc, sh));
+                res[wi][i] = r;
+            }
+        }
+    }
+    __syncthreads();                                     // every wave has read its last pixel
+#pragma unroll
+    for (int wi = 0; wi < 7; ++wi) {
+        const int win = wave + 4 * wi;
+        if (win < 25) {
+            v4f pl[3];
+            b3_split8(res[wi][0], res[wi][1], pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+        }
+    }
+}
+
+// L0 of one wave: windows wave, wave + 4, .. (7 for wave 0, 6 otherwise) x their 4 positions, one stream.
+//   position P:  [request the words of P + DEPTH]  |  [v_perm the words of P into plane fragments; its MFMAs;
+//   BatchNorm + ReLU / running max of P - 1]   -- the second group is one scheduling region: the VALU work slots in
+//   between the MFMAs.  ONE_PLANE (plane skipping, see the staging code): only the h | m word array is read, only the
+//   h plane is built, three MFMAs (wh, wm, wl against xh) per channel tile instead of six.
+template <bool ONE_PLANE>
+__device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const unsigned* obsw,
+                                             const float* sstab, v4f* R4, v4f (&res)[ONE_PLANE ? 3 : 5][2],
+                                             int wave, int lane) {
+    constexpr int DEPTH = ONE_PLANE ? 3 : 1;              // positions the word requests run ahead
+    constexpr int NHELD = ONE_PLANE ? 3 : 5;              // windows (per wave) whose output must wait for the barrier
+    static_assert((4 * NHELD) * 3 * kB3Frag >= (ONE_PLANE ? 1 : 2) * kObsFloatsLds * 4, "held windows cover the pixels");
+    constexpr int NW = ONE_PLANE ? 8 : 16;                // words per position
+    const int a = lane & 15, q = lane >> 4;
+    v8b A0[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            A0[i][p] = as_b8(*reinterpret_cast<const v4f*>(pk + EncLayout::kB0 + ((i * 3 + p) * 64 + lane) * 4));
+    int aoff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        aoff[e] = a * kAgentStride + (q < 3 ? q * (kPadHW * kPadHW) + (e / 3) * kPadHW + e % 3
+                                            : e < 3 ? e * (kPadHW * kPadHW) + 2 * kPadHW + 2 : 0);
+    v4f sc[2], sh[2];
+    load_ss(sstab + EncLayout::kBssL0, 32, 0, q, sc[0], sh[0]);
+    load_ss(sstab + EncLayout::kBssL0, 32, 1, q, sc[1], sh[1]);
+    unsigned d[DEPTH + 1][NW];
+    v4f acc[2][2];
+    v4f run[2];
+    auto request = [&](unsigned (&dd)[NW], int P) {        // the pixel words of position P (window P / 4)
+        const int win = wave + 4 * (P >> 2), pp = P & 3;
+        const int wy = win / 5, wx = win - wy * 5;
+        const unsigned* base = obsw + (2 * wy + (pp >> 1)) * kPadHW + 2 * wx + (pp & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dd[e] = base[aoff[e]];
+            if (!ONE_PLANE) dd[8 + e] = base[kObsFloatsLds + aoff[e]];
+        }
+    };
+    auto compute = [&](const unsigned (&dd)[NW], v4f (&ac)[2]) {
+        unsigned bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            bh[w] = __builtin_amdgcn_perm(dd[2 * w + 1], dd[2 * w], 0x05040100u);
+            if (!ONE_PLANE) {
+                bm[w] = __builtin_amdgcn_perm(dd[2 * w + 1], dd[2 * w], 0x07060302u);
+                bl[w] = __builtin_amdgcn_perm(dd[8 + 2 * w + 1], dd[8 + 2 * w], 0x05040100u);
+            }
+        }
+        const v4u bhv = {bh[0], bh[1], bh[2], bh[3]};
+        const v8b Bh = __builtin_bit_cast(v8b, bhv);
+        if (ONE_PLANE) {
+#pragma unroll
+            for (int p = 2; p >= 0; --p)                      // small planes first: wl xh, wm xh, wh xh
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ac[i] = mfma16b(A0[i][p], Bh, p == 2 ? vzero() : ac[i]);
+        } else {
+            const v4u bmv = {bm[0], bm[1], bm[2], bm[3]}, blv = {bl[0], bl[1], bl[2], bl[3]};
+            const v8b B[3] = {Bh, __builtin_bit_cast(v8b, bmv), __builtin_bit_cast(v8b, blv)};
+#pragma unroll
+            for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    ac[i] = mfma16b(A0[i][b3_term_a(term)], B[b3_term_b(term)], term == 0 ? vzero() : ac[i]);
+        }
+    };
+    auto epilogue = [&](const v4f (&ac)[2], int P) {       // BatchNorm + ReLU and the 2x2 max of the window so far
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const v4f t = vfma(ac[i], sc[i], sh[i]);
+            run[i] = (P & 3) == 0 ? vrelu(t) : vmax(run[i], t);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Pin the evaluation HERE: these are pure VALU operations, which the optimiser otherwise sinks to their use
+        // at the end of the window -- every position's accumulators would stay live until then (sched_barrier orders
+        // instructions, not the places where values are computed).
+        asm volatile("" : "+v"(run[0]), "+v"(run[1]));
+#endif
+    };
+    auto window_done = [&](auto wic) {                     // the pooled window wi of this wave: keep, or write now
+        constexpr int wi = decltype(wic)::value;
+        if constexpr (wi < NHELD) {
+            res[wi][0] = run[0];
+            res[wi][1] = run[1];
+        } else {
+            const int win = wave + 4 * wi;
+            v4f pl[3];
+            b3_split8(run[0], run[1], pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+        }
+    };
+    // positions [P0, P1): every index below is a compile-time constant (explicit unrolling: the register arrays must
+    // never be indexed dynamically)
+    auto prologue = [&](auto p0c, auto p1c, auto kc) {
+        constexpr int P = decltype(p0c)::value + decltype(kc)::value;
+        if constexpr (P < decltype(p1c)::value) request(d[P % (DEPTH + 1)], P);
+    };
+    auto body = [&](auto p0c, auto p1c, auto kc) {
+        constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value, P = P0 + decltype(kc)::value;
+        if constexpr (P + DEPTH < P1) request(d[(P + DEPTH) % (DEPTH + 1)], P + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(d[P % (DEPTH + 1)], acc[P & 1]);
+        if constexpr (P > P0) {
+            epilogue(acc[(P - 1) & 1], P - 1);
+            if constexpr (((P - 1) & 3) == 3) window_done(std::integral_constant<int, ((P - 1) >> 2)>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == P1 - 1) {
+            epilogue(acc[P & 1], P);
+            window_done(std::integral_constant<int, (P >> 2)>{});
+        }
+    };
+    auto stream = [&](auto p0c, auto p1c) {
+        constexpr int N = decltype(p1c)::value - decltype(p0c)::value;
+        auto pro = [&](auto... ks) { (prologue(p0c, p1c, ks), ...); };
+        auto run_all = [&](auto... ks) { (body(p0c, p1c, ks), ...); };
+        [&]<int... K>(std::integer_sequence<int, K...>) { pro(std::integral_constant<int, K>{}...); }(
+            std::make_integer_sequence<int, DEPTH>{});
+        [&]<int... K>(std::integer_sequence<int, K...>) { run_all(std::integral_constant<int, K>{}...); }(
+            std::make_integer_sequence<int, N>{});
+    };
+    stream(std::integral_constant<int, 0>{}, std::integral_constant<int, 24>{});
+    if (wave == 0) stream(std::integral_constant<int, 24>{}, std::integral_constant<int, 28>{});   // window 24
+}
+
 template <bool FUSED, int KT>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_b3(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
@@ -241,6 +447,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     v4f* const R4 = reinterpret_cast<v4f*>(gnnpp_smem);              // region R as 16-byte fragments' lanes
     unsigned* const obsw = reinterpret_cast<unsigned*>(gnnpp_smem);  // observation words (h | m << 16), l at + kObsFloatsLds
     float* const sstab = reinterpret_cast<float*>(gnnpp_smem + kB3Table);
+    unsigned* const planeflag = reinterpret_cast<unsigned*>(gnnpp_smem + kB3Table + EncLayout::kBssFloats * 4);   // [4 waves]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: real branches per wave
@@ -313,6 +520,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
         for (int i = tid; i < 2 * kObsFloatsLds / 4; i += kThreads) R4[i] = vzero();
+        unsigned residual = 0;                             // any non-zero m / l plane among this thread's pixels
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (tid + i * kThreads < EncLayout::kBssFloats) sstab[tid + i * kThreads] = ssv[i];
@@ -331,6 +539,9 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             for (int c2 = 0; c2 < 2; ++c2) {
                 unsigned h, m, l;
                 b3_split2(v[k][2 * c2], v[k][2 * c2 + 1], h, m, l);
+                // (a lane's elements outside the tile are copies of valid ones or other agents' pixels: they can only
+                // make the flag conservative)
+                residual |= m | l;
                 w1[2 * c2] = __builtin_amdgcn_perm(m, h, 0x05040100u);        // (h | m << 16) of the even element
                 w1[2 * c2 + 1] = __builtin_amdgcn_perm(m, h, 0x07060302u);    // ... of the odd element
                 w2[2 * c2] = l & 0xffffu;
@@ -355,83 +566,41 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 }
             }
         }
+        // PLANE SKIPPING: when every pixel of the tile is exactly one bf16 plane (the simulator's observations are
+        // {0, 1}: AgentState.toInputTensor, dataloader/statetransformer.py:82-130) the m and l planes are identically
+        // zero and L0 does not issue their products -- skipping exact zeros, the result is the same to the bit.
+        const bool wave_residual = __ballot(residual != 0) != 0ull;
+        if (lane == 0) planeflag[wave] = wave_residual ? 1u : 0u;
     }
     __syncthreads();
     if (GNNPP_STOP_AT(stop, 1)) return;
     if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 0, tid == 0);
 
     // ---- L0: 3 -> 32 @ 11x11 (the 10x10 the pool reads), direct, K = 27 in ONE 32-slot block -------
-    // Lane (q, agent) owns k-slots (q, e) as in the split-f16 schedule: sixteen word reads per position (eight
-    // h | m words, eight l words, position offset = instruction immediate), three v_perm per register pair, then
-    // 6 MFMAs per channel tile.  The pooled outputs stay in registers until every wave is done with the pixels.
+    // Lane (q, agent) owns k-slots (q, e) as in the split-f16 schedule.  A wave walks its windows' positions as ONE
+    // software-pipelined stream (b3_l0_stream below): the pixel words of position P + DEPTH are requested before the
+    // MFMAs of position P are issued, the BatchNorm / ReLU / max epilogue of position P - 1 runs beside them.  The
+    // pooled outputs stay in registers until every wave is done with the pixels.
     {
-        v8b A0[2][3];
+        const v4u pf = *reinterpret_cast<const v4u*>(planeflag);
+        const bool one_plane = (pf[0] | pf[1] | pf[2] | pf[3]) == 0;     // (workgroup-uniform)
+        if (one_plane) {
+            // Window win's output fragments live at R + 3 KiB * win; the h | m pixel words occupy the first 27.1 KiB
+            // of R (the l words behind them are not read on this path): a window beyond them is written as soon as
+            // it is pooled, only a wave's first three windows wait in registers for the barrier.
+            v4f res[3][2];
+            b3_l0_stream<true>(pk, obsw, sstab, R4, res, wave, lane);
+            __syncthreads();                                 // every wave has read its last pixel
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                A0[i][p] = as_b8(*reinterpret_cast<const v4f*>(pk + EncLayout::kB0 + ((i * 3 + p) * 64 + lane) * 4));
-        int aoff[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            aoff[e] = a * kAgentStride + (q < 3 ? q * (kPadHW * kPadHW) + (e / 3) * kPadHW + e % 3
-                                                : e < 3 ? e * (kPadHW * kPadHW) + 2 * kPadHW + 2 : 0);
-        v4f res[7][2];
-#pragma unroll
-        for (int wi = 0; wi < 7; ++wi) {
-            const int win = wave + 4 * wi;
-            if (win < 25) {                                  // (wave-uniform)
-                __builtin_amdgcn_sched_barrier(kSchedItemMask);
-                const int wy = win / 5, wx = win - wy * 5;
-                const unsigned* base = obsw + (2 * wy) * kPadHW + 2 * wx;
-                v4f acc[4][2];
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    unsigned d1[8], d2[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        d1[e] = base[aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
-                        d2[e] = base[kObsFloatsLds + aoff[e] + (pp >> 1) * kPadHW + (pp & 1)];
-                    }
-                    unsigned bh[4], bm[4], bl[4];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        bh[w] = __builtin_amdgcn_perm(d1[2 * w + 1], d1[2 * w], 0x05040100u);
-                        bm[w] = __builtin_amdgcn_perm(d1[2 * w + 1], d1[2 * w], 0x07060302u);
-                        bl[w] = __builtin_amdgcn_perm(d2[2 * w + 1], d2[2 * w], 0x05040100u);
-                    }
-                    const v4u bhv = {bh[0], bh[1], bh[2], bh[3]}, bmv = {bm[0], bm[1], bm[2], bm[3]},
-                              blv = {bl[0], bl[1], bl[2], bl[3]};
-                    const v8b B[3] = {__builtin_bit_cast(v8b, bhv), __builtin_bit_cast(v8b, bmv),
-                                      __builtin_bit_cast(v8b, blv)};
-#pragma unroll
-                    for (int term = 0; term < kB3Terms; ++term)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            acc[pp][i] = mfma16b(A0[i][b3_term_a(term)], B[b3_term_b(term)],
-                                                 term == 0 ? vzero() : acc[pp][i]);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    v4f sc, sh;
-                    load_ss(sstab + EncLayout::kBssL0, 32, i, q, sc, sh);
-                    v4f r = vrelu(vfma(acc[0][i], sc, sh));
-#pragma unroll
-                    for (int pp = 1; pp < 4; ++pp) r = vmax(r, vfma(acc[pp][i], sc, sh));
-                    res[wi][i] = r;
-                }
-            }
-        }
-        __syncthreads();                                     // every wave has read its last pixel
-#pragma unroll
-        for (int wi = 0; wi < 7; ++wi) {
-            const int win = wave + 4 * wi;
-            if (win < 25) {
+            for (int wi = 0; wi < 3; ++wi) {
+                const int win = wave + 4 * wi;
                 v4f pl[3];
                 b3_split8(res[wi][0], res[wi][1], pl);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
             }
+        } else {
+            b3_l0_generic(pk, obsw, sstab, R4, wave, lane);
         }
     }
     __syncthreads();
