@@ -13,6 +13,7 @@
 #include "encoder_kernel_b3.hip"
 #include "lsigf_kernel.hip"
 #include "policy_filter_kernel.hip"
+#include "lsigf_small_kernel.hip"
 #include "train_encoder.hip"
 #include "train_ops.hip"
 
@@ -306,6 +307,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FUSED_POLICY: return g_fused_policy.load();
         case GNNPP_TUNE_FILTER_SPLIT: return g_filter_split.load();
         case GNNPP_TUNE_POLICY_FILTER: return g_filter_policy_kernel.load();
+        case GNNPP_TUNE_FILTER_SMALL: return g_filter_small_kernel.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -335,6 +337,10 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_POLICY_FILTER:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;
             g_filter_policy_kernel.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_SMALL:
+            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
+            g_filter_small_kernel.store(value);
             return GNNPP_OK;
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_ENCODER_STOP:

@@ -868,8 +868,11 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
 }
 
 static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st);   // policy_filter_kernel.hip
+static int lsigf_small_dispatch(LsigfArgs a, hipStream_t st);                            // lsigf_small_kernel.hip
 
 int lsigf_dispatch(const LsigfArgs& a, const LsigfPlan& plan, hipStream_t st) {
+    const int sm = lsigf_small_dispatch(a, st);                       // thousands of small graphs: the throughput kernel
+    if (sm <= 0) return sm;
     const int pf = policy_filter_dispatch(a, plan, st);               // the policy step's shape: its own kernel
     if (pf <= 0) return pf;
     const hipError_t err = plan.nw == 16 ? launch_rtw<16>(plan.rtw, a, plan.grid, plan.smem, st)

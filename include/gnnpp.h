@@ -84,6 +84,11 @@ const char* gnnpp_error_string(int code);
                                          for teams of 17 .. 100 agents (one graph per workgroup,
                                          FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
                                          0: on the general filter kernel (same logits to the last bit or two) */
+#define GNNPP_TUNE_FILTER_SMALL     10  /* 1 (default): graph filters over many small graphs (GNNPP_PREC_FP32, N <= 16,
+                                         G = F = 128, node-major rows, >= 512 workgroups of 48 rows) run on the
+                                         throughput kernel lsigf_small_b3_kernel (bf16x3 planes, two workgroups per
+                                         CU); 0: on the general filter kernel; 2: whenever the shape fits,
+                                         however few graphs (tests)                                        */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

@@ -429,3 +429,47 @@ def test_emu_policy_filter_kernel(emu, N, K, f64, split, B, prec):
     assert np.abs(outs[0] - want).max() <= TOL * scale
     assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
     assert lib.gnnpp_set_tuning(9, 2) == -1
+
+
+@pytest.mark.parametrize('N,K,B,f64,head', [(10, 3, 9, 0, 0), (16, 2, 4, 1, 0), (7, 4, 13, 0, 1), (1, 3, 50, 0, 0),
+                                            (12, 1, 5, 0, 1), (10, 3, 3, 1, 1)])
+def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
+    """lsigf_small_b3_kernel (GNNPP_TUNE_FILTER_SMALL = 2 forces it however few graphs): many small graphs per
+    workgroup, dense in-place shifts, bf16x3 planes written by their producer.  Same results as the general filter
+    kernel (exact-fp32 MFMA contraction) to a few ulps and as the float64 statement within TOL; ragged last workgroup,
+    a workgroup whose rows do not fill its last row tile, fp64 GSOs, K = 1, the fused action head."""
+    el, lib = emu
+    g = np.random.default_rng(1000 * N + 10 * K + B)
+    h = (g.standard_normal((128, 1, K, 128)) / np.sqrt(128 * K)).astype(np.float32)
+    x = np.maximum(g.standard_normal((B, N, 128)), 0).astype(np.float32)
+    S = ((g.random((B, N, N)) < 0.4) * g.random((B, N, N))).astype(np.float64 if f64 else np.float32)
+    bias = (g.standard_normal(128) / 4).astype(np.float32)
+    aw = (g.standard_normal((5, 128)) / 8).astype(np.float32)
+    ab = g.standard_normal(5).astype(np.float32)
+    packed = el.pack_filter(lib, h)
+    outs = []
+    try:
+        for mode in (2, 0):
+            assert lib.gnnpp_set_tuning(10, mode) == 0 and lib.gnnpp_get_tuning(10) == mode
+            if head:
+                out = np.full((N, B, 5), np.nan, dtype=np.float32)
+                assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
+                                                 el.ptr(ab), el.ptr(out), B, N, 128, 128, K, 1, f64, 0, None, None) == 0
+            else:
+                out = np.full((B, N, 128), np.nan, dtype=np.float32)
+                assert lib.gnnpp_lsigf_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(out), B, N, N,
+                                           128, 128, K, 1, f64, 1, 1, 1, 1, 0, 0, None, None) == 0
+            outs.append(out)
+    finally:
+        lib.gnnpp_set_tuning(10, 1)
+    z = x.astype(np.float64)
+    y = np.zeros((B, N, 128))
+    for k in range(K):
+        y += z @ h[:, 0, k, :].astype(np.float64).T
+        z = np.einsum('bmn,bmg->bng', S.astype(np.float32).astype(np.float64), z)
+    y = np.maximum(y + bias, 0)
+    want = (y @ aw.astype(np.float64).T + ab).transpose(1, 0, 2) if head else y
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(outs[0] - want).max() <= TOL * scale
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
+    assert lib.gnnpp_set_tuning(10, 3) == -1
