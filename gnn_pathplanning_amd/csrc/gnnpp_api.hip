@@ -308,6 +308,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_SPLIT: return g_filter_split.load();
         case GNNPP_TUNE_POLICY_FILTER: return g_filter_policy_kernel.load();
         case GNNPP_TUNE_FILTER_SMALL: return g_filter_small_kernel.load();
+        case GNNPP_TUNE_FILTER_SMALL_ROWS: return g_filter_small_rows.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -337,6 +338,10 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_POLICY_FILTER:
             if (value != 0 && value != 1) return GNNPP_ERR_ARG;
             g_filter_policy_kernel.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_SMALL_ROWS:
+            if (value != 0 && value != 32 && value != 48) return GNNPP_ERR_ARG;
+            g_filter_small_rows.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:
             if (value < 0 || value > 2) return GNNPP_ERR_ARG;

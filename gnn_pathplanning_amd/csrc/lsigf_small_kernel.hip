@@ -8,14 +8,15 @@
 // else resident (profiles/r02_c3_filter_pmc.txt: 55 % of the wave time parked, the matrix pipe 18 % busy), and it
 // has no room for bf16x3 planes, so its fp32-equivalent contraction runs on the fp32 MFMA (2.7x the pipe time).
 // Here a workgroup of four waves owns at most 48 rows = floor(48 / N) whole graphs and keeps
-//      z   [48][136] fp32    the CURRENT tap signal, shifted IN PLACE: a wave owns whole graphs; the rows of a graph
-//                            (N <= 16) are all read into registers -- quarter wave per row, dense ascending-m fmaf
-//                            chain over the graph's N rows, bit-identical to the sparse gather (fmaf(0, z, acc) ==
-//                            acc) -- before any of them is written back
+//      z   [48][136] fp32    the CURRENT tap signal, shifted IN PLACE: a wave owns whole graphs, and a graph's shift
+//                            z_{k+1} = S^T z_k is ONE dense 16 x 16 product per 16-feature tile on the exact fp32
+//                            MFMA (the GSO block zero-padded to 16 x 16; all m ascending: bit-identical to the sparse
+//                            gather, fmaf(0, z, acc) == acc) -- 32 MFMAs per graph, all eight result tiles in
+//                            registers before any row is written back
 //      PB  [48][800 B]       the same rows as three bf16 planes, written by whoever produces z_k (the staging loop,
 //                            the shift's write-back): no conversion pass
-//      S   [graphs][N][N+1]  the GSO slabs, column-major (row n = the weights node n gathers with)
-// = 69 KB: TWO workgroups per CU, so one's staging / shift / barrier phases run beside the other's MFMAs.  A wave
+//      S   [graphs][16][17]  the GSO blocks, zero-padded (the shift's B operand)
+// <= 80 KB: TWO workgroups per CU, so one's staging / shift / barrier phases run beside the other's MFMAs.  A wave
 // contracts two 16-feature output tiles over all rows (six MFMAs per 32 channels and row tile, hh products and the
 // five smaller terms in separate accumulators); the tap's 24 A fragments per wave are requested one tap ahead.
 // Epilogue: bias (+ ReLU) -> fp32 rows in z -> fully coalesced 512-byte row stores, or the 128 -> 5 action head.
@@ -25,50 +26,65 @@
 
 namespace gnnpp {
 
-constexpr int kSmRows = 48;                                // rows (graphs x nodes) of one workgroup = 3 row tiles
 constexpr int kSmMaxNodes = 16;
 constexpr int kSmZs = 136;                                 // fp32 row stride (floats)
 constexpr int kSmPRow = 3 * 256 + 32;                      // plane row stride (bytes)
-constexpr int kSmZBytes = kSmRows * kSmZs * 4;             // 26 112
-constexpr int kSmPBytes = kSmRows * kSmPRow;               // 38 400
-constexpr int kSmSOff = kSmZBytes + kSmPBytes;             // GSO slabs: up to 48 rows x 17 floats
-constexpr int kSmSBytes = kSmRows * (kSmMaxNodes + 1) * 4;
-constexpr int kSmCOff = kSmSOff + kSmSBytes;               // constants: bias [128] | act_w [5][128] | act_b [5] (+ pad)
-constexpr int kSmSmem = kSmCOff + 776 * 4;                 // 70 880 B
-static_assert(2 * kSmSmem <= kLdsBytes, "two workgroups per CU");
+constexpr int kSmMaxGraphs = 12;                           // graphs per workgroup (tiny graphs: 12, not ROWS / N)
+constexpr int kSmSBlock = 16 * 17;
+// ROWS = rows (graphs x nodes) of one workgroup: 48 (three row tiles, two workgroups per CU: the fewest tap bytes
+// per agent-step) or 32 (two row tiles, 49 KB: THREE workgroups per CU -- more phases of different workgroups side
+// by side; at N = 10 its 30 rows also fill their tiles better than 40 of 48)
+template <int ROWS> struct SmLayout {
+    static constexpr int kZBytes = ROWS * kSmZs * 4;
+    static constexpr int kPBytes = ROWS * kSmPRow;
+    static constexpr int kCOff = kZBytes + kPBytes;        // constants: bias [128] | act_w [5][128] | act_b [5] (+ pad)
+    static constexpr int kSOff = kCOff + 776 * 4;          // GSO blocks: graphs x 16 x 17 floats
+    static constexpr int smem(int gpw) { return kSOff + gpw * kSmSBlock * 4; }
+};
+static_assert(2 * SmLayout<48>::smem(kSmMaxGraphs) <= kLdsBytes && 3 * SmLayout<32>::smem(3) <= kLdsBytes, "LDS budget");
 
+template <int ROWS>
 __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs p) {
+    typedef SmLayout<ROWS> LY;
+    constexpr int RT = ROWS / 16, XV = ROWS * 32 / 256;
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* const z = reinterpret_cast<float*>(gnnpp_smem);
-    char* const PB = gnnpp_smem + kSmZBytes;
-    float* const Ssm = reinterpret_cast<float*>(gnnpp_smem + kSmSOff);
-    float* const cb = reinterpret_cast<float*>(gnnpp_smem + kSmCOff);
+    char* const PB = gnnpp_smem + LY::kZBytes;
+    float* const Ssm = reinterpret_cast<float*>(gnnpp_smem + LY::kSOff);
+    float* const cb = reinterpret_cast<float*>(gnnpp_smem + LY::kCOff);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 15, q = lane >> 4;
-    const int N = p.N, K = p.K, Np = N + 1;
+    const int N = p.N, K = p.K;
     const int g0 = blockIdx.x * p.gpw;
     const int ng = min(p.gpw, p.B - g0);
-    const int rows = ng * N;                               // <= 48
+    const int rows = ng * N;                               // <= ROWS
     const int ntile = (rows + 15) >> 4;                    // row tiles in use (wave-uniform)
 
+    GNNPP_STAMP(blockIdx.x, 0, tid == 0);
     // ---- every global load of the kernel's front, issued now ------------------------------------------------
     const v4f* xs = reinterpret_cast<const v4f*>(p.x + (size_t)g0 * N * 128);
-    v4f xv[6];
+    v4f xv[XV];
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
+    for (int u = 0; u < XV; ++u) {
         const int i = tid + u * 256;
         if (i < rows * 32) xv[u] = xs[i];
     }
-    float sv[4];
-    const int nS = ng * N * N;                             // <= 4 * 256
+    // the GSO blocks, gathered element by element of the PADDED [graph][16][17] layout (each LDS word is written
+    // exactly once: zeros outside the graph's N x N block); four loads in flight per thread and trip
+    const int nSb = ng * kSmSBlock;
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto s_load = [&](int idx) -> float {
+        const int j = idx / kSmSBlock, e = idx - j * kSmSBlock;
+        const int m = e / 17, n = e - m * 17;
+        if (m >= N || n >= N) return 0.f;
+        const size_t gi = ((size_t)(g0 + j) * N + m) * N + n;
+        return p.s_is_f64 ? (float)reinterpret_cast<const double*>(p.S)[gi] : reinterpret_cast<const float*>(p.S)[gi];
+    };
     if (K > 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + u * 256;
-            if (i < nS) sv[u] = p.s_is_f64 ? (float)(reinterpret_cast<const double*>(p.S)[(size_t)g0 * N * N + i])
-                                           : reinterpret_cast<const float*>(p.S)[(size_t)g0 * N * N + i];
-        }
+        for (int u = 0; u < 4; ++u)
+            if (tid + u * 256 < nSb) sv[u] = s_load(tid + u * 256);
     }
     float cpre[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -92,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
 
     // ---- stage: z_0 as fp32 rows and as planes, the GSO column-major, the constants ----------------------------
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
+    for (int u = 0; u < XV; ++u) {
         const int i = tid + u * 256;
         const bool ok = i < rows * 32;
         const v4f v = ok ? xv[u] : vzero();
@@ -106,34 +122,28 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
         }
     }
     if (K > 1) {
-        const float inv_nn = 1.0f / (float)(N * N), inv_n = 1.0f / (float)N;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + u * 256;
-            if (i < nS) {                                  // element (graph j, m, n) -> Ssm[j][n][m]  (exact float
-                const int j = (int)(((float)i + 0.5f) * inv_nn);          // reciprocal: i < 2^12)
-                const int e = i - j * N * N;
-                const int m = (int)(((float)e + 0.5f) * inv_n), n = e - m * N;
-                Ssm[(j * N + n) * Np + m] = sv[u];
-            }
-        }
+        for (int u = 0; u < 4; ++u)
+            if (tid + u * 256 < nSb) Ssm[tid + u * 256] = sv[u];
+        for (int idx = tid + 1024; idx < nSb; idx += 256) Ssm[idx] = s_load(idx);      // (more than 3 graphs: N <= 12)
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         if (tid + u * 256 < 773) cb[tid + u * 256] = cpre[u];
     load_tap(0);                                           // (behind the staged data in the memory queue)
     __syncthreads();
+    GNNPP_STAMP(blockIdx.x, 1, tid == 0);
 
-    v4f acc[3][2], acc2[3][2];                             // [row tile][channel tile]: hh | the five smaller terms
+    v4f acc[RT][2], acc2[RT][2];                           // [row tile][channel tile]: hh | the five smaller terms
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int m = 0; m < 2; ++m) { acc[t][m] = vzero(); acc2[t][m] = vzero(); }
 
     for (int k = 0; k < K; ++k) {
         // ---- contraction of tap k: D[f, row] += W_k[f, g] z_k[row, g] from the planes ---------------------------
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < RT; ++t) {
             if (t < ntile) {
                 const int pr = min(t * 16 + a, rows - 1);   // (rows >= `rows`: copies, never stored)
 #pragma unroll
@@ -153,61 +163,48 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
                 }
             }
         }
+        GNNPP_STAMP(blockIdx.x, 2 + 3 * k, tid == 0 && k < 3);          // this wave's part of tap k contracted
         if (k + 1 == K) break;
         load_tap(k + 1);                                   // in flight during the shift
         __syncthreads();                                   // every wave is done with the planes of z_k
-        // ---- shift z_k -> z_{k+1} in place: wave w owns graphs w, w + 4, .. -------------------------------------
+        GNNPP_STAMP(blockIdx.x, 3 + 3 * k, tid == 0 && k < 3);
+        // ---- shift z_k -> z_{k+1} in place: wave w owns graphs w, w + 4, ..; one graph = eight 16-feature tiles of
+        // D[feature][node n] = sum_m z_k[m][feature] S[m][n] on the fp32 MFMA (rows past the graph meet zero weights)
         {
-            const int quarter = lane >> 4, ql = lane & 15;
             const bool last = k + 2 == K;                  // z_{K-1} is only needed as planes
             for (int j = wave; j < ng; j += 4) {
-                const float* zg = z + j * N * kSmZs + 4 * ql;
-                v4f r0[4], r1[4];
+                const int r0 = j * N;
+                float Sb[4];
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int n = it * 4 + quarter;
-                    r0[it] = vzero(); r1[it] = vzero();
-                    if (it * 4 < N) {                      // (wave-uniform)
-                        const float* wl = Ssm + (j * N + min(n, N - 1)) * Np;
-                        for (int m = 0; m < N; ++m) {
-                            const float w = wl[m];
-                            const v4f za = *reinterpret_cast<const v4f*>(zg + m * kSmZs);
-                            const v4f zb = *reinterpret_cast<const v4f*>(zg + m * kSmZs + 64);
+                for (int s4 = 0; s4 < 4; ++s4) Sb[s4] = Ssm[j * kSmSBlock + (4 * s4 + q) * 17 + a];
+                v4f d[8];
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                r0[it][c] = fmaf(w, za[c], r0[it][c]);
-                                r1[it][c] = fmaf(w, zb[c], r1[it][c]);
-                            }
-                        }
+                for (int ft = 0; ft < 8; ++ft) {
+                    d[ft] = vzero();
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int m = min(r0 + 4 * s4 + q, ROWS - 1);       // (rows past the buffer: zero weights)
+                        d[ft] = mfma16(z[m * kSmZs + 16 * ft + a], Sb[s4], d[ft]);
                     }
                 }
-                __builtin_amdgcn_wave_barrier();           // every row of the graph is in registers
+                __builtin_amdgcn_wave_barrier();           // every row of the graph has been read
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int n = it * 4 + quarter;
-                    if (it * 4 < N) {
-                        v2f p0[3], p1[3];
-                        b3_split4(r0[it], p0);
-                        b3_split4(r1[it], p1);
-                        if (n < N) {
-                            const int r = j * N + n;
-                            if (!last) {
-                                *reinterpret_cast<v4f*>(z + r * kSmZs + 4 * ql) = r0[it];
-                                *reinterpret_cast<v4f*>(z + r * kSmZs + 64 + 4 * ql) = r1[it];
-                            }
-                            char* row = PB + r * kSmPRow;
+                for (int ft = 0; ft < 8; ++ft) {           // lane (q, a): node a, features 16 ft + 4 q ..
+                    v2f pl[3];
+                    b3_split4(d[ft], pl);
+                    if (a < N) {
+                        const int r = r0 + a;
+                        if (!last) *reinterpret_cast<v4f*>(z + r * kSmZs + 16 * ft + 4 * q) = d[ft];
 #pragma unroll
-                            for (int pp = 0; pp < 3; ++pp) {
-                                *reinterpret_cast<v2f*>(row + pp * 256 + 8 * ql) = p0[pp];
-                                *reinterpret_cast<v2f*>(row + pp * 256 + 128 + 8 * ql) = p1[pp];
-                            }
-                        }
+                        for (int pp = 0; pp < 3; ++pp)
+                            *reinterpret_cast<v2f*>(PB + r * kSmPRow + pp * 256 + (16 * ft + 4 * q) * 2) = pl[pp];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();                                   // planes of z_{k+1} visible
+        GNNPP_STAMP(blockIdx.x, 4 + 3 * k, tid == 0 && k < 3);
     }
 
     // ---- epilogue: bias (+ ReLU) -> fp32 rows in z -> coalesced store / action head ------------------------------
@@ -217,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
         const int f0 = (2 * wave + m) * 16 + 4 * q;
         const v4f bv = *reinterpret_cast<const v4f*>(cb + f0);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < RT; ++t) {
             const int row = t * 16 + a;
             if (t < ntile && row < rows) {
                 v4f v = (acc[t][m] + acc2[t][m]) + bv;
@@ -227,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
         }
     }
     __syncthreads();
+    GNNPP_STAMP(blockIdx.x, 12, tid == 0);
     if (p.y) {
         v4f* yd = reinterpret_cast<v4f*>(p.y + (size_t)g0 * N * 128);
         for (int i = tid; i < rows * 32; i += 256) {
@@ -247,8 +245,10 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
             p.logits[((size_t)n * p.B + (g0 + j)) * 5 + c] = s + cb[768 + c];
         }
     }
+    GNNPP_STAMP(blockIdx.x, 13, tid == 0);
 }
 
+std::atomic<int> g_filter_small_rows{0};                   // GNNPP_TUNE_FILTER_SMALL_ROWS: 0 = heuristic, 32 or 48
 std::atomic<int> g_filter_small_kernel{1};                 // GNNPP_TUNE_FILTER_SMALL: 0 = never, 1 = heuristic, 2 = whenever the shape fits
 
 // Does the planned launch have this kernel's shape?  Returns 1 when not (the caller goes on), 0 / -3 after a launch.
@@ -263,14 +263,26 @@ static int lsigf_small_dispatch(LsigfArgs a, hipStream_t st) {
 #endif
     )
         return 1;
-    // the throughput regime: enough graphs that every CU gets at least two workgroups; below that the general
-    // kernel's wider workgroups win on latency
-    a.gpw = kSmRows / a.N;
+    // Measured (profiles/r03_filter_sweep.jsonl, N = 10, K = 3): 48-row workgroups win once they fill the chip twice
+    // over (B = 2048: 18.6 vs 23.8 us; B = 8192 .. 131072: 1.19 - 1.26 G agent-steps/s vs 1.12 - 1.21 -- fewer tap
+    // bytes per agent-step); below that 32-row workgroups spread the graphs over more CUs (B = 512: 11.5 us vs 14.3,
+    // and vs 15.2 for the general kernel); a handful of graphs stay on the general kernel's wider workgroups.
+    const int forced = g_filter_small_rows.load(std::memory_order_relaxed);
+    const int per48 = 48 / a.N < kSmMaxGraphs ? 48 / a.N : kSmMaxGraphs;
+    const int rows = forced ? forced : ((a.B + per48 - 1) / per48 >= 512 ? 48 : 32);
+    const int per = rows / a.N;
+    a.gpw = per < kSmMaxGraphs ? per : kSmMaxGraphs;
     const int grid = (a.B + a.gpw - 1) / a.gpw;
-    if (grid < 512 && mode != 2) return 1;
-    static LdsAttrOnce once;
-    set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_small_b3_kernel), kSmSmem);
-    hipLaunchKernelGGL(lsigf_small_b3_kernel, dim3(grid), dim3(256), kSmSmem, st, a);
+    if (grid < 64 && mode != 2) return 1;
+    if (rows == 48) {
+        static LdsAttrOnce once;
+        set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_small_b3_kernel<48>), SmLayout<48>::smem(kSmMaxGraphs));
+        hipLaunchKernelGGL(lsigf_small_b3_kernel<48>, dim3(grid), dim3(256), SmLayout<48>::smem(a.gpw), st, a);
+    } else {
+        static LdsAttrOnce once;
+        set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_small_b3_kernel<32>), SmLayout<32>::smem(kSmMaxGraphs));
+        hipLaunchKernelGGL(lsigf_small_b3_kernel<32>, dim3(grid), dim3(256), SmLayout<32>::smem(a.gpw), st, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -85,10 +85,12 @@ const char* gnnpp_error_string(int code);
                                          FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
                                          0: on the general filter kernel (same logits to the last bit or two) */
 #define GNNPP_TUNE_FILTER_SMALL     10  /* 1 (default): graph filters over many small graphs (GNNPP_PREC_FP32, N <= 16,
-                                         G = F = 128, node-major rows, >= 512 workgroups of 48 rows) run on the
+                                         G = F = 128, node-major rows, >= 64 workgroups) run on the
                                          throughput kernel lsigf_small_b3_kernel (bf16x3 planes, two workgroups per
                                          CU); 0: on the general filter kernel; 2: whenever the shape fits,
                                          however few graphs (tests)                                        */
+#define GNNPP_TUNE_FILTER_SMALL_ROWS 11 /* rows per workgroup of that kernel: 0 = heuristic, 32 (three workgroups per
+                                         CU) or 48 (two; fewer tap bytes per agent-step)                   */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

@@ -449,8 +449,9 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
     packed = el.pack_filter(lib, h)
     outs = []
     try:
-        for mode in (2, 0):
+        for mode, rows in ((2, 32), (2, 48), (0, 0)):
             assert lib.gnnpp_set_tuning(10, mode) == 0 and lib.gnnpp_get_tuning(10) == mode
+            assert lib.gnnpp_set_tuning(11, rows) == 0
             if head:
                 out = np.full((N, B, 5), np.nan, dtype=np.float32)
                 assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
@@ -462,6 +463,7 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
             outs.append(out)
     finally:
         lib.gnnpp_set_tuning(10, 1)
+        lib.gnnpp_set_tuning(11, 0)
     z = x.astype(np.float64)
     y = np.zeros((B, N, 128))
     for k in range(K):
@@ -471,5 +473,6 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
     want = (y @ aw.astype(np.float64).T + ab).transpose(1, 0, 2) if head else y
     scale = max(1.0, np.abs(want).max())
     assert np.abs(outs[0] - want).max() <= TOL * scale
-    assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
-    assert lib.gnnpp_set_tuning(10, 3) == -1
+    assert np.array_equal(outs[0], outs[1])                 # 32- and 48-row workgroups: the same arithmetic per row
+    assert np.abs(outs[0] - outs[2]).max() <= 4e-6 * scale
+    assert lib.gnnpp_set_tuning(10, 3) == -1 and lib.gnnpp_set_tuning(11, 40) == -1

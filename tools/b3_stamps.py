@@ -101,3 +101,24 @@ if 'filter' in which:
                 order = [('entry', 0), ('staged', 1), ('lists', 2), ('tap0', 3), ('barrier1', 4), ('shift1+barrier', 5),
                          ('rest of the taps', 12), ('partial', 13), ('stored', 14)]
             report('policy_filter_kernel prec=%d B=%d N=%d' % (prec, B, N), B, order)
+
+if 'small' in which:
+    from gnn_pathplanning_amd.graphML import pack_filter_taps
+    N, K = 10, 3
+    h = (torch.randn(128, 1, K, 128) / (128 * K) ** 0.5).to(dev)
+    taps = pack_filter_taps(h)
+    bias = torch.zeros(128, device=dev)
+    for B in (1024, 2048, 8192):
+        S = torch.from_numpy(orc.synth_gso_geometric(512, N, 20, seed=1337)).float().to(dev).repeat(B // 512, 1, 1).contiguous()
+        x = torch.relu(torch.randn(B * N, 128, device=dev))
+        y = torch.empty_like(x)
+        M.gnnpp_set_tuning(10, 2)
+        for _ in range(6):
+            assert M.gnnpp_lsigf_fwd(x.data_ptr(), S.data_ptr(), taps.data_ptr(), bias.data_ptr(), y.data_ptr(), B, N, N,
+                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, 0, None, st) == 0
+            torch.cuda.synchronize()
+        M.gnnpp_set_tuning(10, 1)
+        report('lsigf_small_b3_kernel B=%d N=10 K=3 (%d workgroups; stamps of the first 1024)' % (B, (B + 3) // 4),
+               min(1024, (B + 3) // 4),
+               [('entry', 0), ('staged', 1), ('tap0', 2), ('barrier', 3), ('shift1', 4), ('tap1', 5), ('barrier', 6),
+                ('shift2', 7), ('tap2', 8), ('y in lds', 12), ('stored', 13)])

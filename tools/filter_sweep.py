@@ -26,11 +26,11 @@ S0 = torch.from_numpy(orc.synth_gso_geometric(512, N, 20, seed=1337)).float().to
 mean_deg = float((S0 != 0).sum() / (512 * N))
 
 
-def run(B, mode, reps):
+def run(B, mode, reps, rows=0):
     S = S0.repeat((B + 511) // 512, 1, 1)[:B].contiguous()
     x = torch.relu(torch.randn(B * N, 128, device=dev))
     y = torch.empty_like(x)
-    assert L.gnnpp_set_tuning(10, mode) == 0
+    assert L.gnnpp_set_tuning(10, mode) == 0 and L.gnnpp_set_tuning(11, rows) == 0
     call = lambda: L.gnnpp_lsigf_fwd(x.data_ptr(), S.data_ptr(), taps.data_ptr(), bias.data_ptr(), y.data_ptr(), B, N, N,  # noqa: E731
                                      128, 128, K, 1, 0, 1, 1, 1, 1, 0, 0, None, st)
     for _ in range(5):
@@ -46,6 +46,7 @@ def run(B, mode, reps):
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e-3 / reps)
     L.gnnpp_set_tuning(10, 1)
+    L.gnnpp_set_tuning(11, 0)
     return sorted(ts)[2], y
 
 
@@ -54,9 +55,11 @@ if len(sys.argv) > 2 and sys.argv[1] == '--pmc-target':
     sys.exit(0)
 for B in (512, 2048, 8192, 32768, 131072):
     ref = None
-    for mode, name in ((1, 'default (small-graph kernel when >= 512 workgroups)'), (0, 'general filter kernel')):
+    for mode, rows, name in ((1, 0, 'default (small-graph kernel when >= 512 workgroups)'),
+                             (2, 32, 'small-graph kernel, 32 rows'), (2, 48, 'small-graph kernel, 48 rows'),
+                             (0, 0, 'general filter kernel')):
         reps = max(3, min(200, int(4e6 / (B * N))))
-        t, y = run(B, mode, reps)
+        t, y = run(B, mode, reps, rows)
         fb = B * N * (1024 + 4 * N) + 196608.0 * K / 3
         ffl = 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * B * N
         rec = {'batch': B, 'agents': N, 'taps': K, 'kernel': name, 'us': round(t * 1e6, 2),
