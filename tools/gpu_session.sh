@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: test smoke bench ab bench35 prof pmc   (default: all but pmc)
+# steps: test smoke bench benchdrv bench35 train distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc
 TAG=${1:-r01}; shift
-STEPS=${@:-test smoke bench ab bench35 prof}
+STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,16 +19,6 @@ if has bench; then stamp "bench c2"
   timeout 400 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
 if has benchdrv; then stamp "bench c2 with the driver's flags"
   timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 | tee $OUT/bench_c2_driverflags.json; fi
-if has abenc; then stamp "ab_bench encoder"
-  timeout 400 python tools/ab_bench.py encoder 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_encoder.jsonl; fi
-if has fusedab; then stamp "fused policy kernel A/B"
-  timeout 300 python tools/ab_bench.py fused 2>&1 | grep -v amdgpu.ids | tee $OUT/fused_ab.jsonl; fi
-if has encphases; then stamp "encoder phases"
-  timeout 300 python tools/ab_bench.py encoder_phases 2>&1 | grep -v amdgpu.ids | tee $OUT/encoder_phases.jsonl; fi
-if has ab; then stamp "ab_bench"
-  timeout 400 python tools/ab_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/ab_bench.jsonl; fi
-if has rollout; then stamp "rollout bench"
-  timeout 300 python tools/ab_bench.py rollout 2>&1 | grep -v amdgpu.ids | tee $OUT/rollout_bench.jsonl; fi
 if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 2>&1 | tail -1 | tee $OUT/train_bench.json
   timeout 300 python tools/train_bench.py --steps 50 --graph 2>&1 | tail -3 | tee $OUT/train_bench_graph.json
@@ -38,16 +28,12 @@ if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path 
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
   stamp "1-rank torchrun nccl"
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
-if has filterab; then stamp "filter kernel A/B"
-  timeout 400 python tools/filter_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_ab.jsonl; fi
+if has b3stamps; then stamp "phase stamps of the policy kernels (per precision)"
+  timeout 300 python tools/b3_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/b3_stamps.jsonl; fi
+if has filtersweep; then stamp "filter-only throughput sweep"
+  timeout 400 python tools/filter_sweep.py 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_sweep.jsonl; fi
 if has stamps; then stamp "phase stamps of the rollout kernels"
   timeout 300 python tools/phase_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tail -14 | tee $OUT/phase_stamps.jsonl; fi
-if has fablate; then stamp "filter ablation"
-  timeout 300 python tools/ab_bench.py filter_ablation 2>&1 | grep -v amdgpu.ids | tee $OUT/filter_ablation.jsonl; fi
-if has pipelined; then stamp "pipelined steps"
-  timeout 300 python tools/ab_bench.py pipelined 2>&1 | grep -v amdgpu.ids | tee $OUT/pipelined.jsonl; fi
-if has dualpipe; then stamp "dual-pipe probe"
-  timeout 300 python tools/dualpipe_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/dualpipe_probe.jsonl; fi
 if has bench35; then for c in c3 c5; do stamp "bench $c"
   timeout 400 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 4 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
@@ -67,7 +53,7 @@ if has proftrain; then stamp "rocprofv3 kernel trace of the training step"
   [ -n "$f" ] && head -24 "$f" | cut -c1-200 | tee $OUT/kernel_stats_head_train.csv
   find $OUT/prof_train -name "*kernel_trace.csv" -size +6M -delete; fi
 if has pmc; then stamp "rocprofv3 pmc passes"
-  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
     timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --pmc-target > $OUT/pmc_$name.log 2>&1
     python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt

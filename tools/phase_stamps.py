@@ -75,10 +75,10 @@ for (N, B, W) in ((10, 512, 20), (16, 512, 20), (100, 128, 100)):
     ptrs = net.policy_pointers()
     enc, taps, gb, aw, ab, K = ptrs
     M.gnnpp_rollout_policy_step.argtypes = [ctypes.POINTER(_native.RolloutStruct)] + [ctypes.c_void_p] * 5 + \
-        [ctypes.c_int, ctypes.c_void_p]
+        [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     for _ in range(3):
         r.currentstep += 1
-        assert M.gnnpp_rollout_policy_step(ctypes.byref(r), enc, taps, gb, aw, ab, K, st_ptr) == 0
+        assert M.gnnpp_rollout_policy_step(ctypes.byref(r), enc, taps, gb, aw, ab, K, 0, st_ptr) == 0
         torch.cuda.synchronize()
     report('policy_step (one launch) N=%d B=%d' % (N, B), stamps(min(B, 1024)),
            ['kernel:start', 'policy:head_done', 'move:entry', 'move:state_loaded', 'move:proposed', 'move:pass1',
@@ -91,7 +91,7 @@ class Cfg2:
     num_agents, nGraphFilterTaps, device = 10, 3, dev
 net = DecentralPlannerNet(Cfg2()).to(dev).eval()
 net.load_state_dict(orc.init_state_dict(3))
-M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
 SLOTS.update({'enc:staged': 0, 'enc:L0': 1, 'enc:L1': 2, 'enc:L2': 3, 'enc:L3': 4, 'enc:L4': 5, 'enc:FC(z0)': 12,
               'filter:shifts': 13, 'filter:contraction': 14})
 N = 10
@@ -106,7 +106,7 @@ for B in (512, 256):
     lg = torch.empty(N, B, 5, device=dev)
     for _ in range(5):
         assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
-                                  B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
+                                  B, N, 3, 1, 0, 0, None, _native.stream_ptr(dev)) == 0
         torch.cuda.synchronize()
     report('policy kernel (B=%d, N=10: %d workgroup(s) per CU)' % (B, B // 256), stamps(B),
            ['kernel:start', 'enc:staged', 'enc:L0', 'enc:L1', 'enc:L2', 'enc:L3', 'enc:L4', 'enc:FC(z0)',
@@ -117,7 +117,7 @@ for B in (512, 256):
 SLOTS.update({'f:entry': 0, 'f:staged': 1, 'f:lists': 2, 'f:shift1': 3, 'f:split0': 4, 'f:tap0': 5, 'f:shift2': 6,
               'f:split1': 7, 'f:tap1': 8, 'f:sync': 9, 'f:split2': 10, 'f:tap2': 11, 'f:contracted': 12,
               'f:y_in_lds': 13, 'f:stored': 14})
-M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
 for (N, B) in ((50, 256), (100, 128)):
     class Cfg3:
         num_agents, nGraphFilterTaps, device = N, 3, dev
@@ -133,7 +133,7 @@ for (N, B) in ((50, 256), (100, 128)):
     lg = torch.empty(N, B, 5, device=dev)
     for _ in range(5):
         assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
-                                  B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
+                                  B, N, 3, 1, 0, 0, None, _native.stream_ptr(dev)) == 0
         torch.cuda.synchronize()
     SLOTS.update({'pf:entry': 0, 'pf:staged': 1, 'pf:lists(wave0)': 2, 'pf:tap0(wave0)': 3, 'pf:barrier1': 4,
                   'pf:shift1(wave0)': 5, 'pf:barrier2': 6, 'pf:shift2': 7, 'pf:split1': 8, 'pf:tap1(wave0)': 9,
@@ -145,7 +145,7 @@ for (N, B) in ((50, 256), (100, 128)):
     assert M.gnnpp_set_tuning(9, 0) == 0
     for _ in range(5):
         assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
-                                  B, N, 3, 1, 0, None, _native.stream_ptr(dev)) == 0
+                                  B, N, 3, 1, 0, 0, None, _native.stream_ptr(dev)) == 0
         torch.cuda.synchronize()
     M.gnnpp_set_tuning(9, 1)
     report('general filter kernel inside the policy step (B=%d, N=%d)' % (B, N), stamps(B),
