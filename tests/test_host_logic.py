@@ -158,11 +158,14 @@ def test_prepowered_gso_api_surface():
 
 def test_committed_bench_lines_follow_the_contract():
     """The bench lines committed under profiles/ (copied from GPU sessions) carry every field of the driver's
-    contract, with consistent arithmetic: value = batch x agents / ms_per_step, roofline.frac = achieved / peak."""
+    contract, with consistent arithmetic: value = batch x agents / ms_per_step, roofline.frac = achieved / peak with
+    the guide's dense peak of the MFMA instruction actually issued (the product count is stated, not folded into the
+    peak), the headline in fp32-equivalent arithmetic, and -- in the C2 line -- the compact records of the other
+    single-GPU configs and of the non-resident (rotating-batch) workload."""
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r02_bench_c*.json')))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench_c*.json')))
     assert len(files) >= 3
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
@@ -171,16 +174,39 @@ def test_committed_bench_lines_follow_the_contract():
             assert key in d, (f, key)
         assert d['unit'] == 'agent-steps/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
         assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config']
+        assert d['dtype'].startswith('f32') and d['precision'] == 'fp32'      # the headline: fp32-equivalent arithmetic
         cfg = d['config']
         per_step = cfg['batch_per_gpu'] * cfg['agents'] * d['n_gpus']
         assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
         rl = d['roofline']
-        for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'instruction', 'mfma_products_per_fp32_mac'):
             assert key in rl, (f, key)
         assert rl['bound'] in ('hbm', 'mfma') and abs(rl['frac'] - rl['achieved'] / rl['peak']) <= 1e-6
+        assert rl['instruction'] == 'v_mfma_f32_16x16x32_bf16' and rl['peak'] == 2500.0
+        assert rl['mfma_products_per_fp32_mac'] == 6
+        assert abs(rl['achieved'] - rl['flops_per_launch'] / (rl['avg_launch_us'] * 1e-6) / 1e12) <= 1e-6 * rl['achieved']
+        assert rl['avg_launch_us'] <= d['ms_per_step'] * 1e3 * 1.001 or not d['step_breakdown_us']['one_kernel_step']
         assert rl['traffic'] is None or rl['traffic'] > 0
         cb = d['cpu_baseline']
         for key in ('value', 'unit', 'cores', 'kind', 'sample'):
             assert key in cb, (f, key)
         assert cb['kind'] in ('port', 'reference') and cb['value'] > 0
-        assert d['parity']['max_abs_dlogit'] <= d['parity']['tolerance']
+        assert d['parity']['max_abs_dlogit'] <= d['parity']['tolerance'] and d['parity']['range_flag'] == 0
+        sec = d['secondary']
+        # the narrower split-f16 mode and the exact fp32 MFMA are labelled secondaries with their own roofline blocks
+        for key, instr in (('split_f16_fast_mode', 'v_mfma_f32_16x16x32_f16'),
+                           ('exact_fp32_mfma_schedule', 'v_mfma_f32_16x16x4_f32')):
+            r2 = sec[key]['roofline']
+            assert r2['instruction'] == instr and abs(r2['frac'] - r2['achieved'] / r2['peak']) <= 1e-6
+            assert sec[key]['max_abs_dlogit_vs_default'] <= 1e-4
+        if cfg['name'] == 'c2':
+            oc = sec['other_configs']
+            assert set(oc) == {'c3_K3', 'c5_K2', 'c5_K3', 'c5_K4'}
+            for k, v in oc.items():
+                assert 'error' not in v, (k, v)
+                assert abs(v['value'] - v['batch'] * v['agents'] / (v['ms_per_step'] * 1e-3)) <= 1e-3 * v['value']
+                assert v['parity_max_abs_dlogit'] <= 1e-4 and v['argmax_equal_on_clear_rows'] is True
+                assert 0 < v['frac'] < 1 / 6 and v['dominant_kernel_us'] < v['ms_per_step'] * 1e3
+            rot = sec['c2_rotating_batches']
+            assert rot['batches'] >= 64 and rot['resident_MB'] > 256 and 0.5 < rot['vs_single_resident_batch'] < 1.1
+            assert any(x['batch'] >= 8192 for x in sec['batch_sweep_filter_only'])
