@@ -376,7 +376,7 @@ def main():
 
     from gnn_pathplanning_amd import _native
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
-    from gnn_pathplanning_amd.sharding import aggregate_throughput
+    from gnn_pathplanning_amd.sharding import aggregate_throughput, gather_rank_devices
     from oracle import policy_oracle as orc           # checker + cpu_baseline leg + synthetic inputs only
     L = _native.lib()
 
@@ -469,9 +469,11 @@ def main():
         pipelined = {'streams': S_n, 'value': v_p, 'ms_per_step': 1e3 * el_p / args.steps,
                      'note': 'K independent batches round-robin on %d HIP streams; not the headline' % S_n}
 
+    rank_devices = gather_rank_devices(dev)                # which physical GPU every rank ran on (tools/check_scale.py)
     result = {
         'metric': 'agent-steps/sec (policy fwd)', 'value': value, 'unit': 'agent-steps/s',
         'n_gpus': world, 'ranks_in_group': dist.get_world_size() if dist is not None else 1,
+        'rank_devices': rank_devices,
         'dist_backend': dist.get_backend() if dist is not None else None,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',

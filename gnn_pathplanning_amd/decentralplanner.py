@@ -23,7 +23,8 @@ updates its running statistics N times per forward (decentralplanner.py:284-290)
 batch-wide reductions per agent between the layers, so train mode is a layer-by-layer schedule of
 hand-written HIP kernels, forward and backward (csrc/train_encoder.hip behind
 gnnpp_encoder_train_fwd / _bwd), plus the graph filter (forward, input gradient, tap gradient) on
-lsigf_kernel through graphML._LSIGFFunction; compressMLP and the action head are library GEMMs.
+lsigf_kernel through graphML._LSIGFFunction; the FORWARD products of compressMLP and the action head are
+library GEMMs (plain GEMMs), their backward products run on gnnpp_gemm_kmajor_multi.
 There is no CPU path.
 """
 import ctypes
@@ -509,11 +510,15 @@ class DecentralPlannerNet(nn.Module):
         return out.permute(1, 0, 2).contiguous()
 
     def _forward_train(self, inputTensor):
-        """Differentiable train-mode forward with the reference's semantics (decentralplanner.py:278-318),
-        on HIP kernels end to end: the per-agent ConvLayers calls (BatchNorm with THAT call's batch
-        statistics, N running-statistics updates per forward) run as _EncoderTrainFunction over all agents
-        at once (csrc/train_encoder.hip, forward and backward); compressMLP and the action head are one
-        library GEMM each; the graph filter layers run on lsigf_kernel (graphML._LSIGFFunction)."""
+        """Differentiable train-mode forward with the reference's semantics (decentralplanner.py:278-318).
+        Hand-written HIP: the per-agent ConvLayers calls (BatchNorm with THAT call's batch statistics, N
+        running-statistics updates per forward) as _EncoderTrainFunction over all agents at once
+        (csrc/train_encoder.hip, forward and backward); the graph-filter layers on lsigf_kernel
+        (graphML._LSIGFFunction: forward with tap dump, input gradient = the transposed filter, tap gradient on
+        gnnpp_gemm_kmajor); the backward products of compressMLP and the action head on gnnpp_gemm_kmajor_multi.
+        Library / aten: the FORWARD of compressMLP and of the action head (torch.nn.functional.linear -> hipBLASLt:
+        plain 640 x 128 x 128 GEMMs) and the ReLU mask of compressMLP.  A GSO with more nodes than numAgents
+        (graphML.py:2464-2469 zero-pads the signal) is honoured as in eval mode."""
         import torch.nn.functional as tF
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
@@ -536,12 +541,21 @@ class DecentralPlannerNet(nn.Module):
                                            float(bn0.eps), *tensors)                     # [B,N,128]
         fc = self.compressMLP[0]
         x = tF.relu(_LinearFunction.apply(feat, fc.weight, fc.bias))                    # [B,N,F]
+        if self.S.shape[0] != B:
+            raise _native.GnnppError('addGSO() was given %d graphs, the input has %d samples' % (self.S.shape[0], B))
+        Ns = self.S.shape[-1]
+        if Ns < N:
+            raise _native.GnnppError('the GSO has %d nodes, the planner %d agents' % (Ns, N))
+        if Ns != N:                                # Nin < N: zero signal on the extra nodes (graphML.py:2464-2469)
+            x = torch.cat([x, x.new_zeros(B, Ns - N, x.shape[2])], 1)
         # every activation stays node-major [B,N,*] (the layout the filter kernel keeps in LDS): no transposing
         # copy between encoder, filter layers and head; each GFL ReLU runs inside its filter launch
         for l in range(self.L):
             gf = self.GFL[2 * l]
             gf.addGSO(self.S)
-            x = gf.forward_node_major(x, relu=True)                                     # [B,N,F_l]
+            x = gf.forward_node_major(x, relu=True)                                     # [B,Ns,F_l]
+        if Ns != N:
+            x = x[:, :N]                           # ... whose outputs are dropped (index_select, :2471-2476)
         act = self.actionsMLP[0]
         return _LinearFunction.apply(x, act.weight, act.bias).permute(1, 0, 2)          # [N,B,5] (a view of [B,N,5])
 

@@ -35,3 +35,27 @@ def aggregate_throughput(units_local, elapsed_local, device=None, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
     return u.item() / t.item(), u.item(), t.item()
+
+
+def device_identity(device):
+    """A string that names the PHYSICAL GPU behind `device`: uuid when this torch exposes it, else PCI bus id, else
+    the ordinal.  Two ranks that were meant to own different GPUs must report different identities."""
+    if device is None or device.type != 'cuda':
+        return 'cpu'
+    props = torch.cuda.get_device_properties(device)
+    for attr in ('uuid', 'pci_bus_id'):
+        v = getattr(props, attr, None)
+        if v not in (None, ''):
+            extra = getattr(props, 'pci_device_id', '')
+            return '%s:%s:%s' % (attr, v, extra)
+    return 'ordinal:%d' % (device.index if device.index is not None else torch.cuda.current_device())
+
+
+def gather_rank_devices(device, group=None):
+    """[identity of rank 0's GPU, rank 1's, ...] on every rank (all_gather of strings; one entry without a group)."""
+    me = device_identity(device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [me]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, me, group=group)
+    return out

@@ -364,12 +364,83 @@ def gen_training(DecentralPlannerNet, gml):
     print('training_grads: %d cases' % len(meta))
 
 
+def gen_multilayer_training(DecentralPlannerNet, gml):
+    """Train-mode forward + loss.backward() of planners with SEVERAL graph-filter layers / E > 1 edge features
+    (the re-wired reference of gen_multilayer, agents/decentralplannerlocal.py:283-317's loss) ->
+    tests/golden/training_multilayer.npz: logits, loss, sum / abs-sum / norm of EVERY gradient and the full
+    gradients of the graph-filter layers and the head."""
+    from oracle.policy_oracle import synth_gso_geometric, synth_gso_sparse, synth_obs
+    z = np.load(os.path.join(OUT, 'policy_model.npz'))
+    sd_enc = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith('sd/')}
+    store, meta = {}, []
+    for ci, (N, B, dims, taps, E, gso) in enumerate(((10, 4, [64, 128], [3, 2], 1, 'geo64'),
+                                                     (5, 3, [128], [3], 2, 'sparse32'),
+                                                     (6, 3, [32, 48], [2, 3], 2, 'sparse32'))):
+        torch.manual_seed(8100 + ci)
+        net = DecentralPlannerNet(Cfg(N, 3))
+        net.load_state_dict(sd_enc)
+        F = [128] + dims
+        layers = []
+        for l in range(len(dims)):
+            layers += [gml.GraphFilterBatch(F[l], F[l + 1], taps[l], E, True), torch.nn.ReLU(inplace=True)]
+        net.GFL = torch.nn.Sequential(*layers)
+        net.L, net.F, net.K, net.E = len(dims), F, taps, E
+        head = torch.nn.Linear(F[-1], 5)
+        torch.nn.init.xavier_normal_(head.weight)
+        with torch.no_grad():
+            head.bias.copy_(0.05 * torch.randn(5))
+        net.actionsMLP = torch.nn.Sequential(head)
+        net.train()
+        obs = synth_obs(B, N, seed=400 + ci)
+        if gso == 'geo64':
+            S = torch.from_numpy(synth_gso_geometric(B * E, N, 20, seed=410 + ci)).float().reshape(B, E, N, N)
+        else:
+            S = synth_gso_sparse(B * E, N, 3.0, seed=410 + ci).reshape(B, E, N, N)
+        g = torch.Generator().manual_seed(420 + ci)
+        tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=g), 5).float()
+        net.addGSO(S.squeeze(1) if E == 1 else S)
+        predict = net(obs)
+        bt = tgt.permute(1, 0, 2)
+        ce = torch.nn.CrossEntropyLoss()
+        loss = 0
+        for n in range(N):
+            loss = loss + ce(predict[n], torch.max(bt[n], 1)[1])
+        loss = loss / N
+        loss.backward()
+        k = 't%d_' % ci
+        for l in range(len(dims)):
+            store[k + 'GFL.%d.weight' % (2 * l)] = net.GFL[2 * l].weight.detach().numpy()
+            store[k + 'GFL.%d.bias' % (2 * l)] = net.GFL[2 * l].bias.detach().numpy()
+        store[k + 'actionsMLP.0.weight'] = head.weight.detach().numpy()
+        store[k + 'actionsMLP.0.bias'] = head.bias.detach().numpy()
+        store[k + 'obs'] = obs.numpy().astype(np.uint8)
+        store[k + 'S'] = S.numpy()
+        store[k + 'target'] = tgt.numpy().astype(np.uint8)
+        store[k + 'logits'] = torch.stack([p.detach() for p in predict], 1).numpy()
+        store[k + 'loss'] = np.array(loss.item(), dtype=np.float64)
+        names, summ = [], []
+        for name, p in net.named_parameters():
+            names.append(name)
+            gr = p.grad.double()
+            summ.append([gr.sum().item(), gr.abs().sum().item(), gr.norm().item()])
+            if name.startswith(('GFL.', 'actionsMLP.')) or name == 'compressMLP.0.weight':
+                store[k + 'grad/' + name] = p.grad.numpy()
+        store[k + 'gradsum'] = np.array(summ)
+        meta.append({'N': N, 'B': B, 'dims': dims, 'taps': taps, 'E': E, 'gso': gso, 'param_names': names})
+    store['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'training_multilayer.npz'), **store)
+    print('training_multilayer: %d cases' % len(meta))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     Net, gml = import_reference()
     sys.path.insert(0, os.path.dirname(HERE))
     if len(sys.argv) > 1 and sys.argv[1] == 'training':
         gen_training(Net, gml)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'multilayer_training':
+        gen_multilayer_training(Net, gml)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'large':
         gen_policy_large(Net)
@@ -379,3 +450,4 @@ if __name__ == '__main__':
     gen_policy_large(Net)
     gen_multilayer(Net, gml)
     gen_training(Net, gml)
+    gen_multilayer_training(Net, gml)

@@ -68,11 +68,16 @@ def multilayer_golden():
     return _load('policy_multilayer.npz')
 
 
-def multilayer_state_dict(zp, zm, ci):
+@pytest.fixture(scope='session')
+def multilayer_training_golden():
+    return _load('training_multilayer.npz')
+
+
+def multilayer_state_dict(zp, zm, ci, prefix='m'):
     """Encoder parameters of policy_model.npz + the graph-filter layers / head of multilayer case ci."""
     import torch
     sd = {k: v for k, v in golden_state_dict(zp, 3).items() if not k.startswith(('GFL.', 'actionsMLP.'))}
-    pre = 'm%d_' % ci
+    pre = '%s%d_' % (prefix, ci)
     for k in zm.files:
         if k.startswith(pre + 'GFL.') or k.startswith(pre + 'actionsMLP.'):
             sd[k[len(pre):]] = torch.from_numpy(np.array(zm[k]))

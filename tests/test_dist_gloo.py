@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gnn_pathplanning_amd.sharding import aggregate_throughput, shard_batch, shard_range
+from gnn_pathplanning_amd.sharding import aggregate_throughput, gather_rank_devices, shard_batch, shard_range
 
 
 def _free_port():
@@ -32,6 +32,8 @@ def _worker(rank, world, port, q):
         thr, units, t = aggregate_throughput(o.shape[0] * 10, 1.0 + rank)
         gathered = [None] * world
         dist.all_gather_object(gathered, g.tolist())
+        devs = gather_rank_devices(torch.device('cpu'))
+        assert devs == ['cpu', 'cpu']                    # one entry per rank, same list on every rank
         q.put((rank, thr, units, t, gathered))
     finally:
         dist.destroy_process_group()
@@ -106,3 +108,25 @@ def test_flat_bucket_dp_two_ranks():
 def test_single_process_aggregation_without_group():
     thr, units, t = aggregate_throughput(100, 0.5)
     assert (thr, units, t) == (200.0, 100, 0.5)
+
+
+def test_rank_devices_without_group_and_scale_checker():
+    """tools/check_scale.py rejects a scaling session whose N-GPU line did not use N ranks on N distinct GPUs, or
+    whose 1-GPU line disagrees with the committed bench line."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import check_scale
+    assert gather_rank_devices(torch.device('cpu')) == ['cpu']
+    metric = 'agent-steps/sec (policy fwd)'
+    ok = [{'n_gpus': 1, 'ranks_in_group': 1, 'rank_devices': ['uuid:a'], 'value': 100.0, 'metric': metric},
+          {'n_gpus': 2, 'ranks_in_group': 2, 'rank_devices': ['uuid:a', 'uuid:b'], 'value': 198.0, 'metric': metric}]
+    ref = {'value': 102.0, 'metric': metric}
+    errs, vals = check_scale.check(ok, ref)
+    assert errs == [] and vals == {1: 100.0, 2: 198.0}
+    shared = [ok[0], dict(ok[1], rank_devices=['uuid:a', 'uuid:a'])]
+    assert any('share physical devices' in e for e in check_scale.check(shared, ref)[0])
+    assert check_scale.check(shared, ref, allow_shared=True)[0] == []
+    assert any('ranks_in_group' in e for e in check_scale.check([ok[0], dict(ok[1], ranks_in_group=1)], ref)[0])
+    assert any('within 5' in e for e in check_scale.check(ok, {'value': 120.0, 'metric': metric})[0])
+    assert any('drops' in e for e in check_scale.check([ok[0], dict(ok[1], value=90.0)], ref)[0])
+    assert any('rank_devices reported' in e for e in check_scale.check([dict(ok[0], rank_devices=[])], None)[0])

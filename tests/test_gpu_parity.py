@@ -571,6 +571,42 @@ def test_default_precision_denormal_and_huge_weights(dev):
     assert (got - want).abs().max().item() <= 3e-5 * scale
 
 
+def test_replaced_parameter_objects_are_seen_by_the_next_forward(dev):
+    """a Parameter / buffer / sub-module OBJECT replaced by hand (no version counter, no
+    load_state_dict, no train() transition in between) must change the logits of the VERY NEXT forward -- the
+    memoised tensor list is validated by object identity on every call."""
+    sd = orc.init_state_dict(3, seed=9)
+    net = _net(6, 3, dev, sd)
+    obs = orc.synth_obs(3, 6, seed=2).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(3, 6, 12, seed=2)).to(dev)
+    net.addGSO(S)
+
+    def check():
+        got = net.forward_logits(obs).cpu()
+        cur = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            want = torch.stack(orc.policy_forward(cur, S.cpu(), obs.cpu()), 0)
+        assert (got - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+        return got
+    a = check()
+    g = torch.Generator().manual_seed(1)
+    conv = net.ConvLayers[4]
+    conv.weight = torch.nn.Parameter((torch.randn(conv.weight.shape, generator=g) * 0.06).to(dev))   # new Parameter object
+    b = check()
+    assert (a - b).abs().max().item() > 1e-3
+    bn = net.ConvLayers[8]
+    bn.running_var = (torch.rand(bn.running_var.shape, generator=g) + 0.5).to(dev)                 # new buffer object
+    c = check()
+    assert (b - c).abs().max().item() > 1e-4
+    lin = torch.nn.Linear(128, 5).to(dev)
+    net.actionsMLP[0] = lin                                                                           # new sub-module
+    d = check()
+    assert (c - d).abs().max().item() > 1e-3
+    net.GFL[0].weight = torch.nn.Parameter(net.GFL[0].weight.detach() * 0.5)
+    e = check()
+    assert (d - e).abs().max().item() > 1e-4
+
+
 def test_unseen_parameter_updates_and_invalidate_packed(dev):
     """`p.data` edits do not bump torch's version counters: invalidate_packed() (or a train()/eval()
     transition) makes the next forward repack."""

@@ -351,3 +351,25 @@ def test_mt19937_tie_break_matches_python_random_choice(dev):
             assert (pos[b] == eps[b].cur).all(), (t, b)
         draws += int(env.choice_count.sum().item())
     assert draws > 100
+
+
+def test_mt19937_word_stream_overflow_is_an_error(dev):
+    """an episode that consumes more Mersenne-Twister words than it was given (the kernel substitutes 0
+    from there on) no longer follows the reference's random.choice stream; results() / check_rng() must raise instead
+    of reporting a silently different rollout."""
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.rollout import BatchedRollout
+    rng = np.random.default_rng(32)
+    B, N, W = 16, 12, 5
+    grids, starts, goals = random_episodes(rng, B, N, W, 0.0)
+    env = BatchedRollout(grids, starts, goals, 50, dev, tie_mode='mt19937', seed=7, rng_words=4)
+    for t in range(8):                                            # a crowded 5 x 5 map: dozens of tie-breaks
+        env.move(actions=torch.from_numpy(rng.integers(0, 5, size=(B, N))).to(dev))
+    assert int(env.choice_count.sum().item()) >= 0
+    assert int((env.rng_cursor > 4).sum().item()) > 0
+    with pytest.raises(_native.GnnppError, match='random words'):
+        env.results()
+    ok = BatchedRollout(grids, starts, goals, 50, dev, tie_mode='mt19937', seed=7)
+    for t in range(8):
+        ok.move(actions=torch.from_numpy(rng.integers(0, 5, size=(B, N))).to(dev))
+    ok.results()                                                  # the default 2048 words: fine

@@ -112,6 +112,45 @@ def test_policy_training_step_matches_reference(dev, training_golden, policy_gol
                 assert close(bufs[name].cpu().float(), z[key].astype(np.float32), 1e-4), name
 
 
+def test_multilayer_training_matches_reference(dev, multilayer_training_golden, policy_golden):
+    """gradient goldens for planners with L = 2 graph-filter layers and / or E = 2 edge features
+    (tests/golden/training_multilayer.npz: the re-wired REAL reference in train mode, loss.backward()): logits, loss,
+    the norm of every parameter's gradient, and the full gradients of every graph-filter layer, the head and
+    compressMLP."""
+    from conftest import multilayer_state_dict
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import policy_loss
+    z, meta = multilayer_training_golden
+    zp, _ = policy_golden
+    for ci, m in enumerate(meta):
+        class C:
+            num_agents, nGraphFilterTaps, device = m['N'], list(m['taps']), dev
+            dimNodeSignals, numEdgeFeatures = list(m['dims']), m['E']
+        net = DecentralPlannerNet(C()).to(dev)
+        net.load_state_dict(multilayer_state_dict(zp, z, ci, prefix='t'))
+        net.train()
+        obs = torch.from_numpy(z['t%d_obs' % ci].astype(np.float32)).to(dev)
+        S = torch.from_numpy(z['t%d_S' % ci]).to(dev)
+        tgt = torch.from_numpy(z['t%d_target' % ci].astype(np.float32)).to(dev)
+        net.addGSO(S.squeeze(1) if m['E'] == 1 else S)
+        out = net(obs)
+        loss = policy_loss(out, tgt)
+        loss.backward()
+        assert abs(loss.item() - float(z['t%d_loss' % ci])) <= 1e-5, (ci, loss.item())
+        assert np.abs(torch.stack(out, 1).detach().cpu().numpy() - z['t%d_logits' % ci]).max() <= 1e-4
+        grads = dict((n, p.grad) for n, p in net.named_parameters())
+        assert list(grads) == m['param_names']
+        full = 0
+        for j, name in enumerate(m['param_names']):
+            want = z['t%d_gradsum' % ci][j]
+            assert abs(grads[name].double().norm().item() - want[2]) <= 5e-4 * max(1e-3, want[2]), (ci, name)
+            key = 't%d_grad/%s' % (ci, name)
+            if key in z.files:
+                assert close(grads[name].cpu(), z[key], 5e-4), (ci, name)
+                full += 1
+        assert full >= 2 * len(m['dims']) + 3
+
+
 def test_train_step_reduces_loss_and_eval_repacks(dev):
     """A few Adam steps on one batch (agents/decentralplannerlocal.py:59 settings) lower the loss,
     and the fused eval path afterwards uses the UPDATED weights (pack cache invalidation)."""
@@ -454,3 +493,37 @@ def test_graphed_train_step_with_fused_adam(dev):
     graphed = [first] + [step(*b).item() for b in batches[1:]]
     for a, b in zip(eager, graphed):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (eager, graphed)
+
+
+def test_train_mode_gso_with_more_nodes_than_agents(dev):
+    """a GSO with more nodes than numAgents (the reference's GraphFilterBatch zero-pads the signal,
+    graphML.py:2464-2469) works in TRAIN mode like in eval mode: same logits as the train-mode forward on the padded
+    graph restricted to the team, gradients flow."""
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 6, 3, dev
+    torch.manual_seed(3)
+    net = DecentralPlannerNet(Cfg()).to(dev).train()
+    B, N, Ns = 5, 6, 9
+    obs = orc.synth_obs(B, N, seed=5).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, Ns, 14, seed=5)).float().to(dev)
+    net.addGSO(S)
+    out = net(obs)
+    assert len(out) == N and out[0].shape == (B, 5)
+    torch.stack(list(out), 0).square().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    # oracle: the reference's train-mode forward with the [B,Ns,Ns] GSO (it pads the [B,128,N] signal itself)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    net2 = DecentralPlannerNet(Cfg()).to(dev).train()
+    net2.load_state_dict(sd)
+    with torch.no_grad():
+        want = orc.policy_forward(sd, S.cpu(), obs.cpu(), training=True)
+    net2.addGSO(S)
+    got = net2(obs)
+    err = max((g.detach().cpu() - w).abs().max().item() for g, w in zip(got, want))
+    assert err <= 1e-4, err
+    with pytest.raises(_native.GnnppError):
+        net2.addGSO(S[:, :4, :4])                          # fewer nodes than agents: a clear error, not an assert
+        net2(obs)

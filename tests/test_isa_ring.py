@@ -61,3 +61,43 @@ def test_checker_catches_violations(tmp_path):
                 good.replace('; ScratchSize: 0', '; ScratchSize: 16')):
         f.write_text(bad)
         assert check_ring_isa.check(str(f))[0], bad
+
+
+def test_checker_follows_per_wave_switch_arms(tmp_path):
+    """The bf16x3 kernel puts a whole layer's ring traffic inside each case of a per-wave switch: every arm has its own
+    copy of the loads / waits / takes.  The walk is path sensitive: equal arms pass; an arm that consumes a different
+    number of items, or takes with too weak a wait, is reported even though the other arm is fine."""
+    import check_ring_isa
+    arm = '''\tglobal_load_dwordx4 v[212:215], v1, s[0:1] ; RINGLOAD 1
+\ts_waitcnt vmcnt(1) ; RINGWAIT
+\tv_mov_b64 v[2:3], v[208:209] ; RINGTAKE 0
+\tv_mov_b64 v[4:5], v[210:211] ; RINGTAKE 0
+\ts_waitcnt vmcnt(0) ; RINGWAIT
+\tv_mov_b64 v[2:3], v[212:213] ; RINGTAKE 1
+\tv_mov_b64 v[4:5], v[214:215] ; RINGTAKE 1
+'''
+    text = ('_ZN5gnnpp17encoder_kernel_b3ILb0ELi3EEEvPKfS2_Pfii:\n'
+            '\tglobal_load_dwordx4 v[208:211], v1, s[0:1] ; RINGLOAD 0\n'
+            '\ts_cmp_eq_u32 s4, 0\n'
+            '\ts_cbranch_scc1 .LBB0_2\n'
+            + arm.replace('v[2:3]', 'v[6:7]') +
+            '\ts_branch .LBB0_3\n'
+            '.LBB0_2:\n' + arm +
+            '.LBB0_3:\n'
+            '\ts_endpgm\n'
+            '.Lfunc_end0:\n; NumVgprs: 256\n; ScratchSize: 0\n; Occupancy: 2\n')
+    f = tmp_path / 'sw.s'
+    f.write_text(text)
+    errors, stats, _ = check_ring_isa.check(str(f), 'encoder_kernel_b3ILb0')
+    assert errors == [] and stats == {'loads': 2, 'takes': 2}
+    second = text.rindex('\tglobal_load_dwordx4 v[212:215]')
+    # (a) the second arm takes slot 0 behind vmcnt(1) only AFTER a second younger load was issued: fine; with
+    #     vmcnt(2) it is not
+    weak = text[:second] + text[second:].replace('vmcnt(1) ; RINGWAIT', 'vmcnt(2) ; RINGWAIT')
+    f.write_text(weak)
+    assert any('younger loads' in e for e in check_ring_isa.check(str(f), 'encoder_kernel_b3ILb0')[0])
+    # (b) the second arm forgets its own load of slot 1 (the first arm has it): reported on that path only
+    short = text[:second] + text[second:].replace('\tglobal_load_dwordx4 v[212:215], v1, s[0:1] ; RINGLOAD 1\n', '')
+    f.write_text(short)
+    errs = check_ring_isa.check(str(f), 'encoder_kernel_b3ILb0')[0]
+    assert any('taken but not loaded' in e for e in errs), errs

@@ -26,6 +26,8 @@ if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench.json; fi
 if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path check only)"
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
+  stamp "2 ranks over RCCL on ONE GPU: GraphedTrainStep(dp=FlatBucketDP) -- the captured all-reduce must execute"
+  GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 tools/train_bench.py --steps 20 --graph 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-500 | tee -a $OUT/distcheck.log
   stamp "1-rank torchrun nccl"
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
 if has b3stamps; then stamp "phase stamps of the policy kernels (per precision)"

@@ -31,4 +31,10 @@ for N in 1 2 4 8; do
   fi
 done
 echo "== policy forward (agent-steps/s, whole job)"; cut -c1-220 $OUT/scale_policy.jsonl
-echo "== training (agent-steps/s, whole job)"; cat $OUT/scale_train.jsonl
+echo "== training (agent-steps/s, whole job)"; cut -c1-400 $OUT/scale_train.jsonl
+# fail loudly unless every N-GPU line really used N ranks on N distinct GPUs, and N = 1 matches the committed line
+RC=0
+python tools/check_scale.py $OUT/scale_policy.jsonl --reference profiles/r03_bench_c2.json | tee $OUT/scale_check.txt || RC=1
+python tools/check_scale.py $OUT/scale_train.jsonl | tee -a $OUT/scale_check.txt || RC=1
+[ $RC -ne 0 ] && echo "!! scaling session INVALID (see messages above)"
+exit $RC

@@ -40,7 +40,7 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
-    from gnn_pathplanning_amd.sharding import aggregate_throughput
+    from gnn_pathplanning_amd.sharding import aggregate_throughput, gather_rank_devices
     from gnn_pathplanning_amd.training import FlatBucketDP, FusedAdam, train_step
     from oracle import policy_oracle as orc                   # synthetic inputs only
 
@@ -86,9 +86,11 @@ def main():
         dist.barrier()
     el = time.perf_counter() - t0
     thr, units, el = aggregate_throughput(B * N * args.steps, el, device=dev)
+    rank_devices = gather_rank_devices(dev)
     if rank == 0:
         print(json.dumps({'metric': 'training agent-steps/s (fwd+bwd+Adam, config 4)', 'value': thr,
                           'n_gpus': world, 'ranks_in_group': dist.get_world_size() if world > 1 else 1,
+                          'rank_devices': rank_devices,
                           'backend': dist.get_backend() if world > 1 else None,
                           'batch_per_gpu': B, 'ms_per_step': 1e3 * el / args.steps,
                           'final_loss': float(loss.item()), 'hip_graph': bool(args.graph),
