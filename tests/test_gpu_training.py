@@ -408,7 +408,9 @@ def test_fused_adam_and_loss_match_torch(dev):
         # follows the noise, and the (inert) biases above feed that noise differently into the two nets from the second
         # step on: the trajectories agree to a fraction of one step, not to rounding.  (The update rule itself is pinned
         # to rounding, on well-conditioned gradients, by test_fused_adam_checkpoint_round_trip.)
-        assert (pa - pb).abs().max().item() <= 5e-4, k
+        # -> bound the worst entry by two full steps and the typical entry tightly
+        assert (pa - pb).abs().max().item() <= 2e-3, k
+        assert (pa - pb).abs().mean().item() <= 1e-4, k
 
 
 def test_fused_adam_checkpoint_round_trip(dev):

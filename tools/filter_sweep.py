@@ -28,7 +28,7 @@ mean_deg = float((S0 != 0).sum() / (512 * N))
 
 def run(B, mode, reps, rows=0):
     S = S0.repeat((B + 511) // 512, 1, 1)[:B].contiguous()
-    x = torch.relu(torch.randn(B * N, 128, device=dev))
+    x = torch.relu(torch.randn(B * N, 128, generator=torch.Generator().manual_seed(B))).to(dev)
     y = torch.empty_like(x)
     assert L.gnnpp_set_tuning(10, mode) == 0 and L.gnnpp_set_tuning(11, rows) == 0
     call = lambda: L.gnnpp_lsigf_fwd(x.data_ptr(), S.data_ptr(), taps.data_ptr(), bias.data_ptr(), y.data_ptr(), B, N, N,  # noqa: E731
@@ -51,7 +51,8 @@ def run(B, mode, reps, rows=0):
 
 
 if len(sys.argv) > 2 and sys.argv[1] == '--pmc-target':
-    run(int(sys.argv[2]), 1, 4)
+    rows = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    run(int(sys.argv[2]), 2 if rows else 1, 4, rows)
     sys.exit(0)
 for B in (512, 2048, 8192, 32768, 131072):
     ref = None

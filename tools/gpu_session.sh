@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: test smoke bench benchdrv bench35 train distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc
+# steps: test smoke bench benchdrv bench35 train distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc filterpmc
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,7 +27,8 @@ if has train; then stamp "train bench"
 if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path check only)"
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
   stamp "2 ranks over RCCL on ONE GPU: GraphedTrainStep(dp=FlatBucketDP) -- the captured all-reduce must execute"
-  GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 tools/train_bench.py --steps 20 --graph 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-500 | tee -a $OUT/distcheck.log
+  GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 tools/train_bench.py --steps 20 --graph > $OUT/rccl_one_gpu.log 2>&1; echo "exit $?" >> $OUT/rccl_one_gpu.log
+  grep -i "error\|duplicate\|invalid\|agent-steps\|^exit" $OUT/rccl_one_gpu.log | grep -v amdgpu.ids | head -12 | cut -c1-400 | tee -a $OUT/distcheck.log
   stamp "1-rank torchrun nccl"
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
 if has b3stamps; then stamp "phase stamps of the policy kernels (per precision)"
@@ -60,6 +61,13 @@ if has pmc; then stamp "rocprofv3 pmc passes"
     timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python $R/bench.py --pmc-target > $OUT/pmc_$name.log 2>&1
     python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt
     find $OUT/pmc_$name -name "*.csv" -size +2M -delete
+  done; fi
+if has filterpmc; then stamp "rocprofv3 pmc passes over the filter-only launch (B = 8192 graphs of 10 nodes)"
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+    name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+    timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/fpmc_$name -o pmc -- python $R/tools/filter_sweep.py --pmc-target 8192 $FILTER_PMC_ROWS > $OUT/fpmc_$name.log 2>&1
+    python $R/tools/pmc_summary.py $OUT/fpmc_$name 2>&1 | grep small | tee -a $OUT/filter_pmc.txt
+    find $OUT/fpmc_$name -name "*.csv" -size +2M -delete
   done; fi
 stamp done
 du -sh $OUT
