@@ -15,18 +15,23 @@ reported region is the MEDIAN one (all of them are listed under `regions_ms`).  
 on the launch stream around the same regions give the device-side time the roofline uses, so the
 kernel time can never exceed the step time it is part of.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel: algorithmic fp32 FLOPs per launch / launch time measured in the timed
-                region itself (one-kernel step) or in an identical back-to-back loop (two-kernel step),
-                against the matrix-pipe peak of /opt/skills/guides/MI355X_MICROARCH.md for the
-                arithmetic the kernel runs; `traffic` = HBM bytes per launch from rocprofv3 --pmc
-                passes run by THIS process (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction),
-                or null when rocprofv3 is not usable
-  cpu_baseline  the CPU oracle (op-for-op restatement of the reference's PyTorch path, pinned to
-                golden vectors) timed on this box's host cores: C2 batch at the fastest thread count
-                (headline), at 1 thread, and the reference's own B = 1 rollout step (C1)
-  parity        max |dlogit| and action-id agreement GPU vs oracle on the bench batch, near-tie rows listed
-  secondary     exact-fp32 schedule, argmax-D2H-inclusive rate, batch sweep, filter-only HBM fraction
+Rank 0 prints ONE JSON line.  `value`, `ms_per_step`, `dtype`, `roofline` and `parity` all describe the DEFAULT
+precision ("fp32": every fp32 operand exactly as three bf16 planes, six plane products on the bf16 MFMA, fp32
+accumulate -- no input domain, nothing narrower than the reference's fp32).  Besides the contract fields:
+  roofline      dominant kernel: ALGORITHMIC fp32 FLOPs per launch / launch time (HIP events on the launch stream,
+                inside the timed regions for the one-kernel step) / the dense peak of the instruction actually
+                issued (MI355X_MICROARCH.md); the number of MFMA products one fp32 MAC costs is stated beside it
+                (`mfma_products_per_fp32_mac`), never folded into `peak`; `traffic` = HBM bytes per launch from
+                rocprofv3 --pmc passes run by THIS process (separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+                correction), or null when rocprofv3 is not usable
+  cpu_baseline  the CPU oracle (op-for-op restatement of the reference's PyTorch path, pinned to golden vectors)
+                timed on this box's host cores (bounded sample)
+  parity        max |dlogit| and action-id agreement GPU vs oracle on the bench batch, near-tie rows listed;
+                `range_flag` as read back from the device
+  secondary     the other two precisions (exact fp32 MFMA; opt-in split-f16, labelled narrower than fp32) with their
+                own roofline blocks, the remaining single-GPU configurations (C3, C5 at K = 2, 3, 4), a
+                rotating-batch variant of C2 (64 distinct batches, > 256 MB: not cache-resident), batch sweeps,
+                the filter-only HBM fraction, the argmax-D2H-inclusive rate, the rollout step
 """
 import argparse
 import csv

@@ -40,8 +40,9 @@ extern "C" {
  *   GNNPP_PREC_FP32 (default)  fp32-equivalent, NO input domain: every fp32 operand is represented exactly as
  *       three bf16 planes (x = h + m + l, fp32's exponent range) and a product keeps six of the nine plane
  *       products on v_mfma_f32_16x16x32_bf16 (dropped terms <= 2^-23 |w x|, below one fp32 rounding).  Where
- *       a kernel has no LDS room for the planes (the graph filter outside the fused policy kernel and the
- *       policy filter of <= 64-node teams) the contraction runs on the exact fp32 MFMA instead -- also exact.
+ *       a kernel has no LDS room for the planes -- the general graph-filter kernel (lsigf_kernel) and the
+ *       policy filter of teams whose rows + planes exceed the 160 KB LDS (N > ~64 agents, e.g. the 100-agent
+ *       configuration) -- the contraction runs on the exact fp32 MFMA instead: exact as well, only slower.
  *   GNNPP_PREC_FP32_MFMA       v_mfma_f32_16x16x4_f32 everywhere: bitwise an fmaf chain, 2.7x more pipe time.
  *   GNNPP_PREC_SPLIT_F16       fast, NARROWER than fp32: operands as f16 hi + lo halves (22 significand bits)
  *       on v_mfma_f32_16x16x32_f16, valid for |activation| < 65504 only -- see "Range guard"; opt-in. */
@@ -144,6 +145,10 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
  *                 dx = sum_k W_k^T . dy . (S^T)^k, i.e. this call with x := dy, taps packed from
  *                 h.permute(3,1,2,0) and s_transposed = 1.  This form always contracts on the exact
  *                 fp32 MFMA, whatever `precision` says (cotangents are far below the f16 normal range).
+ * LIMIT: the training calls keep a graph's rows in one workgroup's LDS: N <= GNNPP_MAX_ROWS (112; 100 guaranteed
+ * at G = F = 128), else GNNPP_ERR_UNSUPPORTED.  Inference has the dense fallback described at GNNPP_MAX_ROWS; the
+ * training path has none (the reference trains on 10-agent teams: configs/dcp_*.json), and the Python layer raises
+ * GnnppError for larger graphs in train mode instead of degrading silently.
  */
 int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
                          float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
