@@ -113,41 +113,4 @@ for B in (512, 256):
             'filter:shifts', 'filter:contraction'])
 
 
-# ---- the stand-alone filter kernel (the second kernel of the policy at N > 16): C3 / C5 shapes, K = 3
-SLOTS.update({'f:entry': 0, 'f:staged': 1, 'f:lists': 2, 'f:shift1': 3, 'f:split0': 4, 'f:tap0': 5, 'f:shift2': 6,
-              'f:split1': 7, 'f:tap1': 8, 'f:sync': 9, 'f:split2': 10, 'f:tap2': 11, 'f:contracted': 12,
-              'f:y_in_lds': 13, 'f:stored': 14})
-M.gnnpp_policy_fwd.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
-for (N, B) in ((50, 256), (100, 128)):
-    class Cfg3:
-        num_agents, nGraphFilterTaps, device = N, 3, dev
-    net = DecentralPlannerNet(Cfg3()).to(dev).eval()
-    net.load_state_dict(orc.init_state_dict(3))
-    obs = orc.synth_obs(B, N, seed=1337).to(dev)
-    S = torch.from_numpy(orc.synth_gso_geometric(B, N, N, seed=1337)).float().to(dev)
-    net.addGSO(S)
-    for _ in range(5):
-        net(obs)
-    enc, taps, gb, aw, ab, K = net.policy_pointers()
-    ws = torch.empty(B * N, 128, device=dev)
-    lg = torch.empty(N, B, 5, device=dev)
-    for _ in range(5):
-        assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
-                                  B, N, 3, 1, 0, 0, None, _native.stream_ptr(dev)) == 0
-        torch.cuda.synchronize()
-    SLOTS.update({'pf:entry': 0, 'pf:staged': 1, 'pf:lists(wave0)': 2, 'pf:tap0(wave0)': 3, 'pf:barrier1': 4,
-                  'pf:shift1(wave0)': 5, 'pf:barrier2': 6, 'pf:shift2': 7, 'pf:split1': 8, 'pf:tap1(wave0)': 9,
-                  'pf:tap2(wave0)': 12, 'pf:partial_logits': 13, 'pf:stored': 14})   # (K = 3)
-    report('policy_filter_kernel inside the policy step (B=%d, N=%d)' % (B, N), stamps(B),
-           ['pf:entry', 'pf:staged', 'pf:lists(wave0)', 'pf:tap0(wave0)', 'pf:barrier1', 'pf:shift1(wave0)',
-            'pf:barrier2', 'pf:shift2', 'pf:split1', 'pf:tap1(wave0)', 'pf:tap2(wave0)', 'pf:partial_logits',
-            'pf:stored'])
-    assert M.gnnpp_set_tuning(9, 0) == 0
-    for _ in range(5):
-        assert M.gnnpp_policy_fwd(obs.data_ptr(), S.data_ptr(), enc, taps, gb, aw, ab, ws.data_ptr(), lg.data_ptr(),
-                                  B, N, 3, 1, 0, 0, None, _native.stream_ptr(dev)) == 0
-        torch.cuda.synchronize()
-    M.gnnpp_set_tuning(9, 1)
-    report('general filter kernel inside the policy step (B=%d, N=%d)' % (B, N), stamps(B),
-           ['f:entry', 'f:staged', 'f:lists', 'f:shift1', 'f:split0', 'f:tap0', 'f:shift2', 'f:split1', 'f:tap1',
-            'f:sync', 'f:split2', 'f:tap2', 'f:contracted', 'f:y_in_lds', 'f:stored'])
+# (the filter kernels' phases: tools/b3_stamps.py filter / small)
