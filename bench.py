@@ -139,7 +139,7 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     tiles = (M + 15) // 16
     info = PRECISION_INFO[prec]
     rl = roofline_block('gnnpp::encoder_kernel_b3<false, 3>', info, 2.0 * ENC_MACS_PER_AGENT * M, t_enc,
-                        8628 * 16384.0 * tiles)
+                        8028 * 16384.0 * tiles)       # ({0, 1} observations: L0 issues 3 of 6 plane products)
     with torch.no_grad():
         want = orc.policy_forward(sd, S_cpu, obs_cpu)
     got = [o.cpu() for o in out]
@@ -542,9 +542,11 @@ def main():
                    '(the step is this one kernel; includes the inter-launch gap)' % args.steps)
             flops = pol_flops
             alg_bytes = M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (ENC_WEIGHT_FLOATS + K * 128 * 128 + 768) * 4.0
-            # bf16 MFMAs per graph tile: encoder 8628 (= 2 x 4314: six plane products where split-f16 issues three)
-            # + filter contraction 192 K
-            exe = (8628 + 192 * K) * 16384.0 * B
+            # bf16 MFMAs per graph tile: encoder 8028 (L1..FC: six plane products where split-f16 issues three = 7428;
+            # L0: 600 -- the bench's {0, 1} observations are ONE bf16 plane, so L0 issues three of its six products:
+            # PLANE SKIPPING, csrc/encoder_kernel_b3.hip) + filter contraction 192 K.  PMC agrees:
+            # SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 / 16384 = 8606 per workgroup at K = 3 (profiles/r03_c2_pmc_summary.txt)
+            exe = (8028 + 192 * K) * 16384.0 * B
             lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
                     'algorithmic work' % (N, N)
         else:
@@ -554,7 +556,7 @@ def main():
                    'this kernel followed by the filter + head kernel')
             flops = enc_flops
             alg_bytes = M * (363 + 128) * 4.0 + ENC_WEIGHT_FLOATS * 4.0
-            exe = 8628 * 16384.0 * tiles                        # MFMAs per 16-agent tile x FLOP each
+            exe = 8028 * 16384.0 * tiles                        # MFMAs per 16-agent tile ({0, 1} observations) x FLOP each
             lanes = ''
         traffic, traffic_detail = None, {'note': 'not measured (--pmc off, N > 1, or not rank 0)'}
         if args.pmc == 'auto' and world == 1:
