@@ -289,9 +289,11 @@ __device__ __forceinline__ void b3_l0_generic(const float* __restrict__ pk, cons
             for (int i = 0; i < 2; ++i) {
                 v4f sc, sh;
                 load_ss(sstab + EncLayout::kBssL0, 32, i, q, sc, sh);
-                v4f r = vrelu(vfma(acc[0][i], sc, sh));
+                // pooled on the raw accumulators; `sc` is |scale| (the sign is in the weights: encoder_pack.hip)
+                v4f r = vmax(vmax(acc[0][i], acc[1][i]), vmax(acc[2][i], acc[3][i]));
+                r = vfma(r, sc, sh);
 #pragma unroll
-                for (int pp = 1; pp < 4; ++pp) r = vmax(r, vfma(acc[pp][i], sc, sh));
+                for (int c = 0; c < 4; ++c) r[c] = b3_relu_clamp(r[c]);
                 res[wi][i] = r;
             }
         }
@@ -302,7 +304,7 @@ __device__ __forceinline__ void b3_l0_generic(const float* __restrict__ pk, cons
         const int win = wave + 4 * wi;
         if (win < 25) {
             v4f pl[3];
-            b3_split8(res[wi][0], res[wi][1], pl);
+            b3_split8_clamped(res[wi][0], res[wi][1], pl);
 #pragma unroll
             for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
         }
@@ -377,11 +379,17 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
                     ac[i] = mfma16b(A0[i][b3_term_a(term)], B[b3_term_b(term)], term == 0 ? vzero() : ac[i]);
         }
     };
-    auto epilogue = [&](const v4f (&ac)[2], int P) {       // BatchNorm + ReLU and the 2x2 max of the window so far
+    // (An inline-asm v_max_f32 here -- to spare the canonicalising v_max x, x, x the compiler puts in front of fmaxf on
+    // MFMA results -- was measured WRONG on the GPU: asm consumers of MFMA results get no hazard wait states.)
+    auto epilogue = [&](const v4f (&ac)[2], int P) {       // the 2x2 max of the window so far, on the RAW accumulators;
+#pragma unroll                                             // BatchNorm (|scale|: the sign is in the weights) + ReLU +
+        for (int i = 0; i < 2; ++i) {                      // the split's clamp once per window
+            run[i] = (P & 3) == 0 ? ac[i] : vmax(run[i], ac[i]);
+            if ((P & 3) == 3) {
+                run[i] = vfma(run[i], sc[i], sh[i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const v4f t = vfma(ac[i], sc[i], sh[i]);
-            run[i] = (P & 3) == 0 ? vrelu(t) : vmax(run[i], t);
+                for (int c = 0; c < 4; ++c) run[i][c] = b3_relu_clamp(run[i][c]);
+            }
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         // Pin the evaluation HERE: these are pure VALU operations, which the optimiser otherwise sinks to their use
@@ -398,7 +406,7 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
         } else {
             const int win = wave + 4 * wi;
             v4f pl[3];
-            b3_split8(run[0], run[1], pl);
+            b3_split8_clamped(run[0], run[1], pl);
 #pragma unroll
             for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
         }
@@ -525,45 +533,55 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
         for (int i = 0; i < 3; ++i)
             if (tid + i * kThreads < EncLayout::kBssFloats) sstab[tid + i * kThreads] = ssv[i];
         __syncthreads();
+        // Scatter into the padded images, BRANCH-FREE (this loop is VALU-issue-bound and runs in both workgroups of a
+        // CU at the same time: every instruction counts).  Flat element e of [agent][3][11][11] -> word
+        //   o = agent * kAgentStride + ch * 144 + (y + 1) * 12 + x + 1 = base + r + y + 13,   r = 11 y + x in 0..120;
+        // a thread's four consecutive elements cross at most ONE channel / agent boundary (r wraps at 121).  Divisions
+        // by constants as 24-bit multiplies + shifts (exact on the ranges used); elements outside the tile go to a
+        // dump word behind the images instead of around a branch.
+        const unsigned dump = 2 * kObsFloatsLds + lane;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e0 = (tid + k * kThreads) * 4 - shift;
-            const int es = max(e0, 0);
-            int ag = es / kObsFloats;
-            const int rem = es - ag * kObsFloats;
-            int ch = rem / 121;
-            const int r2 = rem - ch * 121;
-            int y = r2 / 11, x = r2 - y * 11;
+            const unsigned es = (unsigned)max(e0, 0);
+            const unsigned ag = __umul24(es, 46223u) >> 24;                   // es / 363   (es < 5816)
+            const unsigned rem = es - __umul24(ag, (unsigned)kObsFloats);
+            const unsigned ch = __umul24(rem, 543u) >> 16;                    // rem / 121  (rem < 363)
+            const int r0 = (int)(rem - __umul24(ch, 121u)) + min(e0, 0);        // (e0 < 0: the first thread of an unaligned tile)
+            const unsigned base = __umul24(ag, (unsigned)kAgentStride) + __umul24(ch, (unsigned)(kPadHW * kPadHW)) + 13u;
+            const unsigned wrapped = base + (ch == 2u ? (unsigned)(kAgentStride - 2 * kPadHW * kPadHW) : (unsigned)(kPadHW * kPadHW));
             unsigned w1[4], w2[4];
+            const v4u vb = __builtin_bit_cast(v4u, v[k]);
+            const bool inexact = ((vb[0] | vb[1] | vb[2] | vb[3]) & 0xffffu) != 0u;   // some value of this lane is not ONE bf16
+            const bool any_l = __ballot(inexact) != 0ull;               // (wave-uniform)
+            if (!any_l) {
+                // every value IS its h plane (the simulator's {0, 1} observations): no conversions, no l words
+                w1[0] = vb[0] >> 16; w1[1] = vb[1] >> 16; w1[2] = vb[2] >> 16; w1[3] = vb[3] >> 16;
+            } else {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                unsigned h, m, l;
-                b3_split2(v[k][2 * c2], v[k][2 * c2 + 1], h, m, l);
-                // (a lane's elements outside the tile are copies of valid ones or other agents' pixels: they can only
-                // make the flag conservative)
-                residual |= m | l;
-                w1[2 * c2] = __builtin_amdgcn_perm(m, h, 0x05040100u);        // (h | m << 16) of the even element
-                w1[2 * c2 + 1] = __builtin_amdgcn_perm(m, h, 0x07060302u);    // ... of the odd element
-                w2[2 * c2] = l & 0xffffu;
-                w2[2 * c2 + 1] = l >> 16;
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    unsigned h, m, l;
+                    b3_split2(v[k][2 * c2], v[k][2 * c2 + 1], h, m, l);
+                    // (a lane's elements outside the tile are copies of valid ones or other agents' pixels: they can
+                    // only make the flag conservative)
+                    residual |= m | l;
+                    w1[2 * c2] = __builtin_amdgcn_perm(m, h, 0x05040100u);        // (h | m << 16) of the even element
+                    w1[2 * c2 + 1] = __builtin_amdgcn_perm(m, h, 0x07060302u);    // ... of the odd element
+                    w2[2 * c2] = l & 0xffffu;
+                    w2[2 * c2 + 1] = l >> 16;
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int e = e0 + c;
-                if (e >= 0) {
-                    if (e < valid) {
-                        const int o = ag * kAgentStride + ch * (kPadHW * kPadHW) + (y + 1) * kPadHW + x + 1;
-                        obsw[o] = w1[c];
-                        obsw[kObsFloatsLds + o] = w2[c];
-                    }
-                    if (++x == 11) {
-                        x = 0;
-                        if (++y == 11) {
-                            y = 0;
-                            if (++ch == 3) { ch = 0; ++ag; }
-                        }
-                    }
-                }
+                int r = r0 + c;
+                const bool wrap = r >= 121;
+                r = wrap ? r - 121 : r;
+                const unsigned y = __umul24((unsigned)r & 0xffu, 745u) >> 13;         // r / 11   (0 <= r < 121 where it matters)
+                const unsigned o = (wrap ? wrapped : base) + (unsigned)r + y;
+                const bool ok = e >= 0 && e < valid;
+                obsw[ok ? o : dump] = w1[c];
+                if (any_l) obsw[ok ? o + kObsFloatsLds : dump] = w2[c];
             }
         }
         // PLANE SKIPPING: when every pixel of the tile is exactly one bf16 plane (the simulator's observations are
@@ -595,7 +613,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             for (int wi = 0; wi < 3; ++wi) {
                 const int win = wave + 4 * wi;
                 v4f pl[3];
-                b3_split8(res[wi][0], res[wi][1], pl);
+                b3_split8_clamped(res[wi][0], res[wi][1], pl);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
             }

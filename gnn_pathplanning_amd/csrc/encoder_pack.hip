@@ -182,6 +182,10 @@ __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ p
             float v = 0.f;
             if (qq < 3) v = rp.conv_w[0][(co * 3 + qq) * 9 + e];
             else if (e < 3) v = rp.conv_w[0][(co * 3 + e) * 9 + 8];
+            // L0 is pooled on its RAW accumulators: max_i (s c_i + b) = |s| max_i (sgn(s) c_i) + b (fma is monotone
+            // in c for s >= 0), so the sign of the folded BatchNorm scale goes into the weights (an exact negation)
+            // and the table holds |s| -- the same value to the bit, three VALU operations per output fewer
+            if (rp.bn_w[0][co] / sqrtf(rp.bn_var[0][co] + rp.bn_eps) < 0.f) v = -v;
             unsigned h, m, lo;
             b3_split2(v, 0.f, h, m, lo);
             out[((mt * 3 + 0) * 64 + l) * 8 + e] = (unsigned short)(h & 0xffffu);
@@ -283,7 +287,7 @@ __global__ void pack_encoder_kernel(const EncRawParams rp, float* __restrict__ p
             const int boff = EncLayout::kBss + (layer == 0 ? EncLayout::kBssL0 : layer == 1 ? EncLayout::kBssL1
                                                 : layer == 2 ? EncLayout::kBssL2 : layer == 3 ? EncLayout::kBssL3
                                                 : EncLayout::kBssL4);
-            packed[boff + c] = sc;
+            packed[boff + c] = layer == 0 ? fabsf(sc) : sc;     // (L0: the sign lives in the bf16x3 weights, see above)
             packed[boff + c_n + c] = shf;
         }
     }

@@ -160,6 +160,25 @@ __device__ __forceinline__ void b3_split2(float x0, float x1, unsigned& h, unsig
     const float s1 = b3_sub(r1, b3_bits(m & 0xffff0000u));
     l = b3_cvt_pk(s0, s1);
 }
+// ... of values that are already inside [-big, big] (a ReLU fused with the upper clamp, b3_relu_clamp)
+__device__ __forceinline__ void b3_split2_clamped(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = b3_cvt_pk(x0, x1);
+    const float r0 = b3_sub(x0, b3_bits(h << 16));
+    const float r1 = b3_sub(x1, b3_bits(h & 0xffff0000u));
+    m = b3_cvt_pk(r0, r1);
+    const float s0 = b3_sub(r0, b3_bits(m << 16));
+    const float s1 = b3_sub(r1, b3_bits(m & 0xffff0000u));
+    l = b3_cvt_pk(s0, s1);
+}
+// max(x, 0) and the split's upper clamp in ONE v_med3_f32 (NaN stays NaN on the device: med3 returns min3 then)
+__device__ __forceinline__ float b3_relu_clamp(float x) {
+    const float big = b3_bits(0x7f7f0000u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, 0.f, big);
+#else
+    return x != x ? x : (x < 0.f ? 0.f : x > big ? big : x);
+#endif
+}
 // eight fp32 values (two D tiles: a = k-slots e 0..3, b = e 4..7) -> the three 16-byte plane fragments
 __device__ __forceinline__ void b3_split8(v4f a, v4f b, v4f (&pl)[3]) {
     unsigned h[4], m[4], l[4];
@@ -167,6 +186,17 @@ __device__ __forceinline__ void b3_split8(v4f a, v4f b, v4f (&pl)[3]) {
     b3_split2(a[2], a[3], h[1], m[1], l[1]);
     b3_split2(b[0], b[1], h[2], m[2], l[2]);
     b3_split2(b[2], b[3], h[3], m[3], l[3]);
+    const v4u hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]}, lv = {l[0], l[1], l[2], l[3]};
+    pl[0] = __builtin_bit_cast(v4f, hv);
+    pl[1] = __builtin_bit_cast(v4f, mv);
+    pl[2] = __builtin_bit_cast(v4f, lv);
+}
+__device__ __forceinline__ void b3_split8_clamped(v4f a, v4f b, v4f (&pl)[3]) {
+    unsigned h[4], m[4], l[4];
+    b3_split2_clamped(a[0], a[1], h[0], m[0], l[0]);
+    b3_split2_clamped(a[2], a[3], h[1], m[1], l[1]);
+    b3_split2_clamped(b[0], b[1], h[2], m[2], l[2]);
+    b3_split2_clamped(b[2], b[3], h[3], m[3], l[3]);
     const v4u hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]}, lv = {l[0], l[1], l[2], l[3]};
     pl[0] = __builtin_bit_cast(v4f, hv);
     pl[1] = __builtin_bit_cast(v4f, mv);

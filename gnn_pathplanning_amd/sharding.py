@@ -56,6 +56,11 @@ def gather_rank_devices(device, group=None):
     me = device_identity(device)
     if not (dist.is_available() and dist.is_initialized()):
         return [me]
-    out = [None] * dist.get_world_size(group)
-    dist.all_gather_object(out, me, group=group)
+    world = dist.get_world_size(group)
+    out = [None] * world
+    try:
+        dist.all_gather_object(out, me, group=group)
+    except Exception as e:                                 # reporting must never take the measurement down
+        out = ['unknown (%s)' % type(e).__name__] * world
+        out[dist.get_rank(group)] = me
     return out

@@ -96,6 +96,30 @@ def test_emu_policy_golden(emu, policy_golden, prec):
         assert (acts == want.argmax(-1)).all()
 
 
+def test_emu_encoder_negative_and_zero_batchnorm_scales(emu):
+    """bf16x3 L0 pools its raw accumulators (sign of the folded BatchNorm scale in the packed weights, |scale| in the
+    table): gamma < 0 and gamma = 0 channels, binary and real-valued observations, default and exact-fp32 precision."""
+    import torch
+    from oracle import policy_oracle as orc
+    el, lib = emu
+    sd_t = orc.init_state_dict(3, seed=5)
+    g = torch.Generator().manual_seed(1)
+    sgn = (torch.rand(32, generator=g) < 0.5).float() * 2 - 1
+    sd_t['ConvLayers.1.weight'] = sd_t['ConvLayers.1.weight'].abs() * sgn
+    sd_t['ConvLayers.1.weight'][3] = 0.0
+    enc = el.pack_encoder(lib, {k: v.numpy() for k, v in sd_t.items()})
+    for M, binary in ((16, True), (10, False)):
+        obs_t = orc.synth_obs(1, M, seed=2)
+        if not binary:
+            obs_t = obs_t * torch.randn(obs_t.shape, generator=g)
+        obs = el.f32(obs_t.numpy().reshape(M, 3, 11, 11))
+        want = orc.policy_features(sd_t, obs_t).permute(0, 2, 1).reshape(M, 128).numpy()
+        for prec in (0, 1):
+            feat = np.zeros((M, 128), np.float32)
+            assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), M, prec, None, None) == 0
+            assert np.abs(feat - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), (M, binary, prec)
+
+
 @pytest.mark.parametrize('prec', [0, 2])
 def test_emu_fused_policy_kernel_equals_two_kernels(emu, policy_golden, prec):
     """GNNPP_TUNE_FUSED_POLICY: one workgroup per graph (encoder + dense-MFMA shifts + tap contraction + head).

@@ -305,6 +305,26 @@ def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W, K, prec):
     assert (outs[0].cpu() - want).abs().max().item() <= TOL
 
 
+def test_encoder_negative_and_zero_batchnorm_scales(dev, enc_variant):
+    """A trained BatchNorm may have gamma < 0 or = 0.  The bf16x3 L0 pools its RAW accumulators and applies the affine
+    map once per window (the sign of the folded scale lives in the packed weights, |scale| in the table): must equal
+    the reference, binary and real-valued observations, every precision."""
+    sd = orc.init_state_dict(3, seed=14)
+    g = torch.Generator().manual_seed(2)
+    for bn, c_n in (('ConvLayers.1', 32), ('ConvLayers.5', 32), ('ConvLayers.8', 64)):
+        sgn = (torch.rand(c_n, generator=g) < 0.5).float() * 2 - 1
+        sd[bn + '.weight'] = sd[bn + '.weight'].abs() * sgn
+        sd[bn + '.weight'][3] = 0.0
+    for (B, N), binary in (((4, 10), True), ((1, 23), False)):
+        net = _net(N, 3, dev, sd)
+        obs = orc.synth_obs(B, N, seed=N)
+        if not binary:
+            obs = obs * torch.randn(obs.shape, generator=g)
+        want = orc.policy_features(sd, obs).permute(0, 2, 1)
+        got = net.encode(obs.to(dev)).cpu()
+        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (B, N, binary)
+
+
 def test_encoder_dynamic_range(dev, enc_variant):
     """Weights and activations spread over several decades (the split-f16 schedule rescales the
     weights per layer and keeps subnormal lo halves): the relative error must stay at fp32 level."""
