@@ -1,0 +1,93 @@
+"""torch.ops.gnnpp.* -- the hot-path operators registered with torch.library.
+
+    import gnn_pathplanning_amd.ops          # registers the ops
+    y      = torch.ops.gnnpp.lsigf(h, S, x, bias, relu=False, precision=0)        # BatchLSIGF / LSIGF
+    logits = torch.ops.gnnpp.policy_logits(obs, S, enc_packed, taps_packed, gf_bias, act_w, act_b, K, precision=0)
+    ids    = torch.ops.gnnpp.decode_actions(logits)
+
+The module classes (DecentralPlannerNet, GraphFilter*) call the C ABI through ctypes directly; these registrations
+exist so that torch.compile / torch.export / FX see the same kernels as OPAQUE operators with known output shapes
+(fake implementations below) instead of graph-breaking on ctypes calls.  They are thin: every op is one C entry point
+of include/gnnpp.h on the current stream, fails loudly (GnnppError) without the HIP library or on CPU tensors, and is
+inference-only (no autograd formula is registered: training goes through the modules' autograd Functions,
+graphML._LSIGFFunction / decentralplanner._EncoderTrainFunction).  `precision` is GNNPP_PREC_* (0 = fp32-equivalent
+default).  References: utils/graphUtils/graphML.py:48-141, 2273-2367; graphs/models/decentralplanner.py:266-318;
+utils/multirobotsim_dcenlocal.py:589-591.
+"""
+from typing import Optional
+
+import torch
+
+from . import _native
+from . import graphML as gml
+
+
+
+def _ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@torch.library.custom_op('gnnpp::lsigf', mutates_args=())
+def lsigf(h: torch.Tensor, S: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor] = None,
+          relu: bool = False, precision: int = 0) -> torch.Tensor:
+    """h [F,E,K,G], S [E,N,N] (shared) or [B,E,N,N], x [B,G,N] -> y [B,F,N]   (graphML.py:2273-2367)."""
+    batched = S.dim() == 4
+    return gml._lsigf_device(h, S, x, bias, batched, x.shape[2], relu=relu, precision=int(precision))
+
+
+@lsigf.register_fake
+def _(h, S, x, bias=None, relu=False, precision=0):
+    return x.new_empty((x.shape[0], h.shape[0], x.shape[2]), dtype=torch.float32)
+
+
+@torch.library.custom_op('gnnpp::policy_logits', mutates_args=())
+def policy_logits(obs: torch.Tensor, S: torch.Tensor, enc_packed: torch.Tensor, taps_packed: torch.Tensor,
+                  gf_bias: Optional[torch.Tensor], act_w: torch.Tensor, act_b: torch.Tensor, K: int,
+                  precision: int = 0) -> torch.Tensor:
+    """The whole policy step of the single-layer planner (addGSO + forward, decentralplanner.py:266-318):
+    obs [B,N,3,11,11], S [B,1,N,N] fp32 | fp64, the packed encoder (DecentralPlannerNet.packed_encoder()), the packed
+    taps of GFL[0] (GraphFilterBatch.packed_taps()), its bias [128] or None, actionsMLP weight [5,128] / bias [5]
+    -> logits [N,B,5].  Teams of <= 112 agents; split-f16 (precision 2) is unguarded here (no range flag)."""
+    import ctypes
+    B, N = obs.shape[0], obs.shape[1]
+    dev = _native.require_gpu(obs, S, enc_packed, taps_packed, act_w, act_b)
+    obs_c = obs.detach().contiguous().float()
+    S_c = S.detach().contiguous()
+    if S_c.dtype not in (torch.float32, torch.float64):
+        S_c = S_c.float()
+    aw, ab = act_w.detach().contiguous().float(), act_b.detach().contiguous().float()
+    gb = gf_bias.detach().reshape(-1).contiguous().float() if gf_bias is not None else None
+    ws = torch.empty(B * N, 128, dtype=torch.float32, device=dev)
+    logits = torch.empty(N, B, 5, dtype=torch.float32, device=dev)
+    with _native.device_guard(dev):
+        rc = _native.lib().gnnpp_policy_fwd(_ptr(obs_c), _ptr(S_c), _ptr(enc_packed), _ptr(taps_packed), _ptr(gb),
+                                            _ptr(aw), _ptr(ab), _ptr(ws), _ptr(logits), B, N, int(K), 1,
+                                            int(S_c.dtype is torch.float64), int(precision), None,
+                                            _native.stream_ptr(dev))
+    _native.check(rc, 'gnnpp_policy_fwd')
+    return logits
+
+
+@policy_logits.register_fake
+def _(obs, S, enc_packed, taps_packed, gf_bias, act_w, act_b, K, precision=0):
+    return obs.new_empty((obs.shape[1], obs.shape[0], 5), dtype=torch.float32)
+
+
+@torch.library.custom_op('gnnpp::decode_actions', mutates_args=())
+def decode_actions(logits: torch.Tensor) -> torch.Tensor:
+    """logits [N,B,5] -> int32 [B,N]: argmax of the LogSoftmax the simulator applies, first maximum wins
+    (utils/multirobotsim_dcenlocal.py:589-591)."""
+    N, B = logits.shape[0], logits.shape[1]
+    dev = _native.require_gpu(logits)
+    lg = logits.detach().contiguous().float()
+    acts = torch.empty(B, N, dtype=torch.int32, device=dev)
+    with _native.device_guard(dev):
+        rc = _native.lib().gnnpp_decode_actions(_ptr(lg), _ptr(acts), B, N, _native.stream_ptr(dev))
+    _native.check(rc, 'gnnpp_decode_actions')
+    return acts
+
+
+@decode_actions.register_fake
+def _(logits):
+    return logits.new_empty((logits.shape[1], logits.shape[0]), dtype=torch.int32)

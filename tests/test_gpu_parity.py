@@ -711,3 +711,39 @@ def test_policy_filter_kernel_vs_general_filter(dev, B, N, K, f64, prec):
     assert (outs[0] - outs[1]).abs().max().item() <= 4e-6 * scale
     assert not torch.equal(outs[0], outs[1]) or K == 0 or prec == 1       # (the new kernel did run; under the exact
                                                                           # fp32 MFMA both may round identically)
+
+
+def test_torch_ops_equal_the_module_api_and_trace(dev):
+    """torch.ops.gnnpp.{lsigf, policy_logits, decode_actions}: the same kernels as the module API (bit-identical), and a
+    function built on them compiles with fullgraph=True (no graph break on the ctypes call: the ops are opaque to
+    dynamo, their fake implementations give the shapes)."""
+    import gnn_pathplanning_amd.ops  # noqa: F401
+    from gnn_pathplanning_amd import graphML as gml
+    sd = orc.init_state_dict(3, seed=21)
+    B, N = 6, 10
+    obs = orc.synth_obs(B, N, seed=8).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=8)).to(dev)            # fp64, [B,1,N,N] after addGSO
+    net = _net(N, 3, dev, sd)
+    net.addGSO(S)
+    want = net.forward_logits(obs)
+    gf, act = net.GFL[0], net.actionsMLP[0]
+    got = torch.ops.gnnpp.policy_logits(obs, net.S, net.packed_encoder(), gf.packed_taps(), gf.bias, act.weight,
+                                        act.bias, 3, 0)
+    assert torch.equal(got, want)
+    assert torch.equal(torch.ops.gnnpp.decode_actions(got), net.decode_actions(want))
+    g = torch.Generator().manual_seed(3)
+    h = (torch.randn(96, 1, 3, 128, generator=g) / 20).to(dev)
+    x = torch.randn(B, 128, N, generator=g).to(dev)
+    b = torch.randn(96, 1, generator=g).to(dev)
+    y = torch.ops.gnnpp.lsigf(h, net.S, x, b, False, 0)
+    assert torch.equal(y, gml.BatchLSIGF(h, net.S, x, b))
+
+    enc, taps, gb, aw, ab = net.packed_encoder(), gf.packed_taps(), gf.bias.detach(), act.weight.detach(), act.bias.detach()
+
+    def step(o, s):
+        lg = torch.ops.gnnpp.policy_logits(o, s, enc, taps, gb, aw, ab, 3, 0)
+        return torch.ops.gnnpp.decode_actions(lg), lg * 1.0
+
+    compiled = torch.compile(step, backend='aot_eager', fullgraph=True)
+    ids, lg = compiled(obs, net.S)
+    assert torch.equal(lg, want) and torch.equal(ids, net.decode_actions(want))

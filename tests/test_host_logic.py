@@ -210,3 +210,26 @@ def test_committed_bench_lines_follow_the_contract():
             rot = sec['c2_rotating_batches']
             assert rot['batches'] >= 64 and rot['resident_MB'] > 256 and 0.5 < rot['vs_single_resident_batch'] < 1.1
             assert any(x['batch'] >= 8192 for x in sec['batch_sweep_filter_only'])
+
+
+def test_torch_ops_registration_shapes_and_loud_cpu_failure():
+    """torch.ops.gnnpp.* (gnn_pathplanning_amd/ops.py): registered with fake implementations (output shapes / dtypes
+    under FakeTensorMode, which is what torch.compile / export use) and -- like every entry of the package -- no CPU
+    fallback: a real call with CPU tensors raises GnnppError."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import gnn_pathplanning_amd.ops  # noqa: F401
+    from gnn_pathplanning_amd._native import GnnppError
+    with FakeTensorMode():
+        h, S, x = torch.empty(150, 2, 3, 64), torch.empty(7, 2, 10, 10), torch.empty(7, 64, 10)
+        y = torch.ops.gnnpp.lsigf(h, S, x, torch.empty(150, 1), True, 0)
+        assert tuple(y.shape) == (7, 150, 10) and y.dtype == torch.float32
+        lg = torch.ops.gnnpp.policy_logits(torch.empty(7, 10, 3, 11, 11), torch.empty(7, 1, 10, 10, dtype=torch.float64),
+                                           torch.empty(10), torch.empty(10), None, torch.empty(5, 128), torch.empty(5), 3)
+        assert tuple(lg.shape) == (10, 7, 5)
+        ids = torch.ops.gnnpp.decode_actions(lg)
+        assert tuple(ids.shape) == (7, 10) and ids.dtype == torch.int32
+    with pytest.raises(GnnppError):
+        torch.ops.gnnpp.lsigf(torch.zeros(128, 1, 3, 128), torch.zeros(2, 1, 4, 4), torch.zeros(2, 128, 4), None)
+    with pytest.raises(GnnppError):
+        torch.ops.gnnpp.decode_actions(torch.zeros(4, 2, 5))
