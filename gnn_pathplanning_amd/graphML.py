@@ -72,15 +72,10 @@ def _bias_arg(b, F_out, N):
     return b.detach().contiguous().float(), 1
 
 
-def _lsigf_large(h, S, x, b, batched, relu=False):
-    """The same filter for graphs of MORE than MAX_NODES nodes (whose rows do not fit one workgroup's LDS), node-major:
-    x [B,N,G] -> [B,N,F].  Dense and exact fp32 throughout on gnnpp_gemm_kmajor (fp32 MFMA, ordered partial sums):
-      z_{e,k} = S_e^T z_{e,k-1}  (rows = nodes: z_k[n][g] = sum_m S[m][n] z_{k-1}[m][g], graphML.py:2345-2352),
-      one GEMM per (e, k >= 1) over the batch, written into its column block of Z [B*N, E*K*G];
-      y = Z . h^T  (one GEMM, contraction E*K*G), then bias and ReLU.
-    The reference has no size limit (BatchLSIGF is a chain of torch.matmul); this keeps the drop-in true for any N
-    at dense-GEMM speed -- the reference's configurations (N <= 100) never take this path."""
-    dev = _native.require_gpu(h, S, x, b)
+def _large_tap_signals(h, S, x, batched):
+    """Z [B,N,E*K,G]: every tap signal z_{e,k} = S_e^T z_{e,k-1} of a node-major x [B,N,G], one gnnpp_gemm_kmajor call per
+    (e, k >= 1) over the batch; and the fp32 GSO it used."""
+    dev = _native.require_gpu(h, S, x)
     F_out, E, K, G = h.shape
     B, N, _ = x.shape
     S32 = S.detach()
@@ -95,13 +90,61 @@ def _lsigf_large(h, S, x, b, batched, relu=False):
             _native.gemm_kmajor(Se, (E * N * N if batched else 0, 1, N),           # A(m = n_out, k = m_in) = S[m_in][n_out]
                                 Z[:, :, e * K + k - 1], (N * EKG, EKG),             # B(k = m_in, n = g)
                                 Z[:, :, e * K + k], (N * EKG, EKG), B, N, G, N)
+    return Z, S32
+
+
+def _lsigf_large(h, S, x, b, batched, relu=False, keep=False):
+    """The same filter for graphs of MORE than MAX_NODES nodes (whose rows do not fit one workgroup's LDS), node-major:
+    x [B,N,G] -> [B,N,F].  Dense and exact fp32 throughout on gnnpp_gemm_kmajor (fp32 MFMA, ordered partial sums):
+      z_{e,k} = S_e^T z_{e,k-1}  (rows = nodes: z_k[n][g] = sum_m S[m][n] z_{k-1}[m][g], graphML.py:2345-2352),
+      one GEMM per (e, k >= 1) over the batch, written into its column block of Z [B*N, E*K*G];
+      y = Z . h^T  (one GEMM, contraction E*K*G), then bias and ReLU.
+    The reference has no size limit (BatchLSIGF is a chain of torch.matmul); this keeps the drop-in true for any N
+    at dense-GEMM speed -- the reference's configurations (N <= 100) never take this path.
+    keep: also return (Z, S32) for the backward pass (_LSIGFFunction, large graphs)."""
+    dev = _native.require_gpu(h, S, x, b)
+    F_out, E, K, G = h.shape
+    B, N, _ = x.shape
+    EKG = E * K * G
+    Z, S32 = _large_tap_signals(h, S, x, batched)
     hT = h.detach().float().permute(1, 2, 3, 0).reshape(EKG, F_out).contiguous()   # [(e,k,g), f]
     y = torch.empty(B, N, F_out, dtype=torch.float32, device=dev)
     _native.gemm_kmajor(Z, (0, EKG, 1), hT, (0, F_out), y, (0, F_out), 1, B * N, F_out, EKG)
     if b is not None:
         bb = b.detach().float()
         y += bb.reshape(1, 1, F_out) if bb.numel() == F_out else bb.t().reshape(1, N, F_out)
-    return torch.relu_(y) if relu else y
+    if relu:
+        torch.relu_(y)
+    return (y, Z, S32) if keep else y
+
+
+def _lsigf_large_backward(h, S32, Z, dy, batched, need_dh, need_dx):
+    """Gradients of the dense large-graph filter for dy [B,N,F] (already masked by the ReLU), on gnnpp_gemm_kmajor:
+      dh[f,(e,k,g)] = sum_(b,n) dy[(b,n),f] Z[(b,n),(e,k,g)]                      one GEMM, contraction B*N;
+      dZ[(b,n),(e,k,g)] = sum_f dy[(b,n),f] h[f,(e,k,g)]                          one GEMM;
+      dz_{e,k-1} += S_e dz_{e,k}  (the adjoint of z_k = S_e^T z_{k-1}), k = K-1 .. 1   one GEMM per (e, k) over the batch;
+      dx = sum_e dz_{e,0}."""
+    F_out, E, K, G = h.shape
+    B, N, _ = dy.shape
+    EKG = E * K * G
+    dev = dy.device
+    dh = dx = None
+    if need_dh:
+        dh = torch.empty(F_out, E, K, G, dtype=torch.float32, device=dev)
+        _native.gemm_kmajor(dy, (0, 1, F_out), Z, (0, EKG), dh, (0, EKG), 1, F_out, EKG, B * N)
+    if need_dx:
+        dZ = torch.empty(B, N, E * K, G, dtype=torch.float32, device=dev)
+        h2 = h.detach().float().reshape(F_out, EKG).contiguous()
+        _native.gemm_kmajor(dy, (0, F_out, 1), h2, (0, EKG), dZ, (0, EKG), 1, B * N, EKG, F_out)
+        tmp = torch.empty(B, N, G, dtype=torch.float32, device=dev)
+        for e in range(E):
+            Se = S32[:, e] if batched else S32[e]
+            for k in range(K - 1, 0, -1):
+                _native.gemm_kmajor(Se, (E * N * N if batched else 0, N, 1),        # A(m = m_in, k = n_out) = S[m_in][n_out]
+                                    dZ[:, :, e * K + k], (N * EKG, EKG), tmp, (N * G, G), B, N, G, N)
+                dZ[:, :, e * K + k - 1] += tmp
+        dx = dZ[:, :, 0].clone() if E == 1 else dZ[:, :, ::K].sum(dim=2)
+    return dh, dx
 
 
 def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
@@ -119,7 +162,8 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
     B = x.shape[0]
     if N > MAX_NODES:
         if transposed or save_taps:
-            raise _native.GnnppError('training on graphs with N=%d > %d nodes is not supported' % (N, MAX_NODES))
+            raise _native.GnnppError('graphs with N=%d > %d nodes: the LDS-resident kernels do not apply '
+                                     '(training goes through _LSIGFFunction\'s dense path)' % (N, MAX_NODES))
         if node_major:
             return _lsigf_large(h, S, x, b, batched, relu)
         xn = torch.zeros(B, N, G, dtype=torch.float32, device=dev)                 # zero padding of missing nodes
@@ -187,11 +231,23 @@ class _LSIGFFunction(torch.autograd.Function):
         """node_major: x [B,N,G] -> y [B,N,F] (train-mode planner: no transposing copies around the filter);
         relu: y = relu(filter) in the same launch (the mask for the backward pass is y > 0)."""
         Nin = x.shape[1] if node_major else x.shape[2]
-        y, zs = _lsigf_device(h, S, x, b, batched, Nin, packed, relu=relu, save_taps=True, node_major=node_major)
-        ctx.save_for_backward(h, S, zs, y if relu else None)
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
         ctx.node_major, ctx.relu = node_major, relu
+        N = S.shape[-1]
+        ctx.large = N > MAX_NODES
+        if ctx.large:
+            # graphs beyond one workgroup's LDS: the dense exact-fp32 form, forward and backward (the reference has no
+            # size limit: graphML.py:2273-2367); node-major inside, zero rows for nodes the signal does not have
+            xn = x.detach().float() if node_major else x.detach().float().permute(0, 2, 1)
+            if Nin != N:
+                xn = torch.cat([xn, xn.new_zeros(xn.shape[0], N - Nin, xn.shape[2])], 1)
+            y, Z, S32 = _lsigf_large(h, S, xn.contiguous(), b, batched, relu, keep=True)
+            ctx.save_for_backward(h, S32, Z, y if relu else None)
+            y = y[:, :Nin]
+            return y.contiguous() if node_major else y.permute(0, 2, 1).contiguous()
+        y, zs = _lsigf_device(h, S, x, b, batched, Nin, packed, relu=relu, save_taps=True, node_major=node_major)
+        ctx.save_for_backward(h, S, zs, y if relu else None)
         return y
 
     @staticmethod
@@ -201,6 +257,24 @@ class _LSIGFFunction(torch.autograd.Function):
         N = S.shape[-1]
         B = dy.shape[0]
         dy = dy.contiguous().float()
+        if ctx.large:
+            dyn = dy if ctx.node_major else dy.permute(0, 2, 1)                     # [B,Nin,F]
+            if ctx.Nin != N:
+                dyn = torch.cat([dyn, dyn.new_zeros(B, N - ctx.Nin, F_out)], 1)
+            dyn = dyn.contiguous()
+            if ctx.relu:
+                dyn = torch.ops.aten.threshold_backward(dyn, yrelu, 0)
+            dh, dxn = _lsigf_large_backward(h, S, zs, dyn, ctx.batched, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
+            dx = db = None
+            if dxn is not None:
+                dxn = dxn[:, :ctx.Nin]
+                dx = dxn.contiguous() if ctx.node_major else dxn.permute(0, 2, 1).contiguous()
+            if ctx.has_bias and ctx.needs_input_grad[3]:
+                if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
+                    db = dyn.sum(dim=(0, 1)).reshape(ctx.bias_shape)
+                else:                                                              # per-node bias [F,N]
+                    db = dyn.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
+            return dh, None, dx, db, None, None, None, None
         if ctx.relu:
             dy = torch.ops.aten.threshold_backward(dy, yrelu, 0)          # dy where y > 0, else 0
         if ctx.node_major:

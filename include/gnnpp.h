@@ -145,10 +145,11 @@ int gnnpp_lsigf_fwd(const float* x, const void* S, const float* packed, const fl
  *                 dx = sum_k W_k^T . dy . (S^T)^k, i.e. this call with x := dy, taps packed from
  *                 h.permute(3,1,2,0) and s_transposed = 1.  This form always contracts on the exact
  *                 fp32 MFMA, whatever `precision` says (cotangents are far below the f16 normal range).
- * LIMIT: the training calls keep a graph's rows in one workgroup's LDS: N <= GNNPP_MAX_ROWS (112; 100 guaranteed
- * at G = F = 128), else GNNPP_ERR_UNSUPPORTED.  Inference has the dense fallback described at GNNPP_MAX_ROWS; the
- * training path has none (the reference trains on 10-agent teams: configs/dcp_*.json), and the Python layer raises
- * GnnppError for larger graphs in train mode instead of degrading silently.
+ * LIMIT: this call keeps a graph's rows in one workgroup's LDS: N <= GNNPP_MAX_ROWS (112; 100 guaranteed at
+ * G = F = 128), else GNNPP_ERR_UNSUPPORTED.  Larger graphs train through the dense form described at GNNPP_MAX_ROWS,
+ * forward AND backward as gnnpp_gemm_kmajor calls (shifts, tap contraction, dh = dy^T Z, dZ = dy h, the adjoint shift
+ * chain dz_{k-1} += S dz_k): graphML._LSIGFFunction does exactly that (the reference trains on 10-agent teams,
+ * configs/dcp_*.json, but BatchLSIGF itself has no size limit).
  */
 int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, const float* bias,
                          float* y, float* zs, int B, int N, int Nin, int G, int F, int K, int E,
