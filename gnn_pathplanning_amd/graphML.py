@@ -200,6 +200,8 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
         xn = torch.zeros(B, N, G, dtype=torch.float32, device=dev)
         xn[:, :Nin] = x.detach().permute(0, 2, 1)
         return _lsigf_large(h, S, xn, b, batched, relu)[:, :Nin].permute(0, 2, 1).contiguous()
+    if rc == -2 and (transposed or save_taps):
+        return None                                # the training driver (_LSIGFFunction) takes its dense path instead
     _native.check(rc, 'gnnpp_lsigf_fwd')
     return (y, zs) if save_taps else y
 
@@ -236,19 +238,23 @@ class _LSIGFFunction(torch.autograd.Function):
         ctx.node_major, ctx.relu = node_major, relu
         N = S.shape[-1]
         ctx.large = N > MAX_NODES
-        if ctx.large:
-            # graphs beyond one workgroup's LDS: the dense exact-fp32 form, forward and backward (the reference has no
-            # size limit: graphML.py:2273-2367); node-major inside, zero rows for nodes the signal does not have
-            xn = x.detach().float() if node_major else x.detach().float().permute(0, 2, 1)
-            if Nin != N:
-                xn = torch.cat([xn, xn.new_zeros(xn.shape[0], N - Nin, xn.shape[2])], 1)
-            y, Z, S32 = _lsigf_large(h, S, xn.contiguous(), b, batched, relu, keep=True)
-            ctx.save_for_backward(h, S32, Z, y if relu else None)
-            y = y[:, :Nin]
-            return y.contiguous() if node_major else y.permute(0, 2, 1).contiguous()
-        y, zs = _lsigf_device(h, S, x, b, batched, Nin, packed, relu=relu, save_taps=True, node_major=node_major)
-        ctx.save_for_backward(h, S, zs, y if relu else None)
-        return y
+        res = None if ctx.large else _lsigf_device(h, S, x, b, batched, Nin, packed, relu=relu, save_taps=True,
+                                                   node_major=node_major)
+        if res is not None:
+            y, zs = res
+            ctx.save_for_backward(h, S, zs, y if relu else None)
+            return y
+        # graphs whose rows do not fit one workgroup's LDS (N > MAX_NODES, or fewer nodes with wide input features:
+        # GNNPP_ERR_UNSUPPORTED): the dense exact-fp32 form, forward and backward (the reference has no size limit:
+        # graphML.py:2273-2367); node-major inside, zero rows for nodes the signal does not have
+        ctx.large = True
+        xn = x.detach().float() if node_major else x.detach().float().permute(0, 2, 1)
+        if Nin != N:
+            xn = torch.cat([xn, xn.new_zeros(xn.shape[0], N - Nin, xn.shape[2])], 1)
+        y, Z, S32 = _lsigf_large(h, S, xn.contiguous(), b, batched, relu, keep=True)
+        ctx.save_for_backward(h, S32, Z, y if relu else None)
+        y = y[:, :Nin]
+        return y.contiguous() if node_major else y.permute(0, 2, 1).contiguous()
 
     @staticmethod
     def backward(ctx, dy):
@@ -284,6 +290,8 @@ class _LSIGFFunction(torch.autograd.Function):
             hT = h.detach().permute(3, 1, 2, 0)                          # [G,E,K,F] (shape only)
             dx = _lsigf_device(hT, S, dy, None, ctx.batched, ctx.Nin, _packed_transposed_taps(h),
                                transposed=True)
+            if dx is None:                                               # (wide F: the dense adjoint, needs no Z)
+                dx = _LSIGFFunction._dense_dx(ctx, h, S, dy.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
         if ctx.needs_input_grad[0]:
             dyp = dy if ctx.Nin == N else torch.nn.functional.pad(dy, (0, N - ctx.Nin))
             dy2 = dyp.permute(1, 0, 2).reshape(F_out, B * N)             # [F, B*N] (one copy)
@@ -300,6 +308,17 @@ class _LSIGFFunction(torch.autograd.Function):
         return dh, None, dx, db, None, None, None, None
 
     @staticmethod
+    def _dense_dx(ctx, h, S, dyn):
+        """dx [B,Nin,G] for dy [B,Nin,F] (node-major) through the dense adjoint (no saved tap signals needed)."""
+        N, B = S.shape[-1], dyn.shape[0]
+        if ctx.Nin != N:
+            dyn = torch.cat([dyn, dyn.new_zeros(B, N - ctx.Nin, dyn.shape[2])], 1)
+        S32 = S.detach()
+        S32 = (S32 if S32.dtype is torch.float32 else S32.float()).contiguous()
+        _, dxn = _lsigf_large_backward(h, S32, None, dyn.contiguous(), ctx.batched, False, True)
+        return dxn[:, :ctx.Nin]
+
+    @staticmethod
     def _backward_node_major(ctx, h, S, zs, dy):
         """dy [B,N,F] (rows (b,n), the row order of the saved tap signals): the input gradient is the
         transposed filter on dy, node-major in and out; dh and db come from ONE multi-product GEMM launch."""
@@ -311,6 +330,8 @@ class _LSIGFFunction(torch.autograd.Function):
             hT = h.detach().permute(3, 1, 2, 0)
             dx = _lsigf_device(hT, S, dy, None, ctx.batched, N, _packed_transposed_taps(h), transposed=True,
                                node_major=True)
+            if dx is None:
+                dx = _LSIGFFunction._dense_dx(ctx, h, S, dy)
         specs = []
         if ctx.needs_input_grad[0]:
             dh = torch.empty(F_out, E, K, G, dtype=torch.float32, device=dy.device)

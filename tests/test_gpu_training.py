@@ -621,3 +621,27 @@ def test_planner_training_step_with_more_agents_than_one_workgroup(dev):
         want = sdr[k].grad
         got = grads[k].grad.cpu()
         assert close(got, want, 1e-3), (k, (got - want).abs().max().item(), want.abs().max().item())
+
+
+@pytest.mark.parametrize('G,F_out', [(512, 16), (16, 512)])
+def test_training_with_features_wider_than_one_workgroup_holds(dev, G, F_out):
+    """50 nodes fit the kernels, but 512 input features per node do not fit a workgroup's LDS
+    (GNNPP_ERR_UNSUPPORTED from the forward launch at G = 512; from the input-gradient launch -- the transposed filter,
+    whose input features are F -- at F = 512).  Training must still work: the dense path takes over for exactly the
+    launch that does not fit.  Output and gradients against torch autograd over the oracle."""
+    import gnn_pathplanning_amd.graphML as gml
+    g = torch.Generator().manual_seed(G)
+    B, N, K, E = 2, 50, 3, 1
+    h0 = (torch.rand(F_out, E, K, G, generator=g) * 2 - 1) / (G * K) ** 0.5
+    b0 = torch.randn(F_out, 1, generator=g) * 0.1
+    x0 = torch.randn(B, G, N, generator=g)
+    S = orc.synth_gso_sparse(B, N, 5.0, seed=2).unsqueeze(1)
+    hr, br, xr = h0.clone().requires_grad_(), b0.clone().requires_grad_(), x0.clone().requires_grad_()
+    yr = orc.batch_lsigf(hr, S, xr, br)
+    yr.square().sum().backward()
+    hd, bd, xd = (t.clone().to(dev).requires_grad_() for t in (h0, b0, x0))
+    y = gml.BatchLSIGF(hd, S.to(dev), xd, bd)
+    y.square().sum().backward()
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 1e-4 * max(1.0, yr.abs().max().item())
+    for got, want, name in ((hd.grad, hr.grad, 'dh'), (xd.grad, xr.grad, 'dx'), (bd.grad, br.grad, 'db')):
+        assert (got.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item()), name
