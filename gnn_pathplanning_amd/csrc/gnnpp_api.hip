@@ -309,6 +309,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_POLICY_FILTER: return g_filter_policy_kernel.load();
         case GNNPP_TUNE_FILTER_SMALL: return g_filter_small_kernel.load();
         case GNNPP_TUNE_FILTER_SMALL_ROWS: return g_filter_small_rows.load();
+        case GNNPP_TUNE_FILTER_PIPE_GRID: return g_filter_pipe_grid.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -340,11 +341,15 @@ int gnnpp_set_tuning(int key, int value) {
             g_filter_policy_kernel.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL_ROWS:
-            if (value != 0 && value != 32 && value != 48) return GNNPP_ERR_ARG;
+            if (value != 0 && value != 32 && value != 48 && value != 64) return GNNPP_ERR_ARG;
             g_filter_small_rows.store(value);
             return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_PIPE_GRID:
+            if (value < 0 || value > 4096) return GNNPP_ERR_ARG;
+            g_filter_pipe_grid.store(value);
+            return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:
-            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 3) return GNNPP_ERR_ARG;
             g_filter_small_kernel.store(value);
             return GNNPP_OK;
 #ifdef GNNPP_MEASURE

@@ -89,9 +89,12 @@ const char* gnnpp_error_string(int code);
                                          G = F = 128, node-major rows, >= 64 workgroups) run on the
                                          throughput kernel lsigf_small_b3_kernel (bf16x3 planes, two workgroups per
                                          CU); 0: on the general filter kernel; 2: whenever the shape fits,
-                                         however few graphs (tests)                                        */
-#define GNNPP_TUNE_FILTER_SMALL_ROWS 11 /* rows per workgroup of that kernel: 0 = heuristic, 32 (three workgroups per
-                                         CU) or 48 (two; fewer tap bytes per agent-step)                   */
+                                         however few graphs (tests); 3: the pipeline kernel whenever it fits */
+#define GNNPP_TUNE_FILTER_SMALL_ROWS 11 /* rows per workgroup of that kernel: 0 = heuristic, 32 or 48 (fewer tap bytes per
+                                         agent-step); 64 = the producer / consumer pipeline kernel
+                                         (lsigf_pipe_b3_kernel: one persistent 8-wave workgroup per CU -- the heuristic
+                                         takes it from 4096 groups of 64 rows on; FILTER_SMALL = 3 forces it too)  */
+#define GNNPP_TUNE_FILTER_PIPE_GRID 12  /* persistent workgroups of the pipeline kernel: 0 (default) = one per CU */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

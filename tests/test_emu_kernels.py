@@ -473,7 +473,10 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
     packed = el.pack_filter(lib, h)
     outs = []
     try:
-        for mode, rows in ((2, 32), (2, 48), (0, 0)):
+        # (mode 3: the producer / consumer pipeline kernel -- persistent 8-wave workgroups, 64-row groups; no head form)
+        # (pipeline grid 2 / 1: a persistent workgroup takes several groups -- staging of the next group beside the taps)
+        for mode, rows, pgrid in ((2, 32, 0), (2, 48, 0), (0, 0, 0)) + (() if head else ((3, 0, 0), (3, 0, 2), (3, 0, 1))):
+            assert lib.gnnpp_set_tuning(12, pgrid) == 0
             assert lib.gnnpp_set_tuning(10, mode) == 0 and lib.gnnpp_get_tuning(10) == mode
             assert lib.gnnpp_set_tuning(11, rows) == 0
             if head:
@@ -488,6 +491,7 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
     finally:
         lib.gnnpp_set_tuning(10, 1)
         lib.gnnpp_set_tuning(11, 0)
+        lib.gnnpp_set_tuning(12, 0)
     z = x.astype(np.float64)
     y = np.zeros((B, N, 128))
     for k in range(K):
@@ -498,5 +502,7 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
     scale = max(1.0, np.abs(want).max())
     assert np.abs(outs[0] - want).max() <= TOL * scale
     assert np.array_equal(outs[0], outs[1])                 # 32- and 48-row workgroups: the same arithmetic per row
+    if not head:
+        assert all(np.array_equal(outs[0], o) for o in outs[3:])   # ... and the pipeline kernel's, however the groups are dealt
     assert np.abs(outs[0] - outs[2]).max() <= 4e-6 * scale
-    assert lib.gnnpp_set_tuning(10, 3) == -1 and lib.gnnpp_set_tuning(11, 40) == -1
+    assert lib.gnnpp_set_tuning(10, 4) == -1 and lib.gnnpp_set_tuning(11, 40) == -1

@@ -747,3 +747,40 @@ def test_torch_ops_equal_the_module_api_and_trace(dev):
     compiled = torch.compile(step, backend='aot_eager', fullgraph=True)
     ids, lg = compiled(obs, net.S)
     assert torch.equal(lg, want) and torch.equal(ids, net.decode_actions(want))
+
+
+@pytest.mark.parametrize('N,K,B', [(10, 3, 3000), (16, 2, 1100), (7, 4, 2500), (3, 1, 4000)])
+def test_pipeline_filter_kernel_equals_the_small_graph_kernel(dev, N, K, B):
+    """lsigf_pipe_b3_kernel (persistent 8-wave producer / consumer workgroups, several groups each at these sizes)
+    computes every row with the arithmetic of lsigf_small_b3_kernel: bit-identical outputs; both within tolerance of the
+    float64 statement.  Ragged last group, K = 1 (no shifts), fp64 GSOs."""
+    import ctypes
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.graphML import pack_filter_taps
+    L = _native.lib()
+    g = torch.Generator().manual_seed(N * 100 + K)
+    h = (torch.randn(128, 1, K, 128, generator=g) / (128 * K) ** 0.5)
+    taps = pack_filter_taps(h.to(dev))
+    bias = (torch.randn(128, generator=g) / 4).to(dev)
+    x = torch.relu(torch.randn(B * N, 128, generator=g)).to(dev)
+    S64 = ((torch.rand(B, N, N, generator=g) < 0.4) * torch.rand(B, N, N, generator=g)).double()
+    S = S64.to(dev) if K == 2 else S64.float().to(dev)
+    outs = []
+    try:
+        for mode, pgrid in ((2, 0), (3, 0), (3, 7)):
+            assert L.gnnpp_set_tuning(10, mode) == 0 and L.gnnpp_set_tuning(12, pgrid) == 0
+            y = torch.full_like(x, float('nan'))
+            rc = L.gnnpp_lsigf_fwd(x.data_ptr(), S.data_ptr(), taps.data_ptr(), bias.data_ptr(), y.data_ptr(), B, N, N,
+                                   128, 128, K, 1, int(S.dtype is torch.float64), 1, 1, 1, 1, 0, 0, None,
+                                   _native.stream_ptr(dev))
+            assert rc == 0
+            outs.append(y)
+    finally:
+        L.gnnpp_set_tuning(10, 1)
+        L.gnnpp_set_tuning(12, 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = orc.lsigf_f64(h.numpy(), S64.float().unsqueeze(1).numpy()[:64], x.cpu().reshape(B, N, 128)[:64].permute(0, 2, 1).numpy(),
+                         bias.cpu().numpy().reshape(128, 1))
+    got = outs[1].cpu().reshape(B, N, 128)[:64].permute(0, 2, 1).numpy()
+    want = np.maximum(want, 0)
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())

@@ -122,3 +122,28 @@ if 'small' in which:
                min(1024, (B + 3) // 4),
                [('entry', 0), ('staged', 1), ('tap0', 2), ('barrier', 3), ('shift1', 4), ('tap1', 5), ('barrier', 6),
                 ('shift2', 7), ('tap2', 8), ('y in lds', 12), ('stored', 13)])
+
+if 'pipe' in which:
+    from gnn_pathplanning_amd.graphML import pack_filter_taps
+    N, K = 10, 3
+    h = (torch.randn(128, 1, K, 128) / (128 * K) ** 0.5).to(dev)
+    taps = pack_filter_taps(h)
+    bias = torch.zeros(128, device=dev)
+    for B in (3072, 8192, 32768):
+        S = torch.from_numpy(orc.synth_gso_geometric(512, N, 20, seed=1337)).float().to(dev).repeat(B // 512, 1, 1).contiguous()
+        x = torch.relu(torch.randn(B * N, 128, device=dev))
+        y = torch.empty_like(x)
+        M.gnnpp_set_tuning(10, 3)
+        for _ in range(6):
+            assert M.gnnpp_lsigf_fwd(x.data_ptr(), S.data_ptr(), taps.data_ptr(), bias.data_ptr(), y.data_ptr(), B, N, N,
+                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, 0, None, st) == 0
+            torch.cuda.synchronize()
+        M.gnnpp_set_tuning(10, 1)
+        report('lsigf_pipe_b3_kernel B=%d N=10 K=3, a SHIFT stage (tap 0 of the last group): producer start -> shift done | '
+               'consumer contraction done | barrier passed' % B, 256,
+               [('stage start', 0), ('producer done', 1), ('barrier', 3)])
+        report('   same stage, consumer', 256, [('stage start', 0), ('contraction done', 2), ('barrier', 3)])
+        report('   same stage, producer wave 4 inside shift_group', 256, [('stage start', 0), ('loop entry', 8), ('unit 0: MFMAs done', 9), ('unit 0: written', 10), ('all units', 1)])
+        report('lsigf_pipe_b3_kernel B=%d: a STAGING stage (last tap of the group before)' % B, 256,
+               [('stage start', 4), ('producer done', 5), ('barrier', 7)])
+        report('   same stage, consumer', 256, [('stage start', 4), ('contraction done', 6), ('barrier', 7)])

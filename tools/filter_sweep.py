@@ -52,12 +52,13 @@ def run(B, mode, reps, rows=0):
 
 if len(sys.argv) > 2 and sys.argv[1] == '--pmc-target':
     rows = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    run(int(sys.argv[2]), 2 if rows else 1, 4, rows)
+    run(int(sys.argv[2]), (3 if rows == 64 else 2) if rows else 1, 4, 0 if rows == 64 else rows)
     sys.exit(0)
 for B in (512, 2048, 8192, 32768, 131072):
     ref = None
-    for mode, rows, name in ((1, 0, 'default (small-graph kernel when >= 512 workgroups)'),
+    for mode, rows, name in ((1, 0, 'default (heuristic: small-graph kernel; pipeline kernel from 4096 groups on)'),
                              (2, 32, 'small-graph kernel, 32 rows'), (2, 48, 'small-graph kernel, 48 rows'),
+                             (3, 0, 'pipeline kernel (8-wave producer / consumer, 64-row groups)'),
                              (0, 0, 'general filter kernel')):
         reps = max(3, min(200, int(4e6 / (B * N))))
         t, y = run(B, mode, reps, rows)
