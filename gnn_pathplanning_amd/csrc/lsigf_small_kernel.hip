@@ -43,7 +43,10 @@ template <int ROWS> struct SmLayout {
 };
 static_assert(2 * SmLayout<48>::smem(kSmMaxGraphs) <= kLdsBytes && 3 * SmLayout<32>::smem(3) <= kLdsBytes, "LDS budget");
 
-template <int ROWS>
+// NS4 = ceil(N / 4): the k-steps of the dense shift that can meet a non-zero weight (rows m >= N of a graph's 16 x 16 GSO
+// block are zero: skipping their MFMAs is bit-identical; as a compile-time bound -- a run-time guard broke the unrolled
+// schedule and cost 20 %)
+template <int ROWS, int NS4>
 __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs p) {
     typedef SmLayout<ROWS> LY;
     constexpr int RT = ROWS / 16, XV = ROWS * 32 / 256;
@@ -176,15 +179,15 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
             const bool last = k + 2 == K;                  // z_{K-1} is only needed as planes
             for (int j = wave; j < ng; j += 4) {
                 const int r0 = j * N;
-                float Sb[4];
+                float Sb[NS4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) Sb[s4] = Ssm[j * kSmSBlock + (4 * s4 + q) * 17 + a];
+                for (int s4 = 0; s4 < NS4; ++s4) Sb[s4] = Ssm[j * kSmSBlock + (4 * s4 + q) * 17 + a];
                 v4f d[8];
 #pragma unroll
                 for (int ft = 0; ft < 8; ++ft) {
                     d[ft] = vzero();
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
+                    for (int s4 = 0; s4 < NS4; ++s4) {
                         const int m = min(r0 + 4 * s4 + q, ROWS - 1);       // (rows past the buffer: zero weights)
                         d[ft] = mfma16(z[m * kSmZs + 16 * ft + a], Sb[s4], d[ft]);
                     }
@@ -274,6 +277,7 @@ static_assert(kPipeSmem <= kLdsBytes, "LDS budget");
 // of nu shift units (two per graph) the producer waves take the first 2/3 (rounded up to their four waves)
 __host__ __device__ inline int pipe_producer_units(int nu) { const int pu = ((2 * nu + 2) / 3 + 3) & ~3; return pu < nu ? pu : nu; }
 
+template <int NS4>
 __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p) {
     constexpr int RT = kPipeRows / 16, XV = kPipeRows * 32 / 256;  // row tiles; 16-byte pieces of x per producer thread
     constexpr int SV = (kSmMaxGraphs * kSmSBlock + 255) / 256;     // GSO words per producer thread
@@ -351,16 +355,16 @@ __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p
         GNNPP_STAMP(blockIdx.x, 8, tid == 256 && stamp);
         for (int unit = u0 + wave; unit < u1; unit += 4) {
             const int j = unit >> 1, hf = unit & 1, r0 = j * N;
-            float Sb[4];
+            float Sb[NS4];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) Sb[s4] = Ssm[j * kSmSBlock + (4 * s4 + q) * 17 + a];
+            for (int s4 = 0; s4 < NS4; ++s4) Sb[s4] = Ssm[j * kSmSBlock + (4 * s4 + q) * 17 + a];
             v4f d[4];
 #pragma unroll
             for (int f4 = 0; f4 < 4; ++f4) {
                 const int ft = 4 * hf + f4;
                 d[f4] = vzero();
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
+                for (int s4 = 0; s4 < NS4; ++s4) {
                     const int m = min(r0 + 4 * s4 + q, kPipeRows - 1);     // (rows past the buffer: zero weights)
                     d[f4] = mfma16(z[m * kSmZs + 16 * ft + a], Sb[s4], d[f4]);
                 }
@@ -523,6 +527,19 @@ std::atomic<int> g_filter_pipe_grid{0};                    // GNNPP_TUNE_FILTER_
 std::atomic<int> g_filter_small_rows{0};                   // GNNPP_TUNE_FILTER_SMALL_ROWS: 0 = heuristic, 32 or 48
 std::atomic<int> g_filter_small_kernel{1};                 // GNNPP_TUNE_FILTER_SMALL: 0 = never, 1 = heuristic, 2 = whenever the shape fits
 
+template <int ROWS, int NS4>
+static void sm_launch_small(const LsigfArgs& a, int grid, hipStream_t st) {
+    static LdsAttrOnce once;
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_small_b3_kernel<ROWS, NS4>), SmLayout<ROWS>::smem(kSmMaxGraphs));
+    hipLaunchKernelGGL((lsigf_small_b3_kernel<ROWS, NS4>), dim3(grid), dim3(256), SmLayout<ROWS>::smem(a.gpw), st, a);
+}
+template <int NS4>
+static void sm_launch_pipe(const LsigfArgs& a, int grid, hipStream_t st) {
+    static LdsAttrOnce once;
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_pipe_b3_kernel<NS4>), kPipeSmem);
+    hipLaunchKernelGGL((lsigf_pipe_b3_kernel<NS4>), dim3(grid), dim3(512), kPipeSmem, st, a);
+}
+
 // Does the planned launch have this kernel's shape?  Returns 1 when not (the caller goes on), 0 / -3 after a launch.
 static int lsigf_small_dispatch(LsigfArgs a, hipStream_t st) {
     const int mode = g_filter_small_kernel.load(std::memory_order_relaxed);
@@ -551,9 +568,12 @@ static int lsigf_small_dispatch(LsigfArgs a, hipStream_t st) {
             const int knob = g_filter_pipe_grid.load(std::memory_order_relaxed);
             const int resident = knob ? knob : 256;
             const int grid = groups < resident ? groups : resident;
-            static LdsAttrOnce once;
-            set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_pipe_b3_kernel), kPipeSmem);
-            hipLaunchKernelGGL(lsigf_pipe_b3_kernel, dim3(grid), dim3(512), kPipeSmem, st, a);
+            switch ((a.N + 3) >> 2) {
+                case 1: sm_launch_pipe<1>(a, grid, st); break;
+                case 2: sm_launch_pipe<2>(a, grid, st); break;
+                case 3: sm_launch_pipe<3>(a, grid, st); break;
+                default: sm_launch_pipe<4>(a, grid, st); break;
+            }
             return hipGetLastError() == hipSuccess ? 0 : -3;
         }
         if (mode == 3 || rows_knob == 64) return 1;                // (the shape has no pipeline form: the general kernel)
@@ -565,14 +585,21 @@ static int lsigf_small_dispatch(LsigfArgs a, hipStream_t st) {
     a.gpw = per < kSmMaxGraphs ? per : kSmMaxGraphs;
     const int grid = (a.B + a.gpw - 1) / a.gpw;
     if (grid < 64 && mode != 2) return 1;
+    const int ns4 = (a.N + 3) >> 2;
     if (rows == 48) {
-        static LdsAttrOnce once;
-        set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_small_b3_kernel<48>), SmLayout<48>::smem(kSmMaxGraphs));
-        hipLaunchKernelGGL(lsigf_small_b3_kernel<48>, dim3(grid), dim3(256), SmLayout<48>::smem(a.gpw), st, a);
+        switch (ns4) {
+            case 1: sm_launch_small<48, 1>(a, grid, st); break;
+            case 2: sm_launch_small<48, 2>(a, grid, st); break;
+            case 3: sm_launch_small<48, 3>(a, grid, st); break;
+            default: sm_launch_small<48, 4>(a, grid, st); break;
+        }
     } else {
-        static LdsAttrOnce once;
-        set_lds_attr_once(once, reinterpret_cast<const void*>(&lsigf_small_b3_kernel<32>), SmLayout<32>::smem(kSmMaxGraphs));
-        hipLaunchKernelGGL(lsigf_small_b3_kernel<32>, dim3(grid), dim3(256), SmLayout<32>::smem(a.gpw), st, a);
+        switch (ns4) {
+            case 1: sm_launch_small<32, 1>(a, grid, st); break;
+            case 2: sm_launch_small<32, 2>(a, grid, st); break;
+            case 3: sm_launch_small<32, 3>(a, grid, st); break;
+            default: sm_launch_small<32, 4>(a, grid, st); break;
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
