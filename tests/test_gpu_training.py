@@ -645,3 +645,72 @@ def test_training_with_features_wider_than_one_workgroup_holds(dev, G, F_out):
     assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 1e-4 * max(1.0, yr.abs().max().item())
     for got, want, name in ((hd.grad, hr.grad, 'dh'), (xd.grad, xr.grad, 'dx'), (bd.grad, br.grad, 'db')):
         assert (got.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item()), name
+
+
+def _dp_rank(rank, world, port, q):
+    """One data-parallel rank (gloo collectives, BOTH ranks on cuda:0): two real training steps of the planner with
+    FlatBucketDP; reports a gradient check of the first step and the parameters after the second."""
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+        from gnn_pathplanning_amd.training import FlatBucketDP, FusedAdam, policy_loss
+        dev = torch.device('cuda', 0)
+        B, N = 4, 10
+
+        class C:
+            num_agents, nGraphFilterTaps, device = N, 3, dev
+        torch.manual_seed(100 + rank)                            # DIFFERENT initial weights per rank: the broadcast must fix it
+        net = DecentralPlannerNet(C()).to(dev).train()
+        dp = FlatBucketDP(net)
+        opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+        obs = orc.synth_obs(B, N, seed=50 + rank).to(dev)        # each rank its own shard
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=50 + rank)).float().to(dev)
+        g = torch.Generator().manual_seed(rank)
+        tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=g), 5).float().to(dev)
+        grad_err = None
+        for it in range(2):
+            opt.zero_grad()
+            net.addGSO(S)
+            policy_loss(net(obs), tgt).backward()
+            if it == 0:
+                local = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+                both = [torch.empty_like(local) for _ in range(world)]
+                dist.all_gather(both, local)                     # (gloo on CPU copies: the reference for the average)
+            dp.reduce_gradients()
+            if it == 0:
+                got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+                grad_err = (got - sum(both) / world).abs().max().item()
+            opt.step()
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+        q.put((rank, grad_err, flat.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_training_on_one_gpu(dev):
+    """a real model step PER RANK.  Two processes share the one GPU, collectives over gloo (RCCL
+    refuses two ranks on one device): FlatBucketDP broadcasts rank 0's weights, every step averages the gradients of
+    the two ranks' different shards (checked against an independent all_gather), and after two FusedAdam steps both
+    ranks hold bit-identical parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, e0, f0), (_, e1, f1) = res
+    assert e0 <= 1e-7 and e1 <= 1e-7, (e0, e1)                   # the reduced gradient IS the mean of the two ranks'
+    assert np.array_equal(f0, f1)                                # identical replicas after two steps
