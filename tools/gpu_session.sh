@@ -66,7 +66,7 @@ if has filterpmc; then stamp "rocprofv3 pmc passes over the filter-only launch (
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
     timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/fpmc_$name -o pmc -- python $R/tools/filter_sweep.py --pmc-target 8192 $FILTER_PMC_ROWS > $OUT/fpmc_$name.log 2>&1
-    python $R/tools/pmc_summary.py $OUT/fpmc_$name 2>&1 | grep small | tee -a $OUT/filter_pmc.txt
+    python $R/tools/pmc_summary.py $OUT/fpmc_$name 2>&1 | grep "lsigf_" | tee -a $OUT/filter_pmc.txt
     find $OUT/fpmc_$name -name "*.csv" -size +2M -delete
   done; fi
 stamp done
