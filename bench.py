@@ -78,8 +78,11 @@ PRECISION_INFO = {
 }
 
 
-def roofline_block(kernel, info, flops, t_launch, exe_flops, lanes=''):
-    """frac = algorithmic fp32 FLOPs per launch / launch time / the guide's dense peak of the instruction issued."""
+def roofline_block(kernel, info, flops, t_launch, exe_flops, lanes='', column_fill=1.0):
+    """frac = algorithmic fp32 FLOPs per launch / launch time / the guide's dense peak of the instruction issued.
+    `executed_over_algorithmic_flops` and `column_fill` say why frac sits where it does: MFMA FLOPs issued per
+    algorithmic FLOP (plane products x tile padding x skipped structural zeros), and the share of the MFMA tiles'
+    16 columns that carry an agent (or an (agent, position) pair)."""
     ach = flops / t_launch / 1e12
     return {'kernel': kernel, 'bound': 'mfma', 'dtype': info['dtype'], 'instruction': info['instr'],
             'achieved': ach, 'peak': info['peak'], 'unit': 'TFLOP/s', 'frac': ach / info['peak'],
@@ -92,6 +95,7 @@ def roofline_block(kernel, info, flops, t_launch, exe_flops, lanes=''):
             'vs_fp32_mfma_peak': ach / FP32_MFMA_PEAK_TFLOPS,
             'avg_launch_us': t_launch * 1e6, 'flops_per_launch': flops,
             'executed_mfma_flops_per_launch': exe_flops,
+            'executed_over_algorithmic_flops': exe_flops / flops, 'column_fill': column_fill,
             'pipe_busy_frac': exe_flops / t_launch / 1e12 / info['peak']}
 
 
@@ -100,10 +104,12 @@ def fused_rule(L, B, N, K, prec):
     return bool(L.gnnpp_get_tuning(6) == 1 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13))
 
 
-def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel, vp, st):
+def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel, vp, st, batch=None):
     """Compact record of another BASELINE config inside the C2 line: value, ms/step, dominant kernel us, frac,
-    parity (max |dlogit| vs the oracle, near-ties).  Default precision."""
+    parity (max |dlogit| vs the oracle, near-ties).  Default precision.  batch: run only that many graphs of the
+    config (the per-GPU shard of a strong-scaling run: sharding.shard_batch of the global batch, shard 0)."""
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.sharding import shard_batch
     N, W, K, B = CONFIGS[name]
     K = k_over or K
 
@@ -115,7 +121,10 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     obs_cpu = orc.synth_obs(B, N, seed=1337)
     S64 = orc.synth_gso_geometric(B, N, W, seed=1337)
     S_cpu = torch.from_numpy(S64).float()
-    mean_deg = float((S64 != 0).sum() / (B * N))
+    if batch is not None and batch < B:                      # shard 0 of B / batch ranks of the SAME global batch
+        obs_cpu, S_cpu = (t.contiguous() for t in shard_batch((obs_cpu, S_cpu), 0, B // batch))
+        B = obs_cpu.shape[0]
+    mean_deg = float((S_cpu != 0).sum() / (B * N))
     obs, S = obs_cpu.to(dev), S_cpu.to(dev)
     M = B * N
 
@@ -188,6 +197,90 @@ def rotating_batches(orc, net, dev, N, W, B, timed_regions, resident_value, nb=6
 
 
 
+def c4_shard_record(orc, dev, cpu_seconds):
+    """The per-GPU shard of BASELINE config 4 (dcp_onlineExpert training, 64 graphs x 10 agents per GPU, Adam): one
+    optimisation step eager and as a HIP-graph replay (tools/train_bench.measure), the CPU oracle's training step
+    beside it, and the first-step loss / logits against the oracle on the same inputs."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import train_bench
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import policy_loss
+    B, N, K = 64, 10, 3
+    t_eager, _ = train_bench.measure(dev, B, steps=40, warmup=5, graph=False)
+    t_graph, _ = train_bench.measure(dev, B, steps=40, warmup=5, graph=True)
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = N, K, dev
+    torch.manual_seed(1337)
+    net = DecentralPlannerNet(Cfg()).to(dev).train()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    obs = orc.synth_obs(B, N, seed=1337)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337)).float()
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=torch.Generator().manual_seed(0)), 5).float()
+    net.addGSO(S.to(dev))
+    got = net(obs.to(dev))
+    loss_g = float(policy_loss(got, tgt.to(dev)).item())
+    with torch.no_grad():
+        want = orc.policy_forward(sd, S, obs, training=True)
+        loss_w = float(orc.policy_loss(want, tgt).item())
+    err = max((g.detach().cpu() - w).abs().max().item() for g, w in zip(got, want))
+    rec = {'agents': N, 'taps': K, 'batch': B, 'what': 'fwd + loss + bwd + FusedAdam, train-mode BatchNorm; the shard '
+           'every one of the 8 GPUs of config 4 runs (the gradient all-reduce of 826 KB is the only collective)',
+           'value': B * N / t_graph, 'unit': 'agent-steps/s (training step)', 'ms_per_step': 1e3 * t_graph,
+           'how': 'HIP-graph replay of the whole step (GraphedTrainStep), wall clock over 40 steps',
+           'eager_value': B * N / t_eager, 'eager_ms_per_step': 1e3 * t_eager,
+           'dominant_kernel': 'none: ~60 launches of 3-35 us each (profiles/r02a_train_kernel_stats.csv); the step is '
+                              'launch- and latency-bound at 640 agents',
+           'predicted_8gpu_value_without_allreduce': 8 * B * N / t_graph,
+           'parity_train_mode_max_abs_dlogit': err, 'parity_loss_gpu': loss_g, 'parity_loss_oracle': loss_w}
+    if cpu_seconds > 0:
+        cb = train_bench.cpu_baseline(B, cpu_seconds, threads=torch.get_num_threads())
+        cb['speedup_gpu_over_cpu'] = rec['value'] / cb['value']
+        rec['cpu_baseline'] = cb
+    return rec
+
+
+def compact_summary(d):
+    """The per-config figures of the line once more, compactly, as its LAST key (a log that keeps only the tail of
+    the line still holds them).  Records are [M agent-steps/s, ms per step, dominant-kernel us, frac, max |dlogit|]."""
+    def r(x, n=4):
+        return None if x is None else float('%.*g' % (n, x))
+    rl, par = d.get('roofline', {}), d.get('parity', {})
+    out = {'legend': '[M agent-steps/s, ms/step, dominant kernel us, roofline frac, max |dlogit| vs oracle]',
+           d['config']['name']: [r(d['value'] / d['n_gpus'] / 1e6), r(d['ms_per_step']), r(rl.get('avg_launch_us')),
+                                 r(rl.get('frac')), r(par.get('max_abs_dlogit'), 2)],
+           'executed_over_algorithmic_flops': r(rl.get('executed_over_algorithmic_flops')),
+           'column_fill': r(rl.get('column_fill')), 'scaling': d.get('scaling'), 'n_gpus': d.get('n_gpus')}
+    sec = d.get('secondary') or {}
+
+    def rec(v):
+        if 'error' in v:
+            return 'error'
+        return [r(v['value'] / 1e6), r(v['ms_per_step']), r(v.get('dominant_kernel_us')), r(v.get('frac')),
+                r(v.get('parity_max_abs_dlogit'), 2)]
+    for k, v in (sec.get('other_configs') or {}).items():
+        out[k] = rec(v)
+    for k, v in (sec.get('shards_of_8gpu_configs') or {}).items():
+        if k == 'c4_shard' and 'error' not in v:
+            out['c4_shard_train'] = {'M_per_s': r(v['value'] / 1e6), 'ms': r(v['ms_per_step']),
+                                     'eager_ms': r(v['eager_ms_per_step']),
+                                     'cpu_M_per_s': r(v.get('cpu_baseline', {}).get('value', 0) / 1e6) or None,
+                                     'dlogit': r(v['parity_train_mode_max_abs_dlogit'], 2)}
+        elif k.startswith('c5_shard'):
+            out[k] = rec(v)
+    rot = sec.get('c2_rotating_batches') or {}
+    if 'agent_steps_per_s' in rot:
+        out['c2_rotating_M_per_s'] = r(rot['agent_steps_per_s'] / 1e6)
+    fs = sec.get('batch_sweep_filter_only') or []
+    if fs:
+        best = max(fs, key=lambda x: x['hbm_frac_of_8TBps'])
+        out['filter_hbm_frac'] = [r(best['hbm_frac_of_8TBps']), 'B=%d' % best['batch']]
+    cb = d.get('cpu_baseline') or {}
+    if 'value' in cb:
+        out['cpu_M_per_s'] = r(cb['value'] / 1e6)
+    return out
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -242,8 +335,11 @@ def policy_flops_per_agent(K, mean_deg):
     return 2.0 * (1238112 + 16384 + K * 128 * 128 + (K - 1) * mean_deg * 128 + 640)
 
 
-def build_case(orc, name, dev, seed):
+def build_case(orc, name, dev, seed, shard=None):
+    """shard = (rank, world): strong scaling -- the config's GLOBAL batch (same seed on every rank), of which this rank
+    keeps its sharding.shard_batch slice; None: the whole batch (weak scaling: one such batch per GPU)."""
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.sharding import shard_batch
     N, W, K, B = CONFIGS[name]
 
     class Cfg:
@@ -254,7 +350,9 @@ def build_case(orc, name, dev, seed):
     obs_cpu = orc.synth_obs(B, N, seed=seed)
     S64 = orc.synth_gso_geometric(B, N, W, seed=seed)
     S_cpu = torch.from_numpy(S64).float()
-    return net, sd, Cfg, obs_cpu, S_cpu, float((S64 != 0).sum() / (B * N))
+    if shard is not None:
+        obs_cpu, S_cpu = (t.contiguous() for t in shard_batch((obs_cpu, S_cpu), *shard))
+    return net, sd, Cfg, obs_cpu, S_cpu, float((S_cpu != 0).sum() / max(1, obs_cpu.shape[0] * N))
 
 
 def pmc_target(args):
@@ -340,6 +438,10 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
+                    help='weak (default): every rank runs its own batch of the config\'s size; strong: the '
+                         'config\'s batch is the GLOBAL batch, sharded over the ranks with sharding.shard_batch '
+                         '(SURVEY.md section 8e: C5 = 128 graphs -> 16 per GPU at N = 8)')
     ap.add_argument('--repeats', type=int, default=7,
                     help='timed regions of exactly --steps steps each; the median one is reported')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -385,9 +487,13 @@ def main():
     from oracle import policy_oracle as orc           # checker + cpu_baseline leg + synthetic inputs only
     L = _native.lib()
 
-    N, W, K, B = CONFIGS[args.config]
-    seed = 1337 + rank
-    net, sd, Cfg, obs_cpu, S_cpu, mean_deg = build_case(orc, args.config, dev, seed)
+    N, W, K, B_global = CONFIGS[args.config]
+    strong = args.scaling == 'strong'
+    seed = 1337 if strong else 1337 + rank                # strong: every rank generates the SAME global batch
+    net, sd, Cfg, obs_cpu, S_cpu, mean_deg = build_case(orc, args.config, dev, seed,
+                                                        shard=(rank, world) if strong else None)
+    B = obs_cpu.shape[0]                                   # graphs THIS rank steps (strong: its shard)
+    assert B > 0, 'strong scaling: more ranks than graphs'
     obs, S = obs_cpu.to(dev), S_cpu.to(dev)
     M = B * N
 
@@ -435,7 +541,10 @@ def main():
     dist_all = None                              # everything below is rank-local
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, dev_elapsed = regions[order[len(order) // 2]]              # the median region
-    value = world * B * N * args.steps / elapsed
+    # whole job: the graphs ALL ranks stepped / the slowest rank's time (weak: world batches; strong: the one
+    # global batch, whose shards differ by at most one graph)
+    value = (B_global if strong else world * B) * N * args.steps / elapsed
+    value_rank = B * N * args.steps / elapsed             # this rank's own rate (what one GPU does)
 
     # Secondary: the same K steps with `pipeline_streams` independent rollout batches in flight
     # (batch i on stream i % S).  Sequentially dependent steps of ONE batch cannot overlap, so this
@@ -481,7 +590,7 @@ def main():
         'rank_devices': rank_devices,
         'dist_backend': dist.get_backend() if dist is not None else None,
         'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'prewarm_s': args.prewarm_seconds,
         'regions_ms': [round(1e3 * r[0], 4) for r in regions],
         'timing': 'median of %d timed regions of exactly %d steps each (barrier + synchronize on both '
@@ -491,7 +600,10 @@ def main():
                                'batch every step (inputs are L2 / Infinity-Cache warm by construction)'
                                % (N, W, W, K, B),
                    'name': args.config, 'agents': N, 'taps': K, 'batch_per_gpu': B,
-                   'mean_degree': round(mean_deg, 3), 'parallelism': 'replicas x%d' % world},
+                   'global_batch': B_global if strong else world * B,
+                   'mean_degree': round(mean_deg, 3),
+                   'parallelism': ('%d-graph batch sharded over %d ranks (sharding.shard_batch), no data-path '
+                                   'collective' % (B_global, world)) if strong else 'replicas x%d' % world},
     }
     if pipelined is not None:
         result['pipelined'] = pipelined
@@ -549,6 +661,7 @@ def main():
             exe = (8028 + 192 * K) * 16384.0 * B
             lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
                     'algorithmic work' % (N, N)
+            col_fill = N / 16.0
         else:
             kernel, kname = 'gnnpp::encoder_kernel_b3<false, 3>', 'encoder_kernel_b3<false'
             t_dom = t_enc
@@ -558,13 +671,14 @@ def main():
             alg_bytes = M * (363 + 128) * 4.0 + ENC_WEIGHT_FLOATS * 4.0
             exe = 8028 * 16384.0 * tiles                        # MFMAs per 16-agent tile ({0, 1} observations) x FLOP each
             lanes = ''
+            col_fill = M / (16.0 * tiles)
         traffic, traffic_detail = None, {'note': 'not measured (--pmc off, N > 1, or not rank 0)'}
         if args.pmc == 'auto' and world == 1:
             try:
                 traffic, traffic_detail = measure_traffic(args.config, kname)
             except Exception as e:                              # never let the profiler break the bench line
                 traffic, traffic_detail = None, {'note': 'pmc pass raised %s' % type(e).__name__}
-        result['roofline'] = roofline_block(kernel, info, flops, t_dom, exe, lanes)
+        result['roofline'] = roofline_block(kernel, info, flops, t_dom, exe, lanes, col_fill)
         result['roofline'].update({'traffic': traffic, 'traffic_detail': traffic_detail,
                                    'algorithmic_bytes': alg_bytes, 'avg_launch_how': how})
         clk = None
@@ -606,7 +720,7 @@ def main():
             'hbm_frac_of_8TBps': gf_bytes / t_gf / (HBM_PEAK_TBPS * 1e12),
             'mfma_TFLOPs': 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * M / t_gf / 1e12,
             'regime': 'one launch over a %.1f MB working set: launch-latency bound, not HBM bound' % (gf_bytes / 1e6)}
-        result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value / world / 1e12
+        result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value_rank / 1e12
 
         if not args.no_secondary:
             sec = {}
@@ -702,8 +816,28 @@ def main():
                         except Exception as e:                  # an extra: never break the line
                             others['%s_K%s' % (nm, k_over)] = {'error': '%s: %s' % (type(e).__name__, e)}
                     sec['other_configs'] = others
+                    # (5) the per-GPU SHARDS of the 8-GPU configs, measured on this one GPU: what
+                    # each of the 8 ranks of `--scaling strong` executes.  C5: 128 graphs -> 16 per GPU
+                    # (sharding.shard_batch, shard 0); C4: 64 graphs per GPU, one optimisation step.
+                    shards = {}
+                    for kk in (2, 3, 4):
+                        try:
+                            rec = quick_config(orc, L, _native, 'c5', kk, dev, timed_regions, time_kernel, vp, st, batch=16)
+                            rec['predicted_8gpu_value'] = 8.0 * rec['value']
+                            rec['vs_full_batch_rate'] = rec['value'] / others['c5_K%d' % kk]['value']
+                            shards['c5_shard_K%d' % kk] = rec
+                        except Exception as e:
+                            shards['c5_shard_K%d' % kk] = {'error': '%s: %s' % (type(e).__name__, e)}
                     try:
-                        sec['c2_rotating_batches'] = rotating_batches(orc, net, dev, N, W, B, timed_regions, value / world)
+                        shards['c4_shard'] = c4_shard_record(orc, dev, 0.0 if args.no_cpu_baseline
+                                                             else min(4.0, args.cpu_seconds))
+                    except Exception as e:
+                        shards['c4_shard'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                    shards['note'] = ('rollout shards are independent (no data-path collective): the 8-GPU whole-job '
+                                      'value of a strong-scaling run is 8 x the shard rate measured here')
+                    sec['shards_of_8gpu_configs'] = shards
+                    try:
+                        sec['c2_rotating_batches'] = rotating_batches(orc, net, dev, N, W, B, timed_regions, value_rank)
                     except Exception as e:
                         sec['c2_rotating_batches'] = {'error': '%s: %s' % (type(e).__name__, e)}
             result['secondary'] = sec
@@ -770,7 +904,7 @@ def main():
                   'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
                             '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'
                             % (reps, args.config, torch.__version__, spent),
-                  'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value / world / (B * N / med)}
+                  'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value_rank / (B * N / med)}
             # the reference's own rollout step: B = 1 (BASELINE.json configs[0]), same thread count
             o1, S1 = obs_cpu[:1].contiguous(), S_cpu[:1].contiguous()
             med1, reps1, _ = time_cpu(orc, sd, S1, o1, min(3.0, args.cpu_seconds))
@@ -796,6 +930,7 @@ def main():
             cb['one_thread'] = {'agent_steps_per_s': B * N / medt, 'ms_per_step': medt * 1e3, 'repetitions': repst,
                                 'c1_b1_agent_steps_per_s': N / medt1}
             result['cpu_baseline'] = cb
+        result['summary'] = compact_summary(result)           # LAST key: what a 2 000-character tail of the line keeps
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

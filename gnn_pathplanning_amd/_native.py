@@ -20,7 +20,7 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
                '-Wno-unused-result']
 
 EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get_tuning', 'gnnpp_filter_packed_floats',
-           'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_encoder_packed_floats',
+           'gnnpp_filter_pack', 'gnnpp_lsigf_fwd', 'gnnpp_lsigf_fwd_save', 'gnnpp_lsigf_fits', 'gnnpp_encoder_packed_floats',
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_encoder_train_workspace_floats', 'gnnpp_encoder_train_fwd',
            'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_gemm_multi_workspace_floats',
            'gnnpp_gemm_kmajor_multi', 'gnnpp_policy_loss',
@@ -181,6 +181,8 @@ def _bind(path):
     L.gnnpp_lsigf_fwd.argtypes = [vp] * 5 + [ci] * 14 + [vp, vp]
     L.gnnpp_lsigf_fwd_save.argtypes = [vp] * 6 + [ci] * 15 + [vp, vp]
     L.gnnpp_lsigf_fwd_save.restype = ci
+    L.gnnpp_lsigf_fits.argtypes = [ci] * 5
+    L.gnnpp_lsigf_fits.restype = ci
     L.gnnpp_encoder_packed_floats.restype = cs
     L.gnnpp_encoder_packed_floats.argtypes = []
     L.gnnpp_encoder_pack.argtypes = [ctypes.POINTER(EncoderParams), vp, vp]

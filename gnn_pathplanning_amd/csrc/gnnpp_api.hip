@@ -23,7 +23,7 @@ static_assert(GNNPP_OK == 0 && GNNPP_ERR_UNSUPPORTED == -2 && GNNPP_ERR_LAUNCH =
 
 extern "C" {
 
-int gnnpp_version(void) { return 300; }
+int gnnpp_version(void) { return 310; }
 
 const char* gnnpp_error_string(int code) {
     switch (code) {
@@ -85,6 +85,19 @@ int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, con
     a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
     a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag; a.prec = precision;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_lsigf_fits(int N, int G, int F, int K, int E) {
+    if (N <= 0 || G <= 0 || F <= 0 || K <= 0 || E <= 0) return GNNPP_ERR_ARG;
+    if (N > GNNPP_MAX_ROWS) return 0;
+    for (int f0 = 0; f0 < F; f0 += 128) {              // (lsigf_launch's chunks of <= 128 output features)
+        LsigfArgs a = {};
+        a.B = 1; a.N = N; a.Nin = N; a.G = G; a.K = K; a.E = E;
+        a.F_all = F; a.f0 = f0; a.F = F - f0 < 128 ? F - f0 : 128;
+        LsigfPlan plan;
+        if (lsigf_plan(a, plan) != 0) return 0;
+    }
+    return 1;
 }
 
 size_t gnnpp_encoder_packed_floats(void) { return EncLayout::kTotal; }

@@ -142,12 +142,14 @@ __device__ __forceinline__ float b3_bits(unsigned u) {
     __builtin_memcpy(&f, &u, 4);
     return f;
 }
+// (NaN: v_med3_f32 returns min3 of its operands when one of them is NaN, and min ignores a NaN operand -- the h plane
+// of a NaN is -big, the residual x - h is NaN again, so the m plane carries the NaN on: a NaN input stays a NaN.)
 __device__ __forceinline__ float b3_clamp(float x) {
     const float big = b3_bits(0x7f7f0000u);
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_fmed3f(x, -big, big);
 #else
-    return x != x ? x : (x < -big ? -big : x > big ? big : x);
+    return x != x ? -big : (x < -big ? -big : x > big ? big : x);     // (the device's med3, NaN included)
 #endif
 }
 // two fp32 values -> their three planes as packed bf16 pairs (x0 in the low halves)
@@ -170,13 +172,16 @@ __device__ __forceinline__ void b3_split2_clamped(float x0, float x1, unsigned& 
     const float s1 = b3_sub(r1, b3_bits(m & 0xffff0000u));
     l = b3_cvt_pk(s0, s1);
 }
-// max(x, 0) and the split's upper clamp in ONE v_med3_f32 (NaN stays NaN on the device: med3 returns min3 then)
+// max(x, 0) and the split's upper clamp in ONE v_med3_f32.  NON-FINITE activations are flushed here, unlike
+// torch.relu: +inf becomes 3.39e38 (the largest bf16) and NaN becomes 0 (med3 with a NaN operand returns min3, and
+// min ignores the NaN: min3(NaN, 0, big) = 0).  A network whose L0 activations overflow fp32 is outside what the
+// parity tests pin (the reference produces inf / NaN logits there); the host emulation mirrors the device.
 __device__ __forceinline__ float b3_relu_clamp(float x) {
     const float big = b3_bits(0x7f7f0000u);
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_fmed3f(x, 0.f, big);
 #else
-    return x != x ? x : (x < 0.f ? 0.f : x > big ? big : x);
+    return x != x ? 0.f : (x < 0.f ? 0.f : x > big ? big : x);
 #endif
 }
 // eight fp32 values (two D tiles: a = k-slots e 0..3, b = e 4..7) -> the three 16-byte plane fragments

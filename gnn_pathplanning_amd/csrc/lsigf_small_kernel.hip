@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void lsigf_small_b3_kernel(const LsigfArgs 
                     d[ft] = vzero();
 #pragma unroll
                     for (int s4 = 0; s4 < NS4; ++s4) {
-                        const int m = min(r0 + 4 * s4 + q, ROWS - 1);       // (rows past the buffer: zero weights)
+                        // k-slots past the graph's N rows meet zero weights; they re-read the graph's OWN last row,
+                        // never a neighbour's (0 x Inf = NaN must stay inside the sample, as in the reference)
+                        const int m = r0 + min(4 * s4 + q, N - 1);
                         d[ft] = mfma16(z[m * kSmZs + 16 * ft + a], Sb[s4], d[ft]);
                     }
                 }
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p
                 d[f4] = vzero();
 #pragma unroll
                 for (int s4 = 0; s4 < NS4; ++s4) {
-                    const int m = min(r0 + 4 * s4 + q, kPipeRows - 1);     // (rows past the buffer: zero weights)
+                    const int m = r0 + min(4 * s4 + q, N - 1);     // (k-slots past the graph: its OWN last row x zero weight)
                     d[f4] = mfma16(z[m * kSmZs + 16 * ft + a], Sb[s4], d[f4]);
                 }
             }

@@ -33,11 +33,16 @@ from . import _native
 zeroTolerance = 1e-9    # kept for API parity (graphML.py:42-43)
 infiniteNumber = 1e12
 
-# Arithmetic of the tap contraction of the functions / modules below (include/gnnpp.h GNNPP_PREC_*), read at call
-# time: 'fp32' (default, fp32-equivalent: these operators contract on the exact fp32 MFMA), 'fp32_mfma' (the same
-# here), or the opt-in 'split_f16' (22-bit operands, |x| < 65504, unguarded at this level).  The reference's
-# signatures have no room for it, hence a module attribute.
-PRECISION = 'fp32'
+# Arithmetic of the tap contraction (include/gnnpp.h GNNPP_PREC_*): 'fp32' (default, fp32-equivalent: bf16x3 operand
+# planes on the small-graph kernels -- N <= 16, G = F = 128, >= 64 workgroups: lsigf_small_dispatch -- and the exact
+# fp32 MFMA everywhere else), 'fp32_mfma' (exact fp32 MFMA on every path, bitwise an fmaf chain and independent of
+# the batch size; GNNPP_TUNE_FILTER_SMALL=0 gives the same single schedule under 'fp32'), or the opt-in 'split_f16'
+# (22-bit operands, |x| < 65504, unguarded at this level).
+# There is NO process-wide switch: the functions take `precision=` per call (None = DEFAULT_PRECISION), the modules
+# carry `self.precision`, fixed at CONSTRUCTION from the `precision=` argument (None = DEFAULT_PRECISION at that
+# moment).  Nothing reads a module global at call time, so two threads / streams cannot change each other's
+# arithmetic (tests/test_gpu_parity.py::test_filter_precision_is_per_call_and_per_instance).
+DEFAULT_PRECISION = 'fp32'
 
 _MAX_F_PER_LAUNCH = 128
 MAX_NODES = 112         # rows one workgroup holds in LDS (GNNPP_MAX_NODES=100 guaranteed at G=F=128)
@@ -152,11 +157,12 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
     """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
     (and, with save_taps, zs [E*K, B*N, G]).  Any F: the C entry point splits wide filters.
     node_major: x [B,N,G] -> y [B,N,F] (rows = nodes, the layout the kernel keeps in LDS anyway).
-    precision: GNNPP_PREC_* of the tap contraction (0 = fp32-equivalent, the default; this operator contracts on
-    the exact fp32 MFMA then); 2 = the opt-in split-f16 schedule, unguarded here (no range flag is passed)."""
+    precision: GNNPP_PREC_* (or its name) of the tap contraction; None = DEFAULT_PRECISION (fp32-equivalent: bf16x3
+    planes on the small-graph kernels, the exact fp32 MFMA elsewhere); 2 = the opt-in split-f16 schedule, unguarded
+    here (no range flag is passed)."""
     dev = _native.require_gpu(h, S, x, b)
     L = _native.lib()
-    precision = _native.precision_code(PRECISION if precision is None else precision)
+    precision = _native.precision_code(DEFAULT_PRECISION if precision is None else precision)
     F_out, E, K, G = h.shape
     N = S.shape[-1]
     B = x.shape[0]
@@ -192,9 +198,12 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
             rc = L.gnnpp_lsigf_fwd(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y),
                                    B, N, Nin, G, F_out, K, E, s64, int(batched), nm, nm, int(relu),
                                    per_node, int(precision), None, _native.stream_ptr(dev))
+    if rc == -2 and L.gnnpp_lsigf_fits(N, G, F_out, K, E) != 0:
+        _native.check(rc, 'gnnpp_lsigf_fwd')     # GNNPP_ERR_UNSUPPORTED for another reason than LDS room: an error
     if rc == -2 and not (transposed or save_taps):
-        # GNNPP_ERR_UNSUPPORTED below MAX_NODES: the graph's rows do not fit the kernel's LDS budget (wide input
-        # features, or 101..112 nodes at G = F = 128).  The reference has no such limit: the dense exact-fp32 form.
+        # GNNPP_ERR_UNSUPPORTED below MAX_NODES, confirmed by gnnpp_lsigf_fits: the graph's rows do not fit the kernel's
+        # LDS budget (wide input features, or 101..112 nodes at G = F = 128).  The reference has no such limit: the
+        # dense exact-fp32 form.
         if node_major:
             return _lsigf_large(h, S, x, b, batched, relu)
         xn = torch.zeros(B, N, G, dtype=torch.float32, device=dev)
@@ -229,9 +238,10 @@ class _LSIGFFunction(torch.autograd.Function):
     """y = LSIGF(h, S, x, b) with gradients for h, x and b (none for S)."""
 
     @staticmethod
-    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False):
+    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False, precision=None):
         """node_major: x [B,N,G] -> y [B,N,F] (train-mode planner: no transposing copies around the filter);
-        relu: y = relu(filter) in the same launch (the mask for the backward pass is y > 0)."""
+        relu: y = relu(filter) in the same launch (the mask for the backward pass is y > 0);
+        precision: of the forward contraction (the gradient filters run in the default arithmetic)."""
         Nin = x.shape[1] if node_major else x.shape[2]
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
@@ -239,7 +249,7 @@ class _LSIGFFunction(torch.autograd.Function):
         N = S.shape[-1]
         ctx.large = N > MAX_NODES
         res = None if ctx.large else _lsigf_device(h, S, x, b, batched, Nin, packed, relu=relu, save_taps=True,
-                                                   node_major=node_major)
+                                                   node_major=node_major, precision=precision)
         if res is not None:
             y, zs = res
             ctx.save_for_backward(h, S, zs, y if relu else None)
@@ -280,7 +290,7 @@ class _LSIGFFunction(torch.autograd.Function):
                     db = dyn.sum(dim=(0, 1)).reshape(ctx.bias_shape)
                 else:                                                              # per-node bias [F,N]
                     db = dyn.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
-            return dh, None, dx, db, None, None, None, None
+            return dh, None, dx, db, None, None, None, None, None
         if ctx.relu:
             dy = torch.ops.aten.threshold_backward(dy, yrelu, 0)          # dy where y > 0, else 0
         if ctx.node_major:
@@ -305,7 +315,7 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=(0, 2)).reshape(ctx.bias_shape)
             else:                                                         # per-node bias [F,N]
                 db = torch.nn.functional.pad(dy.sum(dim=0), (0, N - ctx.Nin)).reshape(ctx.bias_shape)
-        return dh, None, dx, db, None, None, None, None
+        return dh, None, dx, db, None, None, None, None, None
 
     @staticmethod
     def _dense_dx(ctx, h, S, dyn):
@@ -344,7 +354,7 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
         if specs:
             _native.gemm_kmajor_multi(specs)
-        return dh, None, dx, db, None, None, None, None
+        return dh, None, dx, db, None, None, None, None, None
 
 
 _ones_cache = {}
@@ -361,10 +371,11 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def LSIGF(h, S, x, b=None):
+def LSIGF(h, S, x, b=None, precision=None):
     """Linear shift-invariant graph filter, one GSO for the whole batch (graphML.py:48-141).
 
     h [F,E,K,G] filter taps, S [E,N,N], x [B,G,N], b [F,1] (or [F,N]) -> [B,F,N].
+    precision (keyword, not in the reference's signature): arithmetic of THIS call, None = DEFAULT_PRECISION.
     """
     F_out, E, K, G = h.shape
     assert S.shape[0] == E
@@ -377,13 +388,13 @@ def LSIGF(h, S, x, b=None):
         raise RuntimeError('expected S and x to have the same dtype, but got: %s != %s'
                            % (x.dtype, S.dtype))
     if _wants_grad(h, x, b):
-        return _LSIGFFunction.apply(h, S, x, b, False, None)
-    return _lsigf_device(h, S, x, b, batched=False, Nin=N)
+        return _LSIGFFunction.apply(h, S, x, b, False, None, False, False, precision)
+    return _lsigf_device(h, S, x, b, batched=False, Nin=N, precision=precision)
 
 
-def BatchLSIGF(h, S, x, b=None):
+def BatchLSIGF(h, S, x, b=None, precision=None):
     """Same filter with one GSO per sample (graphML.py:2273-2367).  S [B,E,N,N] may be float64:
-    it is rounded to fp32 on load like the reference's `S.float()` (:2350)."""
+    it is rounded to fp32 on load like the reference's `S.float()` (:2350).  precision: as LSIGF."""
     F_out, E, K, G = h.shape
     assert S.shape[1] == E
     N = S.shape[2]
@@ -392,20 +403,23 @@ def BatchLSIGF(h, S, x, b=None):
     assert x.shape[2] == N
     assert S.shape[0] == x.shape[0]
     if _wants_grad(h, x, b):
-        return _LSIGFFunction.apply(h, S, x, b, True, None)
-    return _lsigf_device(h, S, x, b, batched=True, Nin=N)
+        return _LSIGFFunction.apply(h, S, x, b, True, None, False, False, precision)
+    return _lsigf_device(h, S, x, b, batched=True, Nin=N, precision=precision)
 
 
 class _GraphFilterBase(nn.Module):
     _batched = False
 
-    def __init__(self, G, F, K, E=1, bias=True):
+    def __init__(self, G, F, K, E=1, bias=True, precision=None):
         super().__init__()
         self.G = G
         self.F = F
         self.K = K
         self.E = E
         self.S = None
+        # arithmetic of this INSTANCE's forward, fixed here (a keyword the reference's constructor does not have)
+        self.precision = DEFAULT_PRECISION if precision is None else precision
+        _native.precision_code(self.precision)             # (unknown names fail at construction)
         self.weight = nn.parameter.Parameter(torch.Tensor(F, E, K, G))
         if bias:
             self.bias = nn.parameter.Parameter(torch.Tensor(F, 1))
@@ -442,9 +456,9 @@ class _GraphFilterBase(nn.Module):
         # :2464-2476) are folded into the kernel through Nin
         if _wants_grad(self.weight, x, self.bias):
             return _LSIGFFunction.apply(self.weight, self.S, x, self.bias, self._batched,
-                                        self.packed_taps())
+                                        self.packed_taps(), False, False, self.precision)
         return _lsigf_device(self.weight, self.S, x, self.bias, self._batched, Nin,
-                             packed=self.packed_taps())
+                             packed=self.packed_taps(), precision=self.precision)
 
     def forward_node_major(self, x, relu=False):
         """The same filter on x [B,N,G] -> [B,N,F] (rows = nodes; optionally followed by ReLU in the same launch),
@@ -457,7 +471,7 @@ class _GraphFilterBase(nn.Module):
         if self._batched:
             assert self.S.shape[0] == x.shape[0]
         return _LSIGFFunction.apply(self.weight, self.S, x, self.bias, self._batched, self.packed_taps(), True,
-                                    bool(relu))
+                                    bool(relu), self.precision)
 
     def extra_repr(self):
         s = 'in_features=%d, out_features=%d, ' % (self.G, self.F)
@@ -514,10 +528,11 @@ def matrixPowersBatch(S, K):
     return SK.squeeze(1) if scalar else SK
 
 
-def batchLSIGF(h, SK, x, bias=None):
+def batchLSIGF(h, SK, x, bias=None, precision=None):
     """Graph filter on given per-sample matrices SK [B,E,K,N,N] (graphML.py:2115-2178):
     y[b] = bias + sum_{e,k} h[:,e,k,:] . (x[b] SK[b,e,k]).  Each (e,k) pair is an independent
-    one-hop shift of x, i.e. the LSIGF kernel with E*K "edge features", two taps and a zero tap 0."""
+    one-hop shift of x, i.e. the LSIGF kernel with E*K "edge features", two taps and a zero tap 0.
+    precision: arithmetic of this call (keyword; None = DEFAULT_PRECISION)."""
     F_out, E, K, G = h.shape
     B = SK.shape[0]
     assert SK.shape[1] == E
@@ -531,16 +546,16 @@ def batchLSIGF(h, SK, x, bias=None):
     h2[:, :, 1, :] = h.reshape(F_out, E * K, G)
     S2 = SK.reshape(B, E * K, N, N)
     if _wants_grad(h, x, bias):
-        return _LSIGFFunction.apply(h2, S2, x, bias, True, None)
-    return _lsigf_device(h2, S2, x, bias, batched=True, Nin=N)
+        return _LSIGFFunction.apply(h2, S2, x, bias, True, None, False, False, precision)
+    return _lsigf_device(h2, S2, x, bias, batched=True, Nin=N, precision=precision)
 
 
 class GraphFilterBatchGSO(GraphFilter):
     """Graph filtering layer with a different GSO per sample, powers precomputed at addGSO
     (graphML.py:2180-2271).  addGSO(S [B,N,N] | [B,E,N,N]); forward(x [B,G,N]) -> [B,F,N]."""
 
-    def __init__(self, G, F, K, E=1, bias=True):
-        super().__init__(G, F, K, E, bias)
+    def __init__(self, G, F, K, E=1, bias=True, precision=None):
+        super().__init__(G, F, K, E, bias, precision)
 
     def addGSO(self, S):
         if len(S.shape) == 3 and S.shape[1] == S.shape[2]:
@@ -552,7 +567,7 @@ class GraphFilterBatchGSO(GraphFilter):
         self.SK = matrixPowersBatch(self.S, self.K)
 
     def forward(self, x):
-        return batchLSIGF(self.weight, self.SK, x, self.bias)
+        return batchLSIGF(self.weight, self.SK, x, self.bias, self.precision)
 
     def extra_repr(self):
         s = 'in_features=%d, out_features=%d, ' % (self.G, self.F)

@@ -49,9 +49,26 @@ def policy_logits(obs: torch.Tensor, S: torch.Tensor, enc_packed: torch.Tensor, 
     obs [B,N,3,11,11], S [B,1,N,N] fp32 | fp64, the packed encoder (DecentralPlannerNet.packed_encoder()), the packed
     taps of GFL[0] (GraphFilterBatch.packed_taps()), its bias [128] or None, actionsMLP weight [5,128] / bias [5]
     -> logits [N,B,5].  Teams of <= 112 agents; split-f16 (precision 2) is unguarded here (no range flag)."""
-    import ctypes
     B, N = obs.shape[0], obs.shape[1]
     dev = _native.require_gpu(obs, S, enc_packed, taps_packed, act_w, act_b)
+    # The packs are opaque buffers the kernels index by layout constants: a pack of another build / tap count, or a
+    # GSO of another shape, would be read out of bounds.  (The module API is protected by its PackCache; this op
+    # takes the caller's word, so it checks.)
+    L = _native.lib()
+    K = int(K)
+    if tuple(obs.shape[2:]) != (3, 11, 11) or K < 1:
+        raise _native.GnnppError('policy_logits: obs must be [B,N,3,11,11] and K >= 1')
+    if S.dim() == 3:
+        S = S.unsqueeze(1)
+    if tuple(S.shape) != (B, 1, N, N):
+        raise _native.GnnppError('policy_logits: S must be [B,1,N,N] = %r, got %r' % ((B, 1, N, N), tuple(S.shape)))
+    for name, t, want in (('enc_packed', enc_packed, L.gnnpp_encoder_packed_floats()),
+                          ('taps_packed', taps_packed, L.gnnpp_filter_packed_floats(128, 128, K, 1))):
+        if t.dtype is not torch.float32 or not t.is_contiguous() or t.numel() != want:
+            raise _native.GnnppError('policy_logits: %s must be a contiguous fp32 buffer of %d floats (this build, '
+                                     'K = %d), got %d x %s' % (name, want, K, t.numel(), t.dtype))
+    if tuple(act_w.shape) != (5, 128) or act_b.numel() != 5 or (gf_bias is not None and gf_bias.numel() != 128):
+        raise _native.GnnppError('policy_logits: act_w [5,128], act_b [5], gf_bias [128] expected')
     obs_c = obs.detach().contiguous().float()
     S_c = S.detach().contiguous()
     if S_c.dtype not in (torch.float32, torch.float64):

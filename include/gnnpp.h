@@ -160,6 +160,14 @@ int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, con
                          int y_node_major, int relu, int bias_per_node, int precision, int* range_flag,
                          void* stream);
 
+/* 1 when a graph of N nodes with G input / F output features, K taps and E edge features fits the LDS-resident
+ * filter kernels (gnnpp_lsigf_fwd / _save return GNNPP_OK for it), 0 when they answer GNNPP_ERR_UNSUPPORTED for
+ * LACK OF LDS (N > GNNPP_MAX_ROWS, or fewer nodes with wide features), negative on invalid arguments.  The
+ * reference's BatchLSIGF (utils/graphUtils/graphML.py:2273-2367) has no size limit: a caller uses this to tell
+ * "take the dense-GEMM form" (what graphML._lsigf_large does) from any other GNNPP_ERR_UNSUPPORTED, which must
+ * stay an error (v310). */
+int gnnpp_lsigf_fits(int N, int G, int F, int K, int E);
+
 /* ------------------------------------------------------------------------------------------
  * Per-agent encoder: 5 x (conv3x3 pad 1 -> BatchNorm(eval) -> ReLU [-> MaxPool 2]) -> flatten ->
  * Linear(128,128) -> ReLU.  Replaces ConvLayers + compressMLP as run by

@@ -443,11 +443,10 @@ def test_multilayer_and_edge_feature_planners(dev, policy_golden, multilayer_gol
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'split_f16'])
-def test_filter_split_f16_wide_dynamic_range(dev, prec, monkeypatch):
+def test_filter_split_f16_wide_dynamic_range(dev, prec):
     """The FILTER's contraction (G = 128; split-f16 and the default) with trained-scale taps spread over several
     decades and features from 1e-3 to 1e3: relative error stays at fp32 level against the float64 statement."""
     import gnn_pathplanning_amd.graphML as gml
-    monkeypatch.setattr(gml, 'PRECISION', prec)
     g = torch.Generator().manual_seed(17)
     B, N, K = 64, 10, 3
     for tap_scale, feat_scale in ((1.0, 1.0), (60.0, 300.0), (0.003, 1e-3), (25.0, 2e-2)):
@@ -459,10 +458,64 @@ def test_filter_split_f16_wide_dynamic_range(dev, prec, monkeypatch):
         x[:, ::5] *= 1e-3
         S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=3)).unsqueeze(1)
         ref = orc.lsigf_f64(h.numpy(), S.numpy(), x.numpy(), b.numpy())
-        y = gml.BatchLSIGF(h.to(dev), S.to(dev), x.to(dev), b.to(dev)).cpu().numpy()
+        y = gml.BatchLSIGF(h.to(dev), S.to(dev), x.to(dev), b.to(dev), precision=prec).cpu().numpy()
         scale = np.abs(ref).max()
         assert np.isfinite(y).all() and np.abs(y - ref).max() <= 2e-5 * scale, (tap_scale, feat_scale,
                                                                                np.abs(y - ref).max() / scale)
+
+
+def test_filter_precision_is_per_call_and_per_instance(dev):
+    """No process-wide precision switch in the functional / module API of the graph filter: the
+    functions take `precision=` per call, the modules fix `self.precision` at construction.  Two threads, each on
+    its own stream, run the SAME inputs under different arithmetics at the same time, many times over: every result
+    of a thread is bit-identical to that arithmetic's single-threaded result (and the two arithmetics do differ, so
+    a leak from one thread into the other would be seen)."""
+    import threading
+    import gnn_pathplanning_amd.graphML as gml
+    assert not hasattr(gml, 'PRECISION')                          # the r03 module global is gone
+    g = torch.Generator().manual_seed(5)
+    B, N, K = 256, 10, 3
+    h = (torch.randn(128, 1, K, 128, generator=g) / (128 * K) ** 0.5).to(dev)
+    b = (0.1 * torch.randn(128, 1, generator=g)).to(dev)
+    x = torch.relu(torch.randn(B, 128, N, generator=g)).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=3)).unsqueeze(1).to(dev)
+    want = {p: gml.BatchLSIGF(h, S, x, b, precision=p).clone() for p in ('fp32', 'split_f16')}
+    assert not torch.equal(want['fp32'], want['split_f16'])       # (feature-major calls: exact fp32 MFMA vs f16 pairs)
+    assert (want['fp32'] - want['split_f16']).abs().max().item() <= 1e-4
+    # modules: the arithmetic is the instance's
+    mods = {}
+    for p in ('fp32', 'split_f16'):
+        m = gml.GraphFilterBatch(128, 128, K, 1, True, precision=p).to(dev)
+        with torch.no_grad():
+            m.weight.copy_(h)
+            m.bias.copy_(b)
+        mods[p] = m
+        assert m.precision == p
+    assert gml.GraphFilterBatch(4, 4, 2).precision == gml.DEFAULT_PRECISION == 'fp32'
+    with pytest.raises(Exception):
+        gml.GraphFilterBatch(4, 4, 2, precision='fp64')
+    torch.cuda.synchronize()
+    bad = []
+
+    def worker(p, use_module):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st), torch.no_grad():
+            for _ in range(40):
+                if use_module:
+                    mods[p].addGSO(S)
+                    y = mods[p](x)
+                else:
+                    y = gml.BatchLSIGF(h, S, x, b, precision=p)
+                if not torch.equal(y, want[p]):
+                    bad.append(p)
+        st.synchronize()
+    for use_module in (False, True):
+        ts = [threading.Thread(target=worker, args=(p, use_module)) for p in ('fp32', 'split_f16')]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not bad, bad
 
 
 def test_range_guard_and_exact_fallback(dev):
@@ -731,6 +784,17 @@ def test_torch_ops_equal_the_module_api_and_trace(dev):
                                         act.bias, 3, 0)
     assert torch.equal(got, want)
     assert torch.equal(torch.ops.gnnpp.decode_actions(got), net.decode_actions(want))
+    # the op takes the caller's packs: a tap count that does not match the pack, a truncated encoder pack or a GSO of
+    # another shape is an error, never an out-of-bounds read
+    from gnn_pathplanning_amd._native import GnnppError
+    for bad in (lambda: torch.ops.gnnpp.policy_logits(obs, net.S, net.packed_encoder(), gf.packed_taps(), gf.bias,
+                                                      act.weight, act.bias, 4, 0),
+                lambda: torch.ops.gnnpp.policy_logits(obs, net.S, net.packed_encoder()[:-8].contiguous(),
+                                                      gf.packed_taps(), gf.bias, act.weight, act.bias, 3, 0),
+                lambda: torch.ops.gnnpp.policy_logits(obs, net.S[:, :, :9, :9].contiguous(), net.packed_encoder(),
+                                                      gf.packed_taps(), gf.bias, act.weight, act.bias, 3, 0)):
+        with pytest.raises(GnnppError):
+            bad()
     g = torch.Generator().manual_seed(3)
     h = (torch.randn(96, 1, 3, 128, generator=g) / 20).to(dev)
     x = torch.randn(B, 128, N, generator=g).to(dev)

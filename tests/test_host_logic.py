@@ -42,7 +42,7 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert lib.gnnpp_encoder_packed_floats() > 555000 // 4
     # argument validation happens before any HIP call, so it is checkable without a GPU
     assert lib.gnnpp_encoder_fwd(None, None, None, 16, 0, None, None) == -1
-    assert lib.gnnpp_version() == 300                        # ABI 300: per-call `precision`, no precision knobs
+    assert lib.gnnpp_version() == 310                        # ABI 300: per-call `precision`, no precision knobs
     assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 0) == -1
     assert lib.gnnpp_decode_actions(None, None, 1, 1, None) == -1
 
@@ -156,6 +156,43 @@ def test_prepowered_gso_api_surface():
     assert m.N == 5 and m.B == 2 and 'number_nodes=5' in m.extra_repr()
 
 
+def _check_r04_extras(f, d):
+    """r04: the line ends with a compact `summary` (so that a 2 000-character tail keeps the per-config figures), the
+    roofline says how many MFMA FLOPs were issued per algorithmic FLOP and how full the tiles' columns were, and the
+    C2 line holds the per-GPU SHARDS of the 8-GPU configs (C5: 16 graphs x 100 agents, K = 2, 3, 4; C4: a 64 x 10
+    optimisation step with the CPU oracle's training step beside it)."""
+    import json
+    assert list(d)[-1] == 'summary', f
+    sm, rl = d['summary'], d['roofline']
+    assert len(json.dumps(sm)) <= 1900, (f, len(json.dumps(sm)))
+    name = d['config']['name']
+    assert abs(sm[name][0] * 1e6 - d['value'] / d['n_gpus']) <= 2e-3 * d['value']
+    assert abs(sm[name][1] - d['ms_per_step']) <= 2e-3 * d['ms_per_step']
+    assert abs(rl['executed_over_algorithmic_flops'] - rl['executed_mfma_flops_per_launch'] / rl['flops_per_launch']) <= 1e-9
+    assert rl['executed_over_algorithmic_flops'] > 1 and 0 < rl['column_fill'] <= 1
+    assert abs(sm['executed_over_algorithmic_flops'] - rl['executed_over_algorithmic_flops']) <= 1e-3 * rl['executed_over_algorithmic_flops']
+    if name != 'c2':
+        return
+    sh = d['secondary']['shards_of_8gpu_configs']
+    for k in ('c5_shard_K2', 'c5_shard_K3', 'c5_shard_K4'):
+        v = sh[k]
+        assert 'error' not in v, (k, v)
+        assert v['batch'] == 16 and v['agents'] == 100
+        assert abs(v['value'] - v['batch'] * v['agents'] / (v['ms_per_step'] * 1e-3)) <= 1e-3 * v['value']
+        assert abs(v['predicted_8gpu_value'] - 8 * v['value']) <= 1e-6 * v['value']
+        assert v['parity_max_abs_dlogit'] <= 1e-4 and v['argmax_equal_on_clear_rows'] is True
+        assert abs(sm[k][0] * 1e6 - v['value']) <= 2e-3 * v['value']
+    c4 = sh['c4_shard']
+    assert 'error' not in c4, c4
+    assert c4['batch'] == 64 and c4['agents'] == 10
+    assert abs(c4['value'] - 640 / (c4['ms_per_step'] * 1e-3)) <= 1e-3 * c4['value']
+    assert c4['parity_train_mode_max_abs_dlogit'] <= 1e-4
+    assert abs(c4['parity_loss_gpu'] - c4['parity_loss_oracle']) <= 1e-5
+    assert c4['cpu_baseline']['value'] > 0 and c4['cpu_baseline']['kind'] == 'port'
+    for k in ('c3_K3', 'c5_K2', 'c5_K3', 'c5_K4', 'c2_rotating_M_per_s', 'filter_hbm_frac', 'c4_shard_train'):
+        assert k in sm, k
+
+
 def test_committed_bench_lines_follow_the_contract():
     """The bench lines committed under profiles/ (copied from GPU sessions) carry every field of the driver's
     contract, with consistent arithmetic: value = batch x agents / ms_per_step, roofline.frac = achieved / peak with
@@ -165,14 +202,17 @@ def test_committed_bench_lines_follow_the_contract():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench_c*.json')))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench_c*.json')) +
+                   glob.glob(os.path.join(root, 'profiles', 'r04_bench_c*.json')))
     assert len(files) >= 3
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
+        if os.path.basename(f).startswith('r04'):
+            _check_r04_extras(f, d)
         for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
                     'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
             assert key in d, (f, key)
-        assert d['unit'] == 'agent-steps/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
+        assert d['unit'] == 'agent-steps/s' and d['higher_is_better'] is True and d['scaling'] in ('weak', 'strong')
         assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config']
         assert d['dtype'].startswith('f32') and d['precision'] == 'fp32'      # the headline: fp32-equivalent arithmetic
         cfg = d['config']
