@@ -175,7 +175,7 @@ __device__ __forceinline__ void b3_split2_clamped(float x0, float x1, unsigned& 
 // max(x, 0) and the split's upper clamp in ONE v_med3_f32.  NON-FINITE activations are flushed here, unlike
 // torch.relu: +inf becomes 3.39e38 (the largest bf16) and NaN becomes 0 (med3 with a NaN operand returns min3, and
 // min ignores the NaN: min3(NaN, 0, big) = 0).  A network whose L0 activations overflow fp32 is outside what the
-// parity tests pin (the reference produces inf / NaN logits there); the host emulation mirrors the device.
+// parity tests pin (the reference produces inf / NaN logits there); the host build of this header (tests) mirrors the device.
 __device__ __forceinline__ float b3_relu_clamp(float x) {
     const float big = b3_bits(0x7f7f0000u);
 #if defined(__HIP_DEVICE_COMPILE__)

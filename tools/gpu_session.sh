@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: test smoke bench benchdrv bench35 train distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc filterpmc
+# steps: test smoke bench benchdrv bench35 train traincpu trainprof distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc filterpmc
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -24,6 +24,10 @@ if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 --graph 2>&1 | tail -3 | tee $OUT/train_bench_graph.json
   timeout 300 python tools/train_bench.py --steps 50 --graph --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench_graph.json
   timeout 300 python tools/train_bench.py --steps 50 --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench.json; fi
+if has traincpu; then stamp "train bench with the CPU oracle's training step beside it"
+  timeout 300 python tools/train_bench.py --steps 50 --graph --cpu-seconds 8 2>&1 | tail -1 | tee $OUT/train_bench_cpu.json; fi
+if has trainprof; then stamp "host profile of the eager training step"
+  timeout 300 python tools/train_host_profile.py 2>&1 | grep -v amdgpu.ids | head -60 | tee $OUT/train_host_profile.txt; fi
 if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path check only)"
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
   stamp "2 ranks over RCCL on ONE GPU: GraphedTrainStep(dp=FlatBucketDP) -- the captured all-reduce must execute"
