@@ -99,6 +99,24 @@ def roofline_block(kernel, info, flops, t_launch, exe_flops, lanes='', column_fi
             'pipe_busy_frac': exe_flops / t_launch / 1e12 / info['peak']}
 
 
+CP_MAX_AGENTS = 12                      # csrc/encoder_kernel_b3.hip kCpMaxAgents
+
+
+def fused_mfma_per_graph(N, K, cp):
+    """bf16 MFMAs the one-launch policy kernel issues per graph ({0, 1} observations: L0 issues 3 of its 6 plane
+    products) and the share of those MFMAs' columns that carry an agent / an (agent, position) pair.  Agents on the
+    columns: 8028 + 192 K whatever N.  Column-packed (N <= 12, GNNPP_TUNE_POLICY_CP): L1 = ceil(25 N / 16) tiles x 9
+    taps x 12, L2 = N tiles x 9 taps x 24 (no tap can be skipped at compile time any more)."""
+    l0, late = 600, 768 + 1536 + 192 + 192 * K
+    if cp and N <= CP_MAX_AGENTS:
+        t1 = (25 * N + 15) // 16
+        l1, l2 = t1 * 9 * 12, N * 9 * 24
+        fill = (l0 * N / 16.0 + l1 * (25.0 * N) / (16 * t1) + l2 + late * N / 16.0) / (l0 + l1 + l2 + late)
+    else:
+        l1, l2, fill = 2028, 2904, N / 16.0
+    return l0 + l1 + l2 + late, fill
+
+
 def fused_rule(L, B, N, K, prec):
     """gnnpp_policy_fwd's rule for the one-launch policy kernel (csrc/gnnpp_api.hip fused_policy_applies)."""
     return bool(L.gnnpp_get_tuning(6) == 1 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13))
@@ -206,6 +224,11 @@ def c4_shard_record(orc, dev, cpu_seconds):
     from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
     from gnn_pathplanning_amd.training import policy_loss
     B, N, K = 64, 10, 3
+    with torch.enable_grad():                                # (bench.py's secondary block runs under no_grad)
+        return _c4_shard_record(orc, dev, cpu_seconds, train_bench, DecentralPlannerNet, policy_loss, B, N, K)
+
+
+def _c4_shard_record(orc, dev, cpu_seconds, train_bench, DecentralPlannerNet, policy_loss, B, N, K):
     t_eager, _ = train_bench.measure(dev, B, steps=40, warmup=5, graph=False)
     t_graph, _ = train_bench.measure(dev, B, steps=40, warmup=5, graph=True)
 
@@ -234,7 +257,7 @@ def c4_shard_record(orc, dev, cpu_seconds):
            'predicted_8gpu_value_without_allreduce': 8 * B * N / t_graph,
            'parity_train_mode_max_abs_dlogit': err, 'parity_loss_gpu': loss_g, 'parity_loss_oracle': loss_w}
     if cpu_seconds > 0:
-        cb = train_bench.cpu_baseline(B, cpu_seconds, threads=torch.get_num_threads())
+        cb = train_bench.cpu_baseline(B, cpu_seconds)
         cb['speedup_gpu_over_cpu'] = rec['value'] / cb['value']
         rec['cpu_baseline'] = cb
     return rec
@@ -658,10 +681,16 @@ def main():
             # L0: 600 -- the bench's {0, 1} observations are ONE bf16 plane, so L0 issues three of its six products:
             # PLANE SKIPPING, csrc/encoder_kernel_b3.hip) + filter contraction 192 K.  PMC agrees:
             # SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 / 16384 = 8606 per workgroup at K = 3 (profiles/r03_c2_pmc_summary.txt)
-            exe = (8028 + 192 * K) * 16384.0 * B
-            lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
-                    'algorithmic work' % (N, N)
-            col_fill = N / 16.0
+            cp_on = L.gnnpp_get_tuning(13) == 1
+            mf, col_fill = fused_mfma_per_graph(N, K, cp_on)
+            exe = mf * 16384.0 * B
+            if cp_on and N <= CP_MAX_AGENTS:
+                kernel = kernel.replace('<true, K=%d>' % K, '<true, K=%d, CP>' % K)
+                lanes = ('; teams of <= 12 agents: (agent, position) pairs on the MFMA columns of the two 5x5 layers '
+                         '(%d instead of %d MFMAs per graph), agents on the columns elsewhere' % (mf, 8028 + 192 * K))
+            else:
+                lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
+                        'algorithmic work' % (N, N)
         else:
             kernel, kname = 'gnnpp::encoder_kernel_b3<false, 3>', 'encoder_kernel_b3<false'
             t_dom = t_enc

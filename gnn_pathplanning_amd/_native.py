@@ -92,8 +92,11 @@ def build(force=False, verbose=False, measure=False):
 RING_KERNELS = (('encoder_kernel_h2ILb0ELi3E', 196, 0), ('encoder_kernel_h2ILb1ELi2E', 228, 32),
                 ('encoder_kernel_h2ILb1ELi3E', 244, 32), ('encoder_kernel_h2ILb1ELi4E', 260, 32),
                 # the bf16x3 (fp32-equivalent, default) schedule: three planes per fragment, 24 filter items per tap
-                ('encoder_kernel_b3ILb0ELi3E', 294, 0), ('encoder_kernel_b3ILb1ELi2E', 342, 32),
-                ('encoder_kernel_b3ILb1ELi3E', 366, 32), ('encoder_kernel_b3ILb1ELi4E', 390, 32))
+                ('encoder_kernel_b3ILb0ELi3ELb0E', 294, 0), ('encoder_kernel_b3ILb1ELi2ELb0E', 342, 32),
+                ('encoder_kernel_b3ILb1ELi3ELb0E', 366, 32), ('encoder_kernel_b3ILb1ELi4ELb0E', 390, 32),
+                # ... and its column-packed form for teams of <= 12 agents (third template argument)
+                ('encoder_kernel_b3ILb1ELi2ELb1E', 342, 32), ('encoder_kernel_b3ILb1ELi3ELb1E', 366, 32),
+                ('encoder_kernel_b3ILb1ELi4ELb1E', 390, 32), ('encoder_kernel_b3ILb0ELi3ELb1E', 294, 0))
 
 
 def check_ring_isa(isa_path, verbose=False):

@@ -231,13 +231,95 @@ __device__ __forceinline__ void b3_conv_preload(const WStreamB& ws, v4f (&ring)[
     }, std::make_integer_sequence<int, 9 * NKB>{});
 }
 
+// ==== COLUMN PACKING for teams of N <= kCpMaxAgents agents (fused policy kernel, <true, K, CP = true>) ==================
+// With agents on the MFMA's 16 columns a 10-agent graph uses 10 / 16 of every MFMA.  For the two layers that hold 57 %
+// of the kernel's matrix work the columns are (agent, position) PAIRS instead:
+//   L1 (32 -> 32 @ 5x5)  column c = pos * N + n, c < 25 N: ceil(25 N / 16) tiles of 16 consecutive columns (N = 10: 16
+//        tiles x 9 taps instead of 25 position tiles x 6.76 reachable taps = 144 instead of 169 tile-taps), a wave takes
+//        tiles wave, wave + 4, ..: 4 / 4 / 4 / 4 instead of 7 / 6 / 6 / 6 positions;
+//   L2 (32 -> 64 @ 5x5, the 4x4 the pool reads)  one tile PER AGENT whose 16 columns are the 16 output positions, the four
+//        positions of a pool window in four adjacent lanes (the 2x2 max is two quad_perm DPP steps): N tiles x 9 taps
+//        instead of 16 position tiles x 7.56 (N = 10: 90 instead of 121 tile-taps).
+// A tap is then a per-lane LDS address, not a compile-time fragment: a column whose tap leaves the image reads a cell
+// of zeros (its products are exact zeros: acc + 0 == acc, so every output keeps the value -- and the bits -- of the
+// agents-on-columns schedule, whose first reachable tap starts from a zero accumulator too).  L0 keeps agents on its
+// columns (it is VALU- / latency-bound, not pipe-bound) and only writes its pooled windows in L1's input layout;
+// L3 / L4 / FC / the filter tail are unchanged (2x2 images: tap skipping beats packing there).
+//
+// LDS layouts (both inside region R; a "row" = 16 cells x [plane 3][q 4] x 16 bytes = 3 KiB, cell slot s at
+// row + plane * 1024 + q * 256 + s * 16, so the 16 lanes (q, q + 1 halves) of a ds_read_b128 group hit 16 distinct slots):
+//   L1 input (L0's output)  cell u = pos * N + n at row u >> 4, slot u & 15; the rows END at the end of R (L0 writes
+//        them while the pixel words at the front of R are still being read); the zero cell is slot 15 of the last row
+//        (25 N is not a multiple of 16 for N < 16);
+//   L2 input (L1's output)  agent n's 25 cells: slot (4 (y & 3) + (x & 3) + o(n)) & 15, o(n) = 4 (n & 3) + (n >> 2), in row
+//        n (y, x < 4) | 12 + (n >> 2) (y = 4) | 15 + (n & 3) (x = 4) | 19 (y = x = 4); row 20 = zeros.  Any 4x4 window of
+//        one agent's 5x5 image lies in 16 distinct slots (conflict-free tap reads), and the rows are shared between
+//        agents without collisions (the rotation o(n) interleaves them): 20 rows hold 12 x 25 cells.
+constexpr int kCpMaxAgents = 12;
+constexpr int kCpRow = 3 * kB3Frag;                        // 3 072
+constexpr int kCpL1Tiles = 5;                              // column tiles of L1 per wave: ceil(ceil(25 * 12 / 16) / 4)
+constexpr int kCpL2Tiles = 6;                              // agent tiles of L2 per wave: ceil(12 / 2)
+constexpr int kCpL2Rows = 21;
+static_assert(kCpL2Rows * kCpRow <= kB3Region && ((25 * kCpMaxAgents + 15) / 16 + 3) / 4 <= kCpL1Tiles, "column-packed layouts fit R");
+
+// A wave-uniform value the optimiser must not correlate with its other uses.  The tile loops below test `i < na` with
+// the SAME run-time count in every tap; left visible, jump threading specialises the whole rest of the kernel for each
+// value of the count (measured: 348 000 instead of 30 000 lines of ISA, 816 bytes of scratch).
+__device__ __forceinline__ int cp_opaque(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = __builtin_amdgcn_readfirstlane(v);               // (uniform by construction; this puts it in an SGPR for the asm)
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
+struct CpGeom {                   // wave-uniform (SGPRs)
+    int N, ncol, T1, l1in;
+    unsigned rcpN;                // (c * rcpN) >> 16 == c / N for c < 5 000
+};
+__device__ __forceinline__ CpGeom cp_geom(int N) {
+    CpGeom g;
+    g.N = N;
+    g.ncol = 25 * N;
+    g.T1 = (25 * N + 15) >> 4;
+    g.l1in = kB3Region - g.T1 * kCpRow;
+    g.rcpN = (unsigned)(65536.f / (float)N) + 1u;
+    return g;
+}
+// byte offset of cell (y, x) of agent n inside a (plane, q) block of the L2-input layout
+__device__ __forceinline__ int cp_l2in_cell(int y, int x, int n) {
+    const int o = 4 * (n & 3) + (n >> 2);
+    const int slot = (4 * (y & 3) + (x & 3) + o) & 15;
+    const int row = y == 4 ? (x == 4 ? 19 : 12 + (n >> 2)) : (x == 4 ? 15 + (n & 3) : n);
+    return row * kCpRow + slot * 16;
+}
+// L0's pooled window `win` (three plane fragments of lane (q, agent a)): fragment win of R, or -- CP -- cell win * N + a of
+// the L1-input layout (lanes beyond the graph's agents hold nothing)
+template <bool CP>
+__device__ __forceinline__ void b3_store_window(char* smem, const CpGeom& g, int win, int lane, const v4f (&pl)[3]) {
+    if (!CP) {
+        v4f* const R4 = reinterpret_cast<v4f*>(smem);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+    } else {
+        const int a = lane & 15, q = lane >> 4;
+        if (a < g.N) {
+            const int u = win * g.N + a;
+            char* const dst = smem + g.l1in + (u >> 4) * kCpRow + q * 256 + (u & 15) * 16;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<v4f*>(dst + p * kB3Frag) = pl[p];
+        }
+    }
+}
+
 // L0 for observations that need all three planes (anything but exact bf16 values): window by window, sixteen word
 // reads per position (eight h | m words, eight l words, position offset = instruction immediate), three v_perm per
 // register pair, 6 MFMAs per channel tile; the pooled outputs of all of a wave's windows stay in registers until
 // every wave is done with the pixels.  (Scheduling left to the compiler: this is the rare path -- the simulator's
 // observations take b3_l0_stream<true> -- and the explicit stream's two word sets do not fit beside 56 held outputs.)
+template <bool CP>
 __device__ __forceinline__ void b3_l0_generic(const float* __restrict__ pk, const unsigned* obsw, const float* sstab,
-                                              v4f* R4, int wave, int lane) {
+                                              char* smem, const CpGeom& g, int wave, int lane) {
     const int a = lane & 15, q = lane >> 4;
     v8b A0[2][3];
 #pragma unroll
@@ -305,8 +387,7 @@ __device__ __forceinline__ void b3_l0_generic(const float* __restrict__ pk, cons
         if (win < 25) {
             v4f pl[3];
             b3_split8_clamped(res[wi][0], res[wi][1], pl);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+            b3_store_window<CP>(smem, g, win, lane, pl);
         }
     }
 }
@@ -316,13 +397,15 @@ __device__ __forceinline__ void b3_l0_generic(const float* __restrict__ pk, cons
 //   BatchNorm + ReLU / running max of P - 1]   -- the second group is one scheduling region: the VALU work slots in
 //   between the MFMAs.  ONE_PLANE (plane skipping, see the staging code): only the h | m word array is read, only the
 //   h plane is built, three MFMAs (wh, wm, wl against xh) per channel tile instead of six.
-template <bool ONE_PLANE>
+template <bool ONE_PLANE, bool CP>
 __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const unsigned* obsw,
-                                             const float* sstab, v4f* R4, v4f (&res)[ONE_PLANE ? 3 : 5][2],
-                                             int wave, int lane) {
+                                             const float* sstab, char* smem, const CpGeom& g,
+                                             v4f (&res)[ONE_PLANE ? 3 : 5][2], int wave, int lane) {
     constexpr int DEPTH = ONE_PLANE ? 3 : 1;              // positions the word requests run ahead
     constexpr int NHELD = ONE_PLANE ? 3 : 5;              // windows (per wave) whose output must wait for the barrier
     static_assert((4 * NHELD) * 3 * kB3Frag >= (ONE_PLANE ? 1 : 2) * kObsFloatsLds * 4, "held windows cover the pixels");
+    // (CP: window win >= 4 NHELD is written at l1in + ((win N) >> 4) rows >= 40 KB for every N <= kCpMaxAgents, behind
+    // the 27 KB of h | m pixel words the ONE_PLANE stream reads: cp_direct_windows_clear_pixels below)
     constexpr int NW = ONE_PLANE ? 8 : 16;                // words per position
     const int a = lane & 15, q = lane >> 4;
     v8b A0[2][3];
@@ -407,8 +490,7 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
             const int win = wave + 4 * wi;
             v4f pl[3];
             b3_split8_clamped(run[0], run[1], pl);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+            b3_store_window<CP>(smem, g, win, lane, pl);
         }
     };
     // positions [P0, P1): every index below is a compile-time constant (explicit unrolling: the register arrays must
@@ -445,7 +527,187 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
     if (wave == 0) stream(std::integral_constant<int, 24>{}, std::integral_constant<int, 28>{});   // window 24
 }
 
-template <bool FUSED, int KT>
+// ---- L1, column-packed: 32 -> 32 @ 5x5, columns c = pos * N + n; this wave's tiles are wave, wave + 4, .. ---------------
+// Per tap the source column of lane j is c + (dy 5 + dx) N: tile-independent slot (j + shift) & 15 and a tile-independent
+// row offset, so a tile's three plane reads are `base + immediate`; a lane whose tap leaves the 5x5 image (four flag
+// bits per tile, computed once) reads the zero cell instead.  The plane fragments of tile i + 1 are requested before
+// the MFMAs of tile i are issued.
+template <int END>
+__device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH], char* smem, const float* sstab,
+                                          const CpGeom& g, int wave, int lane, int tid) {
+    constexpr int NT = kCpL1Tiles;
+    const int j = lane & 15, q = lane >> 4;
+    const int na = min(max((g.T1 - wave + 3) >> 2, 0), NT);        // tiles of this wave (wave-uniform)
+    unsigned fl = 0;                                                // per tile: y == 0 | y == 4 | x == 0 | x == 4
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int c = 16 * (wave + 4 * i) + j;
+        const int pos = (int)(((unsigned)c * g.rcpN) >> 16);
+        const int y = (pos * 13) >> 6, x = pos - 5 * y;            // pos / 5, pos % 5   (pos < 25 where it matters)
+        unsigned f = (y == 0 ? 1u : 0u) | (y == 4 ? 2u : 0u) | (x == 0 ? 4u : 0u) | (x == 4 ? 8u : 0u);
+        if (c >= g.ncol) f = 15u;                                   // no such column: every shifted tap reads zeros
+        fl |= f << (4 * i);
+    }
+    const int zaddr = g.l1in + (g.T1 - 1) * kCpRow + q * 256 + 15 * 16;
+    v4f acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
+    b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+        constexpr int tap = decltype(itc)::value;
+        constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        constexpr unsigned tmask = (dy < 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dx < 0 ? 4u : 0u) | (dx > 0 ? 8u : 0u);
+        const int sh = j + (dy * 5 + dx) * g.N;                    // (arithmetic shift / mask below: floor semantics)
+        const int base = g.l1in + (wave + (sh >> 4)) * kCpRow + q * 256 + (sh & 15) * 16;
+        v4f Bb[2][3];
+        auto load_tile = [&](int i, v4f (&B)[3]) {                  // (i is a constant after unrolling)
+            int addr = base;
+            if (tmask != 0u) addr = ((fl >> (4 * i)) & tmask) != 0u ? zaddr - i * 4 * kCpRow : base;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                B[p] = *reinterpret_cast<const v4f*>(smem + addr + i * 4 * kCpRow + p * kB3Frag);
+        };
+        const int nat = cp_opaque(na);
+        if (nat > 0) load_tile(0, Bb[0]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (i + 1 < NT && i + 1 < nat) load_tile(i + 1, Bb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nat) {
+#pragma unroll
+                for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[i & 1][b3_term_b(term)]), acc[i][m]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }, std::make_integer_sequence<int, 9>{});
+    __syncthreads();                                               // everyone is done reading L0's output
+    if (tid < kCpRow / 16) *reinterpret_cast<v4f*>(smem + 20 * kCpRow + tid * 16) = vzero();   // L2 input's zero row
+    v4f sc[2], shf[2];
+    load_ss(sstab + EncLayout::kBssL1, 32, 0, q, sc[0], shf[0]);
+    load_ss(sstab + EncLayout::kBssL1, 32, 1, q, sc[1], shf[1]);
+    const int nae = cp_opaque(na);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if (i < nae) {
+            const int c = 16 * (wave + 4 * i) + j;
+            const int pos = (int)(((unsigned)c * g.rcpN) >> 16), n = c - pos * g.N;
+            const int y = (pos * 13) >> 6, x = pos - 5 * y;
+            v4f pl[3];
+            b3_split8(vrelu(vfma(acc[i][0], sc[0], shf[0])), vrelu(vfma(acc[i][1], sc[1], shf[1])), pl);
+            if (c < g.ncol) {
+                char* const dst = smem + cp_l2in_cell(y, x, n) + q * 256;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4f*>(dst + p * kB3Frag) = pl[p];
+            }
+        }
+    }
+}
+
+// ---- L2, column-packed: 32 -> 64 @ 5x5 (the 4x4 the pool reads) -> 2x2 max -> L3's input fragments ---------------------
+// Wave (mp, pair): channel tiles 2 mp, 2 mp + 1 of the agents pair, pair + 2, ..; one MFMA tile = one agent, column
+// j = its output position (window w = j >> 2, position p = j & 3 inside the window).  After BatchNorm the 2x2 max runs
+// over the four lanes of a quad as a reduce-scatter (two quad_perm steps): lane p ends with the pooled channel pair p
+// of its fragment, splits THAT pair and stores its three dwords -- no lane repeats another lane's conversion.
+template <int END>
+__device__ __forceinline__ void cp_layer2(const WStreamB& ws, v4f (&ring)[kRingH], char* smem, const float* sstab,
+                                          const CpGeom& g, int wave, int lane) {
+    constexpr int NT = kCpL2Tiles;
+    const int mp = wave & 1, pair = wave >> 1;
+    const int na = min(max((g.N - pair + 1) >> 1, 0), NT);         // agents of this wave (wave-uniform)
+    const int j = lane & 15, q = lane >> 4, w = j >> 2, p = j & 3;
+    const int y = 2 * (w >> 1) + (p >> 1), x = 2 * (w & 1) + (p & 1);
+    v4f acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
+    b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+        constexpr int tap = decltype(itc)::value;
+        constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int yy = y + dy, xx = x + dx;                        // source cell of this lane: in -1 .. 4
+        const bool outside = (dy < 0 && yy < 0) || (dx < 0 && xx < 0);
+        const bool ey = dy > 0 && yy == 4, ex = dx > 0 && xx == 4;
+        const int slot0 = 4 * (yy & 3) + (xx & 3);
+        v4f Bb[2][3];
+        auto load_tile = [&](int i, v4f (&B)[3]) {
+            const int n = pair + 2 * i;                             // (wave-uniform)
+            const int o = 4 * (n & 3) + (n >> 2);
+            int row = n;
+            if (dy > 0) row = ey ? 12 + (n >> 2) : row;
+            if (dx > 0) row = ex ? (ey ? 19 : 15 + (n & 3)) : row;
+            if (dy < 0 || dx < 0) row = outside ? 20 : row;
+            const int addr = row * kCpRow + q * 256 + ((slot0 + o) & 15) * 16;
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) B[pp] = *reinterpret_cast<const v4f*>(smem + addr + pp * kB3Frag);
+        };
+        const int nat = cp_opaque(na);
+        if (nat > 0) load_tile(0, Bb[0]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (i + 1 < NT && i + 1 < nat) load_tile(i + 1, Bb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nat) {
+#pragma unroll
+                for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[i & 1][b3_term_b(term)]), acc[i][m]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }, std::make_integer_sequence<int, 9>{});
+    v4f sc[2], shf[2];
+    load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp, q, sc[0], shf[0]);
+    load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp + 1, q, sc[1], shf[1]);
+    const bool hi2 = (p & 2) != 0, hi1 = (p & 1) != 0;
+    float pooled[NT][2];
+    const int nap = cp_opaque(na);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        pooled[i][0] = pooled[i][1] = 0.f;
+        if (i < nap) {
+            const v4f v0 = vfma(acc[i][0], sc[0], shf[0]), v1 = vfma(acc[i][1], sc[1], shf[1]);
+            // step 1, partner lane ^ 2: lanes with bit 1 clear keep channel tile 0 (pairs 0, 1), the others tile 1
+            v4f keep, send;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                keep[c] = hi2 ? v1[c] : v0[c];
+                send[c] = hi2 ? v0[c] : v1[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) keep[c] = fmaxf(keep[c], quad_xor2(send[c]));
+            // step 2, partner lane ^ 1: bit 0 clear keeps registers 0, 1 (the even pair), set keeps 2, 3
+            const float k0 = hi1 ? keep[2] : keep[0], k1 = hi1 ? keep[3] : keep[1];
+            const float s0 = hi1 ? keep[0] : keep[2], s1 = hi1 ? keep[1] : keep[3];
+            pooled[i][0] = fmaxf(fmaxf(k0, quad_xor1(s0)), 0.f);    // + ReLU (commutes with the max)
+            pooled[i][1] = fmaxf(fmaxf(k1, quad_xor1(s1)), 0.f);
+        }
+    }
+    __syncthreads();                                               // everyone is done reading L1's output
+    // fragment (window w, block mp, plane) of L3's input, lane slot (q, agent n), dword p = channel pair p
+    const int naw = cp_opaque(na);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if (i < naw) {
+            const int n = pair + 2 * i;
+            unsigned h, m, l;
+            b3_split2(pooled[i][0], pooled[i][1], h, m, l);
+            char* const dst = smem + kB3L2out + ((w * 2 + mp) * 3) * kB3Frag + (q * 16 + n) * 16 + p * 4;
+            *reinterpret_cast<unsigned*>(dst) = h;
+            *reinterpret_cast<unsigned*>(dst + kB3Frag) = m;
+            *reinterpret_cast<unsigned*>(dst + 2 * kB3Frag) = l;
+        }
+    }
+    // the lane slots of agents the graph does not have: zeros (finite values down to the filter tail, whose dense shift
+    // multiplies their rows by zero GSO weights)
+    if (j >= g.N) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            *reinterpret_cast<v4f*>(smem + kB3L2out + (wave + 4 * k) * kB3Frag + lane * 16) = vzero();
+    }
+}
+
+template <bool FUSED, int KT, bool CP = false>
 __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kernel_b3(const float* __restrict__ obs,
                                                                  const float* __restrict__ pk,
                                                                  float* __restrict__ feat, int M, int stop,
@@ -461,7 +723,14 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: real branches per wave
     const int a = lane & 15;
     const int q = lane >> 4;
-    const int agent0 = blockIdx.x * (FUSED ? pt.N : kTileAgents);   // FUSED: the tile is graph blockIdx.x
+    // FUSED: the tile is graph blockIdx.x (pt.N agents).  <false, K, CP>: the encoder in the LATENCY regime -- tiles of
+    // pt.N <= kCpMaxAgents agents, chosen by encoder_launch_b3 so that every tile has a CU to itself (a 16-agent tile
+    // alone on a CU takes 31 us however few tiles the launch has; with (agent, position) pairs on the columns of L1 /
+    // L2 a tile's work shrinks with its agents).
+    const int tile_agents = (FUSED || CP) ? pt.N : kTileAgents;
+    const int agent0 = blockIdx.x * tile_agents;
+    const int n_agents = FUSED ? pt.N : min(tile_agents, M - agent0);   // (>= 1: the grid is ceil(M / tile))
+    const CpGeom geom = cp_geom(CP ? n_agents : kTileAgents);        // (CP only; folded away otherwise)
     GNNPP_STAMP(blockIdx.x, 11, tid == 0);
 
     WStreamB ws;
@@ -508,7 +777,6 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     {
         constexpr int NV4 = (kTileAgents * kObsFloats + 3) / 4 + 1;
         constexpr int PER = (NV4 + kThreads - 1) / kThreads;
-        const int n_agents = FUSED ? pt.N : min(kTileAgents, M - agent0);
         const int valid = n_agents * kObsFloats;
         const float* src = obs + (size_t)agent0 * kObsFloats;
         const int shift = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3);
@@ -528,6 +796,8 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
         for (int i = tid; i < 2 * kObsFloatsLds / 4; i += kThreads) R4[i] = vzero();
+        if (CP && tid < kCpRow / 16)                       // the last row of L1's input holds its zero cell
+            *reinterpret_cast<v4f*>(gnnpp_smem + geom.l1in + (geom.T1 - 1) * kCpRow + tid * 16) = vzero();
         unsigned residual = 0;                             // any non-zero m / l plane among this thread's pixels
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -607,18 +877,17 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             // of R (the l words behind them are not read on this path): a window beyond them is written as soon as
             // it is pooled, only a wave's first three windows wait in registers for the barrier.
             v4f res[3][2];
-            b3_l0_stream<true>(pk, obsw, sstab, R4, res, wave, lane);
+            b3_l0_stream<true, CP>(pk, obsw, sstab, gnnpp_smem, geom, res, wave, lane);
             __syncthreads();                                 // every wave has read its last pixel
 #pragma unroll
             for (int wi = 0; wi < 3; ++wi) {
                 const int win = wave + 4 * wi;
                 v4f pl[3];
                 b3_split8_clamped(res[wi][0], res[wi][1], pl);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) R4[(win * 3 + p) * 64 + lane] = pl[p];
+                b3_store_window<CP>(gnnpp_smem, geom, win, lane, pl);
             }
         } else {
-            b3_l0_generic(pk, obsw, sstab, R4, wave, lane);
+            b3_l0_generic<CP>(pk, obsw, sstab, gnnpp_smem, geom, wave, lane);
         }
     }
     __syncthreads();
@@ -626,7 +895,9 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 1, tid == 0);
 
     // ---- L1: 32 -> 32 @ 5x5, in place; wave = its positions x both channel tiles ---------------------
-    {
+    if constexpr (CP) {
+        cp_layer1<END>(ws, ring, gnnpp_smem, sstab, geom, wave, lane, tid);
+    } else {
         v4f acc[7][2];                                    // first touched by a zero-source MFMA (b3_mfma_chunk)
         constexpr int CH1 = 2;                            // slots per chunk: 6 LDS reads in flight beside <= 24 MFMAs
         v4f Bb[2][CH1][3];
@@ -668,7 +939,9 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     if (!pt.with_sim) GNNPP_STAMP(blockIdx.x, 2, tid == 0);
 
     // ---- L2: 32 -> 64 @ 5x5 (the 4x4 the pool reads), pool -> [4][kb 2], in place (front of R) --------
-    {
+    if constexpr (CP) {
+        cp_layer2<END>(ws, ring, gnnpp_smem, sstab, geom, wave, lane);
+    } else {
         const int mp = wave & 1, pair = wave >> 1;         // channel tiles 2 mp, 2 mp + 1 = block mp
         v4f acc[8][2];                                    // first touched by a zero-source MFMA (b3_mfma_chunk)
         constexpr int CH2 = 2;
@@ -813,7 +1086,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
                 for (int p = 0; p < 3; ++p)
                     *reinterpret_cast<v2f*>(P0 + a * kB3PRow + p * 256 + (mt * 16 + q * 4) * 2) = pl[p];
             }
-        } else if (agent0 + a < M) {
+        } else if (a < n_agents) {                                  // (agent0 + a < M; lanes beyond a CP tile: other tiles' agents)
             float* dst = feat + (size_t)(agent0 + a) * 128 + q * 4;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -946,7 +1219,29 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
     }
 }
 
+std::atomic<int> g_policy_column_packing{1};   // GNNPP_TUNE_POLICY_CP: 0 = agents on the MFMA columns for every team size
+std::atomic<int> g_encoder_cp_tile{0};   // GNNPP_TUNE_ENCODER_CP_TILE: 0 = heuristic, 1 .. 12 = agents per tile, 16 = never
+
+// Few agents (M <= 256 x 12): column-packed tiles of ceil(M / 256) agents, one per CU (latency regime: the per-GPU shards
+// of the 8-GPU configs, 1 600 agents); otherwise 16-agent tiles, two per CU (throughput regime).
+static int encoder_cp_tile(int M) {
+    const int knob = g_encoder_cp_tile.load(std::memory_order_relaxed);
+    if (knob >= 1 && knob <= kCpMaxAgents) return knob;
+    if (knob != 0 || g_policy_column_packing.load(std::memory_order_relaxed) == 0) return 0;
+    const int t = (M + 255) / 256;
+    return t <= kCpMaxAgents ? t : 0;
+}
+
 int encoder_launch_b3(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {
+    if (const int tile = encoder_cp_tile(M)) {
+        static LdsAttrOnce once_cp;
+        set_lds_attr_once(once_cp, reinterpret_cast<const void*>(&encoder_kernel_b3<false, 3, true>), (int)kB3Smem);
+        PolicyTail pt{};
+        pt.N = tile;
+        hipLaunchKernelGGL((encoder_kernel_b3<false, 3, true>), dim3((M + tile - 1) / tile), dim3(kThreads), kB3Smem, st,
+                           obs, packed, feat, M, GNNPP_ENCODER_STOP_VALUE, pt);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     static LdsAttrOnce once;
     set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_b3<false, 3>), (int)kB3Smem);
     const int grid = (M + kTileAgents - 1) / kTileAgents;
@@ -956,21 +1251,26 @@ int encoder_launch_b3(const float* obs, const float* packed, float* feat, int M,
 }
 
 // whole policy step of B graphs with N <= 16 agents and K = 2, 3 or 4 taps: one workgroup per graph
-template <int KT>
+template <int KT, bool CP>
 static int policy_launch_fused_b3_k(const float* obs, const float* packed, const PolicyTail& pt, hipStream_t st) {
     static LdsAttrOnce once;
-    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_b3<true, KT>), (int)kB3SmemFused);
-    hipLaunchKernelGGL((encoder_kernel_b3<true, KT>), dim3(pt.B), dim3(kThreads), kB3SmemFused, st, obs, packed,
+    set_lds_attr_once(once, reinterpret_cast<const void*>(&encoder_kernel_b3<true, KT, CP>), (int)kB3SmemFused);
+    hipLaunchKernelGGL((encoder_kernel_b3<true, KT, CP>), dim3(pt.B), dim3(kThreads), kB3SmemFused, st, obs, packed,
                        static_cast<float*>(nullptr), pt.B * pt.N, 0, pt);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// pt.filt_h2 must point at the b3 region of the filter pack
+// pt.filt_h2 must point at the b3 region of the filter pack.  Teams of <= kCpMaxAgents agents take the column-packed
+// front half (same logits to the bit: tests/test_gpu_parity.py::test_column_packed_policy_kernel_is_bit_identical).
 int policy_launch_fused_b3(const float* obs, const float* packed, const PolicyTail& pt, int K, hipStream_t st) {
+    const bool cp = pt.N <= kCpMaxAgents && g_policy_column_packing.load(std::memory_order_relaxed) != 0;
     switch (K) {
-        case 2: return policy_launch_fused_b3_k<2>(obs, packed, pt, st);
-        case 3: return policy_launch_fused_b3_k<3>(obs, packed, pt, st);
-        case 4: return policy_launch_fused_b3_k<4>(obs, packed, pt, st);
+        case 2: return cp ? policy_launch_fused_b3_k<2, true>(obs, packed, pt, st)
+                          : policy_launch_fused_b3_k<2, false>(obs, packed, pt, st);
+        case 3: return cp ? policy_launch_fused_b3_k<3, true>(obs, packed, pt, st)
+                          : policy_launch_fused_b3_k<3, false>(obs, packed, pt, st);
+        case 4: return cp ? policy_launch_fused_b3_k<4, true>(obs, packed, pt, st)
+                          : policy_launch_fused_b3_k<4, false>(obs, packed, pt, st);
         default: return -2;
     }
 }

@@ -133,8 +133,9 @@ static bool fused_policy_applies(int B, int N, int K, int prec) {
     if (g_filter_ablate.load(std::memory_order_relaxed) || g_encoder_stop.load(std::memory_order_relaxed))
         return false;
 #endif
-    const bool fused_pays = B <= 2 * 256 || N >= 13;
-    return g_fused_policy.load(std::memory_order_relaxed) && fused_pays && prec != kPrecFp32Mfma &&
+    const int knob = g_fused_policy.load(std::memory_order_relaxed);            // 2: whatever the batch size
+    const bool fused_pays = B <= 2 * 256 || N >= 13 || knob == 2;
+    return knob && fused_pays && prec != kPrecFp32Mfma &&
            N <= kTileAgents && K >= kPolicyTapsMin && K <= kPolicyTapsMax;
 }
 
@@ -323,6 +324,8 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_SMALL: return g_filter_small_kernel.load();
         case GNNPP_TUNE_FILTER_SMALL_ROWS: return g_filter_small_rows.load();
         case GNNPP_TUNE_FILTER_PIPE_GRID: return g_filter_pipe_grid.load();
+        case GNNPP_TUNE_POLICY_CP: return g_policy_column_packing.load();
+        case GNNPP_TUNE_ENCODER_CP_TILE: return g_encoder_cp_tile.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -338,7 +341,7 @@ int gnnpp_set_tuning(int key, int value) {
             g_filter_gpw.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FUSED_POLICY:
-            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
             g_fused_policy.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_WAVES:
@@ -360,6 +363,14 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_FILTER_PIPE_GRID:
             if (value < 0 || value > 4096) return GNNPP_ERR_ARG;
             g_filter_pipe_grid.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_POLICY_CP:
+            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            g_policy_column_packing.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_ENCODER_CP_TILE:
+            if (value != 0 && value != 16 && (value < 1 || value > 12)) return GNNPP_ERR_ARG;
+            g_encoder_cp_tile.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:
             if (value < 0 || value > 3) return GNNPP_ERR_ARG;

@@ -110,8 +110,10 @@ __device__ __forceinline__ v4f mfma16b(v8b a, v8b b, v4f c) {
 constexpr int kB3Planes = 3;
 constexpr int kB3Terms = 6;
 // (weight plane, activation plane) of term t, small terms first
-__host__ __device__ constexpr int b3_term_a(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0; }
-__host__ __device__ constexpr int b3_term_b(int t) { return t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : t == 4 ? 0 : 0; }
+// (always inlined: left to the inliner's budget, the calls survive in the largest kernels -- the plane index then is a
+// run-time value and every fragment array a dynamically indexed one: 350 000 lines of select chains and spills)
+__host__ __device__ __forceinline__ constexpr int b3_term_a(int t) { return t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0; }
+__host__ __device__ __forceinline__ constexpr int b3_term_b(int t) { return t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : t == 4 ? 0 : 0; }
 
 __device__ __forceinline__ unsigned b3_cvt_pk(float lo, float hi) {      // two fp32 -> two bf16 (RNE), lo in bits 0..15
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -249,6 +251,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
+}
+
+// value of `v` held by the lane whose index differs in bit 0 / bit 1 (the partner inside a quad of four lanes): one
+// v_mov_b32_dpp quad_perm -- no LDS, no SALU.  Every lane of the wave must take part.
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
 }
 
 // value of `v` held by lane `src` (src must be wave-uniform)

@@ -80,7 +80,8 @@ const char* gnnpp_error_string(int code);
                                          or N >= 13, gnnpp_policy_fwd is ONE kernel -- a workgroup
                                          encodes one graph's agents, then runs that graph's filter and
                                          action head on chip (identical logits); 0: always the encoder
-                                         kernel followed by the filter kernel                        */
+                                         kernel followed by the filter kernel; 2: the one kernel for
+                                         every batch size (measurement: tools/cp_ab.py)              */
 #define GNNPP_TUNE_POLICY_FILTER    9  /* 1 (default): the filter + action head of gnnpp_policy_fwd / the rollout step
                                          for teams of 17 .. 100 agents (one graph per workgroup,
                                          FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
@@ -95,6 +96,14 @@ const char* gnnpp_error_string(int code);
                                          (lsigf_pipe_b3_kernel: one persistent 8-wave workgroup per CU -- the heuristic
                                          takes it from 4096 groups of 64 rows on; FILTER_SMALL = 3 forces it too)  */
 #define GNNPP_TUNE_FILTER_PIPE_GRID 12  /* persistent workgroups of the pipeline kernel: 0 (default) = one per CU */
+#define GNNPP_TUNE_POLICY_CP        13  /* 1 (default): the one-launch policy kernel of teams of <= 12 agents puts (agent,
+                                         position) pairs on the MFMA columns in its 5x5 layers (a 10-agent graph then
+                                         fills 15/16 of those tiles instead of 10/16); 0 = agents on the columns for
+                                         every team size.  Same logits to the bit either way (v310)                     */
+#define GNNPP_TUNE_ENCODER_CP_TILE   14  /* agents per tile of the (unfused) encoder kernel's column-packed form: 0 (default)
+                                         = heuristic -- M <= 3072 agents: tiles of ceil(M / 256) agents, one per CU
+                                         (latency regime), else 16-agent tiles --, 1 .. 12 = that tile size for every
+                                         M, 16 = always 16-agent tiles.  Same features to the bit (v310)                */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

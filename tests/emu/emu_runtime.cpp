@@ -128,6 +128,18 @@ float shfl_xor(float v, int mask) {
     return r;
 }
 
+int mov_dpp_quad(int v, int ctrl) {
+    if (ctrl < 0 || ctrl > 0xff) { std::fprintf(stderr, "emu: only quad_perm DPP controls are modelled\n"); std::abort(); }
+    Fiber& f = fibers[cur_idx];
+    Wave& w = waves[f.wave];
+    w.iv[f.lane] = v;
+    wave_barrier();
+    const int src = (f.lane & ~3) | ((ctrl >> (2 * (f.lane & 3))) & 3);
+    const int r = w.iv[src];
+    wave_barrier();
+    return r;
+}
+
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int) {
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];

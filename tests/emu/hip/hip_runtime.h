@@ -72,6 +72,7 @@ void sync_block();
 unsigned long long ballot(int pred);
 int readlane(int v, int src_lane);
 float shfl_xor(float v, int mask);   // value of lane (lane ^ mask); every lane of the wave takes part
+int mov_dpp_quad(int v, int ctrl);   // v_mov_b32_dpp quad_perm:[ctrl & 3, ctrl >> 2 & 3, ctrl >> 4 & 3, ctrl >> 6 & 3]
 void wave_sync();                 // lockstep point: every lane of the wave reaches it before any leaves
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int);
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -97,6 +98,8 @@ f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int);
 #define __umul24(a, b) ((unsigned)(a) * (unsigned)(b))
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __shfl_xor(v, m) gnnpp_emu::shfl_xor((v), (m))
+// (only the quad_perm controls 0x00..0xff with full row / bank masks are used by the kernels)
+#define __builtin_amdgcn_mov_dpp(v, ctrl, row_mask, bank_mask, bound_ctrl) gnnpp_emu::mov_dpp_quad((v), (ctrl))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 gnnpp_emu::mfma16x16x4
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 gnnpp_emu::mfma16x16x32_bf16

@@ -506,3 +506,74 @@ def test_emu_small_graph_throughput_kernel(emu, N, K, B, f64, head):
         assert all(np.array_equal(outs[0], o) for o in outs[3:])   # ... and the pipeline kernel's, however the groups are dealt
     assert np.abs(outs[0] - outs[2]).max() <= 4e-6 * scale
     assert lib.gnnpp_set_tuning(10, 4) == -1 and lib.gnnpp_set_tuning(11, 40) == -1
+
+
+@pytest.mark.parametrize('N,K,B,real_obs', [(10, 3, 2, False), (12, 3, 1, False), (1, 2, 2, False), (5, 4, 1, False),
+                                            (9, 3, 1, True), (11, 2, 1, False), (7, 3, 1, False), (3, 3, 1, True)])
+def test_emu_column_packed_policy_kernel_is_bit_identical(emu, N, K, B, real_obs):
+    """GNNPP_TUNE_POLICY_CP: the one-launch policy kernel of teams of <= 12 agents with (agent, position) pairs on the
+    MFMA columns of its 5x5 layers computes the SAME logits, bit for bit, as the agents-on-columns schedule (every
+    output sums the same products in the same order; a tap outside the image adds exact zeros) -- every team size class
+    (tiles that end inside a row, waves without a tile, a last tile with missing columns), K = 2, 3, 4, binary and
+    real-valued (three-plane) observations -- and matches the oracle."""
+    import torch
+    from oracle import policy_oracle as orc
+    el, lib = emu
+    sd_t = orc.init_state_dict(K, seed=70 + N)
+    sd = {k: v.numpy() for k, v in sd_t.items()}
+    enc = el.pack_encoder(lib, sd)
+    filt = el.pack_filter(lib, sd['GFL.0.weight'])
+    gb = el.f32(sd['GFL.0.bias'].reshape(-1))
+    aw, ab = el.f32(sd['actionsMLP.0.weight']), el.f32(sd['actionsMLP.0.bias'])
+    obs_t = orc.synth_obs(B, N, seed=N + K)
+    if real_obs:
+        obs_t = obs_t * torch.randn(obs_t.shape, generator=torch.Generator().manual_seed(N))
+    S_t = torch.from_numpy(orc.synth_gso_geometric(B, N, 12, seed=K)).float()
+    obs, S = el.f32(obs_t.numpy()), el.f32(S_t.numpy())
+    outs = []
+    try:
+        for cp in (1, 0):
+            assert lib.gnnpp_set_tuning(13, cp) == 0 and lib.gnnpp_get_tuning(13) == cp
+            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+            ws = np.zeros((B * N, 128), dtype=np.float32)
+            assert lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(S), el.ptr(enc), el.ptr(filt), el.ptr(gb), el.ptr(aw),
+                                        el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K, 1, 0, 0, None, None) == 0
+            assert not ws.any()                              # the one-launch kernel ran (both times)
+            outs.append(logits)
+    finally:
+        lib.gnnpp_set_tuning(13, 1)
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd_t, S_t, obs_t), 0).numpy()
+    assert np.abs(outs[0] - want).max() <= TOL
+    assert lib.gnnpp_set_tuning(13, 2) == -1
+
+
+@pytest.mark.parametrize('M,tile', [(23, 7), (16, 12), (5, 1), (30, 4), (37, 0), (25, 10)])
+def test_emu_column_packed_encoder_tiles_are_bit_identical(emu, M, tile):
+    """GNNPP_TUNE_ENCODER_CP_TILE: the unfused encoder in its latency form (column-packed tiles of <= 12 agents; 0 = the
+    heuristic ceil(M / 256) -> one agent per tile here) writes the SAME features, bit for bit, as 16-agent tiles: ragged
+    last tiles, tiles whose first agent is not 16-byte aligned, binary and real-valued observations."""
+    import torch
+    from oracle import policy_oracle as orc
+    el, lib = emu
+    sd_t = orc.init_state_dict(3, seed=90 + M)
+    enc = el.pack_encoder(lib, {k: v.numpy() for k, v in sd_t.items()})
+    obs_t = orc.synth_obs(1, M, seed=M)
+    if M % 2:
+        obs_t = obs_t * torch.randn(obs_t.shape, generator=torch.Generator().manual_seed(M))
+    obs = el.f32(obs_t.numpy().reshape(M, 3, 11, 11))
+    feats = []
+    try:
+        for knob in (tile, 16):
+            assert lib.gnnpp_set_tuning(14, knob) == 0 and lib.gnnpp_get_tuning(14) == knob
+            feat = np.full((M, 128), np.nan, np.float32)
+            assert lib.gnnpp_encoder_fwd(el.ptr(obs), el.ptr(enc), el.ptr(feat), M, 0, None, None) == 0
+            feats.append(feat)
+    finally:
+        lib.gnnpp_set_tuning(14, 0)
+    assert np.isfinite(feats[0]).all() and np.array_equal(feats[0], feats[1]), np.abs(feats[0] - feats[1]).max()
+    want = orc.policy_features(sd_t, obs_t).permute(0, 2, 1).reshape(M, 128).numpy()
+    assert np.abs(feats[0] - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    assert lib.gnnpp_set_tuning(14, 13) == -1

@@ -305,6 +305,71 @@ def test_fused_policy_kernel_equals_two_kernels(dev, B, N, W, K, prec):
     assert (outs[0].cpu() - want).abs().max().item() <= TOL
 
 
+@pytest.mark.parametrize('B,N,K,real_obs', [(512, 10, 3, False), (37, 12, 3, False), (64, 1, 2, False), (9, 5, 4, True),
+                                            (130, 9, 3, True), (33, 11, 2, False), (65, 7, 3, False), (512, 8, 4, False),
+                                            (17, 2, 3, False), (256, 10, 3, True)])
+def test_column_packed_policy_kernel_is_bit_identical(dev, B, N, K, real_obs):
+    """for teams of <= 12 agents the one-launch policy kernel puts (agent, position) pairs on the
+    MFMA columns of its two 5x5 layers (GNNPP_TUNE_POLICY_CP, default on).  Every logit must keep its BITS: each
+    output sums the same plane products in the same order, a tap that leaves the image adds exact zeros.  All team-size
+    classes (waves without a tile at N = 1 / 2, a last tile with missing columns, 19 tiles at N = 12), K = 2, 3, 4,
+    fp64 and fp32 GSOs, binary and real-valued (three-plane L0) observations; and against the oracle."""
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    sd = orc.init_state_dict(K, seed=40 + N)
+    net = _net(N, K, dev, sd)
+    obs = orc.synth_obs(B, N, seed=B + N)
+    if real_obs:
+        obs = obs * torch.randn(obs.shape, generator=torch.Generator().manual_seed(N))
+    S64 = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=N + K))
+    obs_d = obs.to(dev)
+    try:
+        for S in (S64.to(dev), S64.float().to(dev)):
+            net.addGSO(S)
+            outs = []
+            for cp in (1, 0, 1):
+                assert L.gnnpp_set_tuning(13, cp) == 0 and L.gnnpp_get_tuning(13) == cp
+                outs.append(net.forward_logits(obs_d).clone())
+            assert torch.isfinite(outs[0]).all()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (outs[0] - outs[1]).abs().max().item()
+    finally:
+        L.gnnpp_set_tuning(13, 1)
+    want = torch.stack(orc.policy_forward(sd, S64.float(), obs), 0)
+    assert (outs[0].cpu() - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize('M,tile', [(1600, 0), (1600, 7), (23, 5), (3000, 12), (257, 0), (640, 3), (40, 1)])
+def test_column_packed_encoder_tiles_are_bit_identical(dev, M, tile):
+    """GNNPP_TUNE_ENCODER_CP_TILE: the unfused encoder's LATENCY form -- column-packed tiles of ceil(M / 256) <= 12
+    agents, one per CU, for launches of at most 3072 agents (the per-GPU shards of the 8-GPU configs: 16 graphs of
+    100 agents) -- writes the same features, bit for bit, as 16-agent tiles; ragged last tiles, unaligned tile starts,
+    binary and real-valued observations; and equals the oracle."""
+    import ctypes
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    sd = orc.init_state_dict(3, seed=60)
+    net = _net(10, 3, dev, sd)
+    enc = net.packed_encoder()
+    obs = orc.synth_obs(1, M, seed=M)
+    if M % 2:
+        obs = obs * torch.randn(obs.shape, generator=torch.Generator().manual_seed(M))
+    obs_d = obs.reshape(M, 3, 11, 11).contiguous().to(dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                # noqa: E731
+    feats = []
+    try:
+        for knob in (tile, 16, tile):
+            assert L.gnnpp_set_tuning(14, knob) == 0
+            feat = torch.full((M, 128), float('nan'), device=dev)
+            assert L.gnnpp_encoder_fwd(vp(obs_d), vp(enc), vp(feat), M, 0, None, _native.stream_ptr(dev)) == 0
+            feats.append(feat)
+    finally:
+        L.gnnpp_set_tuning(14, 0)
+    assert torch.isfinite(feats[0]).all()
+    assert torch.equal(feats[0], feats[1]) and torch.equal(feats[0], feats[2]), (feats[0] - feats[1]).abs().max().item()
+    want = orc.policy_features(sd, obs).permute(0, 2, 1).reshape(M, 128)
+    assert (feats[0].cpu() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
 def test_encoder_negative_and_zero_batchnorm_scales(dev, enc_variant):
     """A trained BatchNorm may have gamma < 0 or = 0.  The bf16x3 L0 pools its RAW accumulators and applies the affine
     map once per window (the sign of the folded scale lives in the packed weights, |scale| in the table): must equal

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: test smoke bench benchdrv bench35 train traincpu trainprof distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc filterpmc
+# steps: test smoke bench benchdrv bench35 train traincpu trainprof cpab distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc filterpmc
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -35,6 +35,8 @@ if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path 
   grep -i "error\|duplicate\|invalid\|agent-steps\|^exit" $OUT/rccl_one_gpu.log | grep -v amdgpu.ids | head -12 | cut -c1-400 | tee -a $OUT/distcheck.log
   stamp "1-rank torchrun nccl"
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
+if has cpab; then stamp "column-packed policy kernel A/B (+ phase stamps)"
+  timeout 400 python tools/cp_ab.py stamps 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/cp_ab.jsonl; fi
 if has b3stamps; then stamp "phase stamps of the policy kernels (per precision)"
   timeout 300 python tools/b3_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/b3_stamps.jsonl; fi
 if has filtersweep; then stamp "filter-only throughput sweep"
