@@ -262,17 +262,6 @@ constexpr int kCpL2Tiles = 6;                              // agent tiles of L2 
 constexpr int kCpL2Rows = 21;
 static_assert(kCpL2Rows * kCpRow <= kB3Region && ((25 * kCpMaxAgents + 15) / 16 + 3) / 4 <= kCpL1Tiles, "column-packed layouts fit R");
 
-// A wave-uniform value the optimiser must not correlate with its other uses.  The tile loops below test `i < na` with
-// the SAME run-time count in every tap; left visible, jump threading specialises the whole rest of the kernel for each
-// value of the count (measured: 348 000 instead of 30 000 lines of ISA, 816 bytes of scratch).
-__device__ __forceinline__ int cp_opaque(int v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    v = __builtin_amdgcn_readfirstlane(v);               // (uniform by construction; this puts it in an SGPR for the asm)
-    asm volatile("" : "+s"(v));
-#endif
-    return v;
-}
-
 struct CpGeom {                   // wave-uniform (SGPRs)
     int N, ncol, T1, l1in;
     unsigned rcpN;                // (c * rcpN) >> 16 == c / N for c < 5 000
@@ -530,15 +519,108 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
 // ---- L1, column-packed: 32 -> 32 @ 5x5, columns c = pos * N + n; this wave's tiles are wave, wave + 4, .. ---------------
 // Per tap the source column of lane j is c + (dy 5 + dx) N: tile-independent slot (j + shift) & 15 and a tile-independent
 // row offset, so a tile's three plane reads are `base + immediate`; a lane whose tap leaves the 5x5 image (four flag
-// bits per tile, computed once) reads the zero cell instead.  The plane fragments of tile i + 1 are requested before
-// the MFMAs of tile i are issued.
+// bits per tile, computed once) reads the zero cell instead.
+// The MFMA stream of a wave is the sequence of units (tap, tile); the plane fragments of unit u + 1 -- the next tile, or
+// the first tile of the next tap -- are requested before the MFMAs of unit u are issued (two register sets).  NA, the
+// number of tiles of THIS wave, is a template argument: a run-time `if (i < na)` around every unit puts each unit in
+// its own basic block, the compiler then waits for lgkmcnt(0) -- the prefetch included -- in front of every MFMA group
+// (measured: L2 14.7 us instead of 11.9 for 26 % fewer MFMAs); the layer is instantiated for NA = 0 .. NT and the
+// wave jumps to its copy once (every copy carries the same ring traffic: tools/check_ring_isa.py walks each path).
+// One unit = the 12 MFMAs of a (tap, tile).  Software pipeline, two stages deep: at the START of unit u the three plane
+// reads of unit u + 1 are issued (their address was computed during unit u - 1), and the address arithmetic of unit
+// u + 2 is spread between the MFMAs of unit u -- one scheduling region, ordered by sched_group_barrier: (MFMA, LDS
+// read) x 3, then (MFMA, 3 VALU) x 4, then the remaining MFMAs.  History (C2, two workgroups per CU): run-time `if (i < na)` around
+// every unit -> lgkmcnt(0) in front of every MFMA group, L2 14.7 us; static units, addresses + reads as a block in
+// front of the MFMAs -> 11.9 us (the ~10 address instructions leave the pipe idle: an in-order wave issues nothing
+// else meanwhile); interleaved, reads after the fourth MFMA -> 10.9 us; this form: see profiles/r04_cp_ab.jsonl.
+__device__ __forceinline__ void cp_interleave_unit() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read (a plane of the next unit)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);          // 3 VALU (the address of the unit after the next)
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);              // the other MFMAs
+}
+// the address of the unit after the next is COMPLETE when its unit ends (left to the optimiser its last additions
+// sink to the reads that use it, in front of the next unit's first MFMA)
+__device__ __forceinline__ void cp_pin(int& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+}
+
+struct CpL1Lane {                 // per-lane constants of cp_layer1
+    int j, q, zaddr;
+    unsigned fl;                  // per tile: y == 0 | y == 4 | x == 0 | x == 4  (4 bits each)
+};
+// LDS address (without the tile's immediate I * 4 rows) of lane j's planes for unit (TAP, I): the source column of lane
+// j is c + (dy 5 + dx) N -- tile-independent slot (j + shift) & 15 and row offset --, or the zero cell when the tap
+// leaves the image
+template <int TAP, int I>
+__device__ __forceinline__ int cp_l1_addr(const CpGeom& g, const CpL1Lane& ln, int wave) {
+    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+    constexpr unsigned tmask = (dy < 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dx < 0 ? 4u : 0u) | (dx > 0 ? 8u : 0u);
+    const int sh = ln.j + (dy * 5 + dx) * g.N;                     // (arithmetic shift / mask below: floor semantics)
+    const int base = g.l1in + (wave + (sh >> 4)) * kCpRow + ln.q * 256 + (sh & 15) * 16;
+    if (tmask == 0u) return base;
+    // (branch-free on purpose: as a ternary the compiler turns this into a divergent branch around the address
+    // arithmetic, and EXEC games inside the ring's region are what tools/check_ring_isa.py refuses to reason about)
+    const int zero_cell = ln.zaddr - I * 4 * kCpRow;
+    const int outside = -(int)(((ln.fl >> (4 * I)) & tmask) != 0u);     // all ones / zero
+    return base ^ ((base ^ zero_cell) & outside);
+}
+template <int I>
+__device__ __forceinline__ void cp_l1_load(const char* smem, int addr, v4f (&B)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) B[p] = *reinterpret_cast<const v4f*>(smem + addr + I * 4 * kCpRow + p * kB3Frag);
+}
+template <int END, int NA>
+__device__ __forceinline__ void cp_layer1_main(const WStreamB& ws, v4f (&ring)[kRingH], const char* smem, const CpGeom& g,
+                                               const CpL1Lane& ln, int wave, v4f (&acc)[kCpL1Tiles][2]) {
+    constexpr int NU = 9 * NA;                                      // units of this wave
+    v4f Bb[2][3];
+    int addr_next = 0;                                              // address of unit u + 1 at the start of unit u
+    if constexpr (NA > 0) {
+        cp_l1_load<0>(smem, cp_l1_addr<0, 0>(g, ln, wave), Bb[0]);
+        if constexpr (NU > 1) addr_next = cp_l1_addr<1 / NA, 1 % NA>(g, ln, wave);
+    }
+    b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+        constexpr int tap = decltype(itc)::value;
+        if constexpr (NA > 0) {
+            auto unit = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, u = tap * NA + i;
+                if constexpr (u + 1 < NU) cp_l1_load<(u + 1) % NA>(smem, addr_next, Bb[(u + 1) & 1]);
+                if constexpr (u + 2 < NU) addr_next = cp_l1_addr<(u + 2) / NA, (u + 2) % NA>(g, ln, wave);
+#pragma unroll
+                for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[u & 1][b3_term_b(term)]), acc[i][m]);
+                cp_pin(addr_next);
+                cp_interleave_unit();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
+                std::make_integer_sequence<int, NA>{});
+        }
+    }, std::make_integer_sequence<int, 9>{});
+}
+
 template <int END>
 __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH], char* smem, const float* sstab,
                                           const CpGeom& g, int wave, int lane, int tid) {
     constexpr int NT = kCpL1Tiles;
-    const int j = lane & 15, q = lane >> 4;
+    CpL1Lane ln;
+    ln.j = lane & 15;
+    ln.q = lane >> 4;
+    const int j = ln.j, q = ln.q;
     const int na = min(max((g.T1 - wave + 3) >> 2, 0), NT);        // tiles of this wave (wave-uniform)
-    unsigned fl = 0;                                                // per tile: y == 0 | y == 4 | x == 0 | x == 4
+    ln.fl = 0;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int c = 16 * (wave + 4 * i) + j;
@@ -546,51 +628,29 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
         const int y = (pos * 13) >> 6, x = pos - 5 * y;            // pos / 5, pos % 5   (pos < 25 where it matters)
         unsigned f = (y == 0 ? 1u : 0u) | (y == 4 ? 2u : 0u) | (x == 0 ? 4u : 0u) | (x == 4 ? 8u : 0u);
         if (c >= g.ncol) f = 15u;                                   // no such column: every shifted tap reads zeros
-        fl |= f << (4 * i);
+        ln.fl |= f << (4 * i);
     }
-    const int zaddr = g.l1in + (g.T1 - 1) * kCpRow + q * 256 + 15 * 16;
+    ln.zaddr = g.l1in + (g.T1 - 1) * kCpRow + q * 256 + 15 * 16;
     v4f acc[NT][2];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
-    b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
-        constexpr int tap = decltype(itc)::value;
-        constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        constexpr unsigned tmask = (dy < 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dx < 0 ? 4u : 0u) | (dx > 0 ? 8u : 0u);
-        const int sh = j + (dy * 5 + dx) * g.N;                    // (arithmetic shift / mask below: floor semantics)
-        const int base = g.l1in + (wave + (sh >> 4)) * kCpRow + q * 256 + (sh & 15) * 16;
-        v4f Bb[2][3];
-        auto load_tile = [&](int i, v4f (&B)[3]) {                  // (i is a constant after unrolling)
-            int addr = base;
-            if (tmask != 0u) addr = ((fl >> (4 * i)) & tmask) != 0u ? zaddr - i * 4 * kCpRow : base;
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                B[p] = *reinterpret_cast<const v4f*>(smem + addr + i * 4 * kCpRow + p * kB3Frag);
-        };
-        const int nat = cp_opaque(na);
-        if (nat > 0) load_tile(0, Bb[0]);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            if (i + 1 < NT && i + 1 < nat) load_tile(i + 1, Bb[(i + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i < nat) {
-#pragma unroll
-                for (int term = 0; term < kB3Terms; ++term)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[i & 1][b3_term_b(term)]), acc[i][m]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }, std::make_integer_sequence<int, 9>{});
+    static_assert(NT == 5, "one case per tile count");
+    switch (na) {                                                   // (wave-uniform: a scalar branch)
+        case 0: cp_layer1_main<END, 0>(ws, ring, smem, g, ln, wave, acc); break;
+        case 1: cp_layer1_main<END, 1>(ws, ring, smem, g, ln, wave, acc); break;
+        case 2: cp_layer1_main<END, 2>(ws, ring, smem, g, ln, wave, acc); break;
+        case 3: cp_layer1_main<END, 3>(ws, ring, smem, g, ln, wave, acc); break;
+        case 4: cp_layer1_main<END, 4>(ws, ring, smem, g, ln, wave, acc); break;
+        default: cp_layer1_main<END, 5>(ws, ring, smem, g, ln, wave, acc); break;
+    }
     __syncthreads();                                               // everyone is done reading L0's output
     if (tid < kCpRow / 16) *reinterpret_cast<v4f*>(smem + 20 * kCpRow + tid * 16) = vzero();   // L2 input's zero row
     v4f sc[2], shf[2];
     load_ss(sstab + EncLayout::kBssL1, 32, 0, q, sc[0], shf[0]);
     load_ss(sstab + EncLayout::kBssL1, 32, 1, q, sc[1], shf[1]);
-    const int nae = cp_opaque(na);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        if (i < nae) {
+        if (i < na) {
             const int c = 16 * (wave + 4 * i) + j;
             const int pos = (int)(((unsigned)c * g.rcpN) >> 16), n = c - pos * g.N;
             const int y = (pos * 13) >> 6, x = pos - 5 * y;
@@ -610,6 +670,59 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
 // j = its output position (window w = j >> 2, position p = j & 3 inside the window).  After BatchNorm the 2x2 max runs
 // over the four lanes of a quad as a reduce-scatter (two quad_perm steps): lane p ends with the pooled channel pair p
 // of its fragment, splits THAT pair and stores its three dwords -- no lane repeats another lane's conversion.
+// Units (tap, agent) are software-pipelined and the agent count is a template argument, as in cp_layer1.
+struct CpL2Lane {
+    int q, y, x;
+};
+// LDS address of the planes of this lane's source cell for unit (TAP, agent n)   (n: wave-uniform)
+template <int TAP>
+__device__ __forceinline__ int cp_l2_addr(const CpL2Lane& ln, int n) {
+    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+    const int yy = ln.y + dy, xx = ln.x + dx;                       // source cell of this lane: in -1 .. 4
+    const int o = 4 * (n & 3) + (n >> 2);
+    int row = n;
+    if (dy > 0) row = yy == 4 ? 12 + (n >> 2) : row;
+    if (dx > 0) row = xx == 4 ? ((dy > 0 && yy == 4) ? 19 : 15 + (n & 3)) : row;
+    if (dy < 0) row = yy < 0 ? 20 : row;
+    if (dx < 0) row = xx < 0 ? 20 : row;
+    return row * kCpRow + ln.q * 256 + ((4 * (yy & 3) + (xx & 3) + o) & 15) * 16;
+}
+__device__ __forceinline__ void cp_l2_load(const char* smem, int addr, v4f (&B)[3]) {
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) B[pp] = *reinterpret_cast<const v4f*>(smem + addr + pp * kB3Frag);
+}
+template <int END, int NA>
+__device__ __forceinline__ void cp_layer2_main(const WStreamB& ws, v4f (&ring)[kRingH], const char* smem,
+                                               const CpL2Lane& ln, int pair, v4f (&acc)[kCpL2Tiles][2]) {
+    constexpr int NU = 9 * NA;
+    v4f Bb[2][3];
+    int addr_next = 0;
+    if constexpr (NA > 0) {
+        cp_l2_load(smem, cp_l2_addr<0>(ln, pair), Bb[0]);
+        if constexpr (NU > 1) addr_next = cp_l2_addr<1 / NA>(ln, pair + 2 * (1 % NA));
+    }
+    b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
+        constexpr int tap = decltype(itc)::value;
+        if constexpr (NA > 0) {
+            auto unit = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, u = tap * NA + i;
+                if constexpr (u + 1 < NU) cp_l2_load(smem, addr_next, Bb[(u + 1) & 1]);
+                if constexpr (u + 2 < NU) addr_next = cp_l2_addr<(u + 2) / NA>(ln, pair + 2 * ((u + 2) % NA));
+#pragma unroll
+                for (int term = 0; term < kB3Terms; ++term)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[u & 1][b3_term_b(term)]), acc[i][m]);
+                cp_pin(addr_next);
+                cp_interleave_unit();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
+                std::make_integer_sequence<int, NA>{});
+        }
+    }, std::make_integer_sequence<int, 9>{});
+}
+
 template <int END>
 __device__ __forceinline__ void cp_layer2(const WStreamB& ws, v4f (&ring)[kRingH], char* smem, const float* sstab,
                                           const CpGeom& g, int wave, int lane) {
@@ -617,55 +730,32 @@ __device__ __forceinline__ void cp_layer2(const WStreamB& ws, v4f (&ring)[kRingH
     const int mp = wave & 1, pair = wave >> 1;
     const int na = min(max((g.N - pair + 1) >> 1, 0), NT);         // agents of this wave (wave-uniform)
     const int j = lane & 15, q = lane >> 4, w = j >> 2, p = j & 3;
-    const int y = 2 * (w >> 1) + (p >> 1), x = 2 * (w & 1) + (p & 1);
+    CpL2Lane ln;
+    ln.q = q;
+    ln.y = 2 * (w >> 1) + (p >> 1);
+    ln.x = 2 * (w & 1) + (p & 1);
     v4f acc[NT][2];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
-    b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
-        constexpr int tap = decltype(itc)::value;
-        constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int yy = y + dy, xx = x + dx;                        // source cell of this lane: in -1 .. 4
-        const bool outside = (dy < 0 && yy < 0) || (dx < 0 && xx < 0);
-        const bool ey = dy > 0 && yy == 4, ex = dx > 0 && xx == 4;
-        const int slot0 = 4 * (yy & 3) + (xx & 3);
-        v4f Bb[2][3];
-        auto load_tile = [&](int i, v4f (&B)[3]) {
-            const int n = pair + 2 * i;                             // (wave-uniform)
-            const int o = 4 * (n & 3) + (n >> 2);
-            int row = n;
-            if (dy > 0) row = ey ? 12 + (n >> 2) : row;
-            if (dx > 0) row = ex ? (ey ? 19 : 15 + (n & 3)) : row;
-            if (dy < 0 || dx < 0) row = outside ? 20 : row;
-            const int addr = row * kCpRow + q * 256 + ((slot0 + o) & 15) * 16;
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) B[pp] = *reinterpret_cast<const v4f*>(smem + addr + pp * kB3Frag);
-        };
-        const int nat = cp_opaque(na);
-        if (nat > 0) load_tile(0, Bb[0]);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            if (i + 1 < NT && i + 1 < nat) load_tile(i + 1, Bb[(i + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i < nat) {
-#pragma unroll
-                for (int term = 0; term < kB3Terms; ++term)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[i & 1][b3_term_b(term)]), acc[i][m]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }, std::make_integer_sequence<int, 9>{});
+    static_assert(NT == 6, "one case per agent count");
+    switch (na) {
+        case 0: cp_layer2_main<END, 0>(ws, ring, smem, ln, pair, acc); break;
+        case 1: cp_layer2_main<END, 1>(ws, ring, smem, ln, pair, acc); break;
+        case 2: cp_layer2_main<END, 2>(ws, ring, smem, ln, pair, acc); break;
+        case 3: cp_layer2_main<END, 3>(ws, ring, smem, ln, pair, acc); break;
+        case 4: cp_layer2_main<END, 4>(ws, ring, smem, ln, pair, acc); break;
+        case 5: cp_layer2_main<END, 5>(ws, ring, smem, ln, pair, acc); break;
+        default: cp_layer2_main<END, 6>(ws, ring, smem, ln, pair, acc); break;
+    }
     v4f sc[2], shf[2];
     load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp, q, sc[0], shf[0]);
     load_ss(sstab + EncLayout::kBssL2, 64, 2 * mp + 1, q, sc[1], shf[1]);
     const bool hi2 = (p & 2) != 0, hi1 = (p & 1) != 0;
     float pooled[NT][2];
-    const int nap = cp_opaque(na);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         pooled[i][0] = pooled[i][1] = 0.f;
-        if (i < nap) {
+        if (i < na) {
             const v4f v0 = vfma(acc[i][0], sc[0], shf[0]), v1 = vfma(acc[i][1], sc[1], shf[1]);
             // step 1, partner lane ^ 2: lanes with bit 1 clear keep channel tile 0 (pairs 0, 1), the others tile 1
             v4f keep, send;
@@ -685,10 +775,9 @@ __device__ __forceinline__ void cp_layer2(const WStreamB& ws, v4f (&ring)[kRingH
     }
     __syncthreads();                                               // everyone is done reading L1's output
     // fragment (window w, block mp, plane) of L3's input, lane slot (q, agent n), dword p = channel pair p
-    const int naw = cp_opaque(na);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        if (i < naw) {
+        if (i < na) {
             const int n = pair + 2 * i;
             unsigned h, m, l;
             b3_split2(pooled[i][0], pooled[i][1], h, m, l);

@@ -104,6 +104,7 @@ f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int);
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 gnnpp_emu::mfma16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 gnnpp_emu::mfma16x16x32_bf16
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, sync_id) ((void)0)
 #define __builtin_amdgcn_wave_barrier() gnnpp_emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(x) (x)          // only used on wave-uniform values
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1

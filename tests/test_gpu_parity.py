@@ -689,6 +689,74 @@ def test_default_precision_adversarial_ranges(dev, lo, hi):
     assert scale > 0 and (got - want).abs().max().item() <= 3e-5 * scale, ((got - want).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('case', ['golden', 'binary_c2', 'band_1e-30_1e-20', 'band_1e10_1e20', 'band_1e-6_1e6'])
+def test_default_precision_error_is_comparable_to_the_exact_fp32_mfma(dev, policy_golden, case):
+    """"fp32-equivalent" stated as a COMPARISON, per output and not as one max-scaled bound: on the
+    same inputs, the error of the default arithmetic (bf16x3 planes) against the float64 statement of the network is at
+    most twice the error of the exact fp32 MFMA schedule (an fmaf chain: the reference's own kind of arithmetic) -- for
+    every one of the 128 encoder features and every logit column: RMS over the samples within 2x (+ two ulps of that
+    output's magnitude, at least the median output's: dead-ReLU features; a sum of a few hundred fp32 terms differs by
+    an ulp or two between ANY two summation orders), maximum over the samples within 4x (+ four ulps); the RMS over ALL
+    outputs within 2x with no slack.
+    Golden inputs of the reference, the bench's binary batch, and the adversarial magnitude bands."""
+    z, meta = policy_golden
+    g = torch.Generator().manual_seed(len(case))
+    if case == 'golden':
+        sd = golden_state_dict(z, 3)
+        i = [k for k, m in enumerate(meta) if m['K'] == 3 and m['N'] == 10][0]
+        obs = torch.from_numpy(z['p%d_obs' % i].astype(np.float32))
+        S = torch.from_numpy(np.ascontiguousarray(z['p%d_S' % i])).double()
+        if S.dim() == 4:
+            S = S.squeeze(1)
+    elif case == 'binary_c2':
+        sd = orc.init_state_dict(3, seed=1337)
+        obs = orc.synth_obs(128, 10, seed=1337)
+        S = torch.from_numpy(orc.synth_gso_geometric(128, 10, 20, seed=1337))
+    else:
+        lo, hi = (float(t) for t in case.split('_')[1:])
+        sd = orc.init_state_dict(3, seed=21)
+        B, N = 24, 6
+        e = torch.rand((B, N, 3, 11, 11), generator=g) * (np.log10(hi) - np.log10(lo)) + np.log10(lo)
+        obs = (10.0 ** e.double()).float() * (torch.randint(0, 2, e.shape, generator=g) * 2 - 1).float()
+        obs = obs * (torch.rand(e.shape, generator=g) < 0.3)
+        sd['ConvLayers.0.weight'] = sd['ConvLayers.0.weight'] / float(np.sqrt(lo * hi))
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, 12, seed=5))
+    B, N = obs.shape[0], obs.shape[1]
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        ref_feat = torch.stack([orc.encoder_one_agent(sd64, obs[:, n].double()) for n in range(N)], 1)   # [B,N,128] f64
+    y = orc.lsigf_f64(sd['GFL.0.weight'].numpy(), S.unsqueeze(1).numpy(), ref_feat.permute(0, 2, 1).numpy(),
+                      sd['GFL.0.bias'].numpy())
+    y = torch.relu(torch.from_numpy(y)).permute(0, 2, 1)                                                # [B,N,128]
+    ref_logits = y @ sd64['actionsMLP.0.weight'].t() + sd64['actionsMLP.0.bias']                        # [B,N,5]
+    net = _net(N, 3, dev, sd)
+    net.addGSO(S.to(dev))
+    err = {}
+    for prec in ('fp32', 'fp32_mfma'):
+        net.precision = prec
+        feat = net.encode(obs.to(dev)).cpu().double().reshape(B, N, 128)
+        logits = net.forward_logits(obs.to(dev)).cpu().double().permute(1, 0, 2)                        # [B,N,5]
+        assert torch.isfinite(feat).all() and torch.isfinite(logits).all()
+        err[prec] = ((feat - ref_feat).abs().reshape(-1, 128), (logits - ref_logits).abs().reshape(-1, N * 5)
+                     if False else (logits - ref_logits).abs().permute(1, 2, 0).reshape(N * 5, B).t())
+    for which, ref in ((0, ref_feat.abs().reshape(-1, 128)), (1, ref_logits.abs().permute(1, 2, 0).reshape(N * 5, B).t())):
+        e_b3, e_mf = err['fp32'][which], err['fp32_mfma'][which]
+        # an output's own magnitude, but not less than the typical output's: a feature that ReLU holds at (or near) zero
+        # is the sum of terms of the typical size, and neither arithmetic resolves that sum finer than fp32 does
+        colmax = ref.max(0).values
+        ulp = torch.maximum(colmax, colmax.median()) * 2.0 ** -23
+        # per output: RMS error over the samples within a factor of two (+ two ulps); the MAXIMUM over the samples -- a noisy
+        # statistic of two dozen to a few thousand samples -- within a factor of four (+ four ulps)
+        r_b3, r_mf = e_b3.pow(2).mean(0).sqrt(), e_mf.pow(2).mean(0).sqrt()
+        bad = r_b3 > 2.0 * r_mf + 2.0 * ulp
+        assert not bad.any(), (case, which, 'rms', int(bad.sum()), (r_b3 / (r_mf + ulp)).max().item())
+        worst_b3, worst_mf = e_b3.max(0).values, e_mf.max(0).values
+        bad = worst_b3 > 4.0 * worst_mf + 4.0 * ulp
+        assert not bad.any(), (case, which, 'max', int(bad.sum()), (worst_b3 / (worst_mf + ulp)).max().item())
+        rms_b3, rms_mf = e_b3.pow(2).mean().sqrt().item(), e_mf.pow(2).mean().sqrt().item()
+        assert rms_b3 <= 2.0 * rms_mf + 1e-300, (case, which, rms_b3, rms_mf)
+
+
 def test_default_precision_denormal_and_huge_weights(dev):
     """Weights in fp32's denormal range (|w| ~ 1e-40: exactly representable by bf16 planes only down to their own
     subnormals -- the contribution is below fp32's resolution of the sum either way) and weights near 1e30 with
