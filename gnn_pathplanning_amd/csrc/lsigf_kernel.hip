@@ -67,6 +67,8 @@ struct LsigfArgs {
     int* range_flag;       // optional device int: set to 1 when the split-f16 contraction saw |z| >= 65504
     int pf_part_off;       // policy_filter_kernel.hip: LDS byte offset of the partial logits
     int pf_plane_off;      // policy_filter_kernel.hip, bf16x3 mode: LDS byte offset of the plane buffer
+    int pf_const_off;      // policy_filter_kernel.hip: LDS byte offset of the epilogue constants
+    int pf_csr_cap;        // policy_filter_kernel.hip, MODE 3: entries of the compact neighbour lists
     int ablate;            // GNNPP_MEASURE builds only (tools/ab_bench.py): bit 0 skip the shifts, bit 1
                            // skip the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };

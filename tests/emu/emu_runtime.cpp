@@ -63,6 +63,9 @@ int block_arrived = 0;
 unsigned block_gen = 0;
 const std::function<void()>* body_fn = nullptr;
 
+unsigned long progress = 0;            // barriers completed + fibers finished: a scheduler pass without any is a deadlock
+int wait_kind[4096];                   // what fiber t is parked on: 1 wave-level collective, 2 workgroup barrier
+const char* wait_what[4096];           // ... and which collective
 void yield() { gnnpp_emu_switch(&fibers[cur_idx].sp, sched_sp); }
 
 void trampoline() {
@@ -78,8 +81,11 @@ void wave_barrier() {
     if (++w.arrived == w.n) {
         w.arrived = 0;
         ++w.gen;
+        ++progress;
     } else {
+        wait_kind[cur_idx] = 1;
         while (w.gen == g) yield();
+        wait_kind[cur_idx] = 0;
     }
 }
 }  // namespace
@@ -89,14 +95,18 @@ void sync_block() {
     if (++block_arrived == (int)fibers.size()) {
         block_arrived = 0;
         ++block_gen;
+        ++progress;
     } else {
+        wait_kind[cur_idx] = 2;
         while (block_gen == g) yield();
+        wait_kind[cur_idx] = 0;
     }
 }
 
-void wave_sync() { wave_barrier(); }
+void wave_sync() { wait_what[cur_idx] = "wave_barrier"; wave_barrier(); }
 
 unsigned long long ballot(int pred) {
+    wait_what[cur_idx] = "ballot";
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
     w.iv[f.lane] = pred;
@@ -109,6 +119,7 @@ unsigned long long ballot(int pred) {
 }
 
 int readlane(int v, int src) {
+    wait_what[cur_idx] = "readlane";
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
     w.iv[f.lane] = v;
@@ -119,6 +130,7 @@ int readlane(int v, int src) {
 }
 
 float shfl_xor(float v, int mask) {
+    wait_what[cur_idx] = "shfl_xor";
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
     w.a[f.lane] = v;
@@ -129,6 +141,7 @@ float shfl_xor(float v, int mask) {
 }
 
 int mov_dpp_quad(int v, int ctrl) {
+    wait_what[cur_idx] = "mov_dpp";
     if (ctrl < 0 || ctrl > 0xff) { std::fprintf(stderr, "emu: only quad_perm DPP controls are modelled\n"); std::abort(); }
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
@@ -141,6 +154,7 @@ int mov_dpp_quad(int v, int ctrl) {
 }
 
 f4 mfma16x16x4(float a, float b, f4 c, int, int, int) {
+    wait_what[cur_idx] = "mfma f32";
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
     if (w.n != 64) { std::fprintf(stderr, "emu: MFMA needs a full wave\n"); std::abort(); }
@@ -159,6 +173,7 @@ f4 mfma16x16x4(float a, float b, f4 c, int, int, int) {
 }
 
 f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int) {
+    wait_what[cur_idx] = "mfma f16";
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
     if (w.n != 64) { std::fprintf(stderr, "emu: MFMA needs a full wave\n"); std::abort(); }
@@ -183,6 +198,7 @@ f4 mfma16x16x32_f16(h8 a, h8 b, f4 c, int, int, int) {
 // v_mfma_f32_16x16x32_bf16: same lane map as the f16 form; operands are bf16 bit patterns (the upper half of an
 // fp32), products exact, the sum formed in double and rounded once
 f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int) {
+    wait_what[cur_idx] = "mfma bf16";
     Fiber& f = fibers[cur_idx];
     Wave& w = waves[f.wave];
     if (w.n != 64) { std::fprintf(stderr, "emu: MFMA needs a full wave\n"); std::abort(); }
@@ -257,12 +273,31 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
         }
         int live = nt;
         while (live > 0) {
+            const unsigned long before = progress;
             for (int t = 0; t < nt; ++t) {
                 if (fibers[t].done) continue;
                 cur_idx = t;
                 cur = &fibers[t].item;
                 gnnpp_emu_switch(&sched_sp, fibers[t].sp);
-                if (fibers[t].done) --live;
+                if (fibers[t].done) { --live; ++progress; }
+            }
+            if (live > 0 && progress == before) {
+                // every live work-item is parked and nothing completed: divergent barriers / collectives (on the GPU:
+                // a hang, or lanes silently missing from a ballot)
+                int nw = 0, nb = 0, first_w = -1, first_b = -1;
+                for (int t = 0; t < nt; ++t) {
+                    if (fibers[t].done) continue;
+                    if (wait_kind[t] == 1) { if (first_w < 0) first_w = t; ++nw; }
+                    if (wait_kind[t] == 2) { if (first_b < 0) first_b = t; ++nb; }
+                }
+                std::fprintf(stderr, "gnnpp emu: DEADLOCK in workgroup %u: %d work-items finished, %d parked on a wave "
+                             "collective (first: thread %d, in %s), %d on __syncthreads (first: thread %d)\n", bb,
+                             nt - live, nw, first_w, first_w >= 0 && wait_what[first_w] ? wait_what[first_w] : "?", nb,
+                             first_b);
+                for (int t = 0; t < nt; ++t)
+                    if (!fibers[t].done && wait_kind[t] == 1 && (t % 64 == 0 || wait_kind[t - 1] != 1))
+                        std::fprintf(stderr, "   thread %d.. : %s\n", t, wait_what[t] ? wait_what[t] : "?");
+                std::abort();
             }
         }
         lds_canary(smem_bytes, true);

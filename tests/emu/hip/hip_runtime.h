@@ -110,7 +110,9 @@ f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int);
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 1
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
-#define __hip_atomic_fetch_add(ptr, val, order, scope) (*(ptr) += (val))
+// (returns the OLD value, like the builtin; fibers of a workgroup run one at a time, so a plain update is atomic here)
+template <class T, class V> inline T gnnpp_emu_fetch_add(T* p, V v) { const T old = *p; *p = (T)(old + v); return old; }
+#define __hip_atomic_fetch_add(ptr, val, order, scope) gnnpp_emu_fetch_add((ptr), (val))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(n) ((void)0)

@@ -577,3 +577,49 @@ def test_emu_column_packed_encoder_tiles_are_bit_identical(emu, M, tile):
     want = orc.policy_features(sd_t, obs_t).permute(0, 2, 1).reshape(M, 128).numpy()
     assert np.abs(feats[0] - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
     assert lib.gnnpp_set_tuning(14, 13) == -1
+
+
+@pytest.mark.parametrize('N,K,f64,B,density', [(100, 3, 0, 2, 0.06), (100, 3, 1, 1, 0.3), (72, 2, 0, 2, 0.08),
+                                               (100, 4, 1, 1, 0.05), (88, 3, 0, 1, 0.02), (100, 2, 0, 1, 0.19)])
+def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
+    """policy_filter_kernel MODE 3 (teams of 65 .. 100 agents, two workgroups per graph, default precision): bf16x3
+    planes beside COMPACT (CSR) neighbour lists -- the dense slab is staged in the second z buffer and compacted with one
+    LDS atomic per node.  Sparse graphs (the lists fit: bf16x3 contraction), dense graphs (the lists overflow: that
+    workgroup finishes as MODE 1), a hub node, isolated nodes (degree 0: a padded list of four zero weights), fp64
+    slabs: the general filter kernel's logits to rounding, the float64 statement's within TOL."""
+    el, lib = emu
+    g = np.random.default_rng(1000 * N + 10 * K + int(100 * density))
+    h = (g.standard_normal((128, 1, K, 128)) / np.sqrt(128 * K)).astype(np.float32)
+    x = np.maximum(g.standard_normal((B, N, 128)), 0).astype(np.float32)
+    S = ((g.random((B, N, N)) < density) * g.random((B, N, N))).astype(np.float64 if f64 else np.float32)
+    S[0, :, N // 2] = g.random(N)                            # a hub: node N/2 gathers from everybody
+    S[:, :, 3] = 0                                           # an isolated node (nobody to gather from)
+    S[:, :, N - 1] = 0                                       # ... and the last one
+    for b in range(B):
+        np.fill_diagonal(S[b], 0)
+    bias = (g.standard_normal(128) / 4).astype(np.float32)
+    aw = (g.standard_normal((5, 128)) / 8).astype(np.float32)
+    ab = g.standard_normal(5).astype(np.float32)
+    packed = el.pack_filter(lib, h)
+    outs = []
+    lib.gnnpp_set_tuning(2, 0)
+    try:
+        assert lib.gnnpp_set_tuning(7, 2) == 0 and lib.gnnpp_set_tuning(1, 1) == 0     # two workgroups per graph
+        for mode in (1, 0):
+            assert lib.gnnpp_set_tuning(9, mode) == 0
+            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+            assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
+                                             el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, 0, None, None) == 0
+            outs.append(logits)
+    finally:
+        lib.gnnpp_set_tuning(9, 1); lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0)
+    z = x.astype(np.float64)
+    y = np.zeros((B, N, 128))
+    for k in range(K):
+        y += z @ h[:, 0, k, :].astype(np.float64).T
+        z = np.einsum('bmn,bmg->bng', S.astype(np.float32).astype(np.float64), z)
+    want = (np.maximum(y + bias, 0) @ aw.astype(np.float64).T + ab).transpose(1, 0, 2)
+    scale = max(1.0, np.abs(want).max())
+    assert np.isfinite(outs[0]).all()
+    assert np.abs(outs[0] - want).max() <= TOL * scale, np.abs(outs[0] - want).max()
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale

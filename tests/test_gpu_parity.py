@@ -845,6 +845,55 @@ def test_unseen_parameter_updates_and_invalidate_packed(dev):
     assert (d - a).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize('B,N,K,f64', [(6, 100, 3, 0), (9, 100, 2, 1), (4, 80, 4, 0), (128, 100, 3, 0)])
+def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
+    """policy_filter_kernel MODE 3 (default precision, 65 .. 100 agents, two workgroups per graph): bf16x3 planes beside
+    compact (CSR) neighbour lists.  A batch that MIXES sparse graphs (lists fit: bf16x3 contraction), near-cliques (the
+    lists overflow: that workgroup alone finishes as MODE 1), hubs and isolated nodes: every graph against the general
+    filter kernel (to rounding) and the float64 statement (TOL); repeated launches are bit-identical (the order of the
+    LDS atomics that place the lists must not matter)."""
+    from gnn_pathplanning_amd import _native
+    L = _native.lib()
+    g = torch.Generator().manual_seed(B * 17 + N + K)
+    h = torch.randn(128, 1, K, 128, generator=g) / (128 * K) ** 0.5
+    x = torch.relu(torch.randn(B, N, 128, generator=g))
+    dens = torch.tensor([0.06 if b % 3 else 0.35 for b in range(B)]).reshape(B, 1, 1)     # every third graph: dense
+    S = ((torch.rand(B, N, N, generator=g) < dens) * torch.rand(B, N, N, generator=g))
+    S[1 % B, :, N // 2] = torch.rand(N, generator=g)                                     # a hub in a sparse graph
+    S[:, :, 5] = 0                                                                       # an isolated node everywhere
+    S = S * (1 - torch.eye(N))
+    S = S.double() if f64 else S.float()
+    bias, aw, ab = torch.randn(128, generator=g) / 4, torch.randn(5, 128, generator=g) / 8, torch.randn(5, generator=g)
+    packed = torch.empty(L.gnnpp_filter_packed_floats(128, 128, K, 1), dtype=torch.float32, device=dev)
+    hd = h.to(dev)
+    assert L.gnnpp_filter_pack(hd.data_ptr(), packed.data_ptr(), 128, 128, K, 1, None) == 0
+    xd, Sd, bd, awd, abd = x.to(dev), S.to(dev), bias.to(dev), aw.to(dev), ab.to(dev)
+    outs = []
+    try:
+        for mode in (1, 0, 1, 1):
+            assert L.gnnpp_set_tuning(9, mode) == 0
+            lg = torch.full((N, B, 5), float('nan'), device=dev)
+            assert L.gnnpp_filter_head_fwd(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(),
+                                           awd.data_ptr(), abd.data_ptr(), lg.data_ptr(), B, N, 128, 128, K, 1, f64,
+                                           0, None, None) == 0
+            torch.cuda.synchronize()
+            outs.append(lg.cpu())
+    finally:
+        L.gnnpp_set_tuning(9, 1)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    z = x.double()
+    y = torch.zeros(B, N, 128, dtype=torch.float64)
+    Sf = S.float().double()
+    for k in range(K):
+        y += z @ h[:, 0, k, :].double().t()
+        z = torch.einsum('bmn,bmg->bng', Sf, z)
+    want = (torch.relu(y + bias.double()) @ aw.double().t() + ab.double()).permute(1, 0, 2)
+    scale = max(1.0, want.abs().max().item())
+    assert (outs[0].double() - want).abs().max().item() <= TOL * scale
+    assert (outs[0] - outs[1]).abs().max().item() <= 4e-6 * scale
+
+
 @pytest.mark.parametrize('B,N,K,f64', [(256, 50, 3, 0), (128, 100, 3, 1), (128, 100, 2, 0), (7, 17, 3, 0), (300, 64, 4, 1),
                                        (5, 89, 3, 0), (5, 90, 3, 1), (130, 97, 1, 0), (40, 33, 2, 0), (64, 100, 4, 0)])
 @pytest.mark.parametrize('prec', [0, 1, 2])
