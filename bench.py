@@ -291,6 +291,9 @@ def compact_summary(d):
                                      'dlogit': r(v['parity_train_mode_max_abs_dlogit'], 2)}
         elif k.startswith('c5_shard'):
             out[k] = rec(v)
+    rv = sec.get('real_valued_observations') or {}
+    if 'agent_steps_per_s' in rv:
+        out['real_valued_obs_M_per_s'] = r(rv['agent_steps_per_s'] / 1e6)
     rot = sec.get('c2_rotating_batches') or {}
     if 'agent_steps_per_s' in rot:
         out['c2_rotating_M_per_s'] = r(rot['agent_steps_per_s'] / 1e6)
@@ -765,6 +768,24 @@ def main():
                                           'ms_per_step': 1e3 * r / max(20, args.steps // 4),
                                           'what': 'addGSO + forward + decode_actions kernel + .cpu() of the [B,N] int32 '
                                                   'ids, synchronous every step (multirobotsim_dcenlocal.py:589-599)'}
+                # (1b) the same step on REAL-VALUED observations: the simulator's observations are {0, 1}, one bf16 plane,
+                # and L0 then issues three of its six plane products (plane skipping: bit-identical, exact zeros); any
+                # other observation takes the general L0 (all six products, compiler-scheduled) -- its cost, stated
+                obs_real = (obs * torch.randn(obs.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7)))
+
+                def step_real():
+                    net.addGSO(S)
+                    return net(obs_real)
+                for _ in range(10):
+                    out_real = step_real()
+                nst_r = max(20, args.steps // 2)
+                r = sorted(x[0] for x in timed_regions(step_real, nst_r, 5))[2] / nst_r
+                want_real = orc.policy_forward(sd, S_cpu, obs_real.cpu())
+                sec['real_valued_observations'] = {
+                    'agent_steps_per_s': M / r, 'ms_per_step': 1e3 * r, 'vs_binary_observations': (M / r) / value_rank,
+                    'parity_max_abs_dlogit': max((g_.cpu() - w_).abs().max().item() for g_, w_ in zip(out_real, want_real)),
+                    'what': 'observations x N(0, 1): three bf16 planes per pixel, L0 issues all six plane products '
+                            '(b3_l0_generic); everything behind L0 is unchanged'}
                 # (2) the other two arithmetics on the same step, each with its own roofline block: the exact fp32
                 # MFMA, and the opt-in split-f16 mode (NARROWER than fp32: a labelled secondary, never the headline)
                 for pname, key in (('fp32_mfma', 'exact_fp32_mfma_schedule'), ('split_f16', 'split_f16_fast_mode')):

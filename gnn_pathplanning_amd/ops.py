@@ -8,13 +8,15 @@
 The module classes (DecentralPlannerNet, GraphFilter*) call the C ABI through ctypes directly; these registrations
 exist so that torch.compile / torch.export / FX see the same kernels as OPAQUE operators with known output shapes
 (fake implementations below) instead of graph-breaking on ctypes calls.  They are thin: every op is one C entry point
-of include/gnnpp.h on the current stream, fails loudly (GnnppError) without the HIP library or on CPU tensors, and is
-inference-only (no autograd formula is registered: training goes through the modules' autograd Functions,
-graphML._LSIGFFunction / decentralplanner._EncoderTrainFunction).  `precision` is GNNPP_PREC_* (0 = fp32-equivalent
-default).  References: utils/graphUtils/graphML.py:48-141, 2273-2367; graphs/models/decentralplanner.py:266-318;
+of include/gnnpp.h on the current stream and fails loudly (GnnppError) without the HIP library or on CPU tensors.
+`lsigf` is DIFFERENTIABLE through the dispatcher (r04): its registered autograd formula calls `gnnpp::lsigf_backward`
+-- the kernels of graphML._LSIGFFunction: input gradient = the transposed filter, tap gradient on gnnpp_gemm_kmajor --
+so a training step written on torch.ops.gnnpp.lsigf traces under torch.compile (AOTAutograd sees both ops through their
+fake implementations).  `policy_logits` / `decode_actions` are inference ops (training the whole planner goes through
+the modules: decentralplanner._EncoderTrainFunction).  `precision` is GNNPP_PREC_* (0 = fp32-equivalent default).  References: utils/graphUtils/graphML.py:48-141, 2273-2367; graphs/models/decentralplanner.py:266-318;
 utils/multirobotsim_dcenlocal.py:589-591.
 """
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -39,6 +41,45 @@ def lsigf(h: torch.Tensor, S: torch.Tensor, x: torch.Tensor, bias: Optional[torc
 @lsigf.register_fake
 def _(h, S, x, bias=None, relu=False, precision=0):
     return x.new_empty((x.shape[0], h.shape[0], x.shape[2]), dtype=torch.float32)
+
+
+@torch.library.custom_op('gnnpp::lsigf_backward', mutates_args=())
+def lsigf_backward(h: torch.Tensor, S: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], dy: torch.Tensor,
+                   relu: bool = False, precision: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dh, dx, dbias) of y = lsigf(h, S, x, bias, relu) for the cotangent dy [B,F,N] (agents/decentralplannerlocal.py:314
+    `loss.backward()` through graphML.py:2273-2367).  The forward is re-run with its tap signals kept (one more filter
+    launch: the op pair carries no hidden state between forward and backward), then graphML._LSIGFFunction's backward:
+    dx = the same kernel on dy with transposed taps and S^T, dh = one split-K GEMM, dbias = a reduction.  No gradient
+    for S.  dbias is an empty tensor when there is no bias."""
+    batched = S.dim() == 4
+    with torch.enable_grad():
+        hh, xx = h.detach().requires_grad_(True), x.detach().requires_grad_(True)
+        bb = bias.detach().requires_grad_(True) if bias is not None else None
+        y = gml._LSIGFFunction.apply(hh, S.detach(), xx, bb, batched, None, False, bool(relu), int(precision))
+        grads = torch.autograd.grad(y, [hh, xx] + ([bb] if bb is not None else []), dy.detach().contiguous())
+    db = grads[2] if bb is not None else h.new_empty(0)
+    return grads[0], grads[1], db
+
+
+@lsigf_backward.register_fake
+def _(h, S, x, bias, dy, relu=False, precision=0):
+    return (torch.empty_like(h, dtype=torch.float32), torch.empty_like(x, dtype=torch.float32),
+            torch.empty_like(bias, dtype=torch.float32) if bias is not None else h.new_empty(0))
+
+
+def _lsigf_setup_context(ctx, inputs, output):
+    h, S, x, bias, relu, precision = inputs
+    ctx.save_for_backward(h, S, x, bias)
+    ctx.relu, ctx.precision, ctx.has_bias = bool(relu), int(precision), bias is not None
+
+
+def _lsigf_autograd(ctx, dy):
+    h, S, x, bias = ctx.saved_tensors
+    dh, dx, db = torch.ops.gnnpp.lsigf_backward(h, S, x, bias, dy, ctx.relu, ctx.precision)
+    return dh, None, dx, (db if ctx.has_bias else None), None, None
+
+
+lsigf.register_autograd(_lsigf_autograd, setup_context=_lsigf_setup_context)
 
 
 @torch.library.custom_op('gnnpp::policy_logits', mutates_args=())

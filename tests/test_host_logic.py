@@ -273,3 +273,16 @@ def test_torch_ops_registration_shapes_and_loud_cpu_failure():
         torch.ops.gnnpp.lsigf(torch.zeros(128, 1, 3, 128), torch.zeros(2, 1, 4, 4), torch.zeros(2, 128, 4), None)
     with pytest.raises(GnnppError):
         torch.ops.gnnpp.decode_actions(torch.zeros(4, 2, 5))
+    # r04: lsigf carries a registered autograd formula (gnnpp::lsigf_backward): under FakeTensorMode -- what AOTAutograd
+    # traces with -- the gradients of the taps, the signal and the bias have the inputs' shapes, the GSO gets none
+    with FakeTensorMode():
+        h = torch.empty(150, 2, 3, 64, requires_grad=True)
+        x = torch.empty(7, 64, 10, requires_grad=True)
+        b = torch.empty(150, 1, requires_grad=True)
+        S = torch.empty(7, 2, 10, 10, requires_grad=True)
+        y = torch.ops.gnnpp.lsigf(h, S, x, b, True, 0)
+        assert y.requires_grad
+        dh, dx, db, dS = torch.autograd.grad(y, [h, x, b, S], torch.empty_like(y), allow_unused=True)
+        assert dh.shape == h.shape and dx.shape == x.shape and db.shape == b.shape and dS is None
+        g3 = torch.ops.gnnpp.lsigf_backward(h, S, x, None, torch.empty_like(y), False, 0)
+        assert g3[0].shape == h.shape and g3[1].shape == x.shape and g3[2].numel() == 0

@@ -41,10 +41,13 @@ def time_launches(lib, args, reps):
 
 def main():
     want_stamps = 'stamps' in sys.argv[1:]
+    global M
     M = None
     if want_stamps:
         M = _native.measure_lib()
         M.gnnpp_measure_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    if 'tiles' in sys.argv[1:]:
+        return encoder_tiles(M)
     for (B, N, K) in SHAPES:
         class Cfg:
             num_agents, nGraphFilterTaps, device = N, K, dev
@@ -98,6 +101,63 @@ def main():
         print(json.dumps(row), flush=True)
     L.gnnpp_set_tuning(13, 1)
     L.gnnpp_set_tuning(6, 1)
+
+
+M = None
+
+
+def encoder_tiles(M):
+    """The unfused encoder in the latency regime (the per-GPU shard of configs 3 / 5: 1 600 agents): 16-agent tiles
+    against column-packed tiles of 4 / 7 (= the heuristic) / 10 / 12 agents -- launch time and phase stamps."""
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    net = DecentralPlannerNet(Cfg()).to(dev).eval()
+    net.load_state_dict(orc.init_state_dict(3))
+    enc = net.packed_encoder()
+    for Mag in (1600, 640, 3000):
+        obs = orc.synth_obs(Mag // 10 + 1, 10, seed=3).reshape(-1, 3, 11, 11)[:Mag].contiguous().to(dev)
+        feat = torch.empty(Mag, 128, device=dev)
+        row = {'encoder_M': Mag}
+        ref = None
+        for tile in (16, 0, 4, 7, 10, 12):
+            assert L.gnnpp_set_tuning(14, tile) == 0
+            args = (obs.data_ptr(), enc.data_ptr(), feat.data_ptr(), Mag, 0, None, st)
+            for _ in range(20):
+                assert L.gnnpp_encoder_fwd(*args) == 0
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(200):
+                    L.gnnpp_encoder_fwd(*args)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / 200)
+            row['tile%d_us' % tile] = round(sorted(ts)[2], 2)
+            if ref is None:
+                ref = feat.clone()
+            else:
+                row['tile%d_bit_identical' % tile] = bool(torch.equal(ref, feat))
+            if M is not None:
+                assert M.gnnpp_set_tuning(14, tile) == 0
+                for _ in range(6):
+                    assert M.gnnpp_encoder_fwd(*args) == 0
+                    torch.cuda.synchronize()
+                tl = tile if tile not in (0, 16) else (16 if tile == 16 else max(1, (Mag + 255) // 256))
+                nwg = min((Mag + tl - 1) // tl, 1024)
+                buf = np.zeros(1024 * 32, np.uint64)
+                assert M.gnnpp_measure_read_stamps(buf.ctypes.data, buf.size) == 0
+                rows = buf.reshape(1024, 32)[:nwg].astype(np.float64)
+                us_ = rows[:, :16] * 0.01
+                order = [('start', 11), ('staged', 0), ('L0', 1), ('L1', 2), ('L2', 3), ('L3', 4), ('L4', 5), ('FC', 6)]
+                ph = {nb: round(float(np.median(us_[:, b] - us_[:, a])), 2) for (na, a), (nb, b) in zip(order[:-1], order[1:])}
+                ph['total_median'] = round(float(np.median(us_[:, 6] - us_[:, 11])), 2)
+                ph['span'] = round(float(us_[:, 6].max() - us_[:, 11].min()), 2)
+                row['stamps_tile%d' % tile] = ph
+                M.gnnpp_set_tuning(14, 0)
+        L.gnnpp_set_tuning(14, 0)
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == '__main__':

@@ -37,6 +37,10 @@ if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path 
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
 if has cpab; then stamp "column-packed policy kernel A/B (+ phase stamps)"
   timeout 400 python tools/cp_ab.py stamps 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/cp_ab.jsonl; fi
+if has cptiles; then stamp "column-packed encoder tiles (latency regime) A/B + stamps"
+  timeout 400 python tools/cp_ab.py stamps tiles 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/cp_tiles.jsonl; fi
+if has filterstamps; then stamp "phase stamps of the policy filter kernels"
+  timeout 300 python tools/b3_stamps.py filter 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/filter_stamps.jsonl; fi
 if has b3stamps; then stamp "phase stamps of the policy kernels (per precision)"
   timeout 300 python tools/b3_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/b3_stamps.jsonl; fi
 if has filtersweep; then stamp "filter-only throughput sweep"
