@@ -1311,14 +1311,17 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
 std::atomic<int> g_policy_column_packing{1};   // GNNPP_TUNE_POLICY_CP: 0 = agents on the MFMA columns for every team size
 std::atomic<int> g_encoder_cp_tile{0};   // GNNPP_TUNE_ENCODER_CP_TILE: 0 = heuristic, 1 .. 12 = agents per tile, 16 = never
 
-// Few agents (M <= 256 x 12): column-packed tiles of ceil(M / 256) agents, one per CU (latency regime: the per-GPU shards
-// of the 8-GPU configs, 1 600 agents); otherwise 16-agent tiles, two per CU (throughput regime).
+// Few agents (M <= 256 x 8): column-packed tiles of ceil(M / 256) agents, one per CU (latency regime: the per-GPU shards
+// of the 8-GPU configs, 1 600 agents); otherwise 16-agent tiles, two per CU (throughput regime).  Measured
+// (profiles/r04_cp_tiles.jsonl, a workgroup alone on its CU): M = 640: 24.1 us (tiles of 3) against 30.3 (16-agent
+// tiles); M = 1 600: 28.0 (7) against 30.4; tiles of 10 or more agents do not pay (30.6 / 32.5 us at 10 / 12: a lone
+// wave runs the packed layers at ~45 % of the pipe's rate, and their weight stream does not shrink with the tile).
 static int encoder_cp_tile(int M) {
     const int knob = g_encoder_cp_tile.load(std::memory_order_relaxed);
     if (knob >= 1 && knob <= kCpMaxAgents) return knob;
     if (knob != 0 || g_policy_column_packing.load(std::memory_order_relaxed) == 0) return 0;
     const int t = (M + 255) / 256;
-    return t <= kCpMaxAgents ? t : 0;
+    return t <= 8 ? t : 0;
 }
 
 int encoder_launch_b3(const float* obs, const float* packed, float* feat, int M, hipStream_t st) {

@@ -101,7 +101,7 @@ const char* gnnpp_error_string(int code);
                                          fills 15/16 of those tiles instead of 10/16); 0 = agents on the columns for
                                          every team size.  Same logits to the bit either way (v310)                     */
 #define GNNPP_TUNE_ENCODER_CP_TILE   14  /* agents per tile of the (unfused) encoder kernel's column-packed form: 0 (default)
-                                         = heuristic -- M <= 3072 agents: tiles of ceil(M / 256) agents, one per CU
+                                         = heuristic -- M <= 2048 agents: tiles of ceil(M / 256) agents, one per CU
                                          (latency regime), else 16-agent tiles --, 1 .. 12 = that tile size for every
                                          M, 16 = always 16-agent tiles.  Same features to the bit (v310)                */
 int         gnnpp_set_tuning(int key, int value);

@@ -341,7 +341,7 @@ def test_column_packed_policy_kernel_is_bit_identical(dev, B, N, K, real_obs):
 @pytest.mark.parametrize('M,tile', [(1600, 0), (1600, 7), (23, 5), (3000, 12), (257, 0), (640, 3), (40, 1)])
 def test_column_packed_encoder_tiles_are_bit_identical(dev, M, tile):
     """GNNPP_TUNE_ENCODER_CP_TILE: the unfused encoder's LATENCY form -- column-packed tiles of ceil(M / 256) <= 12
-    agents, one per CU, for launches of at most 3072 agents (the per-GPU shards of the 8-GPU configs: 16 graphs of
+    agents, one per CU, for launches of at most 2048 agents (the per-GPU shards of the 8-GPU configs: 16 graphs of
     100 agents) -- writes the same features, bit for bit, as 16-agent tiles; ragged last tiles, unaligned tile starts,
     binary and real-valued observations; and equals the oracle."""
     import ctypes
