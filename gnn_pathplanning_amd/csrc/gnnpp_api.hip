@@ -353,7 +353,7 @@ int gnnpp_set_tuning(int key, int value) {
             g_filter_split.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_POLICY_FILTER:
-            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
             g_filter_policy_kernel.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL_ROWS:

@@ -34,8 +34,9 @@
 // six MFMAs per (row tile, 32 channels); needs N * 800 more bytes of LDS, which exists up to about 64 nodes;
 // 1 = exact fp32 MFMA (GNNPP_PREC_FP32_MFMA, and GNNPP_PREC_FP32 on graphs whose planes do not fit): the taps read
 // the fp32 rows directly, 32 MFMAs of K = 4 per (row tile, 128 channels).
-// 3 = bf16x3 for the teams whose planes do NOT fit beside the dense S slab (65 .. 100 agents: 2 x 54 KB of fp32 rows +
-// 40 KB slab + 10 KB index lists + 41 KB planes > 160 KB; r03 ran them as MODE 1, 24 us instead of 16 at N = 100): the
+// 3 (opt-in: GNNPP_TUNE_POLICY_FILTER = 2) = bf16x3 for the teams whose planes do NOT fit beside the dense S slab (65 ..
+// 100 agents: 2 x 54 KB of fp32 rows + 40 KB slab + 10 KB index lists + 41 KB planes > 160 KB; the default runs them as
+// MODE 1, which measured as fast: what MODE 3's contraction saves its plane production spends): the
 // dense slab is staged into the SECOND z buffer (free until the first shift writes it) and compacted from there into
 // CSR lists -- 5 bytes per edge, every node's list padded to a multiple of four entries, space reserved with one LDS
 // atomic per node (the ORDER of the lists in the buffer is arbitrary, their contents are not: same neighbours, same
@@ -691,7 +692,10 @@ static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_
         const long zb = 2L * a.N * kPfZs * 4, cst = (long)kLdsBytes - kPfConsts * 4;
         const long room = cst - (long)rows_own * kPfPRow - zb - 400;
         const int cap = room > 0 ? (int)((room / 5) & ~3L) : 0;
-        if (a.K > 1 && a.N <= 128 && cap >= 8 * a.N && cap < 65536 && (long)a.pf_const_off <= cst &&
+        // (opt-in, GNNPP_TUNE_POLICY_FILTER = 2: the planes' production costs what the cheaper contraction saves --
+        // 26.4 against 25.8 us at 128 graphs of 100 agents, 23.5 against 24.1 at 16: profiles/r04_filter_stamps.jsonl)
+        if (g_filter_policy_kernel.load(std::memory_order_relaxed) == 2 &&
+            a.K > 1 && a.N <= 128 && cap >= 8 * a.N && cap < 65536 && (long)a.pf_const_off <= cst &&
             parts <= (size_t)a.N * kPfZs * 4) {
             mode = 3;
             a.pf_csr_cap = cap;

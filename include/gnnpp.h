@@ -85,7 +85,11 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_POLICY_FILTER    9  /* 1 (default): the filter + action head of gnnpp_policy_fwd / the rollout step
                                          for teams of 17 .. 100 agents (one graph per workgroup,
                                          FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
-                                         0: on the general filter kernel (same logits to the last bit or two) */
+                                         0: on the general filter kernel (same logits to the last bit or two);
+                                         2: as 1, and teams of 65 .. 100 agents contract on bf16x3 planes beside
+                                         COMPACT neighbour lists (policy_filter_kernel MODE 3) instead of on the
+                                         exact fp32 MFMA -- measured 2 % slower at 128 graphs of 100 agents, 2 %
+                                         faster at 16, hence not the default          */
 #define GNNPP_TUNE_FILTER_SMALL     10  /* 1 (default): graph filters over many small graphs (GNNPP_PREC_FP32, N <= 16,
                                          G = F = 128, node-major rows, >= 64 workgroups) run on the
                                          throughput kernel lsigf_small_b3_kernel (bf16x3 planes, two workgroups per

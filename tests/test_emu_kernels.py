@@ -452,7 +452,6 @@ def test_emu_policy_filter_kernel(emu, N, K, f64, split, B, prec):
     scale = max(1.0, np.abs(want).max())
     assert np.abs(outs[0] - want).max() <= TOL * scale
     assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
-    assert lib.gnnpp_set_tuning(9, 2) == -1
 
 
 @pytest.mark.parametrize('N,K,B,f64,head', [(10, 3, 9, 0, 0), (16, 2, 4, 1, 0), (7, 4, 13, 0, 1), (1, 3, 50, 0, 0),
@@ -582,7 +581,7 @@ def test_emu_column_packed_encoder_tiles_are_bit_identical(emu, M, tile):
 @pytest.mark.parametrize('N,K,f64,B,density', [(100, 3, 0, 2, 0.06), (100, 3, 1, 1, 0.3), (72, 2, 0, 2, 0.08),
                                                (100, 4, 1, 1, 0.05), (88, 3, 0, 1, 0.02), (100, 2, 0, 1, 0.19)])
 def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
-    """policy_filter_kernel MODE 3 (teams of 65 .. 100 agents, two workgroups per graph, default precision): bf16x3
+    """policy_filter_kernel MODE 3 (GNNPP_TUNE_POLICY_FILTER = 2; teams of 65 .. 100 agents, two workgroups per graph): bf16x3
     planes beside COMPACT (CSR) neighbour lists -- the dense slab is staged in the second z buffer and compacted with one
     LDS atomic per node.  Sparse graphs (the lists fit: bf16x3 contraction), dense graphs (the lists overflow: that
     workgroup finishes as MODE 1), a hub node, isolated nodes (degree 0: a padded list of four zero weights), fp64
@@ -605,12 +604,13 @@ def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
     lib.gnnpp_set_tuning(2, 0)
     try:
         assert lib.gnnpp_set_tuning(7, 2) == 0 and lib.gnnpp_set_tuning(1, 1) == 0     # two workgroups per graph
-        for mode in (1, 0):
-            assert lib.gnnpp_set_tuning(9, mode) == 0
+        for mode in (2, 0, 1):                               # compact lists (opt-in) | general kernel | default (MODE 1)
+            assert lib.gnnpp_set_tuning(9, mode) == 0 and lib.gnnpp_get_tuning(9) == mode
             logits = np.full((N, B, 5), np.nan, dtype=np.float32)
             assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
                                              el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, 0, None, None) == 0
             outs.append(logits)
+        assert lib.gnnpp_set_tuning(9, 3) == -1
     finally:
         lib.gnnpp_set_tuning(9, 1); lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0)
     z = x.astype(np.float64)
@@ -623,3 +623,5 @@ def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
     assert np.isfinite(outs[0]).all()
     assert np.abs(outs[0] - want).max() <= TOL * scale, np.abs(outs[0] - want).max()
     assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
+    assert np.abs(outs[0] - outs[2]).max() <= 4e-6 * scale
+    assert not np.array_equal(outs[0], outs[2])              # (the opt-in mode really ran: another arithmetic's bits)

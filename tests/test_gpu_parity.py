@@ -847,7 +847,7 @@ def test_unseen_parameter_updates_and_invalidate_packed(dev):
 
 @pytest.mark.parametrize('B,N,K,f64', [(6, 100, 3, 0), (9, 100, 2, 1), (4, 80, 4, 0), (128, 100, 3, 0)])
 def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
-    """policy_filter_kernel MODE 3 (default precision, 65 .. 100 agents, two workgroups per graph): bf16x3 planes beside
+    """policy_filter_kernel MODE 3 (GNNPP_TUNE_POLICY_FILTER = 2; 65 .. 100 agents, two workgroups per graph): bf16x3 planes beside
     compact (CSR) neighbour lists.  A batch that MIXES sparse graphs (lists fit: bf16x3 contraction), near-cliques (the
     lists overflow: that workgroup alone finishes as MODE 1), hubs and isolated nodes: every graph against the general
     filter kernel (to rounding) and the float64 statement (TOL); repeated launches are bit-identical (the order of the
@@ -870,7 +870,7 @@ def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
     xd, Sd, bd, awd, abd = x.to(dev), S.to(dev), bias.to(dev), aw.to(dev), ab.to(dev)
     outs = []
     try:
-        for mode in (1, 0, 1, 1):
+        for mode in (2, 0, 2, 2, 1):                          # compact lists (opt-in) x 3 | general kernel | default
             assert L.gnnpp_set_tuning(9, mode) == 0
             lg = torch.full((N, B, 5), float('nan'), device=dev)
             assert L.gnnpp_filter_head_fwd(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(),
@@ -882,6 +882,7 @@ def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
         L.gnnpp_set_tuning(9, 1)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert not torch.equal(outs[0], outs[4])              # (the opt-in mode really ran: the default is MODE 1's arithmetic)
     z = x.double()
     y = torch.zeros(B, N, 128, dtype=torch.float64)
     Sf = S.float().double()
