@@ -249,8 +249,8 @@ __device__ __forceinline__ void b3_conv_preload(const WStreamB& ws, v4f (&ring)[
 // LDS layouts (both inside region R; a "row" = 16 cells x [plane 3][q 4] x 16 bytes = 3 KiB, cell slot s at
 // row + plane * 1024 + q * 256 + s * 16, so the 16 lanes (q, q + 1 halves) of a ds_read_b128 group hit 16 distinct slots):
 //   L1 input (L0's output)  cell u = pos * N + n at row u >> 4, slot u & 15; the rows END at the end of R (L0 writes
-//        them while the pixel words at the front of R are still being read); the zero cell is slot 15 of the last row
-//        (25 N is not a multiple of 16 for N < 16);
+//        them while the pixel words at the front of R are still being read), followed by one row of zeros (a lane
+//        whose tap leaves the image reads ITS slot of that row);
 //   L2 input (L1's output)  agent n's 25 cells: slot (4 (y & 3) + (x & 3) + o(n)) & 15, o(n) = 4 (n & 3) + (n >> 2), in row
 //        n (y, x < 4) | 12 + (n >> 2) (y = 4) | 15 + (n & 3) (x = 4) | 19 (y = x = 4); row 20 = zeros.  Any 4x4 window of
 //        one agent's 5x5 image lies in 16 distinct slots (conflict-free tap reads), and the rows are shared between
@@ -271,7 +271,7 @@ __device__ __forceinline__ CpGeom cp_geom(int N) {
     g.N = N;
     g.ncol = 25 * N;
     g.T1 = (25 * N + 15) >> 4;
-    g.l1in = kB3Region - g.T1 * kCpRow;
+    g.l1in = kB3Region - (g.T1 + 1) * kCpRow;                      // (+ 1: the row of zeros behind the data rows)
     g.rcpN = (unsigned)(65536.f / (float)N) + 1u;
     return g;
 }
@@ -528,23 +528,44 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
 // wave jumps to its copy once (every copy carries the same ring traffic: tools/check_ring_isa.py walks each path).
 // One unit = the 12 MFMAs of a (tap, tile).  Software pipeline, two stages deep: at the START of unit u the three plane
 // reads of unit u + 1 are issued (their address was computed during unit u - 1), and the address arithmetic of unit
-// u + 2 is spread between the MFMAs of unit u -- one scheduling region, ordered by sched_group_barrier: (MFMA, LDS
-// read) x 3, then (MFMA, 3 VALU) x 4, then the remaining MFMAs.  History (C2, two workgroups per CU): run-time `if (i < na)` around
+// u + 2 is placed between the MFMAs of unit u in a fixed order (cp_unit below).  History (C2, two workgroups per CU): run-time `if (i < na)` around
 // every unit -> lgkmcnt(0) in front of every MFMA group, L2 14.7 us; static units, addresses + reads as a block in
 // front of the MFMAs -> 11.9 us (the ~10 address instructions leave the pipe idle: an in-order wave issues nothing
 // else meanwhile); interleaved, reads after the fourth MFMA -> 10.9 us; this form: see profiles/r04_cp_ab.jsonl.
-__device__ __forceinline__ void cp_interleave_unit() {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read (a plane of the next unit)
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);          // 3 VALU (the address of the unit after the next)
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);              // the other MFMAs
+// The twelve MFMAs of a unit in a FIXED order -- terms ascending, the two channel tiles alternating, so that
+// consecutive MFMAs never share an accumulator (left to the scheduler, sched_group_barrier(MFMA, 1) picks ANY ready
+// MFMA and builds runs of three on one accumulator: dependent back-to-back issue, 18 instead of 16.5 cycles each) --
+// with the next unit's three plane reads behind MFMAs 1 .. 3 and the two stages of the address arithmetic of the unit
+// after the next behind MFMAs 4 and 6.  sched_barrier(0) after every statement: nothing moves across.
+template <class Load, class StageA, class StageB>
+__device__ __forceinline__ void cp_unit(const v8b (&A)[2][3], const v4f (&B)[3], v4f& c0, v4f& c1, Load&& load,
+                                        StageA&& stage_a, StageB&& stage_b) {
+#define GNNPP_CP_M(T, ACC, MI)                                                                          \
+    ACC = mfma16b(A[MI][b3_term_a(T)], as_b8(B[b3_term_b(T)]), ACC);                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(0, c0, 0)
+    load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(0, c1, 1)
+    load(1);
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(1, c0, 0)
+    load(2);
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(1, c1, 1)
+    stage_a();
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(2, c0, 0)
+    GNNPP_CP_M(2, c1, 1)
+    stage_b();
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(3, c0, 0)
+    GNNPP_CP_M(3, c1, 1)
+    GNNPP_CP_M(4, c0, 0)
+    GNNPP_CP_M(4, c1, 1)
+    GNNPP_CP_M(5, c0, 0)
+    GNNPP_CP_M(5, c1, 1)
+#undef GNNPP_CP_M
 }
 // the address of the unit after the next is COMPLETE when its unit ends (left to the optimiser its last additions
 // sink to the reads that use it, in front of the next unit's first MFMA)
@@ -561,18 +582,30 @@ struct CpL1Lane {                 // per-lane constants of cp_layer1
 // LDS address (without the tile's immediate I * 4 rows) of lane j's planes for unit (TAP, I): the source column of lane
 // j is c + (dy 5 + dx) N -- tile-independent slot (j + shift) & 15 and row offset --, or the zero cell when the tap
 // leaves the image
+// stage A: the source cell of the tap (tile-independent part)
+template <int TAP>
+__device__ __forceinline__ int cp_l1_addr_a(const CpGeom& g, const CpL1Lane& ln, int wave) {
+    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+    const int sh = ln.j + (dy * 5 + dx) * g.N;                     // (arithmetic shift / mask below: floor semantics)
+    return g.l1in + (wave + (sh >> 4)) * kCpRow + ln.q * 256 + (sh & 15) * 16;
+}
+// stage B: ... or the zero cell when the tap leaves the image (branch-free on purpose: as a ternary the compiler turns
+// this into a divergent branch around the address arithmetic, and EXEC games inside the ring's region are what
+// tools/check_ring_isa.py refuses to reason about)
 template <int TAP, int I>
-__device__ __forceinline__ int cp_l1_addr(const CpGeom& g, const CpL1Lane& ln, int wave) {
+__device__ __forceinline__ int cp_l1_addr_b(const CpL1Lane& ln, int base) {
     constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
     constexpr unsigned tmask = (dy < 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dx < 0 ? 4u : 0u) | (dx > 0 ? 8u : 0u);
-    const int sh = ln.j + (dy * 5 + dx) * g.N;                     // (arithmetic shift / mask below: floor semantics)
-    const int base = g.l1in + (wave + (sh >> 4)) * kCpRow + ln.q * 256 + (sh & 15) * 16;
     if (tmask == 0u) return base;
-    // (branch-free on purpose: as a ternary the compiler turns this into a divergent branch around the address
-    // arithmetic, and EXEC games inside the ring's region are what tools/check_ring_isa.py refuses to reason about)
-    const int zero_cell = ln.zaddr - I * 4 * kCpRow;
+    // the zero ROW, at the lane's OWN slot: sixteen lanes keep sixteen distinct slots whichever of them are redirected
+    // (one shared zero cell put every redirected lane on the bank of whichever valid lane held that slot: PMC, r04)
+    const int zero_cell = ln.zaddr + (base & 0xf0) - I * 4 * kCpRow;
     const int outside = -(int)(((ln.fl >> (4 * I)) & tmask) != 0u);     // all ones / zero
     return base ^ ((base ^ zero_cell) & outside);
+}
+template <int TAP, int I>
+__device__ __forceinline__ int cp_l1_addr(const CpGeom& g, const CpL1Lane& ln, int wave) {
+    return cp_l1_addr_b<TAP, I>(ln, cp_l1_addr_a<TAP>(g, ln, wave));
 }
 template <int I>
 __device__ __forceinline__ void cp_l1_load(const char* smem, int addr, v4f (&B)[3]) {
@@ -594,16 +627,15 @@ __device__ __forceinline__ void cp_layer1_main(const WStreamB& ws, v4f (&ring)[k
         if constexpr (NA > 0) {
             auto unit = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, u = tap * NA + i;
-                if constexpr (u + 1 < NU) cp_l1_load<(u + 1) % NA>(smem, addr_next, Bb[(u + 1) & 1]);
-                if constexpr (u + 2 < NU) addr_next = cp_l1_addr<(u + 2) / NA, (u + 2) % NA>(g, ln, wave);
-#pragma unroll
-                for (int term = 0; term < kB3Terms; ++term)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[u & 1][b3_term_b(term)]), acc[i][m]);
-                cp_pin(addr_next);
-                cp_interleave_unit();
-                __builtin_amdgcn_sched_barrier(0);
+                int stage = 0;
+                cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
+                        [&](int p) {
+                            if constexpr (u + 1 < NU)
+                                Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr_next + ((u + 1) % NA) * 4 * kCpRow +
+                                                                                  p * kB3Frag);
+                        },
+                        [&]() { if constexpr (u + 2 < NU) stage = cp_l1_addr_a<(u + 2) / NA>(g, ln, wave); },
+                        [&]() { if constexpr (u + 2 < NU) addr_next = cp_l1_addr_b<(u + 2) / NA, (u + 2) % NA>(ln, stage); });
             };
             [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
                 std::make_integer_sequence<int, NA>{});
@@ -630,7 +662,7 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
         if (c >= g.ncol) f = 15u;                                   // no such column: every shifted tap reads zeros
         ln.fl |= f << (4 * i);
     }
-    ln.zaddr = g.l1in + (g.T1 - 1) * kCpRow + q * 256 + 15 * 16;
+    ln.zaddr = g.l1in + g.T1 * kCpRow + q * 256;                    // the row of zeros (slot 0 of this lane's q)
     v4f acc[NT][2];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
@@ -674,18 +706,29 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
 struct CpL2Lane {
     int q, y, x;
 };
-// LDS address of the planes of this lane's source cell for unit (TAP, agent n)   (n: wave-uniform)
+// LDS address of the planes of this lane's source cell for unit (TAP, agent n)   (n: wave-uniform), in two stages:
+// A = the slot inside the row, B = the row of the cell's class (interior / bottom edge / right edge / corner / outside)
 template <int TAP>
-__device__ __forceinline__ int cp_l2_addr(const CpL2Lane& ln, int n) {
+__device__ __forceinline__ int cp_l2_addr_a(const CpL2Lane& ln, int n) {
     constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
     const int yy = ln.y + dy, xx = ln.x + dx;                       // source cell of this lane: in -1 .. 4
     const int o = 4 * (n & 3) + (n >> 2);
+    return ln.q * 256 + ((4 * (yy & 3) + (xx & 3) + o) & 15) * 16;
+}
+template <int TAP>
+__device__ __forceinline__ int cp_l2_addr_b(const CpL2Lane& ln, int n, int slot) {
+    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+    const int yy = ln.y + dy, xx = ln.x + dx;
     int row = n;
     if (dy > 0) row = yy == 4 ? 12 + (n >> 2) : row;
     if (dx > 0) row = xx == 4 ? ((dy > 0 && yy == 4) ? 19 : 15 + (n & 3)) : row;
     if (dy < 0) row = yy < 0 ? 20 : row;
     if (dx < 0) row = xx < 0 ? 20 : row;
-    return row * kCpRow + ln.q * 256 + ((4 * (yy & 3) + (xx & 3) + o) & 15) * 16;
+    return row * kCpRow + slot;
+}
+template <int TAP>
+__device__ __forceinline__ int cp_l2_addr(const CpL2Lane& ln, int n) {
+    return cp_l2_addr_b<TAP>(ln, n, cp_l2_addr_a<TAP>(ln, n));
 }
 __device__ __forceinline__ void cp_l2_load(const char* smem, int addr, v4f (&B)[3]) {
 #pragma unroll
@@ -706,16 +749,17 @@ __device__ __forceinline__ void cp_layer2_main(const WStreamB& ws, v4f (&ring)[k
         if constexpr (NA > 0) {
             auto unit = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, u = tap * NA + i;
-                if constexpr (u + 1 < NU) cp_l2_load(smem, addr_next, Bb[(u + 1) & 1]);
-                if constexpr (u + 2 < NU) addr_next = cp_l2_addr<(u + 2) / NA>(ln, pair + 2 * ((u + 2) % NA));
-#pragma unroll
-                for (int term = 0; term < kB3Terms; ++term)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[i][m] = mfma16b(A[m][b3_term_a(term)], as_b8(Bb[u & 1][b3_term_b(term)]), acc[i][m]);
-                cp_pin(addr_next);
-                cp_interleave_unit();
-                __builtin_amdgcn_sched_barrier(0);
+                int stage = 0;
+                cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
+                        [&](int p) {
+                            if constexpr (u + 1 < NU)
+                                Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr_next + p * kB3Frag);
+                        },
+                        [&]() { if constexpr (u + 2 < NU) stage = cp_l2_addr_a<(u + 2) / NA>(ln, pair + 2 * ((u + 2) % NA)); },
+                        [&]() {
+                            if constexpr (u + 2 < NU)
+                                addr_next = cp_l2_addr_b<(u + 2) / NA>(ln, pair + 2 * ((u + 2) % NA), stage);
+                        });
             };
             [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
                 std::make_integer_sequence<int, NA>{});
@@ -885,8 +929,8 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             }
         }
         for (int i = tid; i < 2 * kObsFloatsLds / 4; i += kThreads) R4[i] = vzero();
-        if (CP && tid < kCpRow / 16)                       // the last row of L1's input holds its zero cell
-            *reinterpret_cast<v4f*>(gnnpp_smem + geom.l1in + (geom.T1 - 1) * kCpRow + tid * 16) = vzero();
+        if (CP && tid < kCpRow / 16)                       // the row of zeros behind L1's input rows
+            *reinterpret_cast<v4f*>(gnnpp_smem + geom.l1in + geom.T1 * kCpRow + tid * 16) = vzero();
         unsigned residual = 0;                             // any non-zero m / l plane among this thread's pixels
 #pragma unroll
         for (int i = 0; i < 3; ++i)

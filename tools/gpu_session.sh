@@ -72,6 +72,10 @@ if has pmc; then stamp "rocprofv3 pmc passes"
     python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt
     find $OUT/pmc_$name -name "*.csv" -size +2M -delete
   done; fi
+if has pmclds; then stamp "rocprofv3 pmc pass: LDS conflicts of the C2 launch"
+  timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_lds -o pmc -- python $R/bench.py --pmc-target > $OUT/pmc_lds.log 2>&1
+  python $R/tools/pmc_summary.py $OUT/pmc_lds 2>&1 | grep "encoder_kernel" | tee $OUT/pmc_lds_summary.txt
+  find $OUT/pmc_lds -name "*.csv" -size +2M -delete; fi
 if has filterpmc; then stamp "rocprofv3 pmc passes over the filter-only launch (B = 8192 graphs of 10 nodes)"
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
