@@ -505,12 +505,16 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
                 dense = true;
                 break;
             }
+            GNNPP_STAMP(blockIdx.x, 7, tid == 0 && k == 2);
             pf_gather<MODE, MODE == 3>(MODE == 3 ? Wc : Sl, MODE == 3 ? Ic : idx, MODE == 3 ? ccnt : cnt, zsrc,
                                        (B3 && last) ? nullptr : zdst, nullptr, Ns, last ? row_lo : 0,
                                        last ? row_hi : N, wave, lane, bad, PB, row_lo, row_hi, coff);
+            GNNPP_STAMP(blockIdx.x, 8, tid == 0 && k == 2);
             __syncthreads();                           // z_k visible
             GNNPP_STAMP(blockIdx.x, 5, tid == 0 && k == 1);
+            GNNPP_STAMP(blockIdx.x, 9, tid == 0 && k == 2);
             contract(zdst, Acur);
+            GNNPP_STAMP(blockIdx.x, 6, tid == 0 && k == 1);
             if (k + 1 < K) load_tap(Acur, k + 1);
         }
         if (MODE == 3 && dense) {
@@ -521,12 +525,13 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
             for (int i = tid; i < N * Ns; i += NT) Sl2[i] = zbuf1[i];
             unsigned* iz = reinterpret_cast<unsigned*>(idx2);
             for (int i = tid; i < (N * Ns) >> 2; i += NT) iz[i] = 0u;
-            v4f A1[8];
+            // (the fp32 fragments of a tap -- eight per wave -- go where the twelve plane fragments were: no second set of
+            // fragment registers for the rare path; one cost the common path 44 bytes of scratch)
             auto load_tap_f32 = [&](int tap) {
                 if (has_mfma) {
                     const float* wt = p.wpk + (size_t)tap * (8 * 8 * 256) + ((size_t)mt * 8 * 64 + lane) * 4;
 #pragma unroll
-                    for (int gg = 0; gg < 8; ++gg) A1[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
+                    for (int gg = 0; gg < 8; ++gg) Acur[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
                 }
             };
             load_tap_f32(1);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
 #pragma unroll
                         for (int st = 0; st < 4; ++st)
 #pragma unroll
-                            for (int t = 0; t < RTW; ++t) acc[t] = mfma16(A1[gg][st], Bf[t][st], acc[t]);
+                            for (int t = 0; t < RTW; ++t) acc[t] = mfma16(Acur[gg][st], Bf[t][st], acc[t]);
                     }
                 }
                 if (k + 1 < K) load_tap_f32(k + 1);

@@ -88,18 +88,21 @@ if 'filter' in which:
         x = torch.relu(torch.randn(B * N, 128, device=dev))
         enc, taps, gb, aw, ab, K = net.policy_pointers()
         lg = torch.empty(N, B, 5, device=dev)
-        for prec in (0, 1, 2):
+        for prec in (0, 3, 1, 2):                       # 3 = default precision with GNNPP_TUNE_POLICY_FILTER = 2 (MODE 3 at N > 64)
+            M.gnnpp_set_tuning(9, 2 if prec == 3 else 1)
             for _ in range(8):
                 assert M.gnnpp_filter_head_fwd(x.data_ptr(), S.data_ptr(), taps, gb, aw, ab, lg.data_ptr(), B, N, 128,
-                                               128, 3, 1, 0, prec, None, st) == 0
+                                               128, 3, 1, 0, 0 if prec == 3 else prec, None, st) == 0
                 torch.cuda.synchronize()
+            M.gnnpp_set_tuning(9, 1)
             if prec == 2:
                 order = [('entry', 0), ('staged', 1), ('lists', 2), ('tap0', 3), ('barrier1', 4), ('shift1', 5),
                          ('barrier2', 6), ('shift2', 7), ('split1', 8), ('tap1', 9), ('tap2', 12), ('partial', 13),
                          ('stored', 14)]
             else:
                 order = [('entry', 0), ('staged', 1), ('lists', 2), ('tap0', 3), ('barrier1', 4), ('shift1+barrier', 5),
-                         ('rest of the taps', 12), ('partial', 13), ('stored', 14)]
+                         ('tap1 issued', 6), ('barrier(k=2)', 7), ('shift2', 8), ('barrier', 9),
+                         ('tap2 issued', 12), ('partial', 13), ('stored', 14)]
             report('policy_filter_kernel prec=%d B=%d N=%d' % (prec, B, N), B, order)
 
 if 'small' in which:
