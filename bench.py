@@ -153,6 +153,27 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
         out = step()
     nst = 30
     r = sorted(x[0] for x in timed_regions(step, nst, 3, collective=False))[1] / nst
+    # the same step replayed from a HIP graph (what a rollout harness with static input buffers can do): without the host's
+    # enqueue cost, which a two-launch step of ~55 us of device time does not hide
+    graphed = None
+    if batch is not None:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                out_g = step()
+            for _ in range(5):
+                cg.replay()
+            rg = sorted(x[0] for x in timed_regions(cg.replay, nst, 3, collective=False))[1] / nst
+            same = all(torch.equal(a_, b_) for a_, b_ in zip(out_g, out))
+            graphed = {'value': M / rg, 'ms_per_step': 1e3 * rg, 'bit_identical_to_eager': bool(same)}
+        except Exception as e:                             # an extra: never break the record
+            graphed = {'error': '%s: %s' % (type(e).__name__, e)}
     prec = net._prec()
     enc = net.packed_encoder()
     feat = torch.empty(M, 128, device=dev)
@@ -175,7 +196,8 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     clear = margin > 1e-5
     ids_w = orc.decode_actions(want)
     ids_g = torch.stack([g.argmax(-1) for g in got], 1)
-    return {'agents': N, 'taps': K, 'batch': B, 'mean_degree': round(mean_deg, 3),
+    rec_extra = {'hip_graph_replay': graphed} if graphed is not None else {}
+    return {**rec_extra, 'agents': N, 'taps': K, 'batch': B, 'mean_degree': round(mean_deg, 3),
             'value': M / r, 'unit': 'agent-steps/s', 'ms_per_step': 1e3 * r,
             'dominant_kernel': rl['kernel'], 'dominant_kernel_us': t_enc * 1e6, 'frac': rl['frac'],
             'frac_of_arithmetic_ceiling': rl['frac_of_arithmetic_ceiling'], 'pipe_busy_frac': rl['pipe_busy_frac'],
@@ -291,6 +313,9 @@ def compact_summary(d):
                                      'dlogit': r(v['parity_train_mode_max_abs_dlogit'], 2)}
         elif k.startswith('c5_shard'):
             out[k] = rec(v)
+            g_ = v.get('hip_graph_replay') or {}
+            if 'value' in g_:
+                out[k + '_graphed_M_per_s'] = r(g_['value'] / 1e6)
     rv = sec.get('real_valued_observations') or {}
     if 'agent_steps_per_s' in rv:
         out['real_valued_obs_M_per_s'] = r(rv['agent_steps_per_s'] / 1e6)

@@ -17,10 +17,18 @@ HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='needs hipcc')
 def test_ring_registers_are_private_to_the_asm(tmp_path):
     import check_ring_isa
-    out = str(tmp_path / 'gnnpp.s')
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
-                           '-Wno-unused-result', '-w',
-                           os.path.join(ROOT, 'gnn_pathplanning_amd', 'csrc', 'gnnpp_api.hip'), '-o', out])
+    # The ISA of the very compilation that produced libgnnpp.so is kept by _native.build() (-save-temps); when it is
+    # at least as new as every source it IS the code that ships: check that.  Otherwise compile here (two minutes).
+    csrc = os.path.join(ROOT, 'gnn_pathplanning_amd', 'csrc')
+    kept = os.path.join(ROOT, 'gnn_pathplanning_amd', 'build', 'product', 'gnnpp_api-hip-amdgcn-amd-amdhsa-gfx950.s')
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
+    newest = max(newest, os.path.getmtime(os.path.join(ROOT, 'include', 'gnnpp.h')))
+    if os.path.exists(kept) and os.path.getmtime(kept) >= newest:
+        out = kept
+    else:
+        out = str(tmp_path / 'gnnpp.s')
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
+                               '-Wno-unused-result', '-w', os.path.join(csrc, 'gnnpp_api.hip'), '-o', out])
     # encoder only (196 stream items) and the fused policy kernels (+ 16 filter-tap fragments per tap, K = 2, 3, 4)
     from gnn_pathplanning_amd._native import RING_KERNELS
     # split-f16: 196 + 16 K; bf16x3 (default): 294 + 24 K; r04: the column-packed forms of the bf16x3 kernels (fused
