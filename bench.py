@@ -899,6 +899,8 @@ def main():
                         try:
                             rec = quick_config(orc, L, _native, 'c5', kk, dev, timed_regions, time_kernel, vp, st, batch=16)
                             rec['predicted_8gpu_value'] = 8.0 * rec['value']
+                            if 'value' in (rec.get('hip_graph_replay') or {}):
+                                rec['predicted_8gpu_value_graph_replay'] = 8.0 * rec['hip_graph_replay']['value']
                             rec['vs_full_batch_rate'] = rec['value'] / others['c5_K%d' % kk]['value']
                             shards['c5_shard_K%d' % kk] = rec
                         except Exception as e:

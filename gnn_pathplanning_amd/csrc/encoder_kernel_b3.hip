@@ -537,9 +537,20 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
 // MFMA and builds runs of three on one accumulator: dependent back-to-back issue, 18 instead of 16.5 cycles each) --
 // with the next unit's three plane reads behind MFMAs 1 .. 3 and the two stages of the address arithmetic of the unit
 // after the next behind MFMAs 4 and 6.  sched_barrier(0) after every statement: nothing moves across.
+// `skip` (wave-uniform): every column of the tile lies outside the image for this tap -- twelve MFMAs on all-zero
+// operands: only the next unit's reads and the address stages are issued.
 template <class Load, class StageA, class StageB>
 __device__ __forceinline__ void cp_unit(const v8b (&A)[2][3], const v4f (&B)[3], v4f& c0, v4f& c1, Load&& load,
-                                        StageA&& stage_a, StageB&& stage_b) {
+                                        StageA&& stage_a, StageB&& stage_b, bool skip = false) {
+    if (skip) {
+        load(0);
+        load(1);
+        load(2);
+        stage_a();
+        stage_b();
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
 #define GNNPP_CP_M(T, ACC, MI)                                                                          \
     ACC = mfma16b(A[MI][b3_term_a(T)], as_b8(B[b3_term_b(T)]), ACC);                                   \
     __builtin_amdgcn_sched_barrier(0);
@@ -578,6 +589,8 @@ __device__ __forceinline__ void cp_pin(int& v) {
 struct CpL1Lane {                 // per-lane constants of cp_layer1
     int j, q, zaddr;
     unsigned fl;                  // per tile: y == 0 | y == 4 | x == 0 | x == 4  (4 bits each)
+    bool skip_up, skip_down;      // (wave-uniform) the wave's FIRST tile lies entirely in image row 0 -- its dy = -1 taps
+                                  // multiply zeros --, its LAST tile entirely in row 4 (or past the last column): dy = +1
 };
 // LDS address (without the tile's immediate I * 4 rows) of lane j's planes for unit (TAP, I): the source column of lane
 // j is c + (dy 5 + dx) N -- tile-independent slot (j + shift) & 15 and row offset --, or the zero cell when the tap
@@ -635,7 +648,8 @@ __device__ __forceinline__ void cp_layer1_main(const WStreamB& ws, v4f (&ring)[k
                                                                                   p * kB3Frag);
                         },
                         [&]() { if constexpr (u + 2 < NU) stage = cp_l1_addr_a<(u + 2) / NA>(g, ln, wave); },
-                        [&]() { if constexpr (u + 2 < NU) addr_next = cp_l1_addr_b<(u + 2) / NA, (u + 2) % NA>(ln, stage); });
+                        [&]() { if constexpr (u + 2 < NU) addr_next = cp_l1_addr_b<(u + 2) / NA, (u + 2) % NA>(ln, stage); },
+                        (tap < 3 && i == 0 && ln.skip_up) || (tap >= 6 && i == NA - 1 && ln.skip_down));
             };
             [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
                 std::make_integer_sequence<int, NA>{});
@@ -663,6 +677,9 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
         ln.fl |= f << (4 * i);
     }
     ln.zaddr = g.l1in + g.T1 * kCpRow + q * 256;                    // the row of zeros (slot 0 of this lane's q)
+    // N = 10: tiles 0 .. 2 are row 0, tiles 13 .. 15 row 4: 18 of the 144 (tile, tap) units are skipped
+    ln.skip_up = na > 0 && __ballot((ln.fl & 1u) == 0u) == 0ull;
+    ln.skip_down = na > 0 && __ballot(((ln.fl >> (4 * max(na - 1, 0))) & 2u) == 0u) == 0ull;
     v4f acc[NT][2];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
