@@ -219,6 +219,35 @@ __device__ __forceinline__ void b3_stream_steps(const WStreamB& ws, v4f (&ring)[
     (step(std::integral_constant<int, IT>{}), ...);
 }
 
+// The same stream for the column-packed layers (NMT = 2), whose steps are short (12 NA MFMAs): the six fragments of step
+// it + 1 are taken (and their slots refilled) BETWEEN the MFMAs of step it -- body(itc, A, item) calls item(kc) for
+// kc = 0 .. 5 at the places it chooses --, two fragment sets alternating.  Ring order, and with it every vmcnt, is the one
+// of b3_stream_steps; only step 0's six takes stay a block in front of the layer.  (A lone wave issues one MFMA per 16
+// cycles and anything else in between for free; as a block the 36 instructions of a step's takes cost it 4 cycles each:
+// tools/probe/cp_stream_probe.hip, profiles/r04_cp_stream_probe.jsonl.)
+template <int END, int START, class Body, int... IT>
+__device__ __forceinline__ void b3_stream_steps_spread(const WStreamB& ws, v4f (&ring)[kRingH], Body&& body,
+                                                       std::integer_sequence<int, IT...>) {
+    constexpr int NIT = sizeof...(IT);
+    v8b A[2][2][3];
+    auto item = [&](auto itc, auto kc) {
+        constexpr int it = decltype(itc)::value, k = decltype(kc)::value, idx = START + it * 6 + k;
+        A[it & 1][k / 3][k % 3] = as_b8(ring_take_f4<END>(ring, idx));
+        h2_ring_load<END>(ws, ring, idx + kRingH);
+    };
+    __builtin_amdgcn_sched_barrier(kSchedItemMask);
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+        (item(std::integral_constant<int, 0>{}, std::integral_constant<int, K>{}), ...);
+    }(std::make_integer_sequence<int, 6>{});
+    auto step = [&](auto itc) {
+        constexpr int it = decltype(itc)::value;
+        body(itc, A[it & 1], [&](auto kc) {
+            if constexpr (it + 1 < NIT) item(std::integral_constant<int, it + 1>{}, kc);
+        });
+    };
+    (step(std::integral_constant<int, IT>{}), ...);
+}
+
 // a whole 2x2 layer for one position set, its input preloaded into registers
 template <int END, int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn>
 __device__ __forceinline__ void b3_conv_preload(const WStreamB& ws, v4f (&ring)[kRingH], const v4f* in,
@@ -526,33 +555,32 @@ __device__ __forceinline__ void b3_l0_stream(const float* __restrict__ pk, const
 // its own basic block, the compiler then waits for lgkmcnt(0) -- the prefetch included -- in front of every MFMA group
 // (measured: L2 14.7 us instead of 11.9 for 26 % fewer MFMAs); the layer is instantiated for NA = 0 .. NT and the
 // wave jumps to its copy once (every copy carries the same ring traffic: tools/check_ring_isa.py walks each path).
-// One unit = the 12 MFMAs of a (tap, tile).  Software pipeline, two stages deep: at the START of unit u the three plane
-// reads of unit u + 1 are issued (their address was computed during unit u - 1), and the address arithmetic of unit
-// u + 2 is placed between the MFMAs of unit u in a fixed order (cp_unit below).  History (C2, two workgroups per CU): run-time `if (i < na)` around
-// every unit -> lgkmcnt(0) in front of every MFMA group, L2 14.7 us; static units, addresses + reads as a block in
-// front of the MFMAs -> 11.9 us (the ~10 address instructions leave the pipe idle: an in-order wave issues nothing
-// else meanwhile); interleaved, reads after the fourth MFMA -> 10.9 us; this form: see profiles/r04_cp_ab.jsonl.
-// The twelve MFMAs of a unit in a FIXED order -- terms ascending, the two channel tiles alternating, so that
-// consecutive MFMAs never share an accumulator (left to the scheduler, sched_group_barrier(MFMA, 1) picks ANY ready
-// MFMA and builds runs of three on one accumulator: dependent back-to-back issue, 18 instead of 16.5 cycles each) --
-// with the next unit's three plane reads behind MFMAs 1 .. 3 and the two stages of the address arithmetic of the unit
-// after the next behind MFMAs 4 and 6.  sched_barrier(0) after every statement: nothing moves across.
-// `skip` (wave-uniform): every column of the tile lies outside the image for this tap -- twelve MFMAs on all-zero
-// operands: only the next unit's reads and the address stages are issued.
-template <class Load, class StageA, class StageB>
-__device__ __forceinline__ void cp_unit(const v8b (&A)[2][3], const v4f (&B)[3], v4f& c0, v4f& c1, Load&& load,
-                                        StageA&& stage_a, StageB&& stage_b, bool skip = false) {
-    if (skip) {
-        load(0);
-        load(1);
-        load(2);
-        stage_a();
-        stage_b();
-        __builtin_amdgcn_sched_barrier(0);
-        return;
-    }
+// One unit = the 12 MFMAs of a (tap, tile).  EVERY unit's per-lane LDS address is computed at the START of the layer
+// (9 NA registers, pinned with an empty asm so that nothing is rematerialised next to its read): a unit's instruction
+// stream is then what the agents-on-columns layers' is -- the three plane reads of unit u + 1 (address register +
+// immediate), twelve MFMAs, one s_waitcnt.  History (C2, two workgroups per CU): run-time `if (i < na)` around every
+// unit -> lgkmcnt(0) in front of every MFMA group, L2 14.7 us; addresses computed per unit, as a block in front of the
+// MFMAs or spread between them -> 10.9 - 11.9 us, 21 - 24 cycles per MFMA whatever the placement (a VALU instruction
+// between two MFMAs costs the wave far more than its issue slot -- MI355X_MICROARCH.md, "one EXTRA issue slot" -- and
+// the compiler re-used freshly written accumulator registers for the temporaries); this form: profiles/r04_cp_ab.jsonl.
+// The twelve MFMAs in a FIXED order -- terms ascending, the two channel tiles alternating, so that consecutive MFMAs
+// never share an accumulator; sched_barrier(0) after every statement: nothing moves across.
+// which of the next step's six ring items (b3_stream_steps_spread) unit i of NA handles at hook slot s (0 .. 5; -1: none):
+// item k belongs to unit k NA / 6, a unit's items are spread evenly over its slots
+__host__ __device__ __forceinline__ constexpr int cp_ring_item_at(int NA, int i, int s) {
+    int first = -1, cnt = 0;
+    for (int k = 0; k < 6; ++k)
+        if (k * NA / 6 == i) { if (first < 0) first = k; ++cnt; }
+    if (cnt == 0 || s % (6 / cnt) != 0 || s / (6 / cnt) >= cnt) return -1;
+    return first + s / (6 / cnt);
+}
+template <class Load, class Hook>
+__device__ __forceinline__ void cp_unit(const v8b (&A)[2][3], const v4f (&B)[3], v4f& c0, v4f& c1, Load&& load, Hook&& hook) {
 #define GNNPP_CP_M(T, ACC, MI)                                                                          \
     ACC = mfma16b(A[MI][b3_term_a(T)], as_b8(B[b3_term_b(T)]), ACC);                                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define GNNPP_CP_H(S)                                                                                   \
+    hook(std::integral_constant<int, S>{});                                                             \
     __builtin_amdgcn_sched_barrier(0);
     GNNPP_CP_M(0, c0, 0)
     load(0);
@@ -564,22 +592,24 @@ __device__ __forceinline__ void cp_unit(const v8b (&A)[2][3], const v4f (&B)[3],
     load(2);
     __builtin_amdgcn_sched_barrier(0);
     GNNPP_CP_M(1, c1, 1)
-    stage_a();
-    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_H(0)
     GNNPP_CP_M(2, c0, 0)
+    GNNPP_CP_H(1)
     GNNPP_CP_M(2, c1, 1)
-    stage_b();
-    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_H(2)
     GNNPP_CP_M(3, c0, 0)
+    GNNPP_CP_H(3)
     GNNPP_CP_M(3, c1, 1)
+    GNNPP_CP_H(4)
     GNNPP_CP_M(4, c0, 0)
+    GNNPP_CP_H(5)
     GNNPP_CP_M(4, c1, 1)
     GNNPP_CP_M(5, c0, 0)
     GNNPP_CP_M(5, c1, 1)
+#undef GNNPP_CP_H
 #undef GNNPP_CP_M
 }
-// the address of the unit after the next is COMPLETE when its unit ends (left to the optimiser its last additions
-// sink to the reads that use it, in front of the next unit's first MFMA)
+// an address is COMPLETE where it is computed (left to the optimiser its last additions sink to the read that uses it)
 __device__ __forceinline__ void cp_pin(int& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(v));
@@ -587,74 +617,67 @@ __device__ __forceinline__ void cp_pin(int& v) {
 }
 
 struct CpL1Lane {                 // per-lane constants of cp_layer1
-    int j, q, zaddr;
+    int j, q, zaddr, tile0;       // tile0: this lane's (q) block of the wave's first tile row
     unsigned fl;                  // per tile: y == 0 | y == 4 | x == 0 | x == 4  (4 bits each)
-    bool skip_up, skip_down;      // (wave-uniform) the wave's FIRST tile lies entirely in image row 0 -- its dy = -1 taps
-                                  // multiply zeros --, its LAST tile entirely in row 4 (or past the last column): dy = +1
 };
-// LDS address (without the tile's immediate I * 4 rows) of lane j's planes for unit (TAP, I): the source column of lane
-// j is c + (dy 5 + dx) N -- tile-independent slot (j + shift) & 15 and row offset --, or the zero cell when the tap
-// leaves the image
-// stage A: the source cell of the tap (tile-independent part)
-template <int TAP>
-__device__ __forceinline__ int cp_l1_addr_a(const CpGeom& g, const CpL1Lane& ln, int wave) {
-    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
-    const int sh = ln.j + (dy * 5 + dx) * g.N;                     // (arithmetic shift / mask below: floor semantics)
-    return g.l1in + (wave + (sh >> 4)) * kCpRow + ln.q * 256 + (sh & 15) * 16;
-}
-// stage B: ... or the zero cell when the tap leaves the image (branch-free on purpose: as a ternary the compiler turns
-// this into a divergent branch around the address arithmetic, and EXEC games inside the ring's region are what
-// tools/check_ring_isa.py refuses to reason about)
-template <int TAP, int I>
-__device__ __forceinline__ int cp_l1_addr_b(const CpL1Lane& ln, int base) {
-    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
-    constexpr unsigned tmask = (dy < 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dx < 0 ? 4u : 0u) | (dx > 0 ? 8u : 0u);
-    if (tmask == 0u) return base;
-    // the zero ROW, at the lane's OWN slot: sixteen lanes keep sixteen distinct slots whichever of them are redirected
-    // (one shared zero cell put every redirected lane on the bank of whichever valid lane held that slot: PMC, r04)
-    const int zero_cell = ln.zaddr + (base & 0xf0) - I * 4 * kCpRow;
-    const int outside = -(int)(((ln.fl >> (4 * I)) & tmask) != 0u);     // all ones / zero
-    return base ^ ((base ^ zero_cell) & outside);
-}
+// LDS address of lane j's planes for unit (TAP, I): the source column of lane j is c + (dy 5 + dx) N -- a tile-independent
+// slot (j + shift) & 15 and row offset, plus the tile's four rows --, or the lane's OWN slot of the zero row when the tap
+// leaves the image: sixteen lanes keep sixteen distinct slots whichever of them are redirected (one shared zero cell put
+// every redirected lane on the bank of whichever valid lane held that slot: PMC, r04).  Branch-free on purpose: as a
+// ternary the compiler turns the choice into a divergent branch around the address arithmetic, and EXEC games inside the
+// ring's region are what tools/check_ring_isa.py refuses to reason about.
 template <int TAP, int I>
 __device__ __forceinline__ int cp_l1_addr(const CpGeom& g, const CpL1Lane& ln, int wave) {
-    return cp_l1_addr_b<TAP, I>(ln, cp_l1_addr_a<TAP>(g, ln, wave));
+    constexpr int dy = TAP / 3 - 1, dx = TAP % 3 - 1;
+    constexpr unsigned tmask = (dy < 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dx < 0 ? 4u : 0u) | (dx > 0 ? 8u : 0u);
+    // (tap part | tile part: written so that the tap part is common to a tap's units and the tile part to a tile's --
+    // as one product (wave + 4 I + (sh >> 4)) * row the compiler issued a 64-bit multiply-add per unit)
+    const int sh = ln.j + (dy * 5 + dx) * g.N;                     // (arithmetic shift / mask below: floor semantics)
+    const int slot = (sh & 15) * 16;
+    const int tap_part = __mul24(sh >> 4, kCpRow) + slot;
+    const int cell = tap_part + (ln.tile0 + I * 4 * kCpRow);
+    if (tmask == 0u) return cell;
+    const int zero_cell = ln.zaddr + slot;
+    const int outside = -(int)(((ln.fl >> (4 * I)) & tmask) != 0u);     // all ones / zero
+    return cell ^ ((cell ^ zero_cell) & outside);
 }
-template <int I>
 __device__ __forceinline__ void cp_l1_load(const char* smem, int addr, v4f (&B)[3]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) B[p] = *reinterpret_cast<const v4f*>(smem + addr + I * 4 * kCpRow + p * kB3Frag);
+    for (int p = 0; p < 3; ++p) B[p] = *reinterpret_cast<const v4f*>(smem + addr + p * kB3Frag);
 }
 template <int END, int NA>
 __device__ __forceinline__ void cp_layer1_main(const WStreamB& ws, v4f (&ring)[kRingH], const char* smem, const CpGeom& g,
                                                const CpL1Lane& ln, int wave, v4f (&acc)[kCpL1Tiles][2]) {
     constexpr int NU = 9 * NA;                                      // units of this wave
     v4f Bb[2][3];
-    int addr_next = 0;                                              // address of unit u + 1 at the start of unit u
     if constexpr (NA > 0) {
-        cp_l1_load<0>(smem, cp_l1_addr<0, 0>(g, ln, wave), Bb[0]);
-        if constexpr (NU > 1) addr_next = cp_l1_addr<1 / NA, 1 % NA>(g, ln, wave);
-    }
-    b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
-        constexpr int tap = decltype(itc)::value;
-        if constexpr (NA > 0) {
+        int addr[NU];                                               // unit u = (tap, tile): this lane's cell, tile row included
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((addr[U] = cp_l1_addr<U / NA, U % NA>(g, ln, wave), cp_pin(addr[U])), ...);
+        }(std::make_integer_sequence<int, NU>{});
+        __builtin_amdgcn_sched_barrier(0);
+        GNNPP_STAMP(blockIdx.x, 7, wave == 0 && ln.j == 0 && ln.q == 0);
+        cp_l1_load(smem, addr[0], Bb[0]);
+        b3_stream_steps_spread<END, kb_L1>(ws, ring, [&](auto itc, const v8b (&A)[2][3], auto&& ring_item) {
+            constexpr int tap = decltype(itc)::value;
             auto unit = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, u = tap * NA + i;
-                int stage = 0;
                 cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
                         [&](int p) {
                             if constexpr (u + 1 < NU)
-                                Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr_next + ((u + 1) % NA) * 4 * kCpRow +
-                                                                                  p * kB3Frag);
+                                Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr[u + 1] + p * kB3Frag);
                         },
-                        [&]() { if constexpr (u + 2 < NU) stage = cp_l1_addr_a<(u + 2) / NA>(g, ln, wave); },
-                        [&]() { if constexpr (u + 2 < NU) addr_next = cp_l1_addr_b<(u + 2) / NA, (u + 2) % NA>(ln, stage); },
-                        (tap < 3 && i == 0 && ln.skip_up) || (tap >= 6 && i == NA - 1 && ln.skip_down));
+                        [&](auto sc) {
+                            constexpr int k = cp_ring_item_at(NA, i, decltype(sc)::value);
+                            if constexpr (k >= 0) ring_item(std::integral_constant<int, k>{});
+                        });
             };
             [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
                 std::make_integer_sequence<int, NA>{});
-        }
-    }, std::make_integer_sequence<int, 9>{});
+        }, std::make_integer_sequence<int, 9>{});
+    } else {
+        b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto, const v8b (&)[2][3]) {}, std::make_integer_sequence<int, 9>{});
+    }
 }
 
 template <int END>
@@ -677,9 +700,7 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
         ln.fl |= f << (4 * i);
     }
     ln.zaddr = g.l1in + g.T1 * kCpRow + q * 256;                    // the row of zeros (slot 0 of this lane's q)
-    // N = 10: tiles 0 .. 2 are row 0, tiles 13 .. 15 row 4: 18 of the 144 (tile, tap) units are skipped
-    ln.skip_up = na > 0 && __ballot((ln.fl & 1u) == 0u) == 0ull;
-    ln.skip_down = na > 0 && __ballot(((ln.fl >> (4 * max(na - 1, 0))) & 2u) == 0u) == 0ull;
+    ln.tile0 = g.l1in + wave * kCpRow + q * 256;
     v4f acc[NT][2];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = vzero();
@@ -692,7 +713,9 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
         case 4: cp_layer1_main<END, 4>(ws, ring, smem, g, ln, wave, acc); break;
         default: cp_layer1_main<END, 5>(ws, ring, smem, g, ln, wave, acc); break;
     }
+    GNNPP_STAMP(blockIdx.x, 8, tid == 0);
     __syncthreads();                                               // everyone is done reading L0's output
+    GNNPP_STAMP(blockIdx.x, 9, tid == 0);
     if (tid < kCpRow / 16) *reinterpret_cast<v4f*>(smem + 20 * kCpRow + tid * 16) = vzero();   // L2 input's zero row
     v4f sc[2], shf[2];
     load_ss(sstab + EncLayout::kBssL1, 32, 0, q, sc[0], shf[0]);
@@ -756,32 +779,34 @@ __device__ __forceinline__ void cp_layer2_main(const WStreamB& ws, v4f (&ring)[k
                                                const CpL2Lane& ln, int pair, v4f (&acc)[kCpL2Tiles][2]) {
     constexpr int NU = 9 * NA;
     v4f Bb[2][3];
-    int addr_next = 0;
     if constexpr (NA > 0) {
-        cp_l2_load(smem, cp_l2_addr<0>(ln, pair), Bb[0]);
-        if constexpr (NU > 1) addr_next = cp_l2_addr<1 / NA>(ln, pair + 2 * (1 % NA));
-    }
-    b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto itc, const v8b (&A)[2][3]) {
-        constexpr int tap = decltype(itc)::value;
-        if constexpr (NA > 0) {
+        int addr[NU];                                               // unit u = (tap, agent pair + 2 (u % NA))
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((addr[U] = cp_l2_addr<U / NA>(ln, pair + 2 * (U % NA)), cp_pin(addr[U])), ...);
+        }(std::make_integer_sequence<int, NU>{});
+        __builtin_amdgcn_sched_barrier(0);
+        GNNPP_STAMP(blockIdx.x, 15, pair == 0 && ln.q == 0 && ln.y == 0 && ln.x == 0);
+        cp_l2_load(smem, addr[0], Bb[0]);
+        b3_stream_steps_spread<END, kb_L2>(ws, ring, [&](auto itc, const v8b (&A)[2][3], auto&& ring_item) {
+            constexpr int tap = decltype(itc)::value;
             auto unit = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, u = tap * NA + i;
-                int stage = 0;
                 cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
                         [&](int p) {
                             if constexpr (u + 1 < NU)
-                                Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr_next + p * kB3Frag);
+                                Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr[u + 1] + p * kB3Frag);
                         },
-                        [&]() { if constexpr (u + 2 < NU) stage = cp_l2_addr_a<(u + 2) / NA>(ln, pair + 2 * ((u + 2) % NA)); },
-                        [&]() {
-                            if constexpr (u + 2 < NU)
-                                addr_next = cp_l2_addr_b<(u + 2) / NA>(ln, pair + 2 * ((u + 2) % NA), stage);
+                        [&](auto sc) {
+                            constexpr int k = cp_ring_item_at(NA, i, decltype(sc)::value);
+                            if constexpr (k >= 0) ring_item(std::integral_constant<int, k>{});
                         });
             };
             [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
                 std::make_integer_sequence<int, NA>{});
-        }
-    }, std::make_integer_sequence<int, 9>{});
+        }, std::make_integer_sequence<int, 9>{});
+    } else {
+        b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto, const v8b (&)[2][3]) {}, std::make_integer_sequence<int, 9>{});
+    }
 }
 
 template <int END>

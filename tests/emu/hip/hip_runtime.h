@@ -96,6 +96,7 @@ f4 mfma16x16x32_bf16(b8 a, b8 b, f4 c, int, int, int);
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
 #define __umul24(a, b) ((unsigned)(a) * (unsigned)(b))
+#define __mul24(a, b) ((int)(a) * (int)(b))
 #define __builtin_amdgcn_readlane(v, l) gnnpp_emu::readlane((v), (l))
 #define __shfl_xor(v, m) gnnpp_emu::shfl_xor((v), (m))
 // (only the quad_perm controls 0x00..0xff with full row / bank masks are used by the kernels)

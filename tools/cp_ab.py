@@ -96,6 +96,12 @@ def main():
                 ph['total_max'] = round(float(np.max(tot)), 2)
                 ok = tot > 0
                 ph['clock_GHz'] = round(float(np.median((cyc[:, 14] - cyc[:, 11])[ok] / tot[ok])) * 1e-3, 3)
+                if cp:
+                    ph['L1_addr'] = round(float(np.median(us_[:, 7] - us_[:, 1])), 2)
+                    ph['L1_stream_wave0'] = round(float(np.median(us_[:, 8] - us_[:, 7])), 2)
+                    ph['L1_barrier'] = round(float(np.median(us_[:, 9] - us_[:, 8])), 2)
+                    ph['L1_epilogue'] = round(float(np.median(us_[:, 2] - us_[:, 9])), 2)
+                    ph['L2_addr'] = round(float(np.median(us_[:, 15] - us_[:, 2])), 2)
                 row['stamps_cp%d' % cp] = ph
             M.gnnpp_set_tuning(13, 1)
         print(json.dumps(row), flush=True)
