@@ -334,8 +334,8 @@ __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p
             const int r = i >> 5, c4 = i & 31;
             // (every row of z is written, zeros past the group's rows: the dense shift multiplies the rows behind a
             // graph by zero weights, and 0 x stale-NaN would still be NaN)
-            if (K > 1) *reinterpret_cast<v4f*>(z + r * kSmZs + 4 * c4) = xv[u];
-            if (i < rows * 32) {
+            if (K > 1 && !GNNPP_ABLATE(p, 0x100)) *reinterpret_cast<v4f*>(z + r * kSmZs + 4 * c4) = xv[u];
+            if (i < rows * 32 && !GNNPP_ABLATE(p, 0x200)) {
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<v2f*>(PBn + r * kSmPRow + pp * 256 + 8 * c4) = pl[pp];
             }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p
 #pragma unroll
                 for (int s4 = 0; s4 < NS4; ++s4) {
                     const int m = r0 + min(4 * s4 + q, N - 1);     // (k-slots past the graph: its OWN last row x zero weight)
-                    d[f4] = mfma16(z[m * kSmZs + 16 * ft + a], Sb[s4], d[f4]);
+                    d[f4] = mfma16(GNNPP_ABLATE(p, 0x40) ? Sb[s4] : z[m * kSmZs + 16 * ft + a], Sb[s4], d[f4]);
                 }
             }
             __builtin_amdgcn_wave_barrier();                       // every row of these columns has been read
@@ -380,10 +380,12 @@ __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p
                 b3_split4(d[f4], pl);
                 if (a < N) {
                     const int r = r0 + a;
-                    *reinterpret_cast<v4f*>(z + r * kSmZs + 16 * ft + 4 * q) = d[f4];
+                    if (!GNNPP_ABLATE(p, 0x20)) *reinterpret_cast<v4f*>(z + r * kSmZs + 16 * ft + 4 * q) = d[f4];
+                    if (!GNNPP_ABLATE(p, 0x10)) {
 #pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-                        *reinterpret_cast<v2f*>(PBn + r * kSmPRow + pp * 256 + (16 * ft + 4 * q) * 2) = pl[pp];
+                        for (int pp = 0; pp < 3; ++pp)
+                            *reinterpret_cast<v2f*>(PBn + r * kSmPRow + pp * 256 + (16 * ft + 4 * q) * 2) = pl[pp];
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -485,7 +487,8 @@ __global__ __launch_bounds__(512, 1) void lsigf_pipe_b3_kernel(const LsigfArgs p
                     const char* zrow = PBc + pr * kSmPRow + kb * 64 + q * 16;
                     v8b Bp[3];
 #pragma unroll
-                    for (int pp = 0; pp < 3; ++pp) Bp[pp] = as_b8(*reinterpret_cast<const v4f*>(zrow + pp * 256));
+                    for (int pp = 0; pp < 3; ++pp)
+                        Bp[pp] = GNNPP_ABLATE(p, 0x80) ? as_b8(A[0][pp]) : as_b8(*reinterpret_cast<const v4f*>(zrow + pp * 256));
 #pragma unroll
                     for (int term = 0; term < kB3Terms; ++term)
 #pragma unroll
@@ -550,7 +553,7 @@ static int lsigf_small_dispatch(LsigfArgs a, hipStream_t st) {
         a.Nin != a.N || a.N > kSmMaxNodes || a.K < 1 || (a.y && !a.y_node_major) || (!a.y && !a.act_w) ||
         (reinterpret_cast<uintptr_t>(a.x) & 15) || (a.y && (reinterpret_cast<uintptr_t>(a.y) & 15))
 #ifdef GNNPP_MEASURE
-        || a.ablate
+        || (a.ablate & 0xf)            // (bits 0x10 .. 0x200 ablate accesses of the pipeline kernel below)
 #endif
     )
         return 1;

@@ -52,7 +52,23 @@ def run(B, mode, reps, rows=0):
 
 if len(sys.argv) > 2 and sys.argv[1] == '--pmc-target':
     rows = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if len(sys.argv) > 4:                                 # access-ablation mask of the pipeline kernel (measure build)
+        L = _native.measure_lib()
+        assert L.gnnpp_set_tuning(3, int(sys.argv[4], 0)) == 0
     run(int(sys.argv[2]), (3 if rows == 64 else 2) if rows else 1, 4, 0 if rows == 64 else rows)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[1] == '--ablate-times':
+    # launch time of the pipeline kernel with single LDS accesses removed (results are wrong by construction; what is
+    # measured is what each access costs): 0x10 plane writes of the shift, 0x20 z write-back, 0x40 A-operand reads of the
+    # shift, 0x80 the consumers' plane reads, 0x100 / 0x200 staging writes (fp32 rows / planes)
+    L = _native.measure_lib()
+    B = int(sys.argv[2])
+    for mask in (0, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200, 0x30, 0x70, 0x3f0):
+        assert L.gnnpp_set_tuning(3, mask) == 0
+        t, _ = run(B, 3, 20)
+        print(json.dumps({'batch': B, 'kernel': 'lsigf_pipe_b3_kernel (measure build)', 'ablate_mask': hex(mask),
+                          'us': round(t * 1e6, 2)}), flush=True)
+    L.gnnpp_set_tuning(3, 0)
     sys.exit(0)
 for B in (512, 2048, 8192, 32768, 131072):
     ref = None

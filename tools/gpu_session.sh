@@ -83,5 +83,14 @@ if has filterpmc; then stamp "rocprofv3 pmc passes over the filter-only launch (
     python $R/tools/pmc_summary.py $OUT/fpmc_$name 2>&1 | grep "lsigf_" | tee -a $OUT/filter_pmc.txt
     find $OUT/fpmc_$name -name "*.csv" -size +2M -delete
   done; fi
+if has pipeablate; then stamp "pipeline filter kernel: launch time and LDS conflict counters with single accesses removed"
+  cd $R; timeout 300 python tools/filter_sweep.py --ablate-times 32768 2>&1 | grep -v amdgpu.ids | tee $OUT/pipe_ablate_times.jsonl
+  cd /tmp
+  for mask in 0 0x10 0x20 0x40 0x80 0x300 0x3f0; do
+    timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/apmc_$mask -o pmc -- python $R/tools/filter_sweep.py --pmc-target 32768 64 $mask > $OUT/apmc_$mask.log 2>&1
+    echo "ablate $mask" | tee -a $OUT/pipe_ablate_pmc.txt
+    python $R/tools/pmc_summary.py $OUT/apmc_$mask 2>&1 | grep "lsigf_" | tee -a $OUT/pipe_ablate_pmc.txt
+    find $OUT/apmc_$mask -name "*.csv" -size +2M -delete
+  done; fi
 stamp done
 du -sh $OUT
