@@ -309,7 +309,7 @@ __device__ __forceinline__ int cp_l2in_cell(int y, int x, int n) {
     const int o = 4 * (n & 3) + (n >> 2);
     const int slot = (4 * (y & 3) + (x & 3) + o) & 15;
     const int row = y == 4 ? (x == 4 ? 19 : 12 + (n >> 2)) : (x == 4 ? 15 + (n & 3) : n);
-    return row * kCpRow + slot * 16;
+    return __mul24(row, kCpRow) + slot * 16;
 }
 // L0's pooled window `win` (three plane fragments of lane (q, agent a)): fragment win of R, or -- CP -- cell win * N + a of
 // the L1-input layout (lanes beyond the graph's agents hold nothing)
@@ -690,14 +690,16 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
     const int j = ln.j, q = ln.q;
     const int na = min(max((g.T1 - wave + 3) >> 2, 0), NT);        // tiles of this wave (wave-uniform)
     ln.fl = 0;
+    int l2dst[NT];                                                  // where the epilogue stores column (tile i, j): L2's input cell
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int c = 16 * (wave + 4 * i) + j;
-        const int pos = (int)(((unsigned)c * g.rcpN) >> 16);
+        const int pos = (int)(__umul24((unsigned)c, g.rcpN) >> 16), n = c - __mul24(pos, g.N);   // (24-bit operands)
         const int y = (pos * 13) >> 6, x = pos - 5 * y;            // pos / 5, pos % 5   (pos < 25 where it matters)
         unsigned f = (y == 0 ? 1u : 0u) | (y == 4 ? 2u : 0u) | (x == 0 ? 4u : 0u) | (x == 4 ? 8u : 0u);
         if (c >= g.ncol) f = 15u;                                   // no such column: every shifted tap reads zeros
         ln.fl |= f << (4 * i);
+        l2dst[i] = c < g.ncol ? cp_l2in_cell(y, x, n) + q * 256 : -1;
     }
     ln.zaddr = g.l1in + g.T1 * kCpRow + q * 256;                    // the row of zeros (slot 0 of this lane's q)
     ln.tile0 = g.l1in + wave * kCpRow + q * 256;
@@ -723,13 +725,10 @@ __device__ __forceinline__ void cp_layer1(const WStreamB& ws, v4f (&ring)[kRingH
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         if (i < na) {
-            const int c = 16 * (wave + 4 * i) + j;
-            const int pos = (int)(((unsigned)c * g.rcpN) >> 16), n = c - pos * g.N;
-            const int y = (pos * 13) >> 6, x = pos - 5 * y;
             v4f pl[3];
-            b3_split8(vrelu(vfma(acc[i][0], sc[0], shf[0])), vrelu(vfma(acc[i][1], sc[1], shf[1])), pl);
-            if (c < g.ncol) {
-                char* const dst = smem + cp_l2in_cell(y, x, n) + q * 256;
+            b3_split8_clamped(vrelu_clamp(vfma(acc[i][0], sc[0], shf[0])), vrelu_clamp(vfma(acc[i][1], sc[1], shf[1])), pl);
+            if (l2dst[i] >= 0) {
+                char* const dst = smem + l2dst[i];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<v4f*>(dst + p * kB3Frag) = pl[p];
             }
@@ -764,7 +763,7 @@ __device__ __forceinline__ int cp_l2_addr_b(const CpL2Lane& ln, int n, int slot)
     if (dx > 0) row = xx == 4 ? ((dy > 0 && yy == 4) ? 19 : 15 + (n & 3)) : row;
     if (dy < 0) row = yy < 0 ? 20 : row;
     if (dx < 0) row = xx < 0 ? 20 : row;
-    return row * kCpRow + slot;
+    return __mul24(row, kCpRow) + slot;                             // (row <= 20)
 }
 template <int TAP>
 __device__ __forceinline__ int cp_l2_addr(const CpL2Lane& ln, int n) {
@@ -1103,7 +1102,7 @@ __global__ GNNPP_H2_VGPR_BUDGET __launch_bounds__(kThreads, 2) void encoder_kern
             const int p = wave + 4 * j;
             if (p < 25) {
                 v4f pl[3];
-                b3_split8(vrelu(vfma(acc[j][0], sc[0], sh[0])), vrelu(vfma(acc[j][1], sc[1], sh[1])), pl);
+                b3_split8_clamped(vrelu_clamp(vfma(acc[j][0], sc[0], sh[0])), vrelu_clamp(vfma(acc[j][1], sc[1], sh[1])), pl);
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp) R4[(p * 3 + pp) * 64 + lane] = pl[pp];
             }

@@ -198,6 +198,14 @@ __device__ __forceinline__ void b3_split8(v4f a, v4f b, v4f (&pl)[3]) {
     pl[1] = __builtin_bit_cast(v4f, mv);
     pl[2] = __builtin_bit_cast(v4f, lv);
 }
+// ReLU + the split's upper clamp of four values, one v_med3_f32 each (same result as vrelu followed by the clamp of
+// b3_split2 for every input, NaN and the infinities included: both give 0 / 0 / big)
+__device__ __forceinline__ v4f vrelu_clamp(v4f v) {
+    v4f r;
+    r[0] = b3_relu_clamp(v[0]); r[1] = b3_relu_clamp(v[1]);
+    r[2] = b3_relu_clamp(v[2]); r[3] = b3_relu_clamp(v[3]);
+    return r;
+}
 __device__ __forceinline__ void b3_split8_clamped(v4f a, v4f b, v4f (&pl)[3]) {
     unsigned h[4], m[4], l[4];
     b3_split2_clamped(a[0], a[1], h[0], m[0], l[0]);
