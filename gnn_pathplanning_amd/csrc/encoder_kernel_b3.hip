@@ -248,6 +248,28 @@ __device__ __forceinline__ void b3_stream_steps_spread(const WStreamB& ws, v4f (
     (step(std::integral_constant<int, IT>{}), ...);
 }
 
+// ... and with the ring's slots as the MFMAs' A operands (ring_mfma16b: no copy out of the ring, tied accumulators): step it
+// waits ONCE for its six items (the six loads of step it + 1 are the only younger ones), body(itc, base, refill) issues the
+// MFMAs on items base .. base + 5 and calls refill(kc) behind the last MFMA that reads fragment kc -- the slot then takes
+// item base + kc + 12.  A fragment is requested one step (12 NA MFMAs) before its first use, not two: waves with a single
+// tile keep the form above.  The ring's invariant at a step boundary (loads issued up to base + 11) is the one of the other
+// two forms, so layers of different forms follow each other; the ORDER of a step's six refills only matters to a following
+// layer that takes fragments one by one (vmcnt counts loads in issue order): body must refill in ascending order then.
+template <int END, int START, class Body, int... IT>
+__device__ __forceinline__ void b3_stream_steps_direct(const WStreamB& ws, v4f (&ring)[kRingH], Body&& body,
+                                                       std::integer_sequence<int, IT...>) {
+    auto step = [&](auto itc) {
+        constexpr int it = decltype(itc)::value, base = START + it * 6;
+        __builtin_amdgcn_sched_barrier(0);
+        ring_wait_for<END>(base + 5, base + 11);
+        __builtin_amdgcn_sched_barrier(0);
+        body(itc, std::integral_constant<int, base>{}, [&](auto kc) {
+            h2_ring_load<END>(ws, ring, base + decltype(kc)::value + kRingH);
+        });
+    };
+    (step(std::integral_constant<int, IT>{}), ...);
+}
+
 // a whole 2x2 layer for one position set, its input preloaded into registers
 template <int END, int START, int NKB, int H, int W, int NMT, int NSLOT, class PosFn>
 __device__ __forceinline__ void b3_conv_preload(const WStreamB& ws, v4f (&ring)[kRingH], const v4f* in,
@@ -609,6 +631,51 @@ __device__ __forceinline__ void cp_unit(const v8b (&A)[2][3], const v4f (&B)[3],
 #undef GNNPP_CP_H
 #undef GNNPP_CP_M
 }
+// The same unit on the ring's registers (b3_stream_steps_direct; BASE = the step's first stream item, fragment (m, plane) =
+// item BASE + 3 m + plane).  LAST: the step's last unit -- every fragment is refilled behind its last reader (plane 2 after
+// term 1, plane 1 after term 4, plane 0 after term 5), or, ORDERED, all six in ascending order behind the unit.
+template <int BASE, bool FRESH, bool LAST, bool ORDERED, class Load, class Refill>
+__device__ __forceinline__ void cp_unit_direct(v4f (&ring)[kRingH], const v4f (&B)[3], v4f& c0, v4f& c1, Load&& load,
+                                               Refill&& refill) {
+    // (FRESH: the layer's first tap -- the accumulators start from the first product, nobody clears them)
+#define GNNPP_CP_M(T, ACC, MI)                                                                          \
+    if constexpr (FRESH && T == 0) ring_mfma16b_first(ring, BASE + 3 * MI + b3_term_a(T), B[b3_term_b(T)], ACC);   \
+    else ring_mfma16b(ring, BASE + 3 * MI + b3_term_a(T), B[b3_term_b(T)], ACC);                       \
+    __builtin_amdgcn_sched_barrier(0);
+#define GNNPP_CP_R(K)                                                                                   \
+    if constexpr (LAST && !ORDERED) { refill(std::integral_constant<int, K>{}); __builtin_amdgcn_sched_barrier(0); }
+    GNNPP_CP_M(0, c0, 0)
+    load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(0, c1, 1)
+    load(1);
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(1, c0, 0)
+    load(2);
+    __builtin_amdgcn_sched_barrier(0);
+    GNNPP_CP_M(1, c1, 1)
+    GNNPP_CP_R(2)
+    GNNPP_CP_M(2, c0, 0)
+    GNNPP_CP_R(5)
+    GNNPP_CP_M(2, c1, 1)
+    GNNPP_CP_M(3, c0, 0)
+    GNNPP_CP_M(3, c1, 1)
+    GNNPP_CP_M(4, c0, 0)
+    GNNPP_CP_R(1)
+    GNNPP_CP_M(4, c1, 1)
+    GNNPP_CP_R(4)
+    GNNPP_CP_M(5, c0, 0)
+    GNNPP_CP_R(0)
+    GNNPP_CP_M(5, c1, 1)
+    GNNPP_CP_R(3)
+    if constexpr (LAST && ORDERED) {
+        [&]<int... K>(std::integer_sequence<int, K...>) { (refill(std::integral_constant<int, K>{}), ...); }(
+            std::make_integer_sequence<int, 6>{});
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef GNNPP_CP_R
+#undef GNNPP_CP_M
+}
 // an address is COMPLETE where it is computed (left to the optimiser its last additions sink to the read that uses it)
 __device__ __forceinline__ void cp_pin(int& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -658,23 +725,43 @@ __device__ __forceinline__ void cp_layer1_main(const WStreamB& ws, v4f (&ring)[k
         __builtin_amdgcn_sched_barrier(0);
         GNNPP_STAMP(blockIdx.x, 7, wave == 0 && ln.j == 0 && ln.q == 0);
         cp_l1_load(smem, addr[0], Bb[0]);
-        b3_stream_steps_spread<END, kb_L1>(ws, ring, [&](auto itc, const v8b (&A)[2][3], auto&& ring_item) {
-            constexpr int tap = decltype(itc)::value;
-            auto unit = [&](auto ic) {
-                constexpr int i = decltype(ic)::value, u = tap * NA + i;
-                cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
+        if constexpr (NA >= 2) {
+            // (ordered refills in the last two steps: whatever form the next layer's copy for THIS wave has -- a wave with one
+            // tile there takes its fragments one by one, and its waits count loads in issue order)
+            b3_stream_steps_direct<END, kb_L1>(ws, ring, [&](auto itc, auto basec, auto&& refill) {
+                constexpr int tap = decltype(itc)::value, base = decltype(basec)::value;
+                constexpr bool ordered = tap >= 7;
+                auto unit = [&](auto ic) {
+                    constexpr int i = decltype(ic)::value, u = tap * NA + i;
+                    cp_unit_direct<base, tap == 0, i == NA - 1, ordered>(ring, Bb[u & 1], acc[i][0], acc[i][1],
                         [&](int p) {
                             if constexpr (u + 1 < NU)
                                 Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr[u + 1] + p * kB3Frag);
-                        },
-                        [&](auto sc) {
-                            constexpr int k = cp_ring_item_at(NA, i, decltype(sc)::value);
-                            if constexpr (k >= 0) ring_item(std::integral_constant<int, k>{});
-                        });
-            };
-            [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
-                std::make_integer_sequence<int, NA>{});
-        }, std::make_integer_sequence<int, 9>{});
+                        }, refill);
+                };
+                [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
+                    std::make_integer_sequence<int, NA>{});
+            }, std::make_integer_sequence<int, 9>{});
+            ring_mfma_fence();
+        } else {
+            b3_stream_steps_spread<END, kb_L1>(ws, ring, [&](auto itc, const v8b (&A)[2][3], auto&& ring_item) {
+                constexpr int tap = decltype(itc)::value;
+                auto unit = [&](auto ic) {
+                    constexpr int i = decltype(ic)::value, u = tap * NA + i;
+                    cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
+                            [&](int p) {
+                                if constexpr (u + 1 < NU)
+                                    Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr[u + 1] + p * kB3Frag);
+                            },
+                            [&](auto sc) {
+                                constexpr int k = cp_ring_item_at(NA, i, decltype(sc)::value);
+                                if constexpr (k >= 0) ring_item(std::integral_constant<int, k>{});
+                            });
+                };
+                [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
+                    std::make_integer_sequence<int, NA>{});
+            }, std::make_integer_sequence<int, 9>{});
+        }
     } else {
         b3_stream_steps<END, kb_L1, 2>(ws, ring, [&](auto, const v8b (&)[2][3]) {}, std::make_integer_sequence<int, 9>{});
     }
@@ -786,23 +873,42 @@ __device__ __forceinline__ void cp_layer2_main(const WStreamB& ws, v4f (&ring)[k
         __builtin_amdgcn_sched_barrier(0);
         GNNPP_STAMP(blockIdx.x, 15, pair == 0 && ln.q == 0 && ln.y == 0 && ln.x == 0);
         cp_l2_load(smem, addr[0], Bb[0]);
-        b3_stream_steps_spread<END, kb_L2>(ws, ring, [&](auto itc, const v8b (&A)[2][3], auto&& ring_item) {
-            constexpr int tap = decltype(itc)::value;
-            auto unit = [&](auto ic) {
-                constexpr int i = decltype(ic)::value, u = tap * NA + i;
-                cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
+        if constexpr (NA >= 2) {
+            // (ordered refills in the last two steps: L3 takes its fragments one by one, its waits count loads in issue order)
+            b3_stream_steps_direct<END, kb_L2>(ws, ring, [&](auto itc, auto basec, auto&& refill) {
+                constexpr int tap = decltype(itc)::value, base = decltype(basec)::value;
+                constexpr bool ordered = tap >= 7;
+                auto unit = [&](auto ic) {
+                    constexpr int i = decltype(ic)::value, u = tap * NA + i;
+                    cp_unit_direct<base, tap == 0, i == NA - 1, ordered>(ring, Bb[u & 1], acc[i][0], acc[i][1],
                         [&](int p) {
                             if constexpr (u + 1 < NU)
                                 Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr[u + 1] + p * kB3Frag);
-                        },
-                        [&](auto sc) {
-                            constexpr int k = cp_ring_item_at(NA, i, decltype(sc)::value);
-                            if constexpr (k >= 0) ring_item(std::integral_constant<int, k>{});
-                        });
-            };
-            [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
-                std::make_integer_sequence<int, NA>{});
-        }, std::make_integer_sequence<int, 9>{});
+                        }, refill);
+                };
+                [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
+                    std::make_integer_sequence<int, NA>{});
+            }, std::make_integer_sequence<int, 9>{});
+            ring_mfma_fence();
+        } else {
+            b3_stream_steps_spread<END, kb_L2>(ws, ring, [&](auto itc, const v8b (&A)[2][3], auto&& ring_item) {
+                constexpr int tap = decltype(itc)::value;
+                auto unit = [&](auto ic) {
+                    constexpr int i = decltype(ic)::value, u = tap * NA + i;
+                    cp_unit(A, Bb[u & 1], acc[i][0], acc[i][1],
+                            [&](int p) {
+                                if constexpr (u + 1 < NU)
+                                    Bb[(u + 1) & 1][p] = *reinterpret_cast<const v4f*>(smem + addr[u + 1] + p * kB3Frag);
+                            },
+                            [&](auto sc) {
+                                constexpr int k = cp_ring_item_at(NA, i, decltype(sc)::value);
+                                if constexpr (k >= 0) ring_item(std::integral_constant<int, k>{});
+                            });
+                };
+                [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(
+                    std::make_integer_sequence<int, NA>{});
+            }, std::make_integer_sequence<int, 9>{});
+        }
     } else {
         b3_stream_steps<END, kb_L2, 2>(ws, ring, [&](auto, const v8b (&)[2][3]) {}, std::make_integer_sequence<int, 9>{});
     }

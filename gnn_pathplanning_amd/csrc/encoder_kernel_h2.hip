@@ -141,6 +141,73 @@ __device__ __forceinline__ v4f ring_take_f4(v4f (&ring)[kRingH], int idx) {
     return ring[idx % kRingH];
 #endif
 }
+// DIRECT use of a ring slot (encoder_kernel_b3.hip, column-packed layers): the bf16 MFMA reads its A operand straight from
+// the slot's registers -- no copy, and the accumulator is a tied operand, so the register allocator cannot move it -- and
+// the slot is refilled behind the LAST MFMA that reads it.  ring_wait_for<END>(idx): item idx has landed, given that the
+// loads up to idx_issued have been issued.  tools/check_ring_isa.py follows RINGUSE like RINGTAKE.
+template <int END>
+__device__ __forceinline__ void ring_wait_for(int idx, int idx_issued) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int last = idx_issued < END - 1 ? idx_issued : END - 1;
+    const int younger = last - idx < 0 ? 0 : last - idx;
+    switch (younger) {
+#define GNNPP_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ") ; RINGWAIT" ::: "memory"); break;
+        GNNPP_W(0) GNNPP_W(1) GNNPP_W(2) GNNPP_W(3) GNNPP_W(4) GNNPP_W(5) GNNPP_W(6) GNNPP_W(7)
+        GNNPP_W(8) GNNPP_W(9) GNNPP_W(10) GNNPP_W(11) GNNPP_W(12) GNNPP_W(13) GNNPP_W(14)
+        default: asm volatile("s_waitcnt vmcnt(15) ; RINGWAIT" ::: "memory"); break;
+#undef GNNPP_W
+    }
+#else
+    (void)idx; (void)idx_issued;
+#endif
+}
+// acc += A(slot of item idx) x B   (v_mfma_f32_16x16x32_bf16)
+__device__ __forceinline__ void ring_mfma16b(v4f (&ring)[kRingH], int idx, const v4f& B, v4f& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)ring;
+    switch (idx % kRingH) {
+#define GNNPP_X(s, a, b, c, d)                                                                 \
+    case s:                                                                                    \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[" #a ":" #d "], %1, %0 ; RINGUSE " #s     \
+                     : "+v"(acc) : "v"(B));                                                    \
+        break;
+        GNNPP_RING_SLOTS(GNNPP_X)
+#undef GNNPP_X
+    }
+#else
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8b, ring[idx % kRingH]), __builtin_bit_cast(v8b, B),
+                                                  acc, 0, 0, 0);
+#endif
+}
+// acc = A(slot of item idx) x B: an accumulator's FIRST product.  (Not `acc = 0` followed by the form above: the hazard
+// recogniser does not know that the asm is an MFMA and leaves out the wait states between the v_mov that clears the
+// accumulator and the MFMA that reads it -- measured as wrong logits at N = 10.)
+__device__ __forceinline__ void ring_mfma16b_first(v4f (&ring)[kRingH], int idx, const v4f& B, v4f& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)ring;
+    switch (idx % kRingH) {
+#define GNNPP_X(s, a, b, c, d)                                                                 \
+    case s:                                                                                    \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[" #a ":" #d "], %1, 0 ; RINGUSE " #s      \
+                     : "=&v"(acc) : "v"(B));                                                   \
+        break;
+        GNNPP_RING_SLOTS(GNNPP_X)
+#undef GNNPP_X
+    }
+#else
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8b, ring[idx % kRingH]), __builtin_bit_cast(v8b, B),
+                                                  z, 0, 0, 0);
+#endif
+}
+// the accumulators the asm MFMAs above wrote are read by compiler-scheduled code next: the wait states the hazard
+// recogniser would insert behind a v_mfma it can see (it cannot see into inline asm)
+__device__ __forceinline__ void ring_mfma_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#endif
+}
+
 template <int END>
 __device__ __forceinline__ v8h h2_ring_take(v4f (&ring)[kRingH], int idx) {
     return __builtin_bit_cast(v8h, ring_take_f4<END>(ring, idx));

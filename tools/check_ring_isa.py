@@ -7,7 +7,9 @@ This script verifies on the ISA hipcc produced that
   1. no other instruction of the kernel mentions v208..v255,
   2. along every control-flow path, a RINGTAKE of slot s follows a load of that slot and a RINGWAIT
      whose vmcnt is <= the number of ring loads issued after that load (loads return in order), and
-     a slot is never reloaded before it was taken,
+     a slot is never reloaded before it was taken -- or, in the DIRECT form of encoder_kernel_b3.hip's column-packed
+     layers (`v_mfma ... ; RINGUSE s`: the slot is the MFMA's A operand), before it was read, every such read behind a
+     wait that covers the slot's load,
   3. the kernel allocates 256 VGPRs, spills nothing and keeps two waves per SIMD.
 
 Every instantiation is checked: encoder_kernel_h2<false, 3> (196 stream items) and the fused policy
@@ -102,7 +104,7 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
     # joins: a block is re-walked for every distinct state that reaches it (a few per block -- the arms of a
     # per-wave switch each carry their own copy of a layer's ring traffic and must leave identical states behind).
     EMPTY = -1
-    start = (tuple([EMPTY] * NSLOT), 0, 0, 0, frozenset(), None)
+    start = (tuple([EMPTY] * NSLOT), 0, 0, 0, frozenset(), None, 0, 0)
     seen = [set() for _ in blocks]
     seen[0].add(start)
     work, reported = [(0, start)], set()
@@ -123,7 +125,8 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
             break
         age, nl, nt, depth = list(st0[0]), st0[1], st0[2], st0[3]
         consts, vcc = dict(st0[4]), st0[5]
-        last_wait = None
+        ready, used = st0[6], st0[7]                       # bit masks over the slots: load known to have landed | read by a
+        last_wait = None                                   # RINGUSE (direct form) since its load
         exec_written = False
         for k, t in enumerate(blocks[i]['ins']):
             code = t.split(';')[0]
@@ -131,13 +134,32 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
                 s = int(t.split('RINGLOAD')[1])
                 if regs_of(code.split(',')[0]) != set(range(RING_LO + 4 * s, RING_LO + 4 * s + 4)):
                     err(i, k, 'load into the wrong registers: ' + t)
-                if age[s] != EMPTY:
-                    err(i, k, 'slot %d reloaded before it was taken: %s' % (s, t))
+                if age[s] != EMPTY and not (used >> s) & 1:
+                    err(i, k, 'slot %d reloaded before it was taken / used: %s' % (s, t))
                 age = [a + 1 if a != EMPTY else a for a in age]
                 age[s] = 0
+                ready &= ~(1 << s)
+                used &= ~(1 << s)
                 nl += 1
             elif 'RINGWAIT' in t:
                 last_wait = int(re.search(r'vmcnt\((\d+)\)', code).group(1))
+                for s2 in range(NSLOT):                    # loads return in order: everything with >= n younger loads is back
+                    if age[s2] != EMPTY and age[s2] >= last_wait:
+                        ready |= 1 << s2
+            elif 'RINGUSE' in t:
+                # direct form: a v_mfma whose A operand is the slot (the accumulator / B operands are the compiler's)
+                s = int(t.split('RINGUSE')[1])
+                ops = [o.strip() for o in code.split(None, 1)[1].split(',')]
+                if not code.strip().startswith('v_mfma') or regs_of(ops[1]) != set(range(RING_LO + 4 * s, RING_LO + 4 * s + 4)) \
+                        or any(r >= RING_LO for o in (ops[0], ops[2], ops[3]) for r in regs_of(o)):
+                    err(i, k, 'use of the wrong registers: ' + t)
+                if age[s] == EMPTY:
+                    err(i, k, 'slot %d used but not loaded: %s' % (s, t))
+                elif not (ready >> s) & 1:
+                    err(i, k, 'slot %d used before a sufficient wait (%d younger loads): %s' % (s, age[s], t))
+                if age[s] != EMPTY and not (used >> s) & 1:
+                    used |= 1 << s
+                    nt += 1
             elif 'RINGTAKE' in t:
                 s = int(t.split('RINGTAKE')[1])
                 if not regs_of(code.split(',')[1]) <= set(range(RING_LO + 4 * s, RING_LO + 4 * s + 4)):
@@ -149,6 +171,7 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
                         % (s, last_wait, age[s], t))
                 if blocks[i]['ins'][k - 1].endswith('RINGTAKE %d' % s):
                     age[s] = EMPTY                      # second half of the fragment: slot is free
+                    ready &= ~(1 << s)
                     nt += 1
             else:
                 # EXEC narrowing: `depth` over-estimates how many exec-narrowing writes are unmatched on this path
@@ -192,6 +215,9 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
                 if cs.startswith('s_waitcnt') and 'vmcnt' in cs:
                     m = re.search(r'vmcnt\((\d+)\)', cs)
                     last_wait = min(last_wait, int(m.group(1))) if last_wait is not None else int(m.group(1))
+                    for s2 in range(NSLOT):
+                        if age[s2] != EMPTY and age[s2] >= int(m.group(1)):
+                            ready |= 1 << s2
         last_ins = blocks[i]['ins'][-1] if blocks[i]['ins'] else ''
         if last_ins.startswith('s_endpgm'):
             exits.add((nl, nt))
@@ -212,7 +238,7 @@ def check(path, name='encoder_kernel_h2ILb0', max_scratch=0):
             # no ring load in flight (before the prologue / behind the last take: the simulator tail's divergent code):
             # what is known about EXEC and the flags cannot matter to the ring any more -- collapse the states
             depth, consts, vcc = 4, {}, None
-        out = (tuple(age), nl, nt, depth, frozenset(consts.items()), vcc)
+        out = (tuple(age), nl, nt, depth, frozenset(consts.items()), vcc, ready, used)
         for j in nexts:
             if out not in seen[j]:
                 if len(seen[j]) > 64:
