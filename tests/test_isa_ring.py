@@ -110,3 +110,51 @@ def test_checker_follows_per_wave_switch_arms(tmp_path):
     f.write_text(short)
     errs = check_ring_isa.check(str(f), 'encoder_kernel_b3ILb0')[0]
     assert any('taken but not loaded' in e for e in errs), errs
+
+
+def test_checker_follows_the_direct_form(tmp_path):
+    """r04: the column-packed layers read a ring slot as the A operand of an inline-asm MFMA (`; RINGUSE s`) and refill it
+    behind its last reader.  Accepted: load -> sufficient wait -> uses -> reload -> wait -> take.  Reported: a use before
+    any sufficient wait, a use of a slot whose reload has not been waited for, a reload before the slot was read, an MFMA
+    whose OTHER operands touch the ring, a use that names the wrong slot."""
+    import check_ring_isa
+    good = '''_ZN5gnnpp17encoder_kernel_b3ILb1ELi3ELb1EEEvPKfS2_Pfii:
+\tglobal_load_dwordx4 v[208:211], v1, s[0:1] ; RINGLOAD 0
+\tglobal_load_dwordx4 v[212:215], v1, s[0:1] ; RINGLOAD 1
+\ts_waitcnt vmcnt(1) ; RINGWAIT
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[208:211], v[4:7], 0 ; RINGUSE 0
+\tglobal_load_dwordx4 v[216:219], v1, s[0:1] ; RINGLOAD 2
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[208:211], v[4:7], v[0:3] ; RINGUSE 0
+\tglobal_load_dwordx4 v[208:211], v1, s[0:1] ; RINGLOAD 0
+\ts_waitcnt vmcnt(2) ; RINGWAIT
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[212:215], v[4:7], v[0:3] ; RINGUSE 1
+\ts_waitcnt vmcnt(1) ; RINGWAIT
+\tv_mov_b64 v[8:9], v[216:217] ; RINGTAKE 2
+\tv_mov_b64 v[10:11], v[218:219] ; RINGTAKE 2
+\ts_waitcnt vmcnt(0) ; RINGWAIT
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[208:211], v[4:7], v[0:3] ; RINGUSE 0
+\ts_endpgm
+.Lfunc_end0:
+; NumVgprs: 256
+; ScratchSize: 0
+; Occupancy: 2
+'''
+    f = tmp_path / 'd.s'
+    f.write_text(good)
+    errors, stats, _ = check_ring_isa.check(str(f), 'encoder_kernel_b3ILb1')
+    assert errors == [] and stats == {'loads': 4, 'takes': 4}, (errors, stats)
+    cases = {
+        'before a sufficient wait': good.replace('\ts_waitcnt vmcnt(1) ; RINGWAIT\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[208:211], v[4:7], 0',
+                                                 '\ts_waitcnt vmcnt(2) ; RINGWAIT\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[208:211], v[4:7], 0'),
+        # the last use of slot 0 reads the RELOADED item: vmcnt(0) removed -> its load is not known to have landed
+        'before a sufficient wait ': good.replace('\ts_waitcnt vmcnt(0) ; RINGWAIT\n', ''),
+        'reloaded before it was taken / used': good.replace('\tv_mfma_f32_16x16x32_bf16 v[0:3], v[212:215], v[4:7], v[0:3] ; RINGUSE 1\n',
+                                                            '\tglobal_load_dwordx4 v[212:215], v1, s[0:1] ; RINGLOAD 1\n'),
+        'wrong registers': good.replace('v[0:3], v[212:215], v[4:7], v[0:3] ; RINGUSE 1', 'v[0:3], v[212:215], v[216:219], v[0:3] ; RINGUSE 1'),
+        'wrong registers ': good.replace('v[0:3], v[212:215], v[4:7], v[0:3] ; RINGUSE 1', 'v[0:3], v[212:215], v[4:7], v[0:3] ; RINGUSE 2'),
+    }
+    for what, bad in cases.items():
+        assert bad != good, what
+        f.write_text(bad)
+        errs = check_ring_isa.check(str(f), 'encoder_kernel_b3ILb1')[0]
+        assert any(what.strip() in e for e in errs), (what, errs)
