@@ -97,5 +97,6 @@ int main() {
     hipMalloc(&in, 4096 * 4); hipMalloc(&out, 4096 * 256 * 16); hipMalloc(&cyc, 4096 * 8);
     hipMemset(in, 0, 4096 * 4);
     for (int w = 1; w <= 2; ++w) { run<1>(w, in, out, cyc); run<2>(w, in, out, cyc); run<3>(w, in, out, cyc); run<4>(w, in, out, cyc); run<8>(w, in, out, cyc); }
+    for (int w = 3; w <= 4; ++w) { run<2>(w, in, out, cyc); run<4>(w, in, out, cyc); }   // three and four waves per SIMD
     return 0;
 }
