@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: test smoke bench benchdrv bench35 train traincpu trainprof cpab distcheck stamps b3stamps filtersweep prof prof35 proftrain pmc filterpmc
+# steps: test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
