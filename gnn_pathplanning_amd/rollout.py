@@ -350,3 +350,47 @@ class GroupedRollout:
             if k != 'steps':
                 out[k] = torch.cat([p[k] for p in parts], 0)
         return out
+
+
+class GraphedPolicyStep:
+    """`model.addGSO(S); model(obs)` of a fixed batch shape as ONE HIP-graph replay.
+
+    For small batches -- one test case per step as in the reference's rollout loop
+    (agents/decentralplannerlocal.py:560-599), or the 16-graph shard a rank holds when a 128-graph batch of
+    100-agent teams is split over 8 GPUs -- the policy step is a chain of one to three kernels that fill a
+    fraction of the chip, and the launch boundaries between them are a tenth of the step.  The libgnnpp
+    kernels are enqueued on torch's capture stream through the C ABI like any other launch, so the whole
+    step (GSO hand-over, encoder, filter + head) becomes one graph; inputs are copied into static buffers
+    before a replay, the returned logits are the graph's own output tensors (valid until the next call).
+
+        step = GraphedPolicyStep(model, obs, S)        # eval mode; captures on the current device
+        logits = step(obs_t, S_t)                      # list of N tensors [B, 5], as model(obs) returns
+
+    Bit-identical to the eager call (tests/test_gpu_parity.py::test_graphed_policy_step_equals_eager)."""
+
+    def __init__(self, model, obs, S, warmup=3):
+        if model.training:
+            raise ValueError('GraphedPolicyStep captures the eval-mode forward (BatchNorm folded into the packed weights)')
+        self.model = model
+        self.obs = obs.clone()
+        self.S = S.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                        # packs, workspaces, allocator
+                model.addGSO(self.S)
+                model(self.obs)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            model.addGSO(self.S)
+            self.out = model(self.obs)
+
+    def __call__(self, obs, S):
+        if obs.shape != self.obs.shape or S.shape != self.S.shape:
+            raise ValueError('GraphedPolicyStep was captured for observations %s and GSOs %s'
+                             % (tuple(self.obs.shape), tuple(self.S.shape)))
+        self.obs.copy_(obs)
+        self.S.copy_(S)
+        self.graph.replay()
+        return self.out

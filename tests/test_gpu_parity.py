@@ -1031,3 +1031,31 @@ def test_pipeline_filter_kernel_equals_the_small_graph_kernel(dev, N, K, B):
     got = outs[1].cpu().reshape(B, N, 128)[:64].permute(0, 2, 1).numpy()
     want = np.maximum(want, 0)
     assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('B,N,K,W', [(1, 10, 3, 20), (16, 100, 3, 100), (64, 10, 3, 20)])
+def test_graphed_policy_step_equals_eager(dev, B, N, K, W):
+    """rollout.GraphedPolicyStep (addGSO + forward as one HIP-graph replay, the latency regime: one case per step, or
+    the 16-graph shard of an 8-GPU run): the replay on NEW inputs gives bit for bit what the eager call gives on them,
+    agrees with the oracle, a second replay does not depend on the first, and a wrong shape is refused."""
+    from gnn_pathplanning_amd.rollout import GraphedPolicyStep
+    sd = orc.init_state_dict(K, seed=1337 + K)
+    net = _net(N, K, dev, sd)
+    obs0 = orc.synth_obs(B, N, seed=1).to(dev)
+    S0 = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=1)).float().to(dev)
+    step = GraphedPolicyStep(net, obs0, S0)
+    for seed in (2, 3):
+        obs = orc.synth_obs(B, N, seed=seed)
+        S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=seed)).float()
+        got = [g.clone() for g in step(obs.to(dev), S.to(dev))]
+        with torch.no_grad():
+            net.addGSO(S.to(dev))
+            eager = net(obs.to(dev))
+            want = orc.policy_forward(sd, S, obs)
+        assert len(got) == N and all(torch.equal(a, b) for a, b in zip(got, eager))
+        assert max((g.cpu() - w).abs().max().item() for g, w in zip(got, want)) <= TOL
+    with pytest.raises(ValueError):
+        step(obs0[:, :-1], S0[:, :-1, :-1]) if N > 1 else step(obs0[:0], S0[:0])
+    net.train()
+    with pytest.raises(ValueError):
+        GraphedPolicyStep(net, obs0, S0)
