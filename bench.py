@@ -119,7 +119,8 @@ def fused_mfma_per_graph(N, K, cp):
 
 def fused_rule(L, B, N, K, prec):
     """gnnpp_policy_fwd's rule for the one-launch policy kernel (csrc/gnnpp_api.hip fused_policy_applies)."""
-    return bool(L.gnnpp_get_tuning(6) == 1 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13))
+    knob = L.gnnpp_get_tuning(6)                             # 0 = never, 1 = the rule, 2 = whenever the kernel applies
+    return bool(knob != 0 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13 or knob == 2))
 
 
 def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel, vp, st, batch=None):

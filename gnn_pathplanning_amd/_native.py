@@ -358,11 +358,16 @@ class PackCache:
         self.key = None
         self.buf = None
 
-    def get(self, tensors, pack_fn):
+    @staticmethod
+    def key_of(tensors):
+        """The key a pack of `tensors` built NOW would carry (no rebuild)."""
         # _version changes on every in-place update; id() changes when .to()/.cuda() replaces the
         # tensor objects' storage holders.  (data_ptr() per tensor is 3x slower than this.)
-        key = tuple([t._version for t in tensors] + [id(t) for t in tensors] +
-                    [tensors[0].data_ptr(), tensors[-1].data_ptr(), _pack_generation])
+        return tuple([t._version for t in tensors] + [id(t) for t in tensors] +
+                     [tensors[0].data_ptr(), tensors[-1].data_ptr(), _pack_generation])
+
+    def get(self, tensors, pack_fn):
+        key = self.key_of(tensors)
         if key != self.key:
             self.buf = pack_fn()
             self.key = key

@@ -408,6 +408,20 @@ class DecentralPlannerNet(nn.Module):
         after = (self._enc_cache.key, self._head_cache.key) + tuple(gf._packed.key for gf in gfs)
         return before != after
 
+    def pack_state(self):
+        """(keys, buffers) of the lazily packed weight copies as the parameters stand NOW: `keys` is what the
+        caches WOULD be keyed on (cheap: version counters and ids, no rebuild, no device work), `buffers` the device
+        tensors the caches currently hold.  rollout.GraphedPolicyStep bakes the buffers' addresses into a HIP graph:
+        it keeps `buffers` alive and compares `keys` before every replay."""
+        enc_t = self._encoder_tensors()                    # (also refreshes self._mods)
+        gfs, act = self._mods
+        gl = gfs[-1]
+        head = (gl.bias, act.weight, act.bias) if gl.bias is not None else (act.weight, act.bias)
+        K = _native.PackCache.key_of
+        keys = (K(enc_t), K(head)) + tuple(K((gf.weight,)) for gf in gfs)
+        bufs = (self._enc_cache.buf, self._head_cache.buf) + tuple(gf._packed.buf for gf in gfs)
+        return keys, bufs
+
     def forward_logits(self, inputTensor):
         """One policy step; returns the logits as ONE tensor [N,B,5] (agent-major, each [n] a
         contiguous [B,5] block) -- what forward() unbinds into the reference's list."""

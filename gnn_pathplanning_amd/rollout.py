@@ -366,18 +366,34 @@ class GraphedPolicyStep:
         step = GraphedPolicyStep(model, obs, S)        # eval mode; captures on the current device
         logits = step(obs_t, S_t)                      # list of N tensors [B, 5], as model(obs) returns
 
+    The weights are FROZEN at capture: the graph holds the device addresses of the model's packed weight copies
+    (encoder pack, filter taps, head constants).  The step keeps those buffers alive and, before every replay,
+    compares the caches' keys (parameter version counters / identities: host-only, a few us) with the captured ones;
+    after load_state_dict / an optimizer step / .to() it RE-CAPTURES (`recaptures` counts them) instead of replaying
+    freed or stale buffers.  precision='split_f16' with range_policy='strict' is refused: its range check reads a
+    device flag on the host, which cannot happen inside a capture (use range_policy='flag' + check_range()).
+
     Bit-identical to the eager call (tests/test_gpu_parity.py::test_graphed_policy_step_equals_eager)."""
 
     def __init__(self, model, obs, S, warmup=3):
         if model.training:
             raise ValueError('GraphedPolicyStep captures the eval-mode forward (BatchNorm folded into the packed weights)')
+        if getattr(model, 'precision', 'fp32') == 'split_f16' and getattr(model, 'range_policy', None) == 'strict':
+            raise ValueError("GraphedPolicyStep cannot capture precision='split_f16' with range_policy='strict' (the "
+                             "range check synchronises with the host); use range_policy='flag' and check_range()")
         self.model = model
         self.obs = obs.clone()
         self.S = S.clone()
+        self.warmup = warmup
+        self.recaptures = -1
+        self._capture()
+
+    def _capture(self):
+        model = self.model
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                        # packs, workspaces, allocator
+            for _ in range(self.warmup):                   # packs, workspaces, allocator
                 model.addGSO(self.S)
                 model(self.obs)
         torch.cuda.current_stream().wait_stream(side)
@@ -385,11 +401,18 @@ class GraphedPolicyStep:
         with torch.cuda.graph(self.graph), torch.no_grad():
             model.addGSO(self.S)
             self.out = model(self.obs)
+        # what the graph's kernels read through raw pointers: keep it alive, remember what it was built from
+        self._keys, self._held = model.pack_state()
+        self.recaptures += 1
 
     def __call__(self, obs, S):
         if obs.shape != self.obs.shape or S.shape != self.S.shape:
             raise ValueError('GraphedPolicyStep was captured for observations %s and GSOs %s'
                              % (tuple(self.obs.shape), tuple(self.S.shape)))
+        if self.model.training:
+            raise ValueError('GraphedPolicyStep replays the eval-mode forward: call model.eval() first')
+        if self.model.pack_state()[0] != self._keys:       # weights changed since the capture
+            self._capture()
         self.obs.copy_(obs)
         self.S.copy_(S)
         self.graph.replay()

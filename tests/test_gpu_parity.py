@@ -1059,3 +1059,53 @@ def test_graphed_policy_step_equals_eager(dev, B, N, K, W):
     net.train()
     with pytest.raises(ValueError):
         GraphedPolicyStep(net, obs0, S0)
+    with pytest.raises(ValueError):
+        step(obs0, S0)                                       # a captured step refuses a model switched to train()
+    net.eval()
+
+
+def test_graphed_policy_step_follows_weight_changes(dev):
+    """the graph bakes in the addresses of the model's packed weight copies.  After load_state_dict, an
+    in-place parameter update or invalidate_packs() the step must neither replay the OLD weights nor read buffers the
+    pack caches have dropped: it re-captures, and its logits equal the eager call's with the NEW weights bit for bit
+    (and agree with the oracle on them)."""
+    from gnn_pathplanning_amd.rollout import GraphedPolicyStep
+    from gnn_pathplanning_amd import _native
+    B, N, K, W = 8, 10, 3, 20
+    sd_a, sd_b = orc.init_state_dict(K, seed=11), orc.init_state_dict(K, seed=12)
+    net = _net(N, K, dev, sd_a)
+    obs = orc.synth_obs(B, N, seed=5)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=5)).float()
+    obs_d, S_d = obs.to(dev), S.to(dev)
+    step = GraphedPolicyStep(net, obs_d, S_d)
+    first = [g.clone() for g in step(obs_d, S_d)]
+    assert step.recaptures == 0
+    step(obs_d, S_d)
+    assert step.recaptures == 0                              # unchanged weights: plain replays
+    held_before = [b.data_ptr() for b in step._held if torch.is_tensor(b)]
+    net.load_state_dict(sd_b)
+    junk = [torch.full((1 << 18,), float('nan'), device=dev) for _ in range(8)]   # reuse whatever the caches freed
+    got = [g.clone() for g in step(obs_d, S_d)]
+    assert step.recaptures == 1
+    with torch.no_grad():
+        net.addGSO(S_d)
+        eager = net(obs_d)
+        want = orc.policy_forward(sd_b, S, obs)
+    assert all(torch.equal(a, b) for a, b in zip(got, eager))
+    assert max((g.cpu() - w).abs().max().item() for g, w in zip(got, want)) <= TOL
+    assert not all(torch.equal(a, b) for a, b in zip(got, first))
+    del junk
+    # an in-place update (what an optimizer step does) and the explicit invalidation are both seen
+    with torch.no_grad():
+        net.actionsMLP[0].bias.add_(0.25)
+    got2 = [g.clone() for g in step(obs_d, S_d)]
+    assert step.recaptures == 2
+    assert all(torch.allclose(a, b + 0.25, atol=1e-6) for a, b in zip(got2, got))
+    _native.invalidate_packs()
+    step(obs_d, S_d)
+    assert step.recaptures == 3
+    assert held_before                                       # (the step did hold device buffers)
+    # split_f16 + strict range policy synchronises with the host after every forward: refused at capture
+    net.precision, net.range_policy = 'split_f16', 'strict'
+    with pytest.raises(ValueError):
+        GraphedPolicyStep(net, obs_d, S_d)

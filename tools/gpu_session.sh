@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
+# steps: wave8 pmc35 test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -11,6 +11,9 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 T0=$(date +%s)
 stamp() { echo "== [$(( $(date +%s) - T0 ))s] $1"; }
+if has wave8; then stamp "8-wave / 128-VGPR stream probe (VERDICT r04 item 1)"
+  # (cross-compiled in the build container: cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o wave8_stream_probe wave8_stream_probe.hip)
+  (cd $R/tools/probe && timeout 120 ./wave8_stream_probe | tee $OUT/wave8_stream_probe.jsonl); fi
 if has test; then stamp "pytest -m gpu"
   timeout 900 python -m pytest tests -q -m gpu --maxfail=8 2>&1 | tail -60 | tee $OUT/pytest_gpu.log; fi
 if has smoke; then stamp smoke
@@ -72,6 +75,13 @@ if has pmc; then stamp "rocprofv3 pmc passes"
     python $R/tools/pmc_summary.py $OUT/pmc_$name 2>&1 | tee -a $OUT/pmc_summary.txt
     find $OUT/pmc_$name -name "*.csv" -size +2M -delete
   done; fi
+if has pmc35; then for c in c3 c5; do stamp "rocprofv3 pmc passes $c"
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+    name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+    timeout 200 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_${c}_$name -o pmc -- python $R/bench.py --pmc-target --config $c > $OUT/pmc_${c}_$name.log 2>&1
+    python $R/tools/pmc_summary.py $OUT/pmc_${c}_$name 2>&1 | tee -a $OUT/pmc_summary_$c.txt
+    find $OUT/pmc_${c}_$name -name "*.csv" -size +2M -delete
+  done; done; fi
 if has pmclds; then stamp "rocprofv3 pmc pass: LDS conflicts of the C2 launch"
   timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_lds -o pmc -- python $R/bench.py --pmc-target > $OUT/pmc_lds.log 2>&1
   python $R/tools/pmc_summary.py $OUT/pmc_lds 2>&1 | grep "encoder_kernel" | tee $OUT/pmc_lds_summary.txt
