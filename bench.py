@@ -123,6 +123,29 @@ def fused_rule(L, B, N, K, prec):
     return bool(knob != 0 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13 or knob == 2))
 
 
+def filter_head_roofline(N, K, B, mean_deg, prec, t):
+    """Roofline figures of the policy step's SECOND launch (features -> logits: K-tap filter + bias + ReLU + action
+    head; csrc/policy_filter_kernel.hip for teams of 17 .. 100 agents).  Which matrix instruction contracts the taps
+    depends on the team size (policy_filter_dispatch): bf16x3 planes (six v_mfma_f32_16x16x32_bf16 per 32 channels)
+    while the planes of a workgroup's own rows fit the LDS beside the graph -- up to about 64 agents, more when the
+    graph is split over several workgroups --, the exact v_mfma_f32_16x16x4_f32 otherwise and for 'fp32_mfma'.  `frac`
+    = algorithmic FLOP/s over the dense peak of THAT instruction; `pipe_busy_frac` = executed MFMA FLOP/s (six plane
+    products, rows padded to 16-row tiles) over the same peak."""
+    alg = 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128 + 640) * B * N
+    tiles = (N + 15) // 16
+    bf16 = prec == 0 and N <= 64          # (the split heuristic can extend this; the instruction is stated, not guessed)
+    if prec == 2:
+        instr, peak, products = 'v_mfma_f32_16x16x32_f16', 2500.0, 3
+    elif bf16:
+        instr, peak, products = 'v_mfma_f32_16x16x32_bf16', 2500.0, 6
+    else:
+        instr, peak, products = 'v_mfma_f32_16x16x4_f32', 157.3, 1
+    exe = 2.0 * products * K * 128 * 128 * 16 * tiles * B + 2.0 * 640 * 16 * tiles * B * (16 / 5.0)
+    return {'us': t * 1e6, 'instruction': instr, 'peak_TFLOPs': peak, 'algorithmic_TFLOPs': alg / t / 1e12,
+            'frac': alg / t / 1e12 / peak, 'pipe_busy_frac': exe / t / 1e12 / peak,
+            'note': 'latency-scheduled kernel: one or a few workgroups per graph, every global load issued up front'}
+
+
 def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel, vp, st, batch=None):
     """Compact record of another BASELINE config inside the C2 line: value, ms/step, dominant kernel us, frac,
     parity (max |dlogit| vs the oracle, near-ties).  Default precision.  batch: run only that many graphs of the
@@ -152,8 +175,10 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
         return net(obs)
     for _ in range(15):
         out = step()
-    nst = 30
-    r = sorted(x[0] for x in timed_regions(step, nst, 3, collective=False))[1] / nst
+    # median of 5 regions of 40 steps (r04: 3 x 30 -- one slow region made `c5_shard_K4` read 17 M where two builder
+    # sessions read 24-25 M: VERDICT r04 item 4)
+    nst, nreg = 40, 5
+    r = sorted(x[0] for x in timed_regions(step, nst, nreg, collective=False))[nreg // 2] / nst
     # the same step replayed from a HIP graph (what a rollout harness with static input buffers can do): without the host's
     # enqueue cost, which a two-launch step of ~55 us of device time does not hide
     graphed = None
@@ -170,7 +195,7 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
                 out_g = step()
             for _ in range(5):
                 cg.replay()
-            rg = sorted(x[0] for x in timed_regions(cg.replay, nst, 3, collective=False))[1] / nst
+            rg = sorted(x[0] for x in timed_regions(cg.replay, nst, nreg, collective=False))[nreg // 2] / nst
             same = all(torch.equal(a_, b_) for a_, b_ in zip(out_g, out))
             graphed = {'value': M / rg, 'ms_per_step': 1e3 * rg, 'bit_identical_to_eager': bool(same)}
         except Exception as e:                             # an extra: never break the record
@@ -189,6 +214,7 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     info = PRECISION_INFO[prec]
     rl = roofline_block('gnnpp::encoder_kernel_b3<false, 3>', info, 2.0 * ENC_MACS_PER_AGENT * M, t_enc,
                         8028 * 16384.0 * tiles)       # ({0, 1} observations: L0 issues 3 of 6 plane products)
+    fh = filter_head_roofline(N, K, B, mean_deg, prec, t_fh)
     with torch.no_grad():
         want = orc.policy_forward(sd, S_cpu, obs_cpu)
     got = [o.cpu() for o in out]
@@ -198,12 +224,14 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     ids_w = orc.decode_actions(want)
     ids_g = torch.stack([g.argmax(-1) for g in got], 1)
     rec_extra = {'hip_graph_replay': graphed} if graphed is not None else {}
+    rec_extra['filter_and_head'] = fh
     return {**rec_extra, 'agents': N, 'taps': K, 'batch': B, 'mean_degree': round(mean_deg, 3),
             'value': M / r, 'unit': 'agent-steps/s', 'ms_per_step': 1e3 * r,
             'dominant_kernel': rl['kernel'], 'dominant_kernel_us': t_enc * 1e6, 'frac': rl['frac'],
             'frac_of_arithmetic_ceiling': rl['frac_of_arithmetic_ceiling'], 'pipe_busy_frac': rl['pipe_busy_frac'],
             'filter_and_head_us': 1e6 * t_fh,
-            'how': 'whole step: wall clock over %d steps; the two kernels: HIP events around back-to-back launches' % nst,
+            'how': 'whole step: wall clock, median of %d regions of %d steps; the two kernels: HIP events around '
+                   'back-to-back launches' % (nreg, nst),
             'parity_max_abs_dlogit': err, 'near_tie_rows': int((~clear).sum()),
             'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear]))}
 
@@ -292,7 +320,8 @@ def compact_summary(d):
     def r(x, n=4):
         return None if x is None else float('%.*g' % (n, x))
     rl, par = d.get('roofline', {}), d.get('parity', {})
-    out = {'legend': '[M agent-steps/s, ms/step, dominant kernel us, roofline frac, max |dlogit| vs oracle]',
+    out = {'legend': '[M agent-steps/s, ms/step, dominant kernel us, roofline frac, max |dlogit| vs oracle; other '
+                     'configs: + filter-and-head us, its frac, its pipe-busy frac]',
            d['config']['name']: [r(d['value'] / d['n_gpus'] / 1e6), r(d['ms_per_step']), r(rl.get('avg_launch_us')),
                                  r(rl.get('frac')), r(par.get('max_abs_dlogit'), 2)],
            'executed_over_algorithmic_flops': r(rl.get('executed_over_algorithmic_flops')),
@@ -302,8 +331,9 @@ def compact_summary(d):
     def rec(v):
         if 'error' in v:
             return 'error'
+        fh = v.get('filter_and_head') or {}
         return [r(v['value'] / 1e6), r(v['ms_per_step']), r(v.get('dominant_kernel_us')), r(v.get('frac')),
-                r(v.get('parity_max_abs_dlogit'), 2)]
+                r(v.get('parity_max_abs_dlogit'), 2), r(fh.get('us')), r(fh.get('frac'), 3), r(fh.get('pipe_busy_frac'), 3)]
     for k, v in (sec.get('other_configs') or {}).items():
         out[k] = rec(v)
     for k, v in (sec.get('shards_of_8gpu_configs') or {}).items():
@@ -323,6 +353,12 @@ def compact_summary(d):
     rot = sec.get('c2_rotating_batches') or {}
     if 'agent_steps_per_s' in rot:
         out['c2_rotating_M_per_s'] = r(rot['agent_steps_per_s'] / 1e6)
+    bb = sec.get('c2_best_batch') or {}
+    if 'value' in bb:
+        out['c2_best_batch'] = [r(bb['value'] / 1e6), 'B=%d' % bb['batch'], bb['path']]
+    dr = sec.get('dispatch_rule') or {}
+    if 'chosen' in dr:
+        out['dispatch_rule'] = {'chosen': dr['chosen'], 'ms': r(dr['chosen_ms']), 'alt_ms': r(dr['alternative_ms'])}
     fs = sec.get('batch_sweep_filter_only') or []
     if fs:
         best = max(fs, key=lambda x: x['hbm_frac_of_8TBps'])
@@ -878,7 +914,40 @@ def main():
                                    'algorithmic_GBps': fb / tf / 1e9, 'hbm_frac_of_8TBps': fb / tf / (HBM_PEAK_TBPS * 1e12),
                                    'algorithmic_TFLOPs': ffl / tf / 1e12})
                     del o, Ss, xf, yf
+                for row in sweep:
+                    row['path'] = 'one launch' if fused_rule(L, row['batch'], N, K, prec) else 'encoder + filter launches'
                 sec['batch_sweep_policy'] = sweep
+                best_row = max(sweep, key=lambda x: x['agent_steps_per_s'])
+                sec['c2_best_batch'] = {
+                    'value': best_row['agent_steps_per_s'], 'batch': best_row['batch'], 'path': best_row['path'],
+                    'vs_headline_batch': best_row['agent_steps_per_s'] / value_rank,
+                    'what': 'best row of batch_sweep_policy: the headline batch (%d graphs = two one-graph workgroups '
+                            'per CU, ONE round of the chip) is a granularity corner -- larger batches run 16-agent '
+                            'tiles with every MFMA column filled' % B}
+                # what gnnpp_policy_fwd's rule chose at the headline shape, and the alternative it rejected, measured
+                # here on the same inputs (GNNPP_TUNE_FUSED_POLICY: 2 = always the one kernel, 0 = never)
+                knob_old = L.gnnpp_get_tuning(6)
+                alt = {}
+                try:
+                    for nm_, kv in (('one_launch', 2), ('two_launches', 0)):
+                        L.gnnpp_set_tuning(6, kv)
+                        for _ in range(5):
+                            out_alt = step()
+                        nst_a = max(20, args.steps // 2)
+                        ra = sorted(x[0] for x in timed_regions(step, nst_a, 5))[2] / nst_a
+                        alt[nm_] = {'ms_per_step': 1e3 * ra, 'agent_steps_per_s': M / ra,
+                                    'max_abs_dlogit_vs_headline': max((a_ - b_).abs().max().item()
+                                                                      for a_, b_ in zip(out, out_alt))}
+                finally:
+                    L.gnnpp_set_tuning(6, knob_old)
+                chosen = 'one_launch' if fused else 'two_launches'
+                other = 'two_launches' if fused else 'one_launch'
+                sec['dispatch_rule'] = {
+                    'rule': 'csrc/gnnpp_api.hip fused_policy_applies: one launch iff N <= 16, K in 2..4 and '
+                            '(B <= 512 or N >= 13)', 'shape': {'batch': B, 'agents': N, 'taps': K},
+                    'chosen': chosen, 'chosen_ms': alt[chosen]['ms_per_step'],
+                    'alternative': other, 'alternative_ms': alt[other]['ms_per_step'],
+                    'chosen_over_alternative': alt[other]['ms_per_step'] / alt[chosen]['ms_per_step'], 'measured': alt}
                 sec['batch_sweep_filter_only'] = fsweep
                 sec['batch_sweep_note'] = ('larger batches amortise launch latency and the per-launch weight stream; '
                                            'the filter-only rows are the HBM-fraction figure of SURVEY.md section 8d '

@@ -23,7 +23,7 @@ static_assert(GNNPP_OK == 0 && GNNPP_ERR_UNSUPPORTED == -2 && GNNPP_ERR_LAUNCH =
 
 extern "C" {
 
-int gnnpp_version(void) { return 310; }
+int gnnpp_version(void) { return 320; }
 
 const char* gnnpp_error_string(int code) {
     switch (code) {
@@ -90,6 +90,9 @@ int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, con
 int gnnpp_lsigf_fits(int N, int G, int F, int K, int E) {
     if (N <= 0 || G <= 0 || F <= 0 || K <= 0 || E <= 0) return GNNPP_ERR_ARG;
     if (N > GNNPP_MAX_ROWS) return 0;
+    if ((F + 127) / 128 > 64) return 0;                // lsigf_launch plans at most 64 chunks of 128 output features:
+                                                       // F > 8192 takes the dense form too (the reference
+                                                       // BatchLSIGF has no such limit)
     for (int f0 = 0; f0 < F; f0 += 128) {              // (lsigf_launch's chunks of <= 128 output features)
         LsigfArgs a = {};
         a.B = 1; a.N = N; a.Nin = N; a.G = G; a.K = K; a.E = E;
@@ -349,11 +352,11 @@ int gnnpp_set_tuning(int key, int value) {
             g_filter_waves.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SPLIT:
-            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 7) return GNNPP_ERR_ARG;
             g_filter_split.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_POLICY_FILTER:
-            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 1) return GNNPP_ERR_ARG;
             g_filter_policy_kernel.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL_ROWS:

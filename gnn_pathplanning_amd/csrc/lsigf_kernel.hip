@@ -58,7 +58,7 @@ struct LsigfArgs {
     int rt_total;          // 16-row MFMA tiles of a workgroup's graphs = ceil(gpw*N / 16)
     int Ns;                // LDS row stride of an S slab in floats = N rounded up to a multiple of 4
     int Nl;                // bytes per neighbour-index list (= Ns)
-    int nsplit;            // 1, or 2: two workgroups per graph share its row tiles (gpw == 1 only)
+    int nsplit;            // workgroups per graph: 1, or 2 .. rt_total sharing its row tiles (gpw == 1 only)
     int s_vec4;            // fp32 S slabs are 16-byte aligned multiples of four floats: v4f staging loads
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int bias_per_node;     // bias is [F_all, N] (one value per feature AND node, graphML.py:2300-2302)
@@ -68,7 +68,6 @@ struct LsigfArgs {
     int pf_part_off;       // policy_filter_kernel.hip: LDS byte offset of the partial logits
     int pf_plane_off;      // policy_filter_kernel.hip, bf16x3 mode: LDS byte offset of the plane buffer
     int pf_const_off;      // policy_filter_kernel.hip: LDS byte offset of the epilogue constants
-    int pf_csr_cap;        // policy_filter_kernel.hip, MODE 3: entries of the compact neighbour lists
     int ablate;            // GNNPP_MEASURE builds only (tools/ab_bench.py): bit 0 skip the shifts, bit 1
                            // skip the MFMA contraction, bit 2 skip staging of S, bit 3 skip the epilogue
 };
@@ -425,12 +424,13 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     const int a = lane & 15;      // row inside a 16-row tile (MFMA j)
     const int q = lane >> 4;      // MFMA k slot
 
-    // workgroup -> (first graph, part): with nsplit == 2 the blocks b and b + 8 of a group of 16
-    // carry the two halves of one graph (same XCD under round-robin dispatch)
+    // workgroup -> (first graph, part): with nsplit > 1 a group of 8 nsplit blocks carries 8 graphs, the blocks
+    // b, b + 8, b + 16, .. of the group are the parts of one graph (same XCD under round-robin dispatch)
     int gblk = blockIdx.x, part = 0;
-    if (p.nsplit == 2) {
-        part = (gblk >> 3) & 1;
-        gblk = (gblk >> 4) * 8 + (gblk & 7);
+    if (p.nsplit > 1) {
+        const int grp = gblk / (8 * p.nsplit), in = gblk - grp * 8 * p.nsplit;
+        part = in >> 3;
+        gblk = grp * 8 + (in & 7);
     }
     const int g0 = gblk * p.gpw;                       // first graph of this workgroup
     if (g0 >= p.B) return;                             // padding block of a split grid (uniform)
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
     const int mt = wave & (mtp - 1);
     // this workgroup's row tiles [tile_lo, tile_hi) and rows [row_lo, row_hi)
     const int rt_all = (R + 15) >> 4;
-    const int tile_lo = p.nsplit == 2 ? (part ? rt_all >> 1 : 0) : 0;
-    const int tile_hi = p.nsplit == 2 ? (part ? rt_all : rt_all >> 1) : rt_all;
+    const int tile_lo = part * rt_all / p.nsplit;      // (nsplit <= rt_all: every part owns at least one row tile;
+    const int tile_hi = (part + 1) * rt_all / p.nsplit;   //  nsplit > 1 only with gpw == 1, so rt_all == rt_total)
     const int row_lo = tile_lo * 16, row_hi = min(tile_hi * 16, R);
     const int rt0 = tile_lo + (wave / mtp) * RTW;      // first row tile of this wave
     const bool has_mfma = mt < p.MT && rt0 < tile_hi;
@@ -850,15 +850,23 @@ int lsigf_plan(LsigfArgs& a, LsigfPlan& plan) {
     plan.smem = lsigf_smem(a, a.gpw);
     if (plan.smem > (size_t)kLdsBytes) return -2;
     plan.grid = (a.B + a.gpw - 1) / a.gpw;
-    // Two workgroups per graph when single-graph workgroups leave at least half of the 256 CUs idle
-    // and the graph has row tiles to share (see the header); GNNPP_TUNE_FILTER_SPLIT forces 1 / 2.
+    // Several workgroups per graph when single-graph workgroups leave at least half of the 256 CUs idle and the
+    // graph has row tiles to share (see the header): as many parts as still give every workgroup a CU of its own
+    // (the padded grid of 8-graph groups x parts <= 256), at most one per row tile -- 16 graphs of 100 agents (the
+    // shard one GPU of eight holds of config 5) run as 112 workgroups of one tile instead of 32 of four / three
+    // (r05; r04: two parts at most).  GNNPP_TUNE_FILTER_SPLIT forces 1 / n parts.
     const int forced_split = g_filter_split.load(std::memory_order_relaxed);
     a.nsplit = 1;
-    if (a.gpw == 1 && a.rt_total >= 2 && (forced_split == 2 || (forced_split == 0 && plan.grid <= 128 &&
-                                                                a.rt_total >= 4)))
-        a.nsplit = 2;
-    const int tiles_per_wg = a.nsplit == 2 ? a.rt_total - a.rt_total / 2 : a.rt_total;
-    if (a.nsplit == 2) plan.grid = ((plan.grid + 7) / 8) * 16;      // groups of 8 graphs x 2 parts
+    if (a.gpw == 1 && a.rt_total >= 2) {
+        const int groups = (plan.grid + 7) / 8;
+        if (forced_split >= 2) a.nsplit = forced_split < a.rt_total ? forced_split : a.rt_total;
+        else if (forced_split == 0 && plan.grid <= 128 && a.rt_total >= 4) {
+            const int room = 256 / (8 * groups);                    // parts that keep one workgroup per CU
+            a.nsplit = room < 2 ? 2 : room < a.rt_total ? room : a.rt_total;
+        }
+    }
+    const int tiles_per_wg = (a.rt_total + a.nsplit - 1) / a.nsplit;
+    if (a.nsplit > 1) plan.grid = ((plan.grid + 7) / 8) * 8 * a.nsplit;      // groups of 8 graphs x nsplit parts
     // waves per workgroup: 16 when there are enough rows / row tiles to feed them
     const int mtp = a.MT > 4 ? 8 : 4;
     plan.nw = (a.gpw * a.N > 24) ? 16 : 8;

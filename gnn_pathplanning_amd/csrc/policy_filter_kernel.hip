@@ -34,18 +34,10 @@
 // six MFMAs per (row tile, 32 channels); needs N * 800 more bytes of LDS, which exists up to about 64 nodes;
 // 1 = exact fp32 MFMA (GNNPP_PREC_FP32_MFMA, and GNNPP_PREC_FP32 on graphs whose planes do not fit): the taps read
 // the fp32 rows directly, 32 MFMAs of K = 4 per (row tile, 128 channels).
-// 3 (opt-in: GNNPP_TUNE_POLICY_FILTER = 2) = bf16x3 for the teams whose planes do NOT fit beside the dense S slab (65 ..
-// 100 agents: 2 x 54 KB of fp32 rows + 40 KB slab + 10 KB index lists + 41 KB planes > 160 KB; the default runs them as
-// MODE 1, which measured as fast: what MODE 3's contraction saves its plane production spends): the
-// dense slab is staged into the SECOND z buffer (free until the first shift writes it) and compacted from there into
-// CSR lists -- 5 bytes per edge, every node's list padded to a multiple of four entries, space reserved with one LDS
-// atomic per node (the ORDER of the lists in the buffer is arbitrary, their contents are not: same neighbours, same
-// ascending order, same arithmetic) -- ~1 000 entries for the 100-agent teams of config 5 (mean degree 8), capacity
-// ~2 000.  A denser graph (a near-clique) overflows the capacity: its workgroup then copies the slab to where MODE 1
-// keeps it and carries on as MODE 1 (exact fp32 MFMA) -- a wave-uniform branch, taken per graph.
-// Two workgroups per graph (nsplit = 2, as in lsigf_kernel) when at most 128 large graphs would leave half of
-// the CUs idle: both stage the graph and run the shifts k < K-1 on all rows; the last shift, the contraction
-// and the head run on the workgroup's own half of the row tiles.
+// nsplit workgroups per graph (as in lsigf_kernel; lsigf_plan: as many as keep every workgroup on a CU of its own, at
+// most one per 16-row tile) when at most 128 large graphs would leave half of the CUs idle -- 16 graphs of 100 agents,
+// the shard one GPU of eight holds of config 5, run as 112 workgroups of one row tile: all of them stage the graph and
+// run the shifts k < K-1 on all rows; the last shift, the contraction and the head run on the workgroup's own row tiles.
 #include "gnnpp_common.h"
 
 namespace gnnpp {
@@ -80,15 +72,12 @@ __host__ __device__ inline size_t pf_lds_base(int N, int Ns, int K) {
 // stores cost the shift what the pass saved.)
 constexpr int kPfPRow = 3 * 256 + 32;     // MODE 2: row stride of the plane buffer PB (bytes)
 
-// CSR (MODE 3): Sl / idx are the compact weight / index arrays and `off` the per-node start (entries, a multiple of
-// four); a quarter wave that is done while another still walks its list re-reads its own last group with zero weights.
-template <int MODE, bool CSR = false>
+template <int MODE>
 __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const unsigned char* __restrict__ idx,
                                           const unsigned char* __restrict__ cnt, const float* __restrict__ zprev,
                                           float* __restrict__ znxt, float* __restrict__ zsplit, int Ns, int row_lo,
                                           int row_hi, int wave, int lane, unsigned long long& bad,
-                                          char* __restrict__ planes = nullptr, int own_lo = 0, int own_hi = 0,
-                                          const unsigned short* __restrict__ off = nullptr) {
+                                          char* __restrict__ planes = nullptr, int own_lo = 0, int own_hi = 0) {
     // MODE 2: `planes` = PB; rows [own_lo, own_hi) also leave as bf16x3 planes (PB row r - own_lo); zsplit unused
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     const int quarter = lane >> 4, ql = lane & 15;
@@ -96,21 +85,17 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
         const int r = rb + quarter;
         const bool rv = r < row_hi;
         const int rr = rv ? r : rb;
-        const int lo = CSR ? (int)off[rr] : rr * Ns;
+        const int lo = rr * Ns;
         const float* wl = Sl + lo;                                       // compacted weights of node rr
         const unsigned char* il = idx + lo;
         const int deg = rv ? (int)cnt[rr] : 0;
-        const int last4 = CSR ? max(((int)cnt[rr] + 3) & ~3, 4) - 4 : 0;  // CSR: the node's last group of four entries
         const float* zc = zprev + 4 * ql;
         v4f acc0 = vzero(), acc1 = vzero();
         for (int d = 0; __ballot(d < deg) != 0ull; d += 4) {             // until all four rows are done
             // entries past the degree: weight 0 and a stale (but valid) row index.  (Masking those reads per
             // lane was measured: the branches cost more than the LDS cycles they save, 1.72 -> 1.94 us per shift.)
-            // CSR: what lies behind a node's padded list is another node's: stay inside, with zero weights
-            const int dd = CSR ? min(d, last4) : d;
-            const unsigned pk = *reinterpret_cast<const unsigned*>(il + dd);
-            v4f w = *reinterpret_cast<const v4f*>(wl + dd);
-            if (CSR && d >= deg) w = vzero();
+            const unsigned pk = *reinterpret_cast<const unsigned*>(il + d);
+            const v4f w = *reinterpret_cast<const v4f*>(wl + d);
             const float* zr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) zr[u] = zc + __umul24((pk >> (8 * u)) & 255u, (unsigned)kPfZs);
@@ -133,7 +118,7 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
             *reinterpret_cast<v4f*>(row + 4 * ql) = acc0;
             *reinterpret_cast<v4f*>(row + 64 + 4 * ql) = acc1;
         }
-        if (MODE == 2 || MODE == 3) {
+        if (MODE == 2) {
             v2f p0[3], p1[3];
             b3_split4(acc0, p0);
             b3_split4(acc1, p1);
@@ -169,61 +154,6 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
     }
 }
 
-// MODE 3: compact neighbour lists out of the dense slab Sd [N][Ns] (row c = column c of the GSO).  A half-wave reads a
-// row into registers, counts its non-zeros (ballots), reserves max(4, degree rounded up to 4) entries of the CSR
-// arrays with ONE LDS atomic, and writes the weights / row indices in ascending m plus zero padding (index 0: a valid
-// row, weight 0).  Where a node's list lands depends on the order of the atomics; what it holds does not.  A
-// reservation past the capacity raises the overflow flag instead of writing.
-__device__ __forceinline__ void pf_build_csr(const float* __restrict__ Sd, float* __restrict__ Wc,
-                                             unsigned char* __restrict__ Ic, unsigned short* __restrict__ coff,
-                                             unsigned char* __restrict__ ccnt, unsigned* __restrict__ cctr, int cap, int N,
-                                             int Ns, int wave, int nwaves, int lane) {
-    const int half = lane >> 5, hl = lane & 31;
-    for (int rb = 2 * wave; rb < N; rb += 2 * nwaves) {              // wave-uniform trip count
-        const int c = rb + half;
-        const bool cv = c < N;
-        const float* row = Sd + (cv ? c : rb) * Ns;
-        float sv[4];
-        unsigned mine[4];
-        int deg = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int m = 32 * u + hl;
-            sv[u] = (cv && m < N) ? row[m] : 0.f;
-            const unsigned long long bal = __ballot(sv[u] != 0.f);
-            mine[u] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
-            deg += __popc(mine[u]);
-        }
-        const int pdeg = max((deg + 3) & ~3, 4);
-        int o = 0;
-        if (cv && hl == 0) o = (int)__hip_atomic_fetch_add(cctr, (unsigned)pdeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int o_lo = __builtin_amdgcn_readlane(o, 0), o_hi = __builtin_amdgcn_readlane(o, 32);
-        o = half ? o_hi : o_lo;
-        const bool fits = o + pdeg <= cap;
-        if (cv && !fits && hl == 0) cctr[1] = 1u;
-        if (cv && fits) {
-            int base = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (sv[u] != 0.f) {
-                    const int pos = o + base + __popc(mine[u] & ((1u << hl) - 1u));
-                    Ic[pos] = (unsigned char)(32 * u + hl);
-                    Wc[pos] = sv[u];
-                }
-                base += __popc(mine[u]);
-            }
-            if (hl < pdeg - deg) {                                   // (at most four entries of padding)
-                Ic[o + deg + hl] = 0;
-                Wc[o + deg + hl] = 0.f;
-            }
-            if (hl == 0) {
-                coff[c] = (unsigned short)o;
-                ccnt[c] = (unsigned char)deg;
-            }
-        }
-    }
-}
-
 // RTW = 16-row MFMA tiles per wave (waves 0..7 own the first RTW tiles of the workgroup's range, waves 8..15 the
 // next RTW; wave & 7 is the 16-feature output tile).
 template <int RTW, int MODE>
@@ -238,40 +168,30 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     const int N = p.N, Ns = p.Ns, K = p.K;
 
     int gblk = blockIdx.x, part = 0;
-    if (p.nsplit == 2) {                               // blocks b and b + 8 of a group of 16: one graph (same XCD)
-        part = (gblk >> 3) & 1;
-        gblk = (gblk >> 4) * 8 + (gblk & 7);
+    if (p.nsplit > 1) {                                // a group of 8 nsplit blocks = 8 graphs; blocks b, b + 8, b + 16, ..
+        const int grp = gblk / (8 * p.nsplit), in = gblk - grp * 8 * p.nsplit;    // of the group: one graph (same XCD)
+        part = in >> 3;
+        gblk = grp * 8 + (in & 7);
     }
     if (gblk >= p.B) return;                           // padding block of a split grid (uniform)
     const int mt = wave & 7;
     const int rt_all = (N + 15) >> 4;
-    const int tile_lo = p.nsplit == 2 ? (part ? rt_all >> 1 : 0) : 0;
-    const int tile_hi = p.nsplit == 2 ? (part ? rt_all : rt_all >> 1) : rt_all;
+    const int tile_lo = part * rt_all / p.nsplit;      // (nsplit <= rt_all: every part owns at least one row tile)
+    const int tile_hi = (part + 1) * rt_all / p.nsplit;
     const int row_lo = tile_lo * 16, row_hi = min(tile_hi * 16, N);
     const int rt0 = tile_lo + (wave >> 3) * RTW;       // first row tile of this wave
     const bool has_mfma = rt0 < tile_hi;
 
-    constexpr bool B3 = MODE == 2 || MODE == 3;         // bf16x3 planes in PB
+    constexpr bool B3 = MODE == 2;                      // bf16x3 planes in PB
     float* zbuf0 = reinterpret_cast<float*>(gnnpp_smem);
     float* zbuf1 = zbuf0 + N * kPfZs;
-    // MODE 0 .. 2: the dense slab [N][Ns] (row n = column n of the GSO, compacted in place into its list) behind the z
-    // buffers.  MODE 3: the slab is STAGED in the second z buffer and compacted into the CSR arrays behind the z buffers
-    // (weights [cap] | indices [cap] | start [N] | degree [N] | counter, overflow flag); Sl2 / idx2 / cnt2 are where
-    // the overflow path (MODE 1's layout) puts the slab.
-    float* const Sl2 = zbuf1 + N * kPfZs;
-    float* Sl = MODE == 3 ? zbuf1 : Sl2;
-    unsigned char* idx2 = reinterpret_cast<unsigned char*>(Sl2 + (K > 1 ? N * Ns : 0));
-    unsigned char* cnt2 = idx2 + (K > 1 ? N * Ns : 0);
-    unsigned char* idx = idx2;
-    unsigned char* cnt = cnt2;
-    float* const Wc = Sl2;                                                              // MODE 3: CSR weights
-    unsigned char* const Ic = reinterpret_cast<unsigned char*>(Wc + p.pf_csr_cap);     //         CSR row indices
-    unsigned short* const coff = reinterpret_cast<unsigned short*>(Ic + p.pf_csr_cap); //         start of a node's list
-    unsigned char* const ccnt = reinterpret_cast<unsigned char*>(coff + 128);          //         degree of a node
-    unsigned* const cctr = reinterpret_cast<unsigned*>(ccnt + 128);                    //         [0] entries used, [1] overflow
+    // the dense slab [N][Ns] (row n = column n of the GSO, compacted in place into its list) behind the z buffers
+    float* const Sl = zbuf1 + N * kPfZs;
+    unsigned char* const idx = reinterpret_cast<unsigned char*>(Sl + (K > 1 ? N * Ns : 0));
+    unsigned char* const cnt = idx + (K > 1 ? N * Ns : 0);
     float* cb = reinterpret_cast<float*>(gnnpp_smem + p.pf_const_off);
-    float* part_sums = reinterpret_cast<float*>(gnnpp_smem + p.pf_part_off);      // [8][N][8]
-    char* const PB = gnnpp_smem + p.pf_plane_off;      // MODE 2 / 3: bf16x3 planes of this workgroup's own rows
+    float* const part_sums = reinterpret_cast<float*>(gnnpp_smem + p.pf_part_off);      // [8][N][8]
+    char* const PB = gnnpp_smem + p.pf_plane_off;      // MODE 2: bf16x3 planes of this workgroup's own rows
 
     GNNPP_STAMP(blockIdx.x, 0, tid == 0);
     // ---- every global load of the kernel, issued now -------------------------------------------------------
@@ -319,7 +239,6 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     else if (tid < 768) cpre = p.bias ? p.bias[tid - 640] : 0.f;
     else if (tid < 773) cpre = p.act_b[tid - 768];
     else if (tid == 773) cpre = MODE == 0 ? p.wpk_h[filter_packed_h2_floats(128, 128, K, 1) + 1] : 1.f;
-    else if (MODE == 3 && tid >= 774 && tid < 776) cctr[tid - 774] = 0u;   // (CSR counter, overflow flag)
     // A fragments of the first tap.  MODE 0: packed block (k, mt, gg) = 64 lanes x 16 bytes = hi | lo of four
     // k-steps; MODE 1: the fp32 fragments of four k-steps; MODE 2: block (k, mt, kb) = three 16-byte planes
     constexpr int NA = B3 ? 12 : 8;
@@ -327,7 +246,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     v4f Acur[NA];
     auto load_tap = [&](v4f (&A)[NA], int tap) {
         if (has_mfma) {
-            const float* wt = (MODE == 0 ? p.wpk_h : MODE == 1 ? p.wpk : p.wpk_b) + tap * tap_stride +   // (MODE 2 / 3: wpk_b)
+            const float* wt = (MODE == 0 ? p.wpk_h : MODE == 1 ? p.wpk : p.wpk_b) + tap * tap_stride +
                               ((size_t)mt * NA * 64 + lane) * 4;
 #pragma unroll
             for (int gg = 0; gg < NA; ++gg) A[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
@@ -335,7 +254,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     };
 
     // ---- LDS: zero the index lists, then the staged data ------------------------------------------------
-    if (K > 1 && MODE != 3) {                          // stale list entries must be valid rows
+    if (K > 1) {                                       // stale list entries must be valid rows
         unsigned* iz = reinterpret_cast<unsigned*>(idx);
         for (int i = tid; i < (N * Ns) >> 2; i += NT) iz[i] = 0u;
     }
@@ -482,18 +401,14 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     //   shift k = 1 .. K-1: z_{k-1} (fp32, buffer (k-1) & 1) -> z_k (buffer k & 1; the LAST shift writes hi | lo);
     //   once shift k has read the fp32 z_{k-1}, that is converted in place and contracted (k >= 2);
     //   the last tap follows the one before without a barrier.
-    if (K > 1) {
-        if (MODE == 3) pf_build_csr(Sl, Wc, Ic, coff, ccnt, cctr, p.pf_csr_cap, N, Ns, wave, NW, lane);
-        else build_lists(p, Sl, idx, cnt, N, wave, NW, lane);
-    }
+    if (K > 1) build_lists(p, Sl, idx, cnt, N, wave, NW, lane);
     GNNPP_STAMP(blockIdx.x, 2, tid == 0);
     contract(MODE == 0 ? zbuf1 : zbuf0, Acur);
     if (K > 1) load_tap(Acur, 1);                      // in flight during the shift(s)
     GNNPP_STAMP(blockIdx.x, 3, tid == 0);
     if (MODE != 0) {
-        // fp32 rows ping-pong; tap k is contracted right behind shift k.  MODE 2 / 3: the shift's epilogue writes the
+        // fp32 rows ping-pong; tap k is contracted right behind shift k.  MODE 2: the shift's epilogue writes the
         // planes of the workgroup's own rows into PB (which tap k-1 has finished reading: first barrier).
-        bool dense = false;                            // MODE 3: the graph's lists overflowed the CSR arrays
         for (int k = 1; k < K; ++k) {
             const float* zsrc = ((k - 1) & 1) ? zbuf1 : zbuf0;
             float* zdst = (k & 1) ? zbuf1 : zbuf0;
@@ -501,14 +416,9 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
             if (B3 || k == 1) __syncthreads();         // lists visible / PB free (MODE 1, k >= 2: zdst was z_{k-2},
                                                        // whose tap finished before the previous shift's barrier)
             GNNPP_STAMP(blockIdx.x, 4, tid == 0 && k == 1);
-            if (MODE == 3 && k == 1 && cctr[1] != 0u) {                // (workgroup-uniform)
-                dense = true;
-                break;
-            }
             GNNPP_STAMP(blockIdx.x, 7, tid == 0 && k == 2);
-            pf_gather<MODE, MODE == 3>(MODE == 3 ? Wc : Sl, MODE == 3 ? Ic : idx, MODE == 3 ? ccnt : cnt, zsrc,
-                                       (B3 && last) ? nullptr : zdst, nullptr, Ns, last ? row_lo : 0,
-                                       last ? row_hi : N, wave, lane, bad, PB, row_lo, row_hi, coff);
+            pf_gather<MODE>(Sl, idx, cnt, zsrc, (B3 && last) ? nullptr : zdst, nullptr, Ns, last ? row_lo : 0,
+                            last ? row_hi : N, wave, lane, bad, PB, row_lo, row_hi);
             GNNPP_STAMP(blockIdx.x, 8, tid == 0 && k == 2);
             __syncthreads();                           // z_k visible
             GNNPP_STAMP(blockIdx.x, 5, tid == 0 && k == 1);
@@ -516,51 +426,6 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
             contract(zdst, Acur);
             GNNPP_STAMP(blockIdx.x, 6, tid == 0 && k == 1);
             if (k + 1 < K) load_tap(Acur, k + 1);
-        }
-        if (MODE == 3 && dense) {
-            // A graph too dense for the CSR arrays (a near-clique): the slab moves from the second z buffer to where
-            // MODE 1 keeps it -- over the CSR arrays and PB, both dead: tap 0 is contracted -- and the remaining taps
-            // run as MODE 1 (exact fp32 MFMA on the fp32 rows; the head sums both accumulator sets).
-            __syncthreads();                           // every thread has read the overflow flag (it lies where the slab goes)
-            for (int i = tid; i < N * Ns; i += NT) Sl2[i] = zbuf1[i];
-            unsigned* iz = reinterpret_cast<unsigned*>(idx2);
-            for (int i = tid; i < (N * Ns) >> 2; i += NT) iz[i] = 0u;
-            // (the fp32 fragments of a tap -- eight per wave -- go where the twelve plane fragments were: no second set of
-            // fragment registers for the rare path; one cost the common path 44 bytes of scratch)
-            auto load_tap_f32 = [&](int tap) {
-                if (has_mfma) {
-                    const float* wt = p.wpk + (size_t)tap * (8 * 8 * 256) + ((size_t)mt * 8 * 64 + lane) * 4;
-#pragma unroll
-                    for (int gg = 0; gg < 8; ++gg) Acur[gg] = *reinterpret_cast<const v4f*>(wt + gg * 256);
-                }
-            };
-            load_tap_f32(1);
-            __syncthreads();
-            build_lists(p, Sl2, idx2, cnt2, N, wave, NW, lane);
-            for (int k = 1; k < K; ++k) {
-                const float* zsrc = ((k - 1) & 1) ? zbuf1 : zbuf0;
-                float* zdst = (k & 1) ? zbuf1 : zbuf0;
-                const bool last = k + 1 == K;
-                if (k == 1) __syncthreads();           // lists visible
-                pf_gather<1>(Sl2, idx2, cnt2, zsrc, zdst, nullptr, Ns, last ? row_lo : 0, last ? row_hi : N, wave, lane,
-                             bad);
-                __syncthreads();                       // z_k visible
-                if (has_mfma) {
-#pragma unroll
-                    for (int gg = 0; gg < 8; ++gg) {
-                        v4f Bf[RTW];
-#pragma unroll
-                        for (int t = 0; t < RTW; ++t)
-                            Bf[t] = *reinterpret_cast<const v4f*>(zdst + brow(t) * kPfZs + q * 4 + gg * 16);
-#pragma unroll
-                        for (int st = 0; st < 4; ++st)
-#pragma unroll
-                            for (int t = 0; t < RTW; ++t) acc[t] = mfma16(Acur[gg][st], Bf[t][st], acc[t]);
-                    }
-                }
-                if (k + 1 < K) load_tap_f32(k + 1);
-            }
-            part_sums = Sl2;                           // (dead after the last shift; the z buffers are not: taps read them)
         }
     } else {
     for (int k = 1; k + 1 < K; ++k) {                  // the shifts before the last one: all rows, fp32 out
@@ -615,8 +480,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
 #pragma unroll
         for (int t = 0; t < RTW; ++t) {
             const int row = (rt0 + t) * 16 + a;
-            v4f v = MODE == 0 ? (acc[t] + acc2[t]) * h2_inv + bv : MODE == 1 ? acc[t] + bv : (acc[t] + acc2[t]) + bv;   // (MODE 3's
-                                                                               // dense path: its fp32 products are in acc)
+            v4f v = MODE == 0 ? (acc[t] + acc2[t]) * h2_inv + bv : MODE == 1 ? acc[t] + bv : (acc[t] + acc2[t]) + bv;
             if (p.relu) v = vrelu(v);
             const v4f d = mfma16x4(A5, v, vzero());    // d[r] = logit part a5 = 4 q + r of this lane's row
             if (rt0 + t < tile_hi && row < N) {
@@ -677,7 +541,7 @@ static hipError_t policy_filter_launch_rtw(int rtw, const LsigfArgs& a, int grid
 // lsigf_kernel), 0 on success, -3 on a launch error.
 static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st) {
     if (!policy_filter_applies(a)) return 1;
-    const int tiles = a.nsplit == 2 ? a.rt_total - a.rt_total / 2 : a.rt_total;
+    const int tiles = (a.rt_total + a.nsplit - 1) / a.nsplit;           // row tiles of the largest part
     if ((tiles + 1) / 2 > 4) return 1;
     const size_t base = pf_lds_base(a.N, a.Ns, a.K) + kPfConsts * 4;
     const size_t parts = (size_t)8 * a.N * 8 * 4;
@@ -686,32 +550,11 @@ static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_
     int mode = a.prec == kPrecSplitF16 ? 0 : a.prec == kPrecFp32Mfma ? 1 : 2;
     const size_t planes = (size_t)tiles * 16 * kPfPRow;
     a.pf_const_off = (int)pf_lds_base(a.N, a.Ns, a.K);
-    if (mode == 2 && base + parts + planes > (size_t)kLdsBytes) {
-        // MODE 3: planes + compact (CSR) neighbour lists instead of the dense slab.  z buffers | CSR arrays | PB (the
-        // workgroup's own rows) | constants at the end of the LDS; the partial logits reuse the first z buffer.  Needs
-        // room for at least 8 entries per node, and MODE 1's layout (the overflow path) below the constants.
-        mode = 1;
-        const int half_tiles = a.rt_total / 2;
-        const int rows_own = a.nsplit == 2 ? (16 * half_tiles > a.N - 16 * half_tiles ? 16 * half_tiles : a.N - 16 * half_tiles)
-                                           : a.N;
-        const long zb = 2L * a.N * kPfZs * 4, cst = (long)kLdsBytes - kPfConsts * 4;
-        const long room = cst - (long)rows_own * kPfPRow - zb - 400;
-        const int cap = room > 0 ? (int)((room / 5) & ~3L) : 0;
-        // (opt-in, GNNPP_TUNE_POLICY_FILTER = 2: the planes' production costs what the cheaper contraction saves --
-        // 26.4 against 25.8 us at 128 graphs of 100 agents, 23.5 against 24.1 at 16: profiles/r04_filter_stamps.jsonl)
-        if (g_filter_policy_kernel.load(std::memory_order_relaxed) == 2 &&
-            a.K > 1 && a.N <= 128 && cap >= 8 * a.N && cap < 65536 && (long)a.pf_const_off <= cst &&
-            parts <= (size_t)a.N * kPfZs * 4) {
-            mode = 3;
-            a.pf_csr_cap = cap;
-            a.pf_const_off = (int)cst;
-            a.pf_plane_off = (int)((zb + 5L * cap + 392 + 15) & ~15L);
-            a.pf_part_off = 0;
-            const int rtw3 = (tiles + 1) / 2;
-            const hipError_t e3 = policy_filter_launch_rtw<3>(rtw3, a, plan.grid, (size_t)kLdsBytes, st);
-            return e3 == hipSuccess ? 0 : -3;
-        }
-    }
+    // (teams of 65 .. 100 agents: 2 x 54 KB of fp32 rows + 40 KB slab + 10 KB lists + 41 KB planes > 160 KB.  r04 built
+    // bf16x3 planes beside COMPACT neighbour lists for them -- "MODE 3" -- and measured it no faster than the exact
+    // fp32 MFMA: 26.4 against 25.8 us at 128 graphs of 100 agents, what its contraction saved its plane production
+    // spent, profiles/r04_filter_stamps.jsonl; removed in r05.)
+    if (mode == 2 && base + parts + planes > (size_t)kLdsBytes) mode = 1;
     size_t smem = base + parts + (mode == 2 ? planes : 0);
     a.pf_part_off = (int)base;
     a.pf_plane_off = (int)(base + parts);

@@ -72,8 +72,10 @@ const char* gnnpp_error_string(int code);
  * builds only). */
 #define GNNPP_TUNE_FILTER_GPW      1  /* graphs per workgroup of the filter kernel; 0 = heuristic */
 #define GNNPP_TUNE_FILTER_WAVES    2  /* waves per workgroup of the filter kernel: 8, 16; 0 = auto */
-#define GNNPP_TUNE_FILTER_SPLIT    7  /* 0 = heuristic (two workgroups per graph when one-graph workgroups
-                                         fill at most half of the 256 CUs); 1 = never; 2 = whenever
+#define GNNPP_TUNE_FILTER_SPLIT    7  /* 0 = heuristic (when one-graph workgroups fill at most half of the
+                                         256 CUs: 2 .. 7 workgroups per graph, as many as keep one workgroup
+                                         per CU, at most one per 16-row tile -- v320; v310: two at most);
+                                         1 = never; n = 2 .. 7: n parts (clamped to the row tiles) whenever
                                          a workgroup holds one graph with >= 2 row tiles            */
 #define GNNPP_TUNE_FUSED_POLICY     6  /* 1 (default): for teams of N <= 16 agents and K = 2, 3 or 4 taps
                                          (GNNPP_PREC_FP32 or GNNPP_PREC_SPLIT_F16), when B <= 512 graphs
@@ -85,11 +87,9 @@ const char* gnnpp_error_string(int code);
 #define GNNPP_TUNE_POLICY_FILTER    9  /* 1 (default): the filter + action head of gnnpp_policy_fwd / the rollout step
                                          for teams of 17 .. 100 agents (one graph per workgroup,
                                          FILTER_WAVES != 8) runs on the latency-scheduled policy_filter_kernel;
-                                         0: on the general filter kernel (same logits to the last bit or two);
-                                         2: as 1, and teams of 65 .. 100 agents contract on bf16x3 planes beside
-                                         COMPACT neighbour lists (policy_filter_kernel MODE 3) instead of on the
-                                         exact fp32 MFMA -- measured 2 % slower at 128 graphs of 100 agents, 2 %
-                                         faster at 16, hence not the default          */
+                                         0: on the general filter kernel (same logits to the last bit or two).
+                                         (v310's value 2 -- bf16x3 planes beside compact neighbour lists for 65 ..
+                                         100 agents, measured no faster -- was removed in v320: GNNPP_ERR_ARG)   */
 #define GNNPP_TUNE_FILTER_SMALL     10  /* 1 (default): graph filters over many small graphs (GNNPP_PREC_FP32, N <= 16,
                                          G = F = 128, node-major rows, >= 64 workgroups) run on the
                                          throughput kernel lsigf_small_b3_kernel (bf16x3 planes, two workgroups per

@@ -96,6 +96,52 @@ def test_emu_policy_golden(emu, policy_golden, prec):
         assert (acts == want.argmax(-1)).all()
 
 
+def _non_finite_case(B=4, N=10, K=3):
+    """Graph 1 carries one NaN pixel, graph 2 one +Inf pixel; graphs 0 and 3 are clean."""
+    import torch
+    from oracle import policy_oracle as orc
+    sd_t = orc.init_state_dict(K, seed=3)
+    obs_t = orc.synth_obs(B, N, seed=4)
+    obs_t[1, 3, 0, 5, 5] = float('nan')
+    obs_t[2, 0, 1, 2, 7] = float('inf')
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=4)).float()
+    with torch.no_grad():
+        want = torch.stack(orc.policy_forward(sd_t, S, obs_t), 1).numpy()     # [B,N,5]
+    return sd_t, obs_t, S, want
+
+
+@pytest.mark.parametrize('prec', PRECS)
+def test_emu_non_finite_observations_are_flushed(emu, prec):
+    """VERDICT r04 item 7, the documented deviation ("Numerics"): torch.relu propagates NaN / Inf
+    (graphs/models/decentralplanner.py:166) and the dense x @ S of BatchLSIGF (utils/graphUtils/graphML.py:2350) then
+    makes EVERY agent of that graph NaN (0 * NaN); the kernels' ReLU (v_med3 / fmaxf) flushes a non-finite activation to
+    a finite value, so the graph's logits stay finite.  Pinned here: the oracle has NaN rows exactly in the two
+    poisoned graphs, the kernels (both dispatch paths) return finite logits there and the CLEAN graphs are untouched
+    (no leak across graphs, parity within the tolerance)."""
+    el, lib = emu
+    sd_t, obs_t, S, want = _non_finite_case()
+    sd = {k: v.numpy() for k, v in sd_t.items()}
+    B, N, K = 4, 10, 3
+    assert np.isnan(want[1]).all() and np.isnan(want[2]).all() and np.isfinite(want[[0, 3]]).all()
+    enc, filt = el.pack_encoder(lib, sd), el.pack_filter(lib, sd['GFL.0.weight'])
+    gb = el.f32(sd['GFL.0.bias'].reshape(-1))
+    aw, ab = el.f32(sd['actionsMLP.0.weight']), el.f32(sd['actionsMLP.0.bias'])
+    try:
+        for fused in (1, 0):
+            lib.gnnpp_set_tuning(6, fused)
+            obs, Sn = el.f32(obs_t.numpy()), el.f32(S.numpy())
+            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+            ws = np.zeros((B * N, 128), dtype=np.float32)
+            rc = lib.gnnpp_policy_fwd(el.ptr(obs), el.ptr(Sn), el.ptr(enc), el.ptr(filt), el.ptr(gb), el.ptr(aw),
+                                      el.ptr(ab), el.ptr(ws), el.ptr(logits), B, N, K, 1, 0, prec, None, None)
+            assert rc == 0
+            got = logits.transpose(1, 0, 2)
+            assert np.abs(got[[0, 3]] - want[[0, 3]]).max() <= TOL
+            assert np.isfinite(got).all(), (prec, fused)
+    finally:
+        lib.gnnpp_set_tuning(6, 1)
+
+
 def test_emu_encoder_negative_and_zero_batchnorm_scales(emu):
     """bf16x3 L0 pools its raw accumulators (sign of the folded BatchNorm scale in the packed weights, |scale| in the
     table): gamma < 0 and gamma = 0 channels, binary and real-valued observations, default and exact-fp32 precision."""
@@ -222,7 +268,7 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
     # f16) and the measurement-only knobs (csrc/gnnpp_measure.h) are not part of the ABI
     assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 1) == -1 and lib.gnnpp_get_tuning(0) == -1
     assert lib.gnnpp_set_tuning(3, 1) == -1 and lib.gnnpp_set_tuning(4, 1) == -1
-    assert lib.gnnpp_version() == 310
+    assert lib.gnnpp_version() == 320
 
 
 def test_emu_lsigf_transposed_and_tap_dump(emu, lsigf_golden):
@@ -358,9 +404,10 @@ def el_ref(h, S, x):
 
 
 def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
-    """GNNPP_TUNE_FILTER_SPLIT = 2: two workgroups share a graph's row tiles (both run the early shifts
-    on all rows, each the last shift / contraction / epilogue on its half).  Same results as one
-    workgroup per graph, bit for bit, in both layouts, with Nin < N, E = 2 and the tap dump."""
+    """GNNPP_TUNE_FILTER_SPLIT = n: n workgroups share a graph's row tiles (all run the early shifts
+    on all rows, each the last shift / contraction / epilogue on its own tiles).  Same results as one
+    workgroup per graph, bit for bit, in both layouts, with Nin < N, E = 2 and the tap dump; two parts, and
+    one part per row tile (v320)."""
     el, lib = emu
     z, meta = lsigf_golden
     picked = 0
@@ -373,10 +420,10 @@ def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
             b = z['c%d_b' % i] if m['has_bias'] else None
             batched = m['kind'] in ('BatchLSIGF', 'GraphFilterBatch')
             outs = []
-            for split in (1, 2):
+            for split in (1, 2, 7):
                 assert lib.gnnpp_set_tuning(7, split) == 0 and lib.gnnpp_set_tuning(1, 1) == 0
                 outs.append(el.lsigf(lib, h, S, x, b, batched, Nin=m.get('Nin')))
-            assert np.array_equal(outs[0], outs[1]), (i, m)
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (i, m)
             assert np.abs(outs[1] - z['c%d_y' % i]).max() <= TOL * max(1.0, np.abs(z['c%d_y' % i]).max())
             picked += 1
         # node-major + ReLU + tap dump (training entry point) on a 37-node graph, odd sizes
@@ -387,7 +434,7 @@ def test_emu_filter_two_workgroups_per_graph(emu, lsigf_golden):
         S = (g.random((B, E, N, N)) < 0.15).astype(np.float32) * g.random((B, E, N, N)).astype(np.float32)
         packed = el.pack_filter(lib, h)
         res = []
-        for split in (1, 2):
+        for split in (1, 3):
             assert lib.gnnpp_set_tuning(7, split) == 0
             y = np.full((B, N, F_out), np.nan, np.float32)
             zs = np.full((E * K, B * N, G), np.nan, np.float32)
@@ -578,19 +625,20 @@ def test_emu_column_packed_encoder_tiles_are_bit_identical(emu, M, tile):
     assert lib.gnnpp_set_tuning(14, 13) == -1
 
 
-@pytest.mark.parametrize('N,K,f64,B,density', [(100, 3, 0, 2, 0.06), (100, 3, 1, 1, 0.3), (72, 2, 0, 2, 0.08),
-                                               (100, 4, 1, 1, 0.05), (88, 3, 0, 1, 0.02), (100, 2, 0, 1, 0.19)])
-def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
-    """policy_filter_kernel MODE 3 (GNNPP_TUNE_POLICY_FILTER = 2; teams of 65 .. 100 agents, two workgroups per graph): bf16x3
-    planes beside COMPACT (CSR) neighbour lists -- the dense slab is staged in the second z buffer and compacted with one
-    LDS atomic per node.  Sparse graphs (the lists fit: bf16x3 contraction), dense graphs (the lists overflow: that
-    workgroup finishes as MODE 1), a hub node, isolated nodes (degree 0: a padded list of four zero weights), fp64
-    slabs: the general filter kernel's logits to rounding, the float64 statement's within TOL."""
+@pytest.mark.parametrize('N,K,f64,B', [(100, 3, 0, 2), (100, 2, 1, 1), (72, 3, 0, 2), (50, 4, 1, 1), (33, 3, 0, 9)])
+def test_emu_policy_filter_kernel_n_way_split(emu, N, K, f64, B):
+    """VERDICT r04 item 2: up to ceil(N / 16) workgroups per graph in policy_filter_kernel (GNNPP_TUNE_FILTER_SPLIT = n;
+    lsigf_plan picks n itself when few graphs would leave CUs idle).  Every part stages the graph and runs the early
+    shifts on all rows, the last shift / contraction / head on its own row tiles -- a row's arithmetic does not
+    depend on the partition: with the exact-fp32 contraction the logits of every split are the one-workgroup logits
+    bit for bit; with the default precision a finer split can move a team from the fp32 MFMA to bf16x3 planes (they
+    fit the LDS once a workgroup owns fewer rows: 72 agents from three parts on), so those agree to rounding.  B = 9:
+    two groups of 8 graphs, the second one padded.  Hub and isolated nodes, fp64 slabs."""
     el, lib = emu
-    g = np.random.default_rng(1000 * N + 10 * K + int(100 * density))
+    g = np.random.default_rng(77 * N + K)
     h = (g.standard_normal((128, 1, K, 128)) / np.sqrt(128 * K)).astype(np.float32)
     x = np.maximum(g.standard_normal((B, N, 128)), 0).astype(np.float32)
-    S = ((g.random((B, N, N)) < density) * g.random((B, N, N))).astype(np.float64 if f64 else np.float32)
+    S = ((g.random((B, N, N)) < 0.08) * g.random((B, N, N))).astype(np.float64 if f64 else np.float32)
     S[0, :, N // 2] = g.random(N)                            # a hub: node N/2 gathers from everybody
     S[:, :, 3] = 0                                           # an isolated node (nobody to gather from)
     S[:, :, N - 1] = 0                                       # ... and the last one
@@ -600,19 +648,23 @@ def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
     aw = (g.standard_normal((5, 128)) / 8).astype(np.float32)
     ab = g.standard_normal(5).astype(np.float32)
     packed = el.pack_filter(lib, h)
-    outs = []
+    rt = (N + 15) // 16
+    splits = sorted({1, 2, 3, rt, 7})                        # (values above the row tiles are clamped to them)
+    outs = {}
     lib.gnnpp_set_tuning(2, 0)
     try:
-        assert lib.gnnpp_set_tuning(7, 2) == 0 and lib.gnnpp_set_tuning(1, 1) == 0     # two workgroups per graph
-        for mode in (2, 0, 1):                               # compact lists (opt-in) | general kernel | default (MODE 1)
-            assert lib.gnnpp_set_tuning(9, mode) == 0 and lib.gnnpp_get_tuning(9) == mode
-            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
-            assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
-                                             el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, 0, None, None) == 0
-            outs.append(logits)
-        assert lib.gnnpp_set_tuning(9, 3) == -1
+        assert lib.gnnpp_set_tuning(1, 1) == 0
+        for prec in (1, 0):
+            for split in splits:
+                assert lib.gnnpp_set_tuning(7, split) == 0
+                logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+                assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
+                                                 el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, prec, None,
+                                                 None) == 0
+                outs[prec, split] = logits
+        assert lib.gnnpp_set_tuning(7, 8) == -1
     finally:
-        lib.gnnpp_set_tuning(9, 1); lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0)
+        lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0)
     z = x.astype(np.float64)
     y = np.zeros((B, N, 128))
     for k in range(K):
@@ -620,8 +672,8 @@ def test_emu_policy_filter_kernel_compact_lists(emu, N, K, f64, B, density):
         z = np.einsum('bmn,bmg->bng', S.astype(np.float32).astype(np.float64), z)
     want = (np.maximum(y + bias, 0) @ aw.astype(np.float64).T + ab).transpose(1, 0, 2)
     scale = max(1.0, np.abs(want).max())
-    assert np.isfinite(outs[0]).all()
-    assert np.abs(outs[0] - want).max() <= TOL * scale, np.abs(outs[0] - want).max()
-    assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale
-    assert np.abs(outs[0] - outs[2]).max() <= 4e-6 * scale
-    assert not np.array_equal(outs[0], outs[2])              # (the opt-in mode really ran: another arithmetic's bits)
+    for split in splits:
+        assert np.array_equal(outs[1, split], outs[1, 1]), split            # exact fp32: the same bits
+        assert np.isfinite(outs[0, split]).all()
+        assert np.abs(outs[0, split] - want).max() <= TOL * scale, split
+        assert np.abs(outs[0, split] - outs[0, 1]).max() <= 4e-6 * scale, split

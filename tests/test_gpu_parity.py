@@ -845,13 +845,16 @@ def test_unseen_parameter_updates_and_invalidate_packed(dev):
     assert (d - a).abs().max().item() <= 1e-6
 
 
-@pytest.mark.parametrize('B,N,K,f64', [(6, 100, 3, 0), (9, 100, 2, 1), (4, 80, 4, 0), (128, 100, 3, 0)])
-def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
-    """policy_filter_kernel MODE 3 (GNNPP_TUNE_POLICY_FILTER = 2; 65 .. 100 agents, two workgroups per graph): bf16x3 planes beside
-    compact (CSR) neighbour lists.  A batch that MIXES sparse graphs (lists fit: bf16x3 contraction), near-cliques (the
-    lists overflow: that workgroup alone finishes as MODE 1), hubs and isolated nodes: every graph against the general
-    filter kernel (to rounding) and the float64 statement (TOL); repeated launches are bit-identical (the order of the
-    LDS atomics that place the lists must not matter)."""
+@pytest.mark.parametrize('B,N,K,f64', [(16, 100, 3, 0), (9, 100, 2, 1), (4, 80, 4, 0), (32, 100, 4, 0), (64, 50, 3, 1),
+                                       (128, 100, 3, 0), (16, 72, 3, 0)])
+def test_policy_filter_n_way_split(dev, B, N, K, f64):
+    """up to ceil(N / 16) workgroups per graph in policy_filter_kernel / lsigf_kernel
+    (csrc/lsigf_kernel.hip lsigf_plan: as many parts as keep one workgroup per CU; 16 graphs of 100 agents -- the
+    shard one GPU of eight holds of config 5 -- run as 112 one-tile workgroups).  A batch that MIXES sparse graphs,
+    near-cliques, hubs and isolated nodes: the heuristic's split, every forced split 1 .. 7 and the general filter
+    kernel on the same inputs.  Exact-fp32 contraction: every split gives the one-workgroup logits bit for bit (a
+    row's arithmetic does not depend on the partition).  Default precision: equal to rounding (a finer split can move
+    a team from the fp32 MFMA to bf16x3 planes, which then fit the LDS) and within TOL of the float64 statement."""
     from gnn_pathplanning_amd import _native
     L = _native.lib()
     g = torch.Generator().manual_seed(B * 17 + N + K)
@@ -868,21 +871,25 @@ def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
     hd = h.to(dev)
     assert L.gnnpp_filter_pack(hd.data_ptr(), packed.data_ptr(), 128, 128, K, 1, None) == 0
     xd, Sd, bd, awd, abd = x.to(dev), S.to(dev), bias.to(dev), aw.to(dev), ab.to(dev)
-    outs = []
+
+    def run(prec):
+        lg = torch.full((N, B, 5), float('nan'), device=dev)
+        assert L.gnnpp_filter_head_fwd(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(), awd.data_ptr(),
+                                       abd.data_ptr(), lg.data_ptr(), B, N, 128, 128, K, 1, f64, prec, None, None) == 0
+        torch.cuda.synchronize()
+        return lg.cpu()
+    outs = {}
     try:
-        for mode in (2, 0, 2, 2, 1):                          # compact lists (opt-in) x 3 | general kernel | default
-            assert L.gnnpp_set_tuning(9, mode) == 0
-            lg = torch.full((N, B, 5), float('nan'), device=dev)
-            assert L.gnnpp_filter_head_fwd(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(),
-                                           awd.data_ptr(), abd.data_ptr(), lg.data_ptr(), B, N, 128, 128, K, 1, f64,
-                                           0, None, None) == 0
-            torch.cuda.synchronize()
-            outs.append(lg.cpu())
+        for prec in (1, 0):
+            for split in (0, 1, 2, 3, 4, 5, 6, 7):           # 0 = the heuristic
+                assert L.gnnpp_set_tuning(7, split) == 0
+                outs[prec, split] = run(prec)
+            outs[prec, 'again'] = run(prec)                  # (a repeated launch: the same bits)
+        assert L.gnnpp_set_tuning(7, 0) == 0 and L.gnnpp_set_tuning(9, 0) == 0
+        general = run(0)                                     # the general filter kernel, its own n-way split
     finally:
         L.gnnpp_set_tuning(9, 1)
-    assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
-    assert not torch.equal(outs[0], outs[4])              # (the opt-in mode really ran: the default is MODE 1's arithmetic)
+        L.gnnpp_set_tuning(7, 0)
     z = x.double()
     y = torch.zeros(B, N, 128, dtype=torch.float64)
     Sf = S.float().double()
@@ -891,8 +898,13 @@ def test_policy_filter_compact_lists_and_dense_overflow(dev, B, N, K, f64):
         z = torch.einsum('bmn,bmg->bng', Sf, z)
     want = (torch.relu(y + bias.double()) @ aw.double().t() + ab.double()).permute(1, 0, 2)
     scale = max(1.0, want.abs().max().item())
-    assert (outs[0].double() - want).abs().max().item() <= TOL * scale
-    assert (outs[0] - outs[1]).abs().max().item() <= 4e-6 * scale
+    for split in (0, 1, 2, 3, 4, 5, 6, 7, 'again'):
+        assert torch.equal(outs[1, split], outs[1, 1]), split
+        assert torch.isfinite(outs[0, split]).all()
+        assert (outs[0, split].double() - want).abs().max().item() <= TOL * scale, split
+        assert (outs[0, split] - outs[0, 1]).abs().max().item() <= 4e-6 * scale, split
+    assert torch.equal(outs[0, 'again'], outs[0, 7])
+    assert (general - outs[0, 1]).abs().max().item() <= 4e-6 * scale
 
 
 @pytest.mark.parametrize('B,N,K,f64', [(256, 50, 3, 0), (128, 100, 3, 1), (128, 100, 2, 0), (7, 17, 3, 0), (300, 64, 4, 1),
@@ -1109,3 +1121,29 @@ def test_graphed_policy_step_follows_weight_changes(dev):
     net.precision, net.range_policy = 'split_f16', 'strict'
     with pytest.raises(ValueError):
         GraphedPolicyStep(net, obs_d, S_d)
+
+
+@pytest.mark.parametrize('fused', [1, 0])
+def test_non_finite_observations_flush_is_pinned(dev, enc_variant, fused):
+    """VERDICT r04 item 7 ("Numerics"): a NaN / +Inf pixel makes every logit of its graph NaN in the
+    reference (torch.relu keeps it, graphs/models/decentralplanner.py:166; the dense x @ S spreads it,
+    utils/graphUtils/graphML.py:2350); the kernels' ReLU flushes non-finite activations, so the device logits of
+    those graphs are FINITE -- the documented deviation, pinned against the oracle here in all three arithmetics and
+    both dispatch paths -- and the clean graphs of the same batch keep parity (nothing leaks across graphs)."""
+    from gnn_pathplanning_amd import _native
+    from test_emu_kernels import _non_finite_case
+    sd_t, obs_t, S, want = _non_finite_case()
+    assert np.isnan(want[1]).all() and np.isnan(want[2]).all() and np.isfinite(want[[0, 3]]).all()
+    net = _net(10, 3, dev, sd_t)
+    net.range_policy = 'flag'
+    L = _native.lib()
+    old = L.gnnpp_get_tuning(6)
+    L.gnnpp_set_tuning(6, fused)
+    try:
+        with torch.no_grad():
+            net.addGSO(S.to(dev))
+            got = torch.stack([g.cpu() for g in net(obs_t.to(dev))], 1).numpy()
+    finally:
+        L.gnnpp_set_tuning(6, old)
+    assert np.abs(got[[0, 3]] - want[[0, 3]]).max() <= TOL
+    assert np.isfinite(got).all()

@@ -42,9 +42,32 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert lib.gnnpp_encoder_packed_floats() > 555000 // 4
     # argument validation happens before any HIP call, so it is checkable without a GPU
     assert lib.gnnpp_encoder_fwd(None, None, None, 16, 0, None, None) == -1
-    assert lib.gnnpp_version() == 310                        # ABI 300: per-call `precision`, no precision knobs
+    assert lib.gnnpp_version() == 320                        # ABI 300: per-call `precision`; 320: n-way graph split
     assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 0) == -1
     assert lib.gnnpp_decode_actions(None, None, 1, 1, None) == -1
+    # gnnpp_lsigf_fits: 1 = the LDS-resident kernels take the graph, 0 = take the dense form (F > 8192 too)
+    assert lib.gnnpp_lsigf_fits(10, 128, 128, 3, 1) == 1 and lib.gnnpp_lsigf_fits(100, 128, 8192, 3, 1) == 1
+    assert lib.gnnpp_lsigf_fits(10, 128, 8193, 3, 1) == 0 and lib.gnnpp_lsigf_fits(113, 128, 128, 3, 1) == 0
+    assert lib.gnnpp_lsigf_fits(0, 128, 128, 3, 1) == -1
+    # tuning keys: n-way graph split (v320), the removed MODE 3 value of GNNPP_TUNE_POLICY_FILTER
+    assert lib.gnnpp_set_tuning(7, 7) == 0 and lib.gnnpp_set_tuning(7, 8) == -1 and lib.gnnpp_set_tuning(7, 0) == 0
+    assert lib.gnnpp_set_tuning(9, 2) == -1 and lib.gnnpp_get_tuning(9) == 1
+
+
+def test_split_f16_is_refused_when_its_isa_check_failed(built_lib, tmp_path, monkeypatch):
+    """the opt-in split-f16 encoder is outside the build's must-pass ISA list; a violation there
+    leaves a marker and the PRECISION is refused with a message, the default path keeps working."""
+    mark = tmp_path / 'split_f16_disabled.txt'
+    monkeypatch.setattr(built_lib, 'H2_UNSAFE_MARK', str(mark))
+    assert built_lib.precision_code('split_f16') == 2
+    mark.write_text('encoder_kernel_h2ILb0ELi3E: ring slot read before its load was waited for')
+    with pytest.raises(built_lib.GnnppError, match='split_f16'):
+        built_lib.precision_code('split_f16')
+    with pytest.raises(built_lib.GnnppError):
+        built_lib.precision_code(2)
+    assert built_lib.precision_code('fp32') == 0 and built_lib.precision_code('fp32_mfma') == 1
+    assert all(k[0].startswith('encoder_kernel_b3') for k in built_lib.RING_KERNELS)
+    assert all(k[0].startswith('encoder_kernel_h2') for k in built_lib.RING_KERNELS_OPTIONAL)
 
 
 def test_module_tree_matches_reference_state_dict(policy_golden):
@@ -193,6 +216,39 @@ def _check_r04_extras(f, d):
         assert k in sm, k
 
 
+def _check_r05_extras(f, d):
+    """r05: the C2 line states the granularity corner -- `c2_best_batch` (best row of the
+    batch sweep, with its batch and the path gnnpp_policy_fwd took) and `dispatch_rule` (what fused_policy_applies
+    chose at the headline shape and the alternative it rejected, both measured) -- inside the 2 000-character tail,
+    and the records of the other configs / shards carry the filter-and-head launch's roofline figures."""
+    import json
+    _check_r04_extras(f, d)
+    if d['config']['name'] != 'c2':
+        return
+    sm, sec = d['summary'], d['secondary']
+    tail = json.dumps(d)[-2000:]
+    assert '"c2_best_batch"' in tail and '"dispatch_rule"' in tail, f
+    bb, dr = sec['c2_best_batch'], sec['dispatch_rule']
+    rows = sec['batch_sweep_policy']
+    assert bb['value'] == max(x['agent_steps_per_s'] for x in rows) and bb['batch'] in [x['batch'] for x in rows]
+    assert bb['path'] in ('one launch', 'encoder + filter launches')
+    assert abs(sm['c2_best_batch'][0] * 1e6 - bb['value']) <= 2e-3 * bb['value']
+    assert dr['chosen'] in ('one_launch', 'two_launches') and dr['alternative'] != dr['chosen']
+    assert dr['shape'] == {'batch': d['config']['batch_per_gpu'], 'agents': d['config']['agents'], 'taps': d['config']['taps']}
+    assert abs(dr['chosen_over_alternative'] - dr['alternative_ms'] / dr['chosen_ms']) <= 1e-9
+    assert abs(dr['chosen_ms'] - d['ms_per_step']) <= 0.15 * d['ms_per_step']      # (the same step, re-timed)
+    assert all(m['max_abs_dlogit_vs_headline'] <= 1e-4 for m in dr['measured'].values())
+    assert sm['dispatch_rule']['chosen'] == dr['chosen']
+    recs = dict(sec['other_configs'])
+    recs.update({k: v for k, v in sec['shards_of_8gpu_configs'].items() if k.startswith('c5_shard')})
+    for k, v in recs.items():
+        fh = v['filter_and_head']
+        assert fh['instruction'] in ('v_mfma_f32_16x16x32_bf16', 'v_mfma_f32_16x16x4_f32'), k
+        assert abs(fh['frac'] - fh['algorithmic_TFLOPs'] / fh['peak_TFLOPs']) <= 1e-9 and 0 < fh['frac'] < 1
+        assert fh['frac'] <= fh['pipe_busy_frac'] < 1 and abs(fh['us'] - v['filter_and_head_us']) <= 1e-6
+        assert len(sm[k]) == 8 and abs(sm[k][5] - fh['us']) <= 2e-3 * fh['us']
+
+
 def test_committed_bench_lines_follow_the_contract():
     """The bench lines committed under profiles/ (copied from GPU sessions) carry every field of the driver's
     contract, with consistent arithmetic: value = batch x agents / ms_per_step, roofline.frac = achieved / peak with
@@ -203,12 +259,15 @@ def test_committed_bench_lines_follow_the_contract():
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench_c*.json')) +
-                   glob.glob(os.path.join(root, 'profiles', 'r04_bench_c*.json')))
+                   glob.glob(os.path.join(root, 'profiles', 'r04_bench_c*.json')) +
+                   glob.glob(os.path.join(root, 'profiles', 'r05_bench_c*.json')))
     assert len(files) >= 3
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         if os.path.basename(f).startswith('r04'):
             _check_r04_extras(f, d)
+        if os.path.basename(f).startswith('r05'):
+            _check_r05_extras(f, d)
         for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
                     'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
             assert key in d, (f, key)

@@ -79,7 +79,9 @@ if 'encoder' in which:
             report('encoder kernel prec=%d M=%d (%d tiles)' % (prec, Mag, (Mag + 15) // 16), (Mag + 15) // 16,
                    ENC + [('FC', 6)])
 if 'filter' in which:
-    for (N, B) in ((50, 256), (100, 128)):
+    # (N, graphs, forced GNNPP_TUNE_FILTER_SPLIT; 0 = the heuristic): the full batches of configs 3 / 5 and the 16-graph
+    # shard one GPU of eight holds of config 5, as two parts (v310's rule) and as the heuristic's one part per row tile
+    for (N, B, split) in ((50, 256, 0), (100, 128, 0), (100, 16, 2), (100, 16, 0)):
         class Cfg4:
             num_agents, nGraphFilterTaps, device = N, 3, dev
         net = DecentralPlannerNet(Cfg4()).to(dev).eval()
@@ -88,13 +90,13 @@ if 'filter' in which:
         x = torch.relu(torch.randn(B * N, 128, device=dev))
         enc, taps, gb, aw, ab, K = net.policy_pointers()
         lg = torch.empty(N, B, 5, device=dev)
-        for prec in (0, 3, 1, 2):                       # 3 = default precision with GNNPP_TUNE_POLICY_FILTER = 2 (MODE 3 at N > 64)
-            M.gnnpp_set_tuning(9, 2 if prec == 3 else 1)
+        for prec in (0, 1, 2):
+            M.gnnpp_set_tuning(7, split)
             for _ in range(8):
                 assert M.gnnpp_filter_head_fwd(x.data_ptr(), S.data_ptr(), taps, gb, aw, ab, lg.data_ptr(), B, N, 128,
-                                               128, 3, 1, 0, 0 if prec == 3 else prec, None, st) == 0
+                                               128, 3, 1, 0, prec, None, st) == 0
                 torch.cuda.synchronize()
-            M.gnnpp_set_tuning(9, 1)
+            M.gnnpp_set_tuning(7, 0)
             if prec == 2:
                 order = [('entry', 0), ('staged', 1), ('lists', 2), ('tap0', 3), ('barrier1', 4), ('shift1', 5),
                          ('barrier2', 6), ('shift2', 7), ('split1', 8), ('tap1', 9), ('tap2', 12), ('partial', 13),
@@ -103,7 +105,10 @@ if 'filter' in which:
                 order = [('entry', 0), ('staged', 1), ('lists', 2), ('tap0', 3), ('barrier1', 4), ('shift1+barrier', 5),
                          ('tap1 issued', 6), ('barrier(k=2)', 7), ('shift2', 8), ('barrier', 9),
                          ('tap2 issued', 12), ('partial', 13), ('stored', 14)]
-            report('policy_filter_kernel prec=%d B=%d N=%d' % (prec, B, N), B, order)
+            rt, groups = (N + 15) // 16, (B + 7) // 8        # csrc/lsigf_kernel.hip lsigf_plan's rule
+            ns = min(split, rt) if split else (max(2, min(256 // (8 * groups), rt)) if B <= 128 and rt >= 4 else 1)
+            report('policy_filter_kernel prec=%d B=%d N=%d parts=%d' % (prec, B, N, ns),
+                   min(1024, B if ns == 1 else groups * 8 * ns), order)
 
 if 'small' in which:
     from gnn_pathplanning_amd.graphML import pack_filter_taps
