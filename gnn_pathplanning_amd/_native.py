@@ -360,6 +360,41 @@ class device_guard:
         return False
 
 
+# ---- gradient sinks: where the backward kernels write d loss / d parameter --------------------------------------
+# training.FlatBucketDP registers every parameter's slice of its ONE flat gradient bucket here; the autograd Functions
+# of this package (encoder, Linear, graph filter) ask grad_out() for the tensor a parameter's gradient is written to,
+# so the gradients of a step are BORN inside the bucket and the data-parallel exchange is one all-reduce + one scale
+# (the exchange used to pack / unpack with 2 x 26 copy launches around the one collective).
+_grad_sinks = {}            # parameter data_ptr -> (weakref to the parameter, bucket, offset in elements)
+
+
+def register_grad_sink(param, bucket, offset):
+    import weakref
+    _grad_sinks[param.data_ptr()] = (weakref.ref(param), bucket, int(offset))
+
+
+def unregister_grad_sinks(bucket):
+    for k in [k for k, e in _grad_sinks.items() if e[1] is bucket]:
+        del _grad_sinks[k]
+
+
+def grad_out(param_ptr, shape, device):
+    """The tensor a backward kernel writes the gradient of the parameter stored at `param_ptr` into: a FRESH view of
+    the registered bucket slice when the parameter has no gradient yet (autograd then adopts that view as `.grad` --
+    a new tensor object nobody else references -- without a copy), else a new tensor (an existing `.grad` -- kept by
+    zero_grad(set_to_none=False), or a second backward of an accumulation step -- is added to in place by autograd:
+    handing out its own memory would double it)."""
+    e = _grad_sinks.get(param_ptr)
+    if e is not None:
+        p = e[0]()
+        if p is None or p.data_ptr() != param_ptr:
+            del _grad_sinks[param_ptr]                       # the parameter died / moved: a stale entry
+        elif p.grad is None and tuple(p.shape) == tuple(shape) and p.dtype is torch.float32 and e[1].device == device:
+            n = p.numel()
+            return e[1][e[2]:e[2] + n].view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
 _pack_generation = 0
 
 

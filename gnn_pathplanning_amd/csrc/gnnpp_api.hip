@@ -329,6 +329,7 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_FILTER_PIPE_GRID: return g_filter_pipe_grid.load();
         case GNNPP_TUNE_POLICY_CP: return g_policy_column_packing.load();
         case GNNPP_TUNE_ENCODER_CP_TILE: return g_encoder_cp_tile.load();
+        case GNNPP_TUNE_TRAIN_FORK: return g_train_fork.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -374,6 +375,10 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_ENCODER_CP_TILE:
             if (value != 0 && value != 16 && (value < 1 || value > 12)) return GNNPP_ERR_ARG;
             g_encoder_cp_tile.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_TRAIN_FORK:
+            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            g_train_fork.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:
             if (value < 0 || value > 3) return GNNPP_ERR_ARG;

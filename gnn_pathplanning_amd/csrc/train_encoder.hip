@@ -36,6 +36,8 @@
 //     conv_mfma_kernel        dx = conv3x3(dy) with the transposed, flipped kernel (skipped for layer 0)
 // The 128 -> 128 compress MLP, the graph filter and the action head are not in here: the MLP is one library
 // GEMM each way (torch), the graph filter runs on lsigf_kernel (graphML._LSIGFFunction).
+#include <mutex>
+
 #include "gnnpp_common.h"
 
 namespace gnnpp {
@@ -754,11 +756,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 // ---- host side: workspace layout and the two entry points -----------------------------------------------------
 // Workspace (floats), for N agents and B samples per agent:
 //   per layer l: y_l [N*B*Cout*P] | x_{l+1} [N*B*Cout*Po] | stat_l [N*Cout*4]
-//   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz (largest y) | dxa, dxb
+//   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz, dz2 (largest y, ping-pong: the weight-
+//            gradient branch of layer l still reads dz while layer l - 1 writes the other one) | dxa, dxb
 //            (gradients w.r.t. layer inputs, ping-pong) | coef (per-agent BN-backward sums) | wpart
 struct TrainWs {
     size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers], wtb[kTrainLayers];
-    size_t part, dz, dxa, dxb, coef, wpart, total;
+    size_t part, dz, dz2, dxa, dxb, coef, wpart, total;
     int chunks[kTrainLayers];
     // conv_wgrad_kernel: image splits, images per split, images per LDS batch, j tiles, K groups per workgroup
     int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
@@ -802,6 +805,7 @@ inline TrainWs train_ws_layout(int N, int B) {
     }
     w.part = take(max_part);
     w.dz = take(max_y);
+    w.dz2 = take(max_y);
     w.dxa = take(max_x);
     w.dxb = take(max_x);
     w.coef = take((size_t)kTrainLayers * N * 128 * 2);   // per-agent sums of the BN backward, [layer][N][128][2]
@@ -884,6 +888,47 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
     return launched_ok() ? 0 : -3;
 }
 
+// ---- the weight-gradient branch of the backward pass on a second stream (r05) ------------------------------------
+// Per layer the backward chain is  R (bn_bwd_reduce) -> A (bn_bwd_apply) -> { D: input gradient -> layer l - 1 }
+//                                                                          { W: weight gradient -> Wr: its reduction }
+// and nothing downstream of W / Wr is needed before the optimizer.  On one stream the ~20 launches run back to back
+// (257 us at 64 x 10, most of them 5 .. 20 us kernels that fill a fraction of the chip for a fraction of their time:
+// profiles/r05_train_kernel_stats.csv); here W / Wr of every layer go to a SIDE stream that forks behind A(l) and
+// joins in front of the parameter-gradient kernel -- also inside a stream capture, where the fork / join events
+// become edges of the HIP graph.  dz is double-buffered so that R(l - 1) does not wait for W(l); R(l - 2), which
+// re-uses W(l)'s buffer, waits for W(l)'s event.  GNNPP_TUNE_TRAIN_FORK = 0 puts everything back on one stream.
+std::atomic<int> g_train_fork{1};
+
+struct BwdFork {
+    hipStream_t side = nullptr;
+    hipEvent_t dz_ready[kTrainLayers] = {}, w_done[kTrainLayers] = {}, join = nullptr;
+    bool ok = false;
+};
+
+// one per device, created on first use OUTSIDE a stream capture (resource creation is not a capturable operation);
+// a call that arrives while `st` is capturing before any eager call has run stays on one stream
+static BwdFork* bwd_fork(hipStream_t st) {
+    static std::mutex mu;
+    static BwdFork forks[16];
+    if (!g_train_fork.load(std::memory_order_relaxed)) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    BwdFork& f = forks[dev];
+    if (!f.ok) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        bool good = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
+        for (int l = 0; l < kTrainLayers && good; ++l)
+            good = hipEventCreateWithFlags(&f.dz_ready[l], hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&f.w_done[l], hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); return nullptr; }
+        f.ok = true;
+    }
+    return &f;
+}
+
 // dfeat: gradient w.r.t. x_5 [N][B][128]; writes d conv_w / d conv_b / d bn_w / d bn_b of every layer
 int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const float* dfeat,
                       float* const* dconv_w, float* const* dconv_b, float* const* dbn_w, float* const* dbn_b,
@@ -892,11 +937,15 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     const long NB = (long)N * B;
     const float* dxn = dfeat;
     float* dx_buf[2] = {ws + L.dxa, ws + L.dxb};
+    float* dz_buf[2] = {ws + L.dz, ws + L.dz2};
     TrainPtrs5 dp = {};
+    BwdFork* const fk = bwd_fork(st);
+    hipStream_t const sw = fk ? fk->side : st;              // where the weight-gradient branch runs
     for (int l = kTrainLayers - 1; l >= 0; --l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
-        float* dz = ws + L.dz;
+        float* dz = dz_buf[l & 1];
+        if (fk && l + 2 < kTrainLayers) hipStreamWaitEvent(st, fk->w_done[l + 2], 0);      // W(l + 2) has read this buffer
 #define GNNPP_BNR(HH, WW, PL)                                                                                    \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<HH, WW, PL>), dim3(N * L.chunks[l], d.Cout / 4), dim3(256), 0, st,  \
                        ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout,    \
@@ -916,9 +965,14 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        wgrad_launch(l, L, xin, dz, ws + L.wpart, (int)NB, sn, sb, B, st);
+        if (fk) {                                            // fork: the side stream waits for dz of this layer
+            hipEventRecord(fk->dz_ready[l], st);
+            hipStreamWaitEvent(sw, fk->dz_ready[l], 0);
+        }
+        wgrad_launch(l, L, xin, dz, ws + L.wpart, (int)NB, sn, sb, B, sw);
+        if (fk) hipEventRecord(fk->w_done[l], sw);           // (the reduction reads wpart only)
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((d.Cout * (d.Cin * 9 + 1) + 31) / 32), dim3(256),
-                           256 * sizeof(float), st, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l] * L.kw[l],
+                           256 * sizeof(float), sw, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l] * L.kw[l],
                            d.Cin, d.Cout, L.jt[l] * 16);
         if (l > 0) {
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
@@ -928,6 +982,10 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
                         (long)d.Cout * P, st);
             dxn = dx;
         }
+    }
+    if (fk) {                                                // join: everything behind this call sees every gradient
+        hipEventRecord(fk->join, sw);
+        hipStreamWaitEvent(st, fk->join, 0);
     }
     hipLaunchKernelGGL(bn_bwd_dparam_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, dp, N);
     return launched_ok() ? 0 : -3;

@@ -114,7 +114,7 @@ class _EncoderTrainFunction(torch.autograd.Function):
         B, N = obs.shape[0], obs.shape[1]
         dev = obs.device
         p, g = _encoder_params(ps, None, ctx.eps), _native.EncoderGrads()
-        grads = [torch.empty_like(t) for t in ps]
+        grads = [_native.grad_out(t.data_ptr(), t.shape, dev) for t in ps]       # (FlatBucketDP: slices of its bucket)
         for i in range(5):
             g.conv_w[i], g.conv_b[i] = grads[4 * i].data_ptr(), grads[4 * i + 1].data_ptr()
             g.bn_w[i], g.bn_b[i] = grads[4 * i + 2].data_ptr(), grads[4 * i + 3].data_ptr()
@@ -134,6 +134,7 @@ class _LinearFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
+        ctx.param_ptrs = (W.data_ptr(), b.data_ptr() if b is not None else 0)
         return torch.nn.functional.linear(x, W, b)
 
     @staticmethod
@@ -149,10 +150,10 @@ class _LinearFunction(torch.autograd.Function):
             dx = torch.empty(R, I, dtype=torch.float32, device=dy.device)
             specs.append((dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O))
         if ctx.needs_input_grad[1]:
-            dW = torch.empty(O, I, dtype=torch.float32, device=dy.device)
+            dW = _native.grad_out(ctx.param_ptrs[0], (O, I), dy.device)
             specs.append((dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R))
         if ctx.needs_input_grad[2]:
-            db = torch.empty(O, dtype=torch.float32, device=dy.device)
+            db = _native.grad_out(ctx.param_ptrs[1], (O,), dy.device)
             specs.append((_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R))
         if specs:
             _native.gemm_kmajor_multi(specs)

@@ -245,6 +245,7 @@ class _LSIGFFunction(torch.autograd.Function):
         Nin = x.shape[1] if node_major else x.shape[2]
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
+        ctx.param_ptrs = (h.data_ptr(), b.data_ptr() if b is not None else 0)    # (_native.grad_out: gradient sinks)
         ctx.node_major, ctx.relu = node_major, relu
         N = S.shape[-1]
         ctx.large = N > MAX_NODES
@@ -307,7 +308,7 @@ class _LSIGFFunction(torch.autograd.Function):
             dy2 = dyp.permute(1, 0, 2).reshape(F_out, B * N)             # [F, B*N] (one copy)
             # dh[f,e,k,g] = sum_(b,n) dy2[f,(b,n)] zs[(e,k),(b,n),g]: E*K small GEMMs with a long contraction,
             # split over workgroups by gnnpp_gemm_kmajor and written straight into the [F,E,K,G] layout
-            dh = torch.empty(F_out, E, K, G, dtype=torch.float32, device=dy.device)
+            dh = _native.grad_out(ctx.param_ptrs[0], (F_out, E, K, G), dy.device)
             _native.gemm_kmajor(dy2, (0, B * N, 1), zs, (B * N * G, G), dh, (G, E * K * G), E * K, F_out, G,
                                 B * N)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -344,11 +345,11 @@ class _LSIGFFunction(torch.autograd.Function):
                 dx = _LSIGFFunction._dense_dx(ctx, h, S, dy)
         specs = []
         if ctx.needs_input_grad[0]:
-            dh = torch.empty(F_out, E, K, G, dtype=torch.float32, device=dy.device)
+            dh = _native.grad_out(ctx.param_ptrs[0], (F_out, E, K, G), dy.device)
             specs.append((dy, (0, 1, F_out), zs, (B * N * G, G), dh, (G, E * K * G), E * K, F_out, G, B * N))
         if ctx.has_bias and ctx.needs_input_grad[3]:
             if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
-                db = torch.empty(ctx.bias_shape, dtype=torch.float32, device=dy.device)      # sum over (b, n)
+                db = _native.grad_out(ctx.param_ptrs[1], ctx.bias_shape, dy.device)          # sum over (b, n)
                 specs.append((_ones(B * N, dy.device), (0, 0, 1), dy, (0, F_out), db, (0, F_out), 1, 1, F_out, B * N))
             else:                                                         # per-node bias [F,N]: sum over b
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)

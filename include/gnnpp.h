@@ -108,6 +108,10 @@ const char* gnnpp_error_string(int code);
                                          = heuristic -- M <= 2048 agents: tiles of ceil(M / 256) agents, one per CU
                                          (latency regime), else 16-agent tiles --, 1 .. 12 = that tile size for every
                                          M, 16 = always 16-agent tiles.  Same features to the bit (v310)                */
+#define GNNPP_TUNE_TRAIN_FORK        15  /* 1 (default): gnnpp_encoder_train_bwd runs the weight-gradient kernels of
+                                         every layer on a second HIP stream that forks behind the layer's BatchNorm
+                                         backward and joins before the call returns control to the stream (also as
+                                         edges of a captured HIP graph); 0: one stream.  Same gradients to the bit (v320) */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

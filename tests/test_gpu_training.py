@@ -249,6 +249,59 @@ def test_graphed_train_step_equals_eager(dev):
             assert (a - b).abs().max().item() <= 2e-4 * max(1.0, a.abs().max().item()), k
 
 
+@pytest.mark.parametrize('B', [8, 64])
+def test_backward_weight_gradient_fork_is_bit_identical(dev, B):
+    """r05: gnnpp_encoder_train_bwd runs the weight-gradient kernels of every layer on a second HIP stream (forks
+    behind each layer's BatchNorm backward, joins before the call hands the stream back; GNNPP_TUNE_TRAIN_FORK).  The
+    same kernels on the same data: every gradient, the loss and the parameters after several optimisation steps are
+    the one-stream run's BIT FOR BIT -- eager, and as a captured HIP graph (where the fork / join are graph edges) --
+    and a race on the double-buffered dz / the shared partial-sum buffers would show up as run-to-run differences."""
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import FusedAdam, GraphedTrainStep, train_step
+    L = _native.lib()
+
+    class Cfg:
+        num_agents, nGraphFilterTaps, device = 10, 3, dev
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(5):
+        obs = orc.synth_obs(B, 10, seed=70 + i).to(dev)
+        S = torch.from_numpy(orc.synth_gso_geometric(B, 10, 20, seed=70 + i)).float().to(dev)
+        tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, 10), generator=g), 5).float().to(dev)
+        batches.append((obs, tgt, S))
+    sd0 = orc.init_state_dict(3, seed=13)
+
+    def run(fork, graphed):
+        assert L.gnnpp_set_tuning(15, fork) == 0 and L.gnnpp_get_tuning(15) == fork
+        net = DecentralPlannerNet(Cfg()).to(dev).train()
+        net.load_state_dict(sd0)
+        opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+        losses, grads = [], None
+        if graphed:
+            step = GraphedTrainStep(net, opt, *batches[0])        # (3 eager warm-up steps, then the capture)
+            losses = [step(*b).item() for b in batches[1:]]
+        else:
+            for _ in range(3):
+                train_step(net, opt, *batches[0])
+            for b in batches[1:]:
+                losses.append(train_step(net, opt, *b).item())
+            grads = [p.grad.clone() for p in net.parameters()]
+        torch.cuda.synchronize()
+        return losses, grads, [p.detach().clone() for p in net.parameters()]
+    try:
+        ref = run(0, False)
+        for fork, graphed in ((1, False), (1, False), (1, True), (0, True)):
+            got = run(fork, graphed)
+            assert got[0] == ref[0], (fork, graphed, got[0], ref[0])
+            assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2])), (fork, graphed)
+            if got[1] is not None:
+                assert all(torch.equal(a, b) for a, b in zip(got[1], ref[1])), (fork, graphed)
+        assert L.gnnpp_set_tuning(15, 2) == -1
+    finally:
+        L.gnnpp_set_tuning(15, 1)
+
+
 def test_small_cotangents_keep_relative_accuracy(dev):
     """dy of 1e-5 .. 1e-8 (what CrossEntropy / (B N) hands the filter at B = 64) sits in the f16
     subnormal range: the input-gradient launch therefore contracts on the exact fp32 MFMA, and the
@@ -679,14 +732,30 @@ def _dp_rank(rank, world, port, q):
                 local = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
                 both = [torch.empty_like(local) for _ in range(world)]
                 dist.all_gather(both, local)                     # (gloo on CPU copies: the reference for the average)
-            dp.reduce_gradients()
+            born_in_bucket = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(dp.params, dp.views))
+            kernels = None
+            if it == 1:                                          # kernel launches inside the exchange
+                try:
+                    from torch.profiler import profile, ProfilerActivity
+                    torch.cuda.synchronize()
+                    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                        dp.reduce_gradients()
+                        torch.cuda.synchronize()
+                    kernels = sum(1 for e in prof.events() if 'cuda' in str(e.device_type).lower()
+                                  and 'memcpy' not in e.name.lower() and 'memset' not in e.name.lower())
+                except Exception:                                # (a profiler that is not available: the counter below still holds)
+                    kernels = None
+                    dp.reduce_gradients()
+            else:
+                dp.reduce_gradients()
+            copies = dp.last_reduce_copies
             if it == 0:
                 got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
                 grad_err = (got - sum(both) / world).abs().max().item()
             opt.step()
         torch.cuda.synchronize()
         flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
-        q.put((rank, grad_err, flat.numpy()))
+        q.put((rank, grad_err, flat.numpy(), born_in_bucket, copies, kernels))
     finally:
         dist.destroy_process_group()
 
@@ -695,7 +764,7 @@ def test_two_rank_data_parallel_training_on_one_gpu(dev):
     """a real model step PER RANK.  Two processes share the one GPU, collectives over gloo (RCCL
     refuses two ranks on one device): FlatBucketDP broadcasts rank 0's weights, every step averages the gradients of
     the two ranks' different shards (checked against an independent all_gather), and after two FusedAdam steps both
-    ranks hold bit-identical parameters."""
+    ranks hold bit-identical parameters.  The gradients live in the bucket: no per-parameter copies around the all-reduce."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -711,9 +780,13 @@ def test_two_rank_data_parallel_training_on_one_gpu(dev):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, e0, f0), (_, e1, f1) = res
+    (_, e0, f0, born0, cp0, k0), (_, e1, f1, born1, cp1, k1) = res
     assert e0 <= 1e-7 and e1 <= 1e-7, (e0, e1)                   # the reduced gradient IS the mean of the two ranks'
     assert np.array_equal(f0, f1)                                # identical replicas after two steps
+    # r05: every gradient of the planner's step is BORN in the flat bucket (gradient sinks): the exchange copies nothing,
+    # and launches at most the scale (+ whatever the collective itself launches): <= 3 kernels
+    assert born0 and born1 and cp0 == 0 and cp1 == 0
+    assert (k0 is None or k0 <= 3) and (k1 is None or k1 <= 3), (k0, k1)
 
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: wave8 pmc35 test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
+# steps: wave8 pmc35 trainab hostov test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,6 +27,12 @@ if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 --graph 2>&1 | tail -3 | tee $OUT/train_bench_graph.json
   timeout 300 python tools/train_bench.py --steps 50 --graph --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench_graph.json
   timeout 300 python tools/train_bench.py --steps 50 --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench.json; fi
+if has trainab; then stamp "train bench: weight-gradient fork on / off (graphed and eager, B = 64 and 512)"
+  for b in 64 512; do for g in "--graph" ""; do for f in "" "--no-fork"; do
+    timeout 300 python tools/train_bench.py --steps 100 $g --batch $b $f 2>&1 | tail -1 | tee -a $OUT/train_fork_ab.jsonl
+  done; done; done; fi
+if has hostov; then stamp "host-side cost of one policy step"
+  timeout 300 python tools/host_overhead.py 2>&1 | grep -v amdgpu.ids | head -70 | tee $OUT/host_overhead.txt; fi
 if has traincpu; then stamp "train bench with the CPU oracle's training step beside it"
   timeout 300 python tools/train_bench.py --steps 50 --graph --cpu-seconds 8 2>&1 | tail -1 | tee $OUT/train_bench_cpu.json; fi
 if has trainprof; then stamp "host profile of the eager training step"
