@@ -377,7 +377,7 @@ int gnnpp_set_tuning(int key, int value) {
             g_encoder_cp_tile.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_TRAIN_FORK:
-            if (value != 0 && value != 1) return GNNPP_ERR_ARG;
+            if (value < 0 || value > 2) return GNNPP_ERR_ARG;
             g_train_fork.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:

@@ -896,8 +896,12 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
 // profiles/r05_train_kernel_stats.csv); here W / Wr of every layer go to a SIDE stream that forks behind A(l) and
 // joins in front of the parameter-gradient kernel -- also inside a stream capture, where the fork / join events
 // become edges of the HIP graph.  dz is double-buffered so that R(l - 1) does not wait for W(l); R(l - 2), which
-// re-uses W(l)'s buffer, waits for W(l)'s event.  GNNPP_TUNE_TRAIN_FORK = 0 puts everything back on one stream.
+// re-uses W(l)'s buffer, waits for W(l)'s event.  Measured (profiles/r05_train_fork_ab.jsonl, same kernels, bit-identical
+// gradients): 512 x 10: eager 1.626 -> 1.514 ms, graphed 1.633 -> 1.612 ms; 64 x 10 (the per-GPU shard of config 4): graphed
+// 0.486 -> 0.566 ms, eager 1.158 -> 1.270 ms -- eleven cross-stream edges cost more than the overlap of 5 .. 20 us kernels
+// buys.  GNNPP_TUNE_TRAIN_FORK: 1 (default) = fork from kTrainForkMinRows agent-samples on, 0 = never, 2 = always.
 std::atomic<int> g_train_fork{1};
+constexpr long kTrainForkMinRows = 4096;
 
 struct BwdFork {
     hipStream_t side = nullptr;
@@ -907,10 +911,11 @@ struct BwdFork {
 
 // one per device, created on first use OUTSIDE a stream capture (resource creation is not a capturable operation);
 // a call that arrives while `st` is capturing before any eager call has run stays on one stream
-static BwdFork* bwd_fork(hipStream_t st) {
+static BwdFork* bwd_fork(hipStream_t st, long rows) {
     static std::mutex mu;
     static BwdFork forks[16];
-    if (!g_train_fork.load(std::memory_order_relaxed)) return nullptr;
+    const int knob = g_train_fork.load(std::memory_order_relaxed);
+    if (knob == 0 || (knob == 1 && rows < kTrainForkMinRows)) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
@@ -939,7 +944,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     float* dx_buf[2] = {ws + L.dxa, ws + L.dxb};
     float* dz_buf[2] = {ws + L.dz, ws + L.dz2};
     TrainPtrs5 dp = {};
-    BwdFork* const fk = bwd_fork(st);
+    BwdFork* const fk = bwd_fork(st, NB);
     hipStream_t const sw = fk ? fk->side : st;              // where the weight-gradient branch runs
     for (int l = kTrainLayers - 1; l >= 0; --l) {
         const TrainLayerDims d = train_layer(l);

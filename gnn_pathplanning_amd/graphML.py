@@ -215,34 +215,43 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
     return (y, zs) if save_taps else y
 
 
-_transposed_packs = {}
+_weight_packs = {}            # (id(weight), transposed) -> (key, weakref(weight), packed buffer)
+
+
+def _cached_pack(h, transposed):
+    """Packed taps of `h` (forward filter) or of h.permute(3,1,2,0) (the input-gradient filter), cached PER WEIGHT
+    OBJECT and weight version: a training step needs each once per filter layer, however many calls share the weight
+    (a planner with several graph-filter layers keeps one entry per layer).  The entry holds a weak reference to the
+    weight: a dead object's id / address can be reused by an unrelated tensor."""
+    key = (h._version, h.data_ptr(), _native._pack_generation)
+    slot = (id(h), bool(transposed))
+    ent = _weight_packs.get(slot)
+    if ent is None or ent[0] != key or ent[1]() is not h:
+        if len(_weight_packs) > 64:
+            _weight_packs.clear()
+        import weakref
+        src = h.detach().permute(3, 1, 2, 0).contiguous() if transposed else h
+        ent = (key, weakref.ref(h), pack_filter_taps(src))
+        _weight_packs[slot] = ent
+    return ent[2]
 
 
 def _packed_transposed_taps(h):
-    """Packed h.permute(3,1,2,0) (the taps of the input-gradient filter), cached PER WEIGHT and weight version: a
-    training step needs it once per filter layer, however many backward calls share the weight (a planner with
-    several graph-filter layers keeps one entry per layer; VERDICT r02: the single-entry cache repacked every
-    backward there)."""
-    key = (h._version, h.data_ptr(), _native._pack_generation)
-    ent = _transposed_packs.get(id(h))
-    if ent is None or ent[0] != key or ent[1]() is not h:
-        if len(_transposed_packs) > 32:
-            _transposed_packs.clear()
-        import weakref
-        ent = (key, weakref.ref(h), pack_filter_taps(h.detach().permute(3, 1, 2, 0).contiguous()))
-        _transposed_packs[id(h)] = ent
-    return ent[2]
+    return _cached_pack(h, True)
 
 
 class _LSIGFFunction(torch.autograd.Function):
     """y = LSIGF(h, S, x, b) with gradients for h, x and b (none for S)."""
 
     @staticmethod
-    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False, precision=None):
+    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False, precision=None, packed_T=None):
         """node_major: x [B,N,G] -> y [B,N,F] (train-mode planner: no transposing copies around the filter);
         relu: y = relu(filter) in the same launch (the mask for the backward pass is y > 0);
-        precision: of the forward contraction (the gradient filters run in the default arithmetic)."""
+        precision: of the forward contraction (the gradient filters run in the default arithmetic);
+        packed_T: the packed taps of the input-gradient filter when the caller already holds them (ops.py: `h` is a
+        per-call alias of the parameter there, which the per-object cache cannot recognise)."""
         Nin = x.shape[1] if node_major else x.shape[2]
+        ctx.packed_T = packed_T
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
         ctx.param_ptrs = (h.data_ptr(), b.data_ptr() if b is not None else 0)    # (_native.grad_out: gradient sinks)
@@ -291,7 +300,7 @@ class _LSIGFFunction(torch.autograd.Function):
                     db = dyn.sum(dim=(0, 1)).reshape(ctx.bias_shape)
                 else:                                                              # per-node bias [F,N]
                     db = dyn.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
-            return dh, None, dx, db, None, None, None, None, None
+            return dh, None, dx, db, None, None, None, None, None, None
         if ctx.relu:
             dy = torch.ops.aten.threshold_backward(dy, yrelu, 0)          # dy where y > 0, else 0
         if ctx.node_major:
@@ -299,7 +308,8 @@ class _LSIGFFunction(torch.autograd.Function):
         dh = dx = db = None
         if ctx.needs_input_grad[2]:
             hT = h.detach().permute(3, 1, 2, 0)                          # [G,E,K,F] (shape only)
-            dx = _lsigf_device(hT, S, dy, None, ctx.batched, ctx.Nin, _packed_transposed_taps(h),
+            dx = _lsigf_device(hT, S, dy, None, ctx.batched, ctx.Nin,
+                               ctx.packed_T if ctx.packed_T is not None else _packed_transposed_taps(h),
                                transposed=True)
             if dx is None:                                               # (wide F: the dense adjoint, needs no Z)
                 dx = _LSIGFFunction._dense_dx(ctx, h, S, dy.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
@@ -316,7 +326,7 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=(0, 2)).reshape(ctx.bias_shape)
             else:                                                         # per-node bias [F,N]
                 db = torch.nn.functional.pad(dy.sum(dim=0), (0, N - ctx.Nin)).reshape(ctx.bias_shape)
-        return dh, None, dx, db, None, None, None, None, None
+        return dh, None, dx, db, None, None, None, None, None, None
 
     @staticmethod
     def _dense_dx(ctx, h, S, dyn):
@@ -339,8 +349,9 @@ class _LSIGFFunction(torch.autograd.Function):
         dh = dx = db = None
         if ctx.needs_input_grad[2]:
             hT = h.detach().permute(3, 1, 2, 0)
-            dx = _lsigf_device(hT, S, dy, None, ctx.batched, N, _packed_transposed_taps(h), transposed=True,
-                               node_major=True)
+            dx = _lsigf_device(hT, S, dy, None, ctx.batched, N,
+                               ctx.packed_T if ctx.packed_T is not None else _packed_transposed_taps(h),
+                               transposed=True, node_major=True)
             if dx is None:
                 dx = _LSIGFFunction._dense_dx(ctx, h, S, dy)
         specs = []
@@ -355,7 +366,7 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
         if specs:
             _native.gemm_kmajor_multi(specs)
-        return dh, None, dx, db, None, None, None, None, None
+        return dh, None, dx, db, None, None, None, None, None, None
 
 
 _ones_cache = {}

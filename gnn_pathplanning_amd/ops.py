@@ -35,7 +35,8 @@ def lsigf(h: torch.Tensor, S: torch.Tensor, x: torch.Tensor, bias: Optional[torc
           relu: bool = False, precision: int = 0) -> torch.Tensor:
     """h [F,E,K,G], S [E,N,N] (shared) or [B,E,N,N], x [B,G,N] -> y [B,F,N]   (graphML.py:2273-2367)."""
     batched = S.dim() == 4
-    return gml._lsigf_device(h, S, x, bias, batched, x.shape[2], relu=relu, precision=int(precision))
+    return gml._lsigf_device(h, S, x, bias, batched, x.shape[2], packed=gml._cached_pack(h, False), relu=relu,
+                             precision=int(precision))
 
 
 @lsigf.register_fake
@@ -45,26 +46,41 @@ def _(h, S, x, bias=None, relu=False, precision=0):
 
 @torch.library.custom_op('gnnpp::lsigf_backward', mutates_args=())
 def lsigf_backward(h: torch.Tensor, S: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], dy: torch.Tensor,
-                   relu: bool = False, precision: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                   relu: bool = False, precision: int = 0, needs: int = 7
+                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(dh, dx, dbias) of y = lsigf(h, S, x, bias, relu) for the cotangent dy [B,F,N] (agents/decentralplannerlocal.py:314
     `loss.backward()` through graphML.py:2273-2367).  The forward is re-run with its tap signals kept (one more filter
     launch: the op pair carries no hidden state between forward and backward), then graphML._LSIGFFunction's backward:
     dx = the same kernel on dy with transposed taps and S^T, dh = one split-K GEMM, dbias = a reduction.  No gradient
-    for S.  dbias is an empty tensor when there is no bias."""
+    for S.  `needs`: bit 0 = dh, bit 1 = dx, bit 2 = dbias -- a gradient nobody asked for is neither computed nor
+    launched and comes back as an EMPTY tensor (so does dbias when there is no bias).  The packed taps (forward and
+    transposed) are cached on the weight OBJECT the caller passed (graphML._cached_pack): a training loop that passes
+    its parameter packs once per weight version, not once per call."""
     batched = S.dim() == 4
+    want_h, want_x, want_b = bool(needs & 1), bool(needs & 2), bool(needs & 4) and bias is not None
+    if not (want_h or want_x or want_b):
+        return h.new_empty(0), h.new_empty(0), h.new_empty(0)
+    packed = gml._cached_pack(h, False)
+    packed_T = gml._cached_pack(h, True) if want_x else None
     with torch.enable_grad():
-        hh, xx = h.detach().requires_grad_(True), x.detach().requires_grad_(True)
-        bb = bias.detach().requires_grad_(True) if bias is not None else None
-        y = gml._LSIGFFunction.apply(hh, S.detach(), xx, bb, batched, None, False, bool(relu), int(precision))
-        grads = torch.autograd.grad(y, [hh, xx] + ([bb] if bb is not None else []), dy.detach().contiguous())
-    db = grads[2] if bb is not None else h.new_empty(0)
-    return grads[0], grads[1], db
+        hh, xx = h.detach().requires_grad_(want_h), x.detach().requires_grad_(want_x)
+        bb = bias.detach().requires_grad_(want_b) if bias is not None else None
+        y = gml._LSIGFFunction.apply(hh, S.detach(), xx, bb, batched, packed, False, bool(relu), int(precision),
+                                     packed_T)
+        wrt = ([hh] if want_h else []) + ([xx] if want_x else []) + ([bb] if want_b else [])
+        grads = list(torch.autograd.grad(y, wrt, dy.detach().contiguous()))
+    dh = grads.pop(0) if want_h else h.new_empty(0)
+    dx = grads.pop(0) if want_x else h.new_empty(0)
+    db = grads.pop(0) if want_b else h.new_empty(0)
+    return dh, dx, db
 
 
 @lsigf_backward.register_fake
-def _(h, S, x, bias, dy, relu=False, precision=0):
-    return (torch.empty_like(h, dtype=torch.float32), torch.empty_like(x, dtype=torch.float32),
-            torch.empty_like(bias, dtype=torch.float32) if bias is not None else h.new_empty(0))
+def _(h, S, x, bias, dy, relu=False, precision=0, needs=7):
+    e = h.new_empty(0)
+    return (torch.empty_like(h, dtype=torch.float32) if needs & 1 else e,
+            torch.empty_like(x, dtype=torch.float32) if needs & 2 else e,
+            torch.empty_like(bias, dtype=torch.float32) if (needs & 4 and bias is not None) else e)
 
 
 def _lsigf_setup_context(ctx, inputs, output):
@@ -75,8 +91,10 @@ def _lsigf_setup_context(ctx, inputs, output):
 
 def _lsigf_autograd(ctx, dy):
     h, S, x, bias = ctx.saved_tensors
-    dh, dx, db = torch.ops.gnnpp.lsigf_backward(h, S, x, bias, dy, ctx.relu, ctx.precision)
-    return dh, None, dx, (db if ctx.has_bias else None), None, None
+    ng = ctx.needs_input_grad                                # (h, S, x, bias, relu, precision)
+    needs = int(ng[0]) | int(ng[2]) << 1 | int(bool(ng[3]) and ctx.has_bias) << 2
+    dh, dx, db = torch.ops.gnnpp.lsigf_backward(h, S, x, bias, dy, ctx.relu, ctx.precision, needs)
+    return (dh if ng[0] else None), None, (dx if ng[2] else None), (db if (ctx.has_bias and ng[3]) else None), None, None
 
 
 lsigf.register_autograd(_lsigf_autograd, setup_context=_lsigf_setup_context)

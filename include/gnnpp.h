@@ -108,10 +108,12 @@ const char* gnnpp_error_string(int code);
                                          = heuristic -- M <= 2048 agents: tiles of ceil(M / 256) agents, one per CU
                                          (latency regime), else 16-agent tiles --, 1 .. 12 = that tile size for every
                                          M, 16 = always 16-agent tiles.  Same features to the bit (v310)                */
-#define GNNPP_TUNE_TRAIN_FORK        15  /* 1 (default): gnnpp_encoder_train_bwd runs the weight-gradient kernels of
-                                         every layer on a second HIP stream that forks behind the layer's BatchNorm
-                                         backward and joins before the call returns control to the stream (also as
-                                         edges of a captured HIP graph); 0: one stream.  Same gradients to the bit (v320) */
+#define GNNPP_TUNE_TRAIN_FORK        15  /* gnnpp_encoder_train_bwd can run the weight-gradient kernels of every layer
+                                         on a second HIP stream that forks behind the layer's BatchNorm backward and
+                                         joins before the call hands the stream back (graph edges under capture):
+                                         1 (default) = from 4096 agent-samples (N x B) on -- measured + 7 % eager at
+                                         512 x 10, - 16 % at 64 x 10 --, 0 = never, 2 = always.  Same gradients to the
+                                         bit (v320)                                                                  */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

@@ -252,7 +252,8 @@ def test_graphed_train_step_equals_eager(dev):
 @pytest.mark.parametrize('B', [8, 64])
 def test_backward_weight_gradient_fork_is_bit_identical(dev, B):
     """r05: gnnpp_encoder_train_bwd runs the weight-gradient kernels of every layer on a second HIP stream (forks
-    behind each layer's BatchNorm backward, joins before the call hands the stream back; GNNPP_TUNE_TRAIN_FORK).  The
+    behind each layer's BatchNorm backward, joins before the call hands the stream back; GNNPP_TUNE_TRAIN_FORK = 2:
+    always, 1: from 4096 agent-samples on, 0: never).  The
     same kernels on the same data: every gradient, the loss and the parameters after several optimisation steps are
     the one-stream run's BIT FOR BIT -- eager, and as a captured HIP graph (where the fork / join are graph edges) --
     and a race on the double-buffered dz / the shared partial-sum buffers would show up as run-to-run differences."""
@@ -291,13 +292,13 @@ def test_backward_weight_gradient_fork_is_bit_identical(dev, B):
         return losses, grads, [p.detach().clone() for p in net.parameters()]
     try:
         ref = run(0, False)
-        for fork, graphed in ((1, False), (1, False), (1, True), (0, True)):
+        for fork, graphed in ((2, False), (2, False), (2, True), (0, True), (1, False)):
             got = run(fork, graphed)
             assert got[0] == ref[0], (fork, graphed, got[0], ref[0])
             assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2])), (fork, graphed)
             if got[1] is not None:
                 assert all(torch.equal(a, b) for a, b in zip(got[1], ref[1])), (fork, graphed)
-        assert L.gnnpp_set_tuning(15, 2) == -1
+        assert L.gnnpp_set_tuning(15, 3) == -1
     finally:
         L.gnnpp_set_tuning(15, 1)
 
@@ -820,6 +821,28 @@ def test_torch_ops_lsigf_autograd_equals_the_module_path_and_traces(dev):
                 grads.append((y.detach(), h.grad, x.grad, b.grad))
             for a, m in zip(grads[0], grads[1]):
                 assert torch.equal(a, m), (relu, (a - m).abs().max().item())
+            if S_use is S and not relu:
+                grads_ref_dh, grads_ref_dx = grads[1][1], grads[1][2]
+
+    # r05: only the gradients somebody asked for are computed, and the packed taps (forward and transposed)
+    # are cached on the weight object: two steps on the same parameter pack twice in all (once per form), not per call
+    packs = []
+    real_pack = gml.pack_filter_taps
+    gml.pack_filter_taps = lambda hh: (packs.append(tuple(hh.shape)), real_pack(hh))[1]
+    try:
+        h = h0.clone().requires_grad_(True)
+        x_only = x0.clone().requires_grad_(True)
+        for _ in range(2):
+            y = torch.ops.gnnpp.lsigf(h.detach(), S, x_only, b0, False, 0)       # taps frozen: only dx is needed
+            (dx_only,) = torch.autograd.grad(y, [x_only], cot)
+        assert torch.equal(dx_only, grads_ref_dx)
+        n_frozen = len(packs)
+        for _ in range(3):
+            torch.ops.gnnpp.lsigf(h, S, x_only, b0, False, 0).backward(cot)
+        assert len(packs) - n_frozen <= 3                     # forward op (uncached by design) x 3 ... and NOT 3 x 3
+        assert torch.equal(h.grad / 3, grads_ref_dh) or (h.grad / 3 - grads_ref_dh).abs().max().item() <= 1e-5
+    finally:
+        gml.pack_filter_taps = real_pack
 
     def loss_fn(h, x, b):
         y = torch.ops.gnnpp.lsigf(h, S, x, b, True, 0)

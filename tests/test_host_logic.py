@@ -345,3 +345,10 @@ def test_torch_ops_registration_shapes_and_loud_cpu_failure():
         assert dh.shape == h.shape and dx.shape == x.shape and db.shape == b.shape and dS is None
         g3 = torch.ops.gnnpp.lsigf_backward(h, S, x, None, torch.empty_like(y), False, 0)
         assert g3[0].shape == h.shape and g3[1].shape == x.shape and g3[2].numel() == 0
+        # r05: `needs` -- a gradient nobody asked for is an empty tensor (and is not computed)
+        g4 = torch.ops.gnnpp.lsigf_backward(h, S, x, b, torch.empty_like(y), False, 0, 2)
+        assert g4[0].numel() == 0 and g4[1].shape == x.shape and g4[2].numel() == 0
+        xo = torch.empty(7, 64, 10, requires_grad=True)
+        yo = torch.ops.gnnpp.lsigf(h.detach(), S, xo, b.detach(), False, 0)
+        (dxo,) = torch.autograd.grad(yo, [xo], torch.empty_like(yo))
+        assert dxo.shape == xo.shape

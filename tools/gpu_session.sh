@@ -28,7 +28,7 @@ if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 --graph --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench_graph.json
   timeout 300 python tools/train_bench.py --steps 50 --batch 512 2>&1 | tail -1 | tee -a $OUT/train_bench.json; fi
 if has trainab; then stamp "train bench: weight-gradient fork on / off (graphed and eager, B = 64 and 512)"
-  for b in 64 512; do for g in "--graph" ""; do for f in "" "--no-fork"; do
+  for b in 64 512; do for g in "--graph" ""; do for f in "--fork" "--no-fork"; do
     timeout 300 python tools/train_bench.py --steps 100 $g --batch $b $f 2>&1 | tail -1 | tee -a $OUT/train_fork_ab.jsonl
   done; done; done; fi
 if has hostov; then stamp "host-side cost of one policy step"
