@@ -54,6 +54,30 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert lib.gnnpp_set_tuning(9, 2) == -1 and lib.gnnpp_get_tuning(9) == 1
 
 
+def test_unvalidated_toolchain_switches_the_asm_scheduled_layers_off(built_lib, tmp_path, monkeypatch):
+    """the column-packed layers rest on hand-placed MFMA wait states; a library built by another hipcc than
+    the validated one loads with the compiler-scheduled forms (same results) and a warning, until re-validated."""
+    import warnings
+    L = built_lib.lib()
+    assert built_lib.built_with() in (None, built_lib.VALIDATED_HIPCC)           # this container IS the validated toolchain
+    assert L.gnnpp_get_tuning(13) == 1 and L.gnnpp_get_tuning(14) == 0
+    stamp = tmp_path / 'toolchain.txt'
+    stamp.write_text('HIP version: 9.9.99999-deadbeef\n')
+    monkeypatch.setattr(built_lib, 'TOOLCHAIN_STAMP', str(stamp))
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            built_lib._apply_toolchain_policy(L)
+        assert sum('column-packed' in str(x.message) for x in w) == 1
+        assert L.gnnpp_get_tuning(13) == 0 and L.gnnpp_get_tuning(14) == 16
+        L.gnnpp_set_tuning(13, 1); L.gnnpp_set_tuning(14, 0)
+        monkeypatch.setenv('GNNPP_TRUST_TOOLCHAIN', '1')
+        built_lib._apply_toolchain_policy(L)
+        assert L.gnnpp_get_tuning(13) == 1 and L.gnnpp_get_tuning(14) == 0
+    finally:
+        L.gnnpp_set_tuning(13, 1); L.gnnpp_set_tuning(14, 0)
+
+
 def test_split_f16_is_refused_when_its_isa_check_failed(built_lib, tmp_path, monkeypatch):
     """the opt-in split-f16 encoder is outside the build's must-pass ISA list; a violation there
     leaves a marker and the PRECISION is refused with a message, the default path keeps working."""
