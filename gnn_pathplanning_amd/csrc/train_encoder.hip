@@ -907,6 +907,11 @@ struct BwdFork {
     hipStream_t side = nullptr;
     hipEvent_t dz_ready[kTrainLayers] = {}, w_done[kTrainLayers] = {}, join = nullptr;
     bool ok = false;
+    // The side stream and its events are ONE set per device.  Two backward calls enqueued at the same time from two
+    // host threads (two models training on two streams) would interleave their record / wait pairs on the shared
+    // events -- a wait would bind to the other call's record --, so a call holds this lock while it ENQUEUES (host
+    // side only: microseconds); the calls' side work then simply queues up on the one side stream.
+    std::mutex enqueue;
 };
 
 // one per device, created on first use OUTSIDE a stream capture (resource creation is not a capturable operation);
@@ -946,6 +951,8 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     TrainPtrs5 dp = {};
     BwdFork* const fk = bwd_fork(st, NB);
     hipStream_t const sw = fk ? fk->side : st;              // where the weight-gradient branch runs
+    std::unique_lock<std::mutex> enqueue_lock;
+    if (fk) enqueue_lock = std::unique_lock<std::mutex>(fk->enqueue);
     for (int l = kTrainLayers - 1; l >= 0; --l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;

@@ -1147,3 +1147,44 @@ def test_non_finite_observations_flush_is_pinned(dev, enc_variant, fused):
         L.gnnpp_set_tuning(6, old)
     assert np.abs(got[[0, 3]] - want[[0, 3]]).max() <= TOL
     assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize('B,N,G,F_out,K,E', [(3, 100, 128, 128, 3, 1), (5, 37, 24, 20, 3, 2), (16, 64, 128, 96, 2, 1)])
+def test_general_filter_n_way_split_is_bit_identical(dev, B, N, G, F_out, K, E):
+    """lsigf_kernel with 1 .. 7 workgroups per graph (GNNPP_TUNE_FILTER_SPLIT; v320, the heuristic included): output in
+    both layouts AND the tap dump of the training entry point (gnnpp_lsigf_fwd_save) are the one-workgroup results bit
+    for bit -- every part runs the early shifts on all rows, a row's last shift / contraction / epilogue does not depend
+    on which part owns it -- and agree with the float64 statement."""
+    from gnn_pathplanning_amd import _native
+    import gnn_pathplanning_amd.graphML as gml
+    L = _native.lib()
+    g = torch.Generator().manual_seed(1000 * N + G + K)
+    h = torch.randn(F_out, E, K, G, generator=g) / (G * K) ** 0.5
+    x = torch.randn(B, N, G, generator=g)
+    S = (torch.rand(B, E, N, N, generator=g) < 0.12).float() * torch.rand(B, E, N, N, generator=g)
+    bias = torch.randn(F_out, generator=g) / 4
+    hd, xd, Sd, bd = h.to(dev), x.to(dev), S.to(dev), bias.to(dev)
+    packed = gml.pack_filter_taps(hd)
+    outs = {}
+    try:
+        for split in (1, 0, 2, 3, 5, 7):
+            assert L.gnnpp_set_tuning(7, split) == 0 and L.gnnpp_set_tuning(1, 1) == 0
+            y = torch.full((B, N, F_out), float('nan'), device=dev)
+            zs = torch.full((E * K, B * N, G), float('nan'), device=dev)
+            rc = L.gnnpp_lsigf_fwd_save(xd.data_ptr(), Sd.data_ptr(), packed.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                        zs.data_ptr(), B, N, N, G, F_out, K, E, 0, 1, 0, 1, 1, 1, 0, 1, None,
+                                        _native.stream_ptr(dev))
+            assert rc == 0
+            yf = gml.BatchLSIGF(hd, Sd, xd.permute(0, 2, 1).contiguous(), bd.reshape(F_out, 1), precision='fp32_mfma')
+            torch.cuda.synchronize()
+            outs[split] = (y.cpu(), zs.cpu(), yf.cpu())
+    finally:
+        L.gnnpp_set_tuning(7, 0)
+        L.gnnpp_set_tuning(1, 0)
+    for split, (y, zs, yf) in outs.items():
+        assert torch.equal(y, outs[1][0]) and torch.equal(zs, outs[1][1]) and torch.equal(yf, outs[1][2]), split
+    want = np.maximum(orc.lsigf_f64(h.numpy(), S.numpy(), x.permute(0, 2, 1).numpy(), bias.numpy().reshape(F_out, 1)), 0)
+    got = outs[7][0].permute(0, 2, 1).numpy()
+    assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max())
+    assert np.abs(outs[7][2].numpy() - orc.lsigf_f64(h.numpy(), S.numpy(), x.permute(0, 2, 1).numpy(),
+                                                      bias.numpy().reshape(F_out, 1))).max() <= TOL * max(1.0, np.abs(want).max())
