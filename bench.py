@@ -369,6 +369,42 @@ def compact_summary(d):
     return out
 
 
+class rank_local_block:
+    """Everything rank 0 does AFTER the timed regions (roofline probes, secondary records, parity gate, CPU baseline) is
+    rank-local: the other ranks are already waiting in the final barrier.  A collective started in here would never be
+    matched -- the job would hang until the process-group timeout (r04's C4 shard record did exactly that through
+    tools/train_bench.measure -> sharding.aggregate_throughput: found by the 2-rank check of r05).  Inside this context
+    every torch.distributed collective raises instead, so such a mistake costs one `error` record, not the run."""
+    NAMES = ('all_reduce', 'barrier', 'all_gather', 'all_gather_object', 'all_gather_into_tensor', 'broadcast',
+             'broadcast_object_list', 'reduce', 'reduce_scatter', 'reduce_scatter_tensor', 'all_to_all',
+             'all_to_all_single', 'gather', 'scatter', 'send', 'recv')
+
+    def __init__(self, active=True):
+        self.active, self.saved = active, {}
+
+    def __enter__(self):
+        if self.active:
+            import torch.distributed as d
+
+            def refuse(name):
+                def f(*a, **k):
+                    raise RuntimeError('torch.distributed.%s() inside the rank-local block of bench.py: the other '
+                                       'ranks are in the final barrier and would never match it' % name)
+                return f
+            for n in self.NAMES:
+                if hasattr(d, n):
+                    self.saved[n] = getattr(d, n)
+                    setattr(d, n, refuse(n))
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as d
+        for n, f in self.saved.items():
+            setattr(d, n, f)
+        self.saved = {}
+        return False
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -699,388 +735,389 @@ def main():
         result['pipelined'] = pipelined
 
     if rank == 0:
-        import ctypes
-        enc = net.packed_encoder()
-        feat = torch.empty(M, 128, device=dev)
-        st = _native.stream_ptr(dev)
-        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None       # noqa: E731
-        gf, act = net.GFL[0], net.actionsMLP[0]
-        aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
-        gbias = gf.bias.detach().reshape(-1).contiguous()
-        taps = gf.packed_taps()
-        lg = torch.empty(N, B, 5, device=dev)
+      with rank_local_block(active=dist is not None):
+          import ctypes
+          enc = net.packed_encoder()
+          feat = torch.empty(M, 128, device=dev)
+          st = _native.stream_ptr(dev)
+          vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None       # noqa: E731
+          gf, act = net.GFL[0], net.actionsMLP[0]
+          aw, ab = act.weight.detach().contiguous(), act.bias.detach().contiguous()
+          gbias = gf.bias.detach().reshape(-1).contiguous()
+          taps = gf.packed_taps()
+          lg = torch.empty(N, B, 5, device=dev)
 
-        def time_kernel(fn, reps=None):
-            """Back-to-back launches of ONE C entry point, timed like the main regions (median of 5)."""
-            reps = reps or max(50, args.steps)
-            for _ in range(10):
-                fn()
-            return sorted(r[1] for r in timed_regions(fn, reps, 5))[2] / reps
+          def time_kernel(fn, reps=None):
+              """Back-to-back launches of ONE C entry point, timed like the main regions (median of 5)."""
+              reps = reps or max(50, args.steps)
+              for _ in range(10):
+                  fn()
+              return sorted(r[1] for r in timed_regions(fn, reps, 5))[2] / reps
 
-        # ---- roofline of the dominant kernel, in the arithmetic the HEADLINE runs: the model's default precision
-        # 'fp32' = bf16x3 operand split (fp32-equivalent; include/gnnpp.h GNNPP_PREC_FP32)
-        prec = net._prec()
-        assert prec == _native.PREC_FP32, 'the headline is measured in the default (fp32-equivalent) arithmetic'
-        info = PRECISION_INFO[prec]
-        tiles = (M + 15) // 16
-        fused = fused_rule(L, B, N, K, prec)
-        t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, prec, None, st))
-        y = torch.empty(M, 128, device=dev)
-        t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(y), B, N, N,
-                                                     128, 128, K, 1, 0, 1, 1, 1, 1, 0, prec, None, st))
-        # the filter launch of the policy step itself: features -> logits (filter + ReLU + action head; for teams
-        # of 17..100 agents that is policy_filter_kernel, else lsigf_kernel with the fused head)
-        lg_fh = torch.empty(N, B, 5, device=dev)
-        t_fh = time_kernel(lambda: L.gnnpp_filter_head_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(aw), vp(ab),
-                                                           vp(lg_fh), B, N, 128, 128, K, 1, 0, prec, None, st))
-        enc_flops = 2.0 * ENC_MACS_PER_AGENT * M
-        pol_flops = policy_flops_per_agent(K, mean_deg) * M
-        if fused:
-            kernel = ('gnnpp::encoder_kernel_b3<true, K=%d> (fused policy kernel: encoder + graph filter + action ' % K +
-                      'head, one workgroup per graph)')
-            kname = 'encoder_kernel_b3<true'                    # (<true, K>: the fused instantiation)
-            t_dom = dev_elapsed / args.steps                   # HIP events around the reported region
-            how = ('HIP events on the launch stream around the reported timed region / its %d launches '
-                   '(the step is this one kernel; includes the inter-launch gap)' % args.steps)
-            flops = pol_flops
-            alg_bytes = M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (ENC_WEIGHT_FLOATS + K * 128 * 128 + 768) * 4.0
-            # bf16 MFMAs per graph tile: encoder 8028 (L1..FC: six plane products where split-f16 issues three = 7428;
-            # L0: 600 -- the bench's {0, 1} observations are ONE bf16 plane, so L0 issues three of its six products:
-            # PLANE SKIPPING, csrc/encoder_kernel_b3.hip) + filter contraction 192 K.  PMC agrees:
-            # SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 / 16384 = 8606 per workgroup at K = 3 (profiles/r03_c2_pmc_summary.txt)
-            cp_on = L.gnnpp_get_tuning(13) == 1
-            mf, col_fill = fused_mfma_per_graph(N, K, cp_on)
-            exe = mf * 16384.0 * B
-            if cp_on and N <= CP_MAX_AGENTS:
-                kernel = kernel.replace('<true, K=%d>' % K, '<true, K=%d, CP>' % K)
-                lanes = ('; teams of <= 12 agents: (agent, position) pairs on the MFMA columns of the two 5x5 layers '
-                         '(%d instead of %d MFMAs per graph), agents on the columns elsewhere' % (mf, 8028 + 192 * K))
-            else:
-                lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
-                        'algorithmic work' % (N, N)
-        else:
-            kernel, kname = 'gnnpp::encoder_kernel_b3<false, 3>', 'encoder_kernel_b3<false'
-            t_dom = t_enc
-            how = ('HIP events around back-to-back launches of the kernel (median of 5 regions); the step is '
-                   'this kernel followed by the filter + head kernel')
-            flops = enc_flops
-            alg_bytes = M * (363 + 128) * 4.0 + ENC_WEIGHT_FLOATS * 4.0
-            exe = 8028 * 16384.0 * tiles                        # MFMAs per 16-agent tile ({0, 1} observations) x FLOP each
-            lanes = ''
-            col_fill = M / (16.0 * tiles)
-        traffic, traffic_detail = None, {'note': 'not measured (--pmc off, N > 1, or not rank 0)'}
-        if args.pmc == 'auto' and world == 1:
-            try:
-                traffic, traffic_detail = measure_traffic(args.config, kname)
-            except Exception as e:                              # never let the profiler break the bench line
-                traffic, traffic_detail = None, {'note': 'pmc pass raised %s' % type(e).__name__}
-        result['roofline'] = roofline_block(kernel, info, flops, t_dom, exe, lanes, col_fill)
-        result['roofline'].update({'traffic': traffic, 'traffic_detail': traffic_detail,
-                                   'algorithmic_bytes': alg_bytes, 'avg_launch_how': how})
-        clk = None
-        if world == 1 and args.pmc == 'auto':
-            try:
-                clk = measure_clock(
-                    fused,
-                    (vp(obs), vp(S), vp(enc), vp(taps), vp(gbias), vp(aw), vp(ab), vp(feat), vp(lg), B, N, K, 1,
-                     int(S.dtype is torch.float64), prec, None, st),
-                    (vp(obs), vp(enc), vp(feat), M, prec, None, st), B if fused else tiles)
-            except Exception as e:                              # a measurement extra: never break the line
-                result['roofline']['effective_clock_note'] = 'not measured: %s' % type(e).__name__
-        if clk:
-            # the same ratios against the pipe's rate at the clock the kernel was measured to run at (the
-            # peak above assumes 2.4 GHz); `frac` stays the contract's figure
-            rl = result['roofline']
-            rl['effective_clock_GHz'] = clk
-            rl['effective_clock_how'] = ('shader cycles / wall time inside the kernel (measure build of the same '
-                                         'kernel, median over its workgroups)')
-            rl['frac_at_effective_clock'] = rl['frac'] * NOMINAL_CLOCK_GHZ / clk
-            rl['pipe_busy_frac_at_effective_clock'] = rl['pipe_busy_frac'] * NOMINAL_CLOCK_GHZ / clk
-        result['precision'] = info['name']
-        result['dtype'] = 'f32 (bf16x3 exact operand split, f32 accumulate)'
-        result['dtype_detail'] = info['dtype']
-        gf_bytes = M * (1024 + 4 * N) + 196608.0 * K / 3
-        result['step_breakdown_us'] = {
-            'whole_step_wall': 1e6 * elapsed / args.steps, 'whole_step_device': 1e6 * dev_elapsed / args.steps,
-            'encoder_kernel_alone': t_enc * 1e6, 'filter_kernel_alone': t_gf * 1e6,
-            'filter_and_head_alone': t_fh * 1e6, 'one_kernel_step': bool(fused)}
-        result['policy_filter'] = {
-            'kernel': ('gnnpp::policy_filter_kernel' if 17 <= N <= 100 and L.gnnpp_get_tuning(9) == 1 else
-                       'gnnpp::lsigf_kernel') + ' (features -> logits: filter + bias + ReLU + action head, the second '
-                      'launch of the two-kernel policy step)',
-            'avg_launch_us': t_fh * 1e6, 'agent_steps_per_s': M / t_fh,
-            'algorithmic_GBps': (gf_bytes - 512.0 * M + 20.0 * M) / t_fh / 1e9}
-        result['filter_kernel'] = {
-            'kernel': 'gnnpp::lsigf_kernel (node-major features in, bias + ReLU fused)', 'avg_launch_us': t_gf * 1e6,
-            'agent_steps_per_s': M / t_gf, 'algorithmic_GBps': gf_bytes / t_gf / 1e9,
-            'hbm_frac_of_8TBps': gf_bytes / t_gf / (HBM_PEAK_TBPS * 1e12),
-            'mfma_TFLOPs': 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * M / t_gf / 1e12,
-            'regime': 'one launch over a %.1f MB working set: launch-latency bound, not HBM bound' % (gf_bytes / 1e6)}
-        result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value_rank / 1e12
+          # ---- roofline of the dominant kernel, in the arithmetic the HEADLINE runs: the model's default precision
+          # 'fp32' = bf16x3 operand split (fp32-equivalent; include/gnnpp.h GNNPP_PREC_FP32)
+          prec = net._prec()
+          assert prec == _native.PREC_FP32, 'the headline is measured in the default (fp32-equivalent) arithmetic'
+          info = PRECISION_INFO[prec]
+          tiles = (M + 15) // 16
+          fused = fused_rule(L, B, N, K, prec)
+          t_enc = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, prec, None, st))
+          y = torch.empty(M, 128, device=dev)
+          t_gf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(y), B, N, N,
+                                                       128, 128, K, 1, 0, 1, 1, 1, 1, 0, prec, None, st))
+          # the filter launch of the policy step itself: features -> logits (filter + ReLU + action head; for teams
+          # of 17..100 agents that is policy_filter_kernel, else lsigf_kernel with the fused head)
+          lg_fh = torch.empty(N, B, 5, device=dev)
+          t_fh = time_kernel(lambda: L.gnnpp_filter_head_fwd(vp(feat), vp(S), vp(taps), vp(gbias), vp(aw), vp(ab),
+                                                             vp(lg_fh), B, N, 128, 128, K, 1, 0, prec, None, st))
+          enc_flops = 2.0 * ENC_MACS_PER_AGENT * M
+          pol_flops = policy_flops_per_agent(K, mean_deg) * M
+          if fused:
+              kernel = ('gnnpp::encoder_kernel_b3<true, K=%d> (fused policy kernel: encoder + graph filter + action ' % K +
+                        'head, one workgroup per graph)')
+              kname = 'encoder_kernel_b3<true'                    # (<true, K>: the fused instantiation)
+              t_dom = dev_elapsed / args.steps                   # HIP events around the reported region
+              how = ('HIP events on the launch stream around the reported timed region / its %d launches '
+                     '(the step is this one kernel; includes the inter-launch gap)' % args.steps)
+              flops = pol_flops
+              alg_bytes = M * 363 * 4.0 + B * N * N * 4.0 + M * 20.0 + (ENC_WEIGHT_FLOATS + K * 128 * 128 + 768) * 4.0
+              # bf16 MFMAs per graph tile: encoder 8028 (L1..FC: six plane products where split-f16 issues three = 7428;
+              # L0: 600 -- the bench's {0, 1} observations are ONE bf16 plane, so L0 issues three of its six products:
+              # PLANE SKIPPING, csrc/encoder_kernel_b3.hip) + filter contraction 192 K.  PMC agrees:
+              # SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 / 16384 = 8606 per workgroup at K = 3 (profiles/r03_c2_pmc_summary.txt)
+              cp_on = L.gnnpp_get_tuning(13) == 1
+              mf, col_fill = fused_mfma_per_graph(N, K, cp_on)
+              exe = mf * 16384.0 * B
+              if cp_on and N <= CP_MAX_AGENTS:
+                  kernel = kernel.replace('<true, K=%d>' % K, '<true, K=%d, CP>' % K)
+                  lanes = ('; teams of <= 12 agents: (agent, position) pairs on the MFMA columns of the two 5x5 layers '
+                           '(%d instead of %d MFMAs per graph), agents on the columns elsewhere' % (mf, 8028 + 192 * K))
+              else:
+                  lanes = '; a graph of %d agents occupies a 16-lane tile, so at most %d/16 of the pipe does ' \
+                          'algorithmic work' % (N, N)
+          else:
+              kernel, kname = 'gnnpp::encoder_kernel_b3<false, 3>', 'encoder_kernel_b3<false'
+              t_dom = t_enc
+              how = ('HIP events around back-to-back launches of the kernel (median of 5 regions); the step is '
+                     'this kernel followed by the filter + head kernel')
+              flops = enc_flops
+              alg_bytes = M * (363 + 128) * 4.0 + ENC_WEIGHT_FLOATS * 4.0
+              exe = 8028 * 16384.0 * tiles                        # MFMAs per 16-agent tile ({0, 1} observations) x FLOP each
+              lanes = ''
+              col_fill = M / (16.0 * tiles)
+          traffic, traffic_detail = None, {'note': 'not measured (--pmc off, N > 1, or not rank 0)'}
+          if args.pmc == 'auto' and world == 1:
+              try:
+                  traffic, traffic_detail = measure_traffic(args.config, kname)
+              except Exception as e:                              # never let the profiler break the bench line
+                  traffic, traffic_detail = None, {'note': 'pmc pass raised %s' % type(e).__name__}
+          result['roofline'] = roofline_block(kernel, info, flops, t_dom, exe, lanes, col_fill)
+          result['roofline'].update({'traffic': traffic, 'traffic_detail': traffic_detail,
+                                     'algorithmic_bytes': alg_bytes, 'avg_launch_how': how})
+          clk = None
+          if world == 1 and args.pmc == 'auto':
+              try:
+                  clk = measure_clock(
+                      fused,
+                      (vp(obs), vp(S), vp(enc), vp(taps), vp(gbias), vp(aw), vp(ab), vp(feat), vp(lg), B, N, K, 1,
+                       int(S.dtype is torch.float64), prec, None, st),
+                      (vp(obs), vp(enc), vp(feat), M, prec, None, st), B if fused else tiles)
+              except Exception as e:                              # a measurement extra: never break the line
+                  result['roofline']['effective_clock_note'] = 'not measured: %s' % type(e).__name__
+          if clk:
+              # the same ratios against the pipe's rate at the clock the kernel was measured to run at (the
+              # peak above assumes 2.4 GHz); `frac` stays the contract's figure
+              rl = result['roofline']
+              rl['effective_clock_GHz'] = clk
+              rl['effective_clock_how'] = ('shader cycles / wall time inside the kernel (measure build of the same '
+                                           'kernel, median over its workgroups)')
+              rl['frac_at_effective_clock'] = rl['frac'] * NOMINAL_CLOCK_GHZ / clk
+              rl['pipe_busy_frac_at_effective_clock'] = rl['pipe_busy_frac'] * NOMINAL_CLOCK_GHZ / clk
+          result['precision'] = info['name']
+          result['dtype'] = 'f32 (bf16x3 exact operand split, f32 accumulate)'
+          result['dtype_detail'] = info['dtype']
+          gf_bytes = M * (1024 + 4 * N) + 196608.0 * K / 3
+          result['step_breakdown_us'] = {
+              'whole_step_wall': 1e6 * elapsed / args.steps, 'whole_step_device': 1e6 * dev_elapsed / args.steps,
+              'encoder_kernel_alone': t_enc * 1e6, 'filter_kernel_alone': t_gf * 1e6,
+              'filter_and_head_alone': t_fh * 1e6, 'one_kernel_step': bool(fused)}
+          result['policy_filter'] = {
+              'kernel': ('gnnpp::policy_filter_kernel' if 17 <= N <= 100 and L.gnnpp_get_tuning(9) == 1 else
+                         'gnnpp::lsigf_kernel') + ' (features -> logits: filter + bias + ReLU + action head, the second '
+                        'launch of the two-kernel policy step)',
+              'avg_launch_us': t_fh * 1e6, 'agent_steps_per_s': M / t_fh,
+              'algorithmic_GBps': (gf_bytes - 512.0 * M + 20.0 * M) / t_fh / 1e9}
+          result['filter_kernel'] = {
+              'kernel': 'gnnpp::lsigf_kernel (node-major features in, bias + ReLU fused)', 'avg_launch_us': t_gf * 1e6,
+              'agent_steps_per_s': M / t_gf, 'algorithmic_GBps': gf_bytes / t_gf / 1e9,
+              'hbm_frac_of_8TBps': gf_bytes / t_gf / (HBM_PEAK_TBPS * 1e12),
+              'mfma_TFLOPs': 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * M / t_gf / 1e12,
+              'regime': 'one launch over a %.1f MB working set: launch-latency bound, not HBM bound' % (gf_bytes / 1e6)}
+          result['policy_TFLOPs'] = policy_flops_per_agent(K, mean_deg) * value_rank / 1e12
 
-        if not args.no_secondary:
-            sec = {}
-            with torch.no_grad():
-                # (1) what the rollout loop needs on the host: forward + argmax decode + D2H of the ids
-                def step_d2h():
-                    net.addGSO(S)
-                    return net.decode_actions(net.forward_logits(obs)).cpu()
-                for _ in range(10):
-                    step_d2h()
-                r = sorted(x[0] for x in timed_regions(step_d2h, max(20, args.steps // 4), 5))[2]
-                sec['with_argmax_d2h'] = {'agent_steps_per_s': M * max(20, args.steps // 4) / r,
-                                          'ms_per_step': 1e3 * r / max(20, args.steps // 4),
-                                          'what': 'addGSO + forward + decode_actions kernel + .cpu() of the [B,N] int32 '
-                                                  'ids, synchronous every step (multirobotsim_dcenlocal.py:589-599)'}
-                # (1b) the same step on REAL-VALUED observations: the simulator's observations are {0, 1}, one bf16 plane,
-                # and L0 then issues three of its six plane products (plane skipping: bit-identical, exact zeros); any
-                # other observation takes the general L0 (all six products, compiler-scheduled) -- its cost, stated
-                obs_real = (obs * torch.randn(obs.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7)))
+          if not args.no_secondary:
+              sec = {}
+              with torch.no_grad():
+                  # (1) what the rollout loop needs on the host: forward + argmax decode + D2H of the ids
+                  def step_d2h():
+                      net.addGSO(S)
+                      return net.decode_actions(net.forward_logits(obs)).cpu()
+                  for _ in range(10):
+                      step_d2h()
+                  r = sorted(x[0] for x in timed_regions(step_d2h, max(20, args.steps // 4), 5))[2]
+                  sec['with_argmax_d2h'] = {'agent_steps_per_s': M * max(20, args.steps // 4) / r,
+                                            'ms_per_step': 1e3 * r / max(20, args.steps // 4),
+                                            'what': 'addGSO + forward + decode_actions kernel + .cpu() of the [B,N] int32 '
+                                                    'ids, synchronous every step (multirobotsim_dcenlocal.py:589-599)'}
+                  # (1b) the same step on REAL-VALUED observations: the simulator's observations are {0, 1}, one bf16 plane,
+                  # and L0 then issues three of its six plane products (plane skipping: bit-identical, exact zeros); any
+                  # other observation takes the general L0 (all six products, compiler-scheduled) -- its cost, stated
+                  obs_real = (obs * torch.randn(obs.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7)))
 
-                def step_real():
-                    net.addGSO(S)
-                    return net(obs_real)
-                for _ in range(10):
-                    out_real = step_real()
-                nst_r = max(20, args.steps // 2)
-                r = sorted(x[0] for x in timed_regions(step_real, nst_r, 5))[2] / nst_r
-                want_real = orc.policy_forward(sd, S_cpu, obs_real.cpu())
-                sec['real_valued_observations'] = {
-                    'agent_steps_per_s': M / r, 'ms_per_step': 1e3 * r, 'vs_binary_observations': (M / r) / value_rank,
-                    'parity_max_abs_dlogit': max((g_.cpu() - w_).abs().max().item() for g_, w_ in zip(out_real, want_real)),
-                    'what': 'observations x N(0, 1): three bf16 planes per pixel, L0 issues all six plane products '
-                            '(b3_l0_generic); everything behind L0 is unchanged'}
-                # (2) the other two arithmetics on the same step, each with its own roofline block: the exact fp32
-                # MFMA, and the opt-in split-f16 mode (NARROWER than fp32: a labelled secondary, never the headline)
-                for pname, key in (('fp32_mfma', 'exact_fp32_mfma_schedule'), ('split_f16', 'split_f16_fast_mode')):
-                    pc = _native.precision_code(pname)
-                    pinfo = PRECISION_INFO[pc]
-                    net.precision = pname
-                    old_policy, net.range_policy = net.range_policy, 'flag'     # (the guard is read once, below: the
-                    try:                                                       # default 'strict' syncs every forward)
-                        for _ in range(10):
-                            outp = step()
-                        nst = max(20, args.steps // 2)
-                        regs = timed_regions(step, nst, 5)
-                        r = sorted(x[0] for x in regs)[2]
-                        rdev = sorted(x[1] for x in regs)[2]
-                        tp = r / nst
-                        t_encp = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, pc, None, st), 50)
-                        flag_p = int(net.range_exceeded()) if pname == 'split_f16' else 0
-                    finally:
-                        net.precision = 'fp32'
-                        net.range_policy = old_policy
-                    fused_p = fused_rule(L, B, N, K, pc)
-                    if pname == 'split_f16':
-                        exe_p = ((4314 + 96 * K) * 16384.0 * B) if fused_p else 4314 * 16384.0 * tiles
-                        kern_p = 'gnnpp::encoder_kernel_h2<%s>' % ('true, K=%d' % K if fused_p else 'false, 3')
-                    else:
-                        exe_p, kern_p = 8876 * 2048.0 * tiles, 'gnnpp::encoder_kernel_f32'
-                    rec = {'precision': pname, 'dtype': pinfo['dtype'], 'agent_steps_per_s': M / tp,
-                           'ms_per_step': 1e3 * tp, 'encoder_kernel_us': t_encp * 1e6,
-                           'max_abs_dlogit_vs_default': max((a - b).abs().max().item() for a, b in zip(out, outp)),
-                           'roofline': roofline_block(kern_p, pinfo, pol_flops if fused_p else enc_flops,
-                                                      rdev / nst if fused_p else t_encp, exe_p, ''),
-                           'range_flag': flag_p}
-                    if pname == 'split_f16':
-                        rec['what'] = ('precision="split_f16" (opt-in): operands as f16 hi+lo pairs, 22 significand '
-                                       'bits, valid for |activation| < 65504 -- narrower than the reference\'s fp32, '
-                                       'hence never the headline')
-                    else:
-                        rec['what'] = 'precision="fp32_mfma": every MFMA is v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain)'
-                    sec[key] = rec
-                # (3) batch sweep: many graphs per launch (throughput regime) -- policy step and filter alone
-                sweep, fsweep = [], []
-                for Bs in (B, 4 * B, 16 * B, 64 * B):
-                    o = orc.synth_obs(min(Bs, 2048), N, seed=7).to(dev)
-                    o = o.repeat((Bs + o.shape[0] - 1) // o.shape[0], 1, 1, 1, 1)[:Bs].contiguous()
-                    Ss = S.repeat((Bs + B - 1) // B, 1, 1)[:Bs].contiguous()
+                  def step_real():
+                      net.addGSO(S)
+                      return net(obs_real)
+                  for _ in range(10):
+                      out_real = step_real()
+                  nst_r = max(20, args.steps // 2)
+                  r = sorted(x[0] for x in timed_regions(step_real, nst_r, 5))[2] / nst_r
+                  want_real = orc.policy_forward(sd, S_cpu, obs_real.cpu())
+                  sec['real_valued_observations'] = {
+                      'agent_steps_per_s': M / r, 'ms_per_step': 1e3 * r, 'vs_binary_observations': (M / r) / value_rank,
+                      'parity_max_abs_dlogit': max((g_.cpu() - w_).abs().max().item() for g_, w_ in zip(out_real, want_real)),
+                      'what': 'observations x N(0, 1): three bf16 planes per pixel, L0 issues all six plane products '
+                              '(b3_l0_generic); everything behind L0 is unchanged'}
+                  # (2) the other two arithmetics on the same step, each with its own roofline block: the exact fp32
+                  # MFMA, and the opt-in split-f16 mode (NARROWER than fp32: a labelled secondary, never the headline)
+                  for pname, key in (('fp32_mfma', 'exact_fp32_mfma_schedule'), ('split_f16', 'split_f16_fast_mode')):
+                      pc = _native.precision_code(pname)
+                      pinfo = PRECISION_INFO[pc]
+                      net.precision = pname
+                      old_policy, net.range_policy = net.range_policy, 'flag'     # (the guard is read once, below: the
+                      try:                                                       # default 'strict' syncs every forward)
+                          for _ in range(10):
+                              outp = step()
+                          nst = max(20, args.steps // 2)
+                          regs = timed_regions(step, nst, 5)
+                          r = sorted(x[0] for x in regs)[2]
+                          rdev = sorted(x[1] for x in regs)[2]
+                          tp = r / nst
+                          t_encp = time_kernel(lambda: L.gnnpp_encoder_fwd(vp(obs), vp(enc), vp(feat), M, pc, None, st), 50)
+                          flag_p = int(net.range_exceeded()) if pname == 'split_f16' else 0
+                      finally:
+                          net.precision = 'fp32'
+                          net.range_policy = old_policy
+                      fused_p = fused_rule(L, B, N, K, pc)
+                      if pname == 'split_f16':
+                          exe_p = ((4314 + 96 * K) * 16384.0 * B) if fused_p else 4314 * 16384.0 * tiles
+                          kern_p = 'gnnpp::encoder_kernel_h2<%s>' % ('true, K=%d' % K if fused_p else 'false, 3')
+                      else:
+                          exe_p, kern_p = 8876 * 2048.0 * tiles, 'gnnpp::encoder_kernel_f32'
+                      rec = {'precision': pname, 'dtype': pinfo['dtype'], 'agent_steps_per_s': M / tp,
+                             'ms_per_step': 1e3 * tp, 'encoder_kernel_us': t_encp * 1e6,
+                             'max_abs_dlogit_vs_default': max((a - b).abs().max().item() for a, b in zip(out, outp)),
+                             'roofline': roofline_block(kern_p, pinfo, pol_flops if fused_p else enc_flops,
+                                                        rdev / nst if fused_p else t_encp, exe_p, ''),
+                             'range_flag': flag_p}
+                      if pname == 'split_f16':
+                          rec['what'] = ('precision="split_f16" (opt-in): operands as f16 hi+lo pairs, 22 significand '
+                                         'bits, valid for |activation| < 65504 -- narrower than the reference\'s fp32, '
+                                         'hence never the headline')
+                      else:
+                          rec['what'] = 'precision="fp32_mfma": every MFMA is v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain)'
+                      sec[key] = rec
+                  # (3) batch sweep: many graphs per launch (throughput regime) -- policy step and filter alone
+                  sweep, fsweep = [], []
+                  for Bs in (B, 4 * B, 16 * B, 64 * B):
+                      o = orc.synth_obs(min(Bs, 2048), N, seed=7).to(dev)
+                      o = o.repeat((Bs + o.shape[0] - 1) // o.shape[0], 1, 1, 1, 1)[:Bs].contiguous()
+                      Ss = S.repeat((Bs + B - 1) // B, 1, 1)[:Bs].contiguous()
 
-                    def sstep():
-                        net.addGSO(Ss)
-                        return net(o)
-                    for _ in range(3):
-                        sstep()
-                    reps = max(5, min(args.steps, int(2e6 / (Bs * N)) + 1))
-                    r = sorted(x[0] for x in timed_regions(sstep, reps, 3))[1]
-                    sweep.append({'batch': Bs, 'agent_steps_per_s': Bs * N * reps / r, 'ms_per_step': 1e3 * r / reps})
-                    xf = torch.relu(torch.randn(Bs * N, 128, device=dev))
-                    yf = torch.empty_like(xf)
-                    tf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(xf), vp(Ss), vp(taps), vp(gbias), vp(yf), Bs, N, N,
-                                                               128, 128, K, 1, 0, 1, 1, 1, 1, 0, prec, None, st), reps)
-                    fb = Bs * N * (1024 + 4 * N) + 196608.0 * K / 3
-                    ffl = 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * Bs * N
-                    fsweep.append({'batch': Bs, 'us': tf * 1e6, 'agent_steps_per_s': Bs * N / tf,
-                                   'algorithmic_GBps': fb / tf / 1e9, 'hbm_frac_of_8TBps': fb / tf / (HBM_PEAK_TBPS * 1e12),
-                                   'algorithmic_TFLOPs': ffl / tf / 1e12})
-                    del o, Ss, xf, yf
-                for row in sweep:
-                    row['path'] = 'one launch' if fused_rule(L, row['batch'], N, K, prec) else 'encoder + filter launches'
-                sec['batch_sweep_policy'] = sweep
-                best_row = max(sweep, key=lambda x: x['agent_steps_per_s'])
-                sec['c2_best_batch'] = {
-                    'value': best_row['agent_steps_per_s'], 'batch': best_row['batch'], 'path': best_row['path'],
-                    'vs_headline_batch': best_row['agent_steps_per_s'] / value_rank,
-                    'what': 'best row of batch_sweep_policy: the headline batch (%d graphs = two one-graph workgroups '
-                            'per CU, ONE round of the chip) is a granularity corner -- larger batches run 16-agent '
-                            'tiles with every MFMA column filled' % B}
-                # what gnnpp_policy_fwd's rule chose at the headline shape, and the alternative it rejected, measured
-                # here on the same inputs (GNNPP_TUNE_FUSED_POLICY: 2 = always the one kernel, 0 = never)
-                knob_old = L.gnnpp_get_tuning(6)
-                alt = {}
-                try:
-                    for nm_, kv in (('one_launch', 2), ('two_launches', 0)):
-                        L.gnnpp_set_tuning(6, kv)
-                        for _ in range(5):
-                            out_alt = step()
-                        nst_a = max(20, args.steps // 2)
-                        ra = sorted(x[0] for x in timed_regions(step, nst_a, 5))[2] / nst_a
-                        alt[nm_] = {'ms_per_step': 1e3 * ra, 'agent_steps_per_s': M / ra,
-                                    'max_abs_dlogit_vs_headline': max((a_ - b_).abs().max().item()
-                                                                      for a_, b_ in zip(out, out_alt))}
-                finally:
-                    L.gnnpp_set_tuning(6, knob_old)
-                chosen = 'one_launch' if fused else 'two_launches'
-                other = 'two_launches' if fused else 'one_launch'
-                sec['dispatch_rule'] = {
-                    'rule': 'csrc/gnnpp_api.hip fused_policy_applies: one launch iff N <= 16, K in 2..4 and '
-                            '(B <= 512 or N >= 13)', 'shape': {'batch': B, 'agents': N, 'taps': K},
-                    'chosen': chosen, 'chosen_ms': alt[chosen]['ms_per_step'],
-                    'alternative': other, 'alternative_ms': alt[other]['ms_per_step'],
-                    'chosen_over_alternative': alt[other]['ms_per_step'] / alt[chosen]['ms_per_step'], 'measured': alt}
-                sec['batch_sweep_filter_only'] = fsweep
-                sec['batch_sweep_note'] = ('larger batches amortise launch latency and the per-launch weight stream; '
-                                           'the filter-only rows are the HBM-fraction figure of SURVEY.md section 8d '
-                                           '(default precision: fp32-equivalent contraction)')
-                # (4) the remaining single-GPU configs of BASELINE.json and a NON-RESIDENT variant of this one:
-                # compact records (value, ms/step, dominant kernel, frac, parity) inside the driver-run line
-                if args.config == 'c2':
-                    others = {}
-                    for nm, k_over in (('c3', None), ('c5', 2), ('c5', 3), ('c5', 4)):
-                        try:
-                            others['%s_K%d' % (nm, k_over or CONFIGS[nm][2])] = quick_config(
-                                orc, L, _native, nm, k_over, dev, timed_regions, time_kernel, vp, st)
-                        except Exception as e:                  # an extra: never break the line
-                            others['%s_K%s' % (nm, k_over)] = {'error': '%s: %s' % (type(e).__name__, e)}
-                    sec['other_configs'] = others
-                    # (5) the per-GPU SHARDS of the 8-GPU configs (SURVEY.md section 8e), measured on this one GPU: what
-                    # each of the 8 ranks of `--scaling strong` executes.  C5: 128 graphs -> 16 per GPU
-                    # (sharding.shard_batch, shard 0); C4: 64 graphs per GPU, one optimisation step.
-                    shards = {}
-                    for kk in (2, 3, 4):
-                        try:
-                            rec = quick_config(orc, L, _native, 'c5', kk, dev, timed_regions, time_kernel, vp, st, batch=16)
-                            rec['predicted_8gpu_value'] = 8.0 * rec['value']
-                            if 'value' in (rec.get('hip_graph_replay') or {}):
-                                rec['predicted_8gpu_value_graph_replay'] = 8.0 * rec['hip_graph_replay']['value']
-                            rec['vs_full_batch_rate'] = rec['value'] / others['c5_K%d' % kk]['value']
-                            shards['c5_shard_K%d' % kk] = rec
-                        except Exception as e:
-                            shards['c5_shard_K%d' % kk] = {'error': '%s: %s' % (type(e).__name__, e)}
-                    try:
-                        shards['c4_shard'] = c4_shard_record(orc, dev, 0.0 if args.no_cpu_baseline
-                                                             else min(4.0, args.cpu_seconds))
-                    except Exception as e:
-                        shards['c4_shard'] = {'error': '%s: %s' % (type(e).__name__, e)}
-                    shards['note'] = ('rollout shards are independent (no data-path collective): the 8-GPU whole-job '
-                                      'value of a strong-scaling run is 8 x the shard rate measured here')
-                    sec['shards_of_8gpu_configs'] = shards
-                    try:
-                        sec['c2_rotating_batches'] = rotating_batches(orc, net, dev, N, W, B, timed_regions, value_rank)
-                    except Exception as e:
-                        sec['c2_rotating_batches'] = {'error': '%s: %s' % (type(e).__name__, e)}
-            result['secondary'] = sec
+                      def sstep():
+                          net.addGSO(Ss)
+                          return net(o)
+                      for _ in range(3):
+                          sstep()
+                      reps = max(5, min(args.steps, int(2e6 / (Bs * N)) + 1))
+                      r = sorted(x[0] for x in timed_regions(sstep, reps, 3))[1]
+                      sweep.append({'batch': Bs, 'agent_steps_per_s': Bs * N * reps / r, 'ms_per_step': 1e3 * r / reps})
+                      xf = torch.relu(torch.randn(Bs * N, 128, device=dev))
+                      yf = torch.empty_like(xf)
+                      tf = time_kernel(lambda: L.gnnpp_lsigf_fwd(vp(xf), vp(Ss), vp(taps), vp(gbias), vp(yf), Bs, N, N,
+                                                                 128, 128, K, 1, 0, 1, 1, 1, 1, 0, prec, None, st), reps)
+                      fb = Bs * N * (1024 + 4 * N) + 196608.0 * K / 3
+                      ffl = 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128) * Bs * N
+                      fsweep.append({'batch': Bs, 'us': tf * 1e6, 'agent_steps_per_s': Bs * N / tf,
+                                     'algorithmic_GBps': fb / tf / 1e9, 'hbm_frac_of_8TBps': fb / tf / (HBM_PEAK_TBPS * 1e12),
+                                     'algorithmic_TFLOPs': ffl / tf / 1e12})
+                      del o, Ss, xf, yf
+                  for row in sweep:
+                      row['path'] = 'one launch' if fused_rule(L, row['batch'], N, K, prec) else 'encoder + filter launches'
+                  sec['batch_sweep_policy'] = sweep
+                  best_row = max(sweep, key=lambda x: x['agent_steps_per_s'])
+                  sec['c2_best_batch'] = {
+                      'value': best_row['agent_steps_per_s'], 'batch': best_row['batch'], 'path': best_row['path'],
+                      'vs_headline_batch': best_row['agent_steps_per_s'] / value_rank,
+                      'what': 'best row of batch_sweep_policy: the headline batch (%d graphs = two one-graph workgroups '
+                              'per CU, ONE round of the chip) is a granularity corner -- larger batches run 16-agent '
+                              'tiles with every MFMA column filled' % B}
+                  # what gnnpp_policy_fwd's rule chose at the headline shape, and the alternative it rejected, measured
+                  # here on the same inputs (GNNPP_TUNE_FUSED_POLICY: 2 = always the one kernel, 0 = never)
+                  knob_old = L.gnnpp_get_tuning(6)
+                  alt = {}
+                  try:
+                      for nm_, kv in (('one_launch', 2), ('two_launches', 0)):
+                          L.gnnpp_set_tuning(6, kv)
+                          for _ in range(5):
+                              out_alt = step()
+                          nst_a = max(20, args.steps // 2)
+                          ra = sorted(x[0] for x in timed_regions(step, nst_a, 5))[2] / nst_a
+                          alt[nm_] = {'ms_per_step': 1e3 * ra, 'agent_steps_per_s': M / ra,
+                                      'max_abs_dlogit_vs_headline': max((a_ - b_).abs().max().item()
+                                                                        for a_, b_ in zip(out, out_alt))}
+                  finally:
+                      L.gnnpp_set_tuning(6, knob_old)
+                  chosen = 'one_launch' if fused else 'two_launches'
+                  other = 'two_launches' if fused else 'one_launch'
+                  sec['dispatch_rule'] = {
+                      'rule': 'csrc/gnnpp_api.hip fused_policy_applies: one launch iff N <= 16, K in 2..4 and '
+                              '(B <= 512 or N >= 13)', 'shape': {'batch': B, 'agents': N, 'taps': K},
+                      'chosen': chosen, 'chosen_ms': alt[chosen]['ms_per_step'],
+                      'alternative': other, 'alternative_ms': alt[other]['ms_per_step'],
+                      'chosen_over_alternative': alt[other]['ms_per_step'] / alt[chosen]['ms_per_step'], 'measured': alt}
+                  sec['batch_sweep_filter_only'] = fsweep
+                  sec['batch_sweep_note'] = ('larger batches amortise launch latency and the per-launch weight stream; '
+                                             'the filter-only rows are the HBM-fraction figure of SURVEY.md section 8d '
+                                             '(default precision: fp32-equivalent contraction)')
+                  # (4) the remaining single-GPU configs of BASELINE.json and a NON-RESIDENT variant of this one:
+                  # compact records (value, ms/step, dominant kernel, frac, parity) inside the driver-run line
+                  if args.config == 'c2':
+                      others = {}
+                      for nm, k_over in (('c3', None), ('c5', 2), ('c5', 3), ('c5', 4)):
+                          try:
+                              others['%s_K%d' % (nm, k_over or CONFIGS[nm][2])] = quick_config(
+                                  orc, L, _native, nm, k_over, dev, timed_regions, time_kernel, vp, st)
+                          except Exception as e:                  # an extra: never break the line
+                              others['%s_K%s' % (nm, k_over)] = {'error': '%s: %s' % (type(e).__name__, e)}
+                      sec['other_configs'] = others
+                      # (5) the per-GPU SHARDS of the 8-GPU configs (SURVEY.md section 8e), measured on this one GPU: what
+                      # each of the 8 ranks of `--scaling strong` executes.  C5: 128 graphs -> 16 per GPU
+                      # (sharding.shard_batch, shard 0); C4: 64 graphs per GPU, one optimisation step.
+                      shards = {}
+                      for kk in (2, 3, 4):
+                          try:
+                              rec = quick_config(orc, L, _native, 'c5', kk, dev, timed_regions, time_kernel, vp, st, batch=16)
+                              rec['predicted_8gpu_value'] = 8.0 * rec['value']
+                              if 'value' in (rec.get('hip_graph_replay') or {}):
+                                  rec['predicted_8gpu_value_graph_replay'] = 8.0 * rec['hip_graph_replay']['value']
+                              rec['vs_full_batch_rate'] = rec['value'] / others['c5_K%d' % kk]['value']
+                              shards['c5_shard_K%d' % kk] = rec
+                          except Exception as e:
+                              shards['c5_shard_K%d' % kk] = {'error': '%s: %s' % (type(e).__name__, e)}
+                      try:
+                          shards['c4_shard'] = c4_shard_record(orc, dev, 0.0 if args.no_cpu_baseline
+                                                               else min(4.0, args.cpu_seconds))
+                      except Exception as e:
+                          shards['c4_shard'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                      shards['note'] = ('rollout shards are independent (no data-path collective): the 8-GPU whole-job '
+                                        'value of a strong-scaling run is 8 x the shard rate measured here')
+                      sec['shards_of_8gpu_configs'] = shards
+                      try:
+                          sec['c2_rotating_batches'] = rotating_batches(orc, net, dev, N, W, B, timed_regions, value_rank)
+                      except Exception as e:
+                          sec['c2_rotating_batches'] = {'error': '%s: %s' % (type(e).__name__, e)}
+              result['secondary'] = sec
 
-            # one whole rollout step on the device (observation builder + communication GSO + this
-            # forward + action decode / collision shielding), B episodes on random maps
-            import numpy as np
-            from gnn_pathplanning_amd.rollout import BatchedRollout
-            rng = np.random.default_rng(1337)
-            grids = (rng.random((B, W, W)) < 0.08).astype(np.uint8)
-            starts = np.zeros((B, N, 2), np.int64)
-            goals = np.zeros((B, N, 2), np.int64)
-            for b_i in range(B):
-                free = np.argwhere(grids[b_i] == 0)
-                pick = rng.choice(len(free), size=2 * N, replace=False)
-                starts[b_i], goals[b_i] = free[pick[:N]], free[pick[N:]]
-            env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed', seed=1337)
-            with torch.no_grad():
-                t_roll1 = time_kernel(lambda: env.step(net), reps=40)
-                t_roll = time_kernel(lambda: env.steps(net, 8), reps=10) / 8
-            # the same episodes as two slices on two HIP streams (episodes are independent: one slice's kernel
-            # tail and launch gap overlap the other's kernel); reported beside the single-stream figure
-            from gnn_pathplanning_amd.rollout import GroupedRollout
-            genv = GroupedRollout(grids, starts, goals, 10 ** 6, dev, groups=2, tie_mode='hashed', seed=1337)
+              # one whole rollout step on the device (observation builder + communication GSO + this
+              # forward + action decode / collision shielding), B episodes on random maps
+              import numpy as np
+              from gnn_pathplanning_amd.rollout import BatchedRollout
+              rng = np.random.default_rng(1337)
+              grids = (rng.random((B, W, W)) < 0.08).astype(np.uint8)
+              starts = np.zeros((B, N, 2), np.int64)
+              goals = np.zeros((B, N, 2), np.int64)
+              for b_i in range(B):
+                  free = np.argwhere(grids[b_i] == 0)
+                  pick = rng.choice(len(free), size=2 * N, replace=False)
+                  starts[b_i], goals[b_i] = free[pick[:N]], free[pick[N:]]
+              env = BatchedRollout(grids, starts, goals, 10 ** 6, dev, tie_mode='hashed', seed=1337)
+              with torch.no_grad():
+                  t_roll1 = time_kernel(lambda: env.step(net), reps=40)
+                  t_roll = time_kernel(lambda: env.steps(net, 8), reps=10) / 8
+              # the same episodes as two slices on two HIP streams (episodes are independent: one slice's kernel
+              # tail and launch gap overlap the other's kernel); reported beside the single-stream figure
+              from gnn_pathplanning_amd.rollout import GroupedRollout
+              genv = GroupedRollout(grids, starts, goals, 10 ** 6, dev, groups=2, tie_mode='hashed', seed=1337)
 
-            with torch.no_grad():
-                genv.steps(net, 8)
-                # (wall clock between device synchronisations: an event on one stream does not see the other)
-                t_roll2 = sorted(r[0] for r in timed_regions(lambda: genv.steps(net, 8, wait_caller=False), 20, 5,
-                                                             collective=False))[2] / 160
-            result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
-                                      'us_one_step_per_call': t_roll1 * 1e6,
-                                      'us_two_streams': t_roll2 * 1e6,
-                                      'agent_steps_per_s_two_streams': B * N / t_roll2,
-                                      'how': 'BatchedRollout.steps(model, 8): eight steps enqueued per host call; '
-                                             'two_streams: GroupedRollout(groups=2), wall clock over 160 steps',
-                                      'what': 'observe + gso + policy forward + move (collision shielding), '
-                                              'all on the device, %d episodes' % B}
+              with torch.no_grad():
+                  genv.steps(net, 8)
+                  # (wall clock between device synchronisations: an event on one stream does not see the other)
+                  t_roll2 = sorted(r[0] for r in timed_regions(lambda: genv.steps(net, 8, wait_caller=False), 20, 5,
+                                                               collective=False))[2] / 160
+              result['rollout_step'] = {'us': t_roll * 1e6, 'agent_steps_per_s': B * N / t_roll,
+                                        'us_one_step_per_call': t_roll1 * 1e6,
+                                        'us_two_streams': t_roll2 * 1e6,
+                                        'agent_steps_per_s_two_streams': B * N / t_roll2,
+                                        'how': 'BatchedRollout.steps(model, 8): eight steps enqueued per host call; '
+                                               'two_streams: GroupedRollout(groups=2), wall clock over 160 steps',
+                                        'what': 'observe + gso + policy forward + move (collision shielding), '
+                                                'all on the device, %d episodes' % B}
 
-        # parity gate on the bench batch + CPU baseline (bounded sample of the same workload)
-        threads = pick_cpu_threads(orc, sd, N, K)
-        with torch.no_grad():
-            want = orc.policy_forward(sd, S_cpu, obs_cpu)
-        got = [o.cpu() for o in out]
-        err = max((g - w).abs().max().item() for g, w in zip(got, want))
-        margin = orc.top2_margin(want)
-        ids_w = orc.decode_actions(want)
-        ids_g = torch.stack([g.argmax(-1) for g in got], 1)
-        clear = margin > 1e-5
-        near = [{'graph': int(b_), 'agent': int(n_), 'margin': float(margin[b_, n_]),
-                 'same_action': bool(ids_g[b_, n_] == ids_w[b_, n_])}
-                for b_, n_ in (~clear).nonzero().tolist()][:16]
-        result['parity'] = {'max_abs_dlogit': err, 'tolerance': 1e-4,
-                            'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear])),
-                            'near_tie_rows': int((~clear).sum()), 'near_tie_list': near,
-                            'rows': int(clear.numel()),
-                            # the default arithmetic has no input domain: no guard exists to be read; the flag of
-                            # the split-f16 secondary is reported with it
-                            'range_flag': int(net.range_exceeded())}
-        if not args.no_cpu_baseline:
-            med, reps, spent = time_cpu(orc, sd, S_cpu, obs_cpu, args.cpu_seconds)
-            cb = {'value': B * N / med, 'unit': 'agent-steps/s', 'cores': threads, 'usable_cores': usable_cores(),
-                  'kind': 'port',
-                  'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
-                            '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'
-                            % (reps, args.config, torch.__version__, spent),
-                  'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value_rank / (B * N / med)}
-            # the reference's own rollout step: B = 1 (BASELINE.json configs[0]), same thread count
-            o1, S1 = obs_cpu[:1].contiguous(), S_cpu[:1].contiguous()
-            med1, reps1, _ = time_cpu(orc, sd, S1, o1, min(3.0, args.cpu_seconds))
-            net1 = DecentralPlannerNet(Cfg()).to(dev).eval()
-            net1.load_state_dict(sd)
-            o1d, S1d = o1.to(dev), S1.to(dev)
+          # parity gate on the bench batch + CPU baseline (bounded sample of the same workload)
+          threads = pick_cpu_threads(orc, sd, N, K)
+          with torch.no_grad():
+              want = orc.policy_forward(sd, S_cpu, obs_cpu)
+          got = [o.cpu() for o in out]
+          err = max((g - w).abs().max().item() for g, w in zip(got, want))
+          margin = orc.top2_margin(want)
+          ids_w = orc.decode_actions(want)
+          ids_g = torch.stack([g.argmax(-1) for g in got], 1)
+          clear = margin > 1e-5
+          near = [{'graph': int(b_), 'agent': int(n_), 'margin': float(margin[b_, n_]),
+                   'same_action': bool(ids_g[b_, n_] == ids_w[b_, n_])}
+                  for b_, n_ in (~clear).nonzero().tolist()][:16]
+          result['parity'] = {'max_abs_dlogit': err, 'tolerance': 1e-4,
+                              'argmax_equal_on_clear_rows': bool(torch.equal(ids_g[clear], ids_w[clear])),
+                              'near_tie_rows': int((~clear).sum()), 'near_tie_list': near,
+                              'rows': int(clear.numel()),
+                              # the default arithmetic has no input domain: no guard exists to be read; the flag of
+                              # the split-f16 secondary is reported with it
+                              'range_flag': int(net.range_exceeded())}
+          if not args.no_cpu_baseline:
+              med, reps, spent = time_cpu(orc, sd, S_cpu, obs_cpu, args.cpu_seconds)
+              cb = {'value': B * N / med, 'unit': 'agent-steps/s', 'cores': threads, 'usable_cores': usable_cores(),
+                    'kind': 'port',
+                    'sample': '%d repetitions (median) of the same %s batch through oracle/policy_oracle.py '
+                              '(torch %s CPU, fp32, eval, no_grad), ~%.0f s of host time'
+                              % (reps, args.config, torch.__version__, spent),
+                    'ms_per_step': med * 1e3, 'speedup_gpu_over_cpu': value_rank / (B * N / med)}
+              # the reference's own rollout step: B = 1 (BASELINE.json configs[0]), same thread count
+              o1, S1 = obs_cpu[:1].contiguous(), S_cpu[:1].contiguous()
+              med1, reps1, _ = time_cpu(orc, sd, S1, o1, min(3.0, args.cpu_seconds))
+              net1 = DecentralPlannerNet(Cfg()).to(dev).eval()
+              net1.load_state_dict(sd)
+              o1d, S1d = o1.to(dev), S1.to(dev)
 
-            def step1():
-                net1.addGSO(S1d)
-                return net1(o1d)
-            with torch.no_grad():
-                for _ in range(20):
-                    step1()
-                g1 = sorted(x[0] for x in timed_regions(step1, 100, 5))[2] / 100
-            cb['c1_b1'] = {'cpu_agent_steps_per_s': N / med1, 'cpu_ms_per_step': med1 * 1e3, 'cores': threads,
-                           'gpu_agent_steps_per_s': N / g1, 'gpu_ms_per_step': g1 * 1e3,
-                           'speedup_gpu_over_cpu': med1 / g1, 'repetitions': reps1,
-                           'what': 'one 10-agent case per step (the rollout loop of agents/decentralplannerlocal.py:560-599)'}
-            torch.set_num_threads(1)
-            medt, repst, _ = time_cpu(orc, sd, S_cpu, obs_cpu, min(6.0, args.cpu_seconds), max_reps=20)
-            medt1, _, _ = time_cpu(orc, sd, S1, o1, 2.0)
-            torch.set_num_threads(threads)
-            cb['one_thread'] = {'agent_steps_per_s': B * N / medt, 'ms_per_step': medt * 1e3, 'repetitions': repst,
-                                'c1_b1_agent_steps_per_s': N / medt1}
-            result['cpu_baseline'] = cb
-        result['summary'] = compact_summary(result)           # LAST key: what a 2 000-character tail of the line keeps
-        print(json.dumps(result))
+              def step1():
+                  net1.addGSO(S1d)
+                  return net1(o1d)
+              with torch.no_grad():
+                  for _ in range(20):
+                      step1()
+                  g1 = sorted(x[0] for x in timed_regions(step1, 100, 5))[2] / 100
+              cb['c1_b1'] = {'cpu_agent_steps_per_s': N / med1, 'cpu_ms_per_step': med1 * 1e3, 'cores': threads,
+                             'gpu_agent_steps_per_s': N / g1, 'gpu_ms_per_step': g1 * 1e3,
+                             'speedup_gpu_over_cpu': med1 / g1, 'repetitions': reps1,
+                             'what': 'one 10-agent case per step (the rollout loop of agents/decentralplannerlocal.py:560-599)'}
+              torch.set_num_threads(1)
+              medt, repst, _ = time_cpu(orc, sd, S_cpu, obs_cpu, min(6.0, args.cpu_seconds), max_reps=20)
+              medt1, _, _ = time_cpu(orc, sd, S1, o1, 2.0)
+              torch.set_num_threads(threads)
+              cb['one_thread'] = {'agent_steps_per_s': B * N / medt, 'ms_per_step': medt * 1e3, 'repetitions': repst,
+                                  'c1_b1_agent_steps_per_s': N / medt1}
+              result['cpu_baseline'] = cb
+          result['summary'] = compact_summary(result)           # LAST key: what a 2 000-character tail of the line keeps
+          print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

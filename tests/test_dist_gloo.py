@@ -198,3 +198,47 @@ def test_rank_devices_without_group_and_scale_checker():
     assert any('within 5' in e for e in check_scale.check(ok, {'value': 120.0, 'metric': metric})[0])
     assert any('drops' in e for e in check_scale.check([ok[0], dict(ok[1], value=90.0)], ref)[0])
     assert any('rank_devices reported' in e for e in check_scale.check([dict(ok[0], rank_devices=[])], None)[0])
+
+
+def _rank_local_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from gnn_pathplanning_amd.sharding import aggregate_throughput
+        refused = None
+        if rank == 0:                                           # what bench.py's rank 0 does after the timed regions
+            with bench.rank_local_block(active=True):
+                try:
+                    aggregate_throughput(10, 1.0)               # (r04's hang: a rank-0-only all_reduce)
+                    refused = False
+                except RuntimeError as e:
+                    refused = 'rank-local block' in str(e)
+        thr, units, t = aggregate_throughput(10.0 * (rank + 1), 1.0 + rank)      # restored: real collectives work again
+        dist.barrier()
+        q.put((rank, refused, thr, units, t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_local_block_refuses_unmatched_collectives():
+    """r05: the 2-rank check of bench.py found that a rank-0-only secondary record (the C4 training shard, r04) started an
+    all-reduce the other rank never matched -- the run hung.  Fixed at the source (tools/train_bench.measure), and
+    bench.py now runs everything behind its timed regions inside `rank_local_block`, where a collective RAISES; the
+    collectives work again behind the block."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_local_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] is True and res[1][1] is None
+    for _, _, thr, units, t in res:
+        assert units == 30.0 and t == 2.0 and abs(thr - 15.0) < 1e-9

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session.  Usage (repo root on the GPU box): bash tools/gpu_session.sh <tag> [steps...]
-# steps: wave8 pmc35 trainab hostov test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
+# steps: wave8 pmc35 trainab hostov distbench test smoke bench benchdrv bench35 train traincpu trainprof cpab cptiles distcheck stamps b3stamps filterstamps filtersweep prof prof35 proftrain pmc pmclds filterpmc pipeablate
 TAG=${1:-r01}; shift
 STEPS=${@:-test smoke bench bench35 prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -44,6 +44,10 @@ if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path 
   grep -i "error\|duplicate\|invalid\|agent-steps\|^exit" $OUT/rccl_one_gpu.log | grep -v amdgpu.ids | head -12 | cut -c1-400 | tee -a $OUT/distcheck.log
   stamp "1-rank torchrun nccl"
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log; fi
+if has distbench; then stamp "2-rank gloo run of bench.py on one GPU, full secondary block (rank-0-only records must not start collectives)"
+  GNNPP_BENCH_DEVICE=0 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29536 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-700 | tee $OUT/distbench.log
+  stamp "the same with --scaling strong --config c5"
+  GNNPP_BENCH_DEVICE=0 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29537 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo --scaling strong --config c5 2>&1 | tail -1 | cut -c1-700 | tee -a $OUT/distbench.log; fi
 if has cpab; then stamp "column-packed policy kernel A/B (+ phase stamps)"
   timeout 400 python tools/cp_ab.py stamps 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tee $OUT/cp_ab.jsonl; fi
 if has cptiles; then stamp "column-packed encoder tiles (latency regime) A/B + stamps"

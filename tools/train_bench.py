@@ -70,7 +70,8 @@ def measure(dev, batch=64, steps=50, warmup=5, graph=False, adam='fused', rank=0
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
-    _, _, el = aggregate_throughput(B * N * steps, el, device=dev)
+    if world > 1:                                             # (world == 1 inside a multi-rank process -- bench.py's rank-0-only
+        _, _, el = aggregate_throughput(B * N * steps, el, device=dev)      # shard record -- must not start a collective)
     return el / steps, float(loss.item())
 
 
