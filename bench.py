@@ -200,6 +200,22 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
             graphed = {'value': M / rg, 'ms_per_step': 1e3 * rg, 'bit_identical_to_eager': bool(same)}
         except Exception as e:                             # an extra: never break the record
             graphed = {'error': '%s: %s' % (type(e).__name__, e)}
+    # The reference's return type is a python LIST of N tensors [B,5] (decentralplanner.py:304-318): at N = 100 building
+    # those 100 view objects costs the host ~30 us per step -- more than the shard's kernels leave room for (r05:
+    # profiles/r05_shard_gap_probe.jsonl: the C call enqueues in 8.8 us and the device needs 42.6 us per step, the python
+    # step 58 us).  forward_logits() hands out the same logits as ONE [N,B,5] tensor (what forward() unbinds, and what
+    # rollout.BatchedRollout consumes): the eager rate of a caller that does not need the list.
+    stacked = None
+    if batch is not None:
+        def step_stacked():
+            net.addGSO(S)
+            return net.forward_logits(obs)
+        for _ in range(10):
+            out_s = step_stacked()
+        rs = sorted(x[0] for x in timed_regions(step_stacked, nst, nreg, collective=False))[nreg // 2] / nst
+        stacked = {'value': M / rs, 'ms_per_step': 1e3 * rs,
+                   'bit_identical_to_forward': bool(all(torch.equal(a_, b_) for a_, b_ in zip(out_s.unbind(0), out))),
+                   'what': 'addGSO + forward_logits(): one [N,B,5] tensor instead of the list of N views'}
     prec = net._prec()
     enc = net.packed_encoder()
     feat = torch.empty(M, 128, device=dev)
@@ -224,6 +240,8 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     ids_w = orc.decode_actions(want)
     ids_g = torch.stack([g.argmax(-1) for g in got], 1)
     rec_extra = {'hip_graph_replay': graphed} if graphed is not None else {}
+    if stacked is not None:
+        rec_extra['forward_logits_eager'] = stacked
     rec_extra['filter_and_head'] = fh
     return {**rec_extra, 'agents': N, 'taps': K, 'batch': B, 'mean_degree': round(mean_deg, 3),
             'value': M / r, 'unit': 'agent-steps/s', 'ms_per_step': 1e3 * r,
@@ -347,6 +365,9 @@ def compact_summary(d):
             g_ = v.get('hip_graph_replay') or {}
             if 'value' in g_:
                 out[k + '_graphed_M_per_s'] = r(g_['value'] / 1e6)
+            s_ = v.get('forward_logits_eager') or {}
+            if 'value' in s_:
+                out[k + '_stacked_M_per_s'] = r(s_['value'] / 1e6)
     rv = sec.get('real_valued_observations') or {}
     if 'agent_steps_per_s' in rv:
         out['real_valued_obs_M_per_s'] = r(rv['agent_steps_per_s'] / 1e6)
@@ -1010,6 +1031,8 @@ def main():
                               rec['predicted_8gpu_value'] = 8.0 * rec['value']
                               if 'value' in (rec.get('hip_graph_replay') or {}):
                                   rec['predicted_8gpu_value_graph_replay'] = 8.0 * rec['hip_graph_replay']['value']
+                              if 'value' in (rec.get('forward_logits_eager') or {}):
+                                  rec['predicted_8gpu_value_forward_logits'] = 8.0 * rec['forward_logits_eager']['value']
                               rec['vs_full_batch_rate'] = rec['value'] / others['c5_K%d' % kk]['value']
                               shards['c5_shard_K%d' % kk] = rec
                           except Exception as e:

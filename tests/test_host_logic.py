@@ -271,6 +271,10 @@ def _check_r05_extras(f, d):
         assert abs(fh['frac'] - fh['algorithmic_TFLOPs'] / fh['peak_TFLOPs']) <= 1e-9 and 0 < fh['frac'] < 1
         assert fh['frac'] <= fh['pipe_busy_frac'] < 1 and abs(fh['us'] - v['filter_and_head_us']) <= 1e-6
         assert len(sm[k]) == 8 and abs(sm[k][5] - fh['us']) <= 2e-3 * fh['us']
+        fl = v.get('forward_logits_eager')                      # (shard records of lines written after the gap probe)
+        if fl is not None:
+            assert fl['bit_identical_to_forward'] is True and fl['value'] >= 0.95 * v['value']
+            assert abs(sm[k + '_stacked_M_per_s'] * 1e6 - fl['value']) <= 2e-3 * fl['value']
 
 
 def test_committed_bench_lines_follow_the_contract():

@@ -33,6 +33,11 @@ if has trainab; then stamp "train bench: weight-gradient fork on / off (graphed 
   done; done; done; fi
 if has hostov; then stamp "host-side cost of one policy step"
   timeout 300 python tools/host_overhead.py 2>&1 | grep -v amdgpu.ids | head -70 | tee $OUT/host_overhead.txt; fi
+if has shardgap; then stamp "eager 16 x 100 policy step: host cost of the pieces, device-side gaps"
+  timeout 200 python tools/shard_gap_probe.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $OUT/shard_gap_probe.jsonl
+  (cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/shardgap -o trace -- python $R/tools/shard_gap_probe.py trace > $OUT/shardgap_run.log 2>&1)
+  python tools/shard_gap_probe.py gaps $OUT/shardgap 2>&1 | tail -1 | tee -a $OUT/shard_gap_probe.jsonl
+  find $OUT/shardgap -name "*.csv" -size +1M -delete; fi
 if has traincpu; then stamp "train bench with the CPU oracle's training step beside it"
   timeout 300 python tools/train_bench.py --steps 50 --graph --cpu-seconds 8 2>&1 | tail -1 | tee $OUT/train_bench_cpu.json; fi
 if has trainprof; then stamp "host profile of the eager training step"
