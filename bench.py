@@ -900,7 +900,7 @@ def main():
                       return net(obs_real)
                   for _ in range(10):
                       out_real = step_real()
-                  nst_r = max(20, args.steps // 2)
+                  nst_r = max(100, args.steps // 2)     # (>= 100 steps: 20-step regions read 0.79x where 100-step ones read 0.89x)
                   r = sorted(x[0] for x in timed_regions(step_real, nst_r, 5))[2] / nst_r
                   want_real = orc.policy_forward(sd, S_cpu, obs_real.cpu())
                   sec['real_valued_observations'] = {
@@ -918,7 +918,7 @@ def main():
                       try:                                                       # default 'strict' syncs every forward)
                           for _ in range(10):
                               outp = step()
-                          nst = max(20, args.steps // 2)
+                          nst = max(100, args.steps // 2)
                           regs = timed_regions(step, nst, 5)
                           r = sorted(x[0] for x in regs)[2]
                           rdev = sorted(x[1] for x in regs)[2]
@@ -991,7 +991,7 @@ def main():
                           L.gnnpp_set_tuning(6, kv)
                           for _ in range(5):
                               out_alt = step()
-                          nst_a = max(20, args.steps // 2)
+                          nst_a = max(100, args.steps // 2)
                           ra = sorted(x[0] for x in timed_regions(step, nst_a, 5))[2] / nst_a
                           alt[nm_] = {'ms_per_step': 1e3 * ra, 'agent_steps_per_s': M / ra,
                                       'max_abs_dlogit_vs_headline': max((a_ - b_).abs().max().item()
