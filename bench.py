@@ -1024,8 +1024,11 @@ def main():
                       # (5) the per-GPU SHARDS of the 8-GPU configs, measured on this one GPU: what
                       # each of the 8 ranks of `--scaling strong` executes.  C5: 128 graphs -> 16 per GPU
                       # (sharding.shard_batch, shard 0); C4: 64 graphs per GPU, one optimisation step.
+                      # Only in the ONE-GPU line: the records capture HIP graphs (the step, the training step) on rank 0 while
+                      # the other ranks sit in a collective -- with RCCL's watchdog thread alive a capture can be invalidated,
+                      # and an N-GPU run has no use for a prediction of itself.
                       shards = {}
-                      for kk in (2, 3, 4):
+                      for kk in ((2, 3, 4) if world == 1 else ()):
                           try:
                               rec = quick_config(orc, L, _native, 'c5', kk, dev, timed_regions, time_kernel, vp, st, batch=16)
                               rec['predicted_8gpu_value'] = 8.0 * rec['value']
@@ -1038,8 +1041,9 @@ def main():
                           except Exception as e:
                               shards['c5_shard_K%d' % kk] = {'error': '%s: %s' % (type(e).__name__, e)}
                       try:
-                          shards['c4_shard'] = c4_shard_record(orc, dev, 0.0 if args.no_cpu_baseline
-                                                               else min(4.0, args.cpu_seconds))
+                          if world == 1:
+                              shards['c4_shard'] = c4_shard_record(orc, dev, 0.0 if args.no_cpu_baseline
+                                                                   else min(4.0, args.cpu_seconds))
                       except Exception as e:
                           shards['c4_shard'] = {'error': '%s: %s' % (type(e).__name__, e)}
                       shards['note'] = ('rollout shards are independent (no data-path collective): the 8-GPU whole-job '
