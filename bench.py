@@ -3,6 +3,7 @@
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...         (no launcher: bench.py starts the N ranks itself, self_launch())
 
 A "step" is one policy forward (DecentralPlannerNet.addGSO + forward) over one batch of synthetic
 input resident in HBM: BASELINE.json configs[1] = 10 agents, K=3, B=512 GSO+observation batch
@@ -15,7 +16,8 @@ reported region is the MEDIAN one (all of them are listed under `regions_ms`).  
 on the launch stream around the same regions give the device-side time the roofline uses, so the
 kernel time can never exceed the step time it is part of.
 
-Rank 0 prints ONE JSON line.  `value`, `ms_per_step`, `dtype`, `roofline` and `parity` all describe the DEFAULT
+Rank 0 prints ONE JSON line of at most 6 KB (driver_line(): the contract keys, `roofline`, `cpu_baseline`, `parity`,
+`summary`, and `details_file` = the side file holding everything else: `secondary`, sweeps, shard records, notes).  `value`, `ms_per_step`, `dtype`, `roofline` and `parity` all describe the DEFAULT
 precision ("fp32": every fp32 operand exactly as three bf16 planes, six plane products on the bf16 MFMA, fp32
 accumulate -- no input domain, nothing narrower than the reference's fp32).  Besides the contract fields:
   roofline      dominant kernel: ALGORITHMIC fp32 FLOPs per launch / launch time (HIP events on the launch stream,
@@ -28,7 +30,7 @@ accumulate -- no input domain, nothing narrower than the reference's fp32).  Bes
                 timed on this box's host cores (bounded sample)
   parity        max |dlogit| and action-id agreement GPU vs oracle on the bench batch, near-tie rows listed;
                 `range_flag` as read back from the device
-  secondary     the other two precisions (exact fp32 MFMA; opt-in split-f16, labelled narrower than fp32) with their
+  secondary     (side file only) the other two precisions (exact fp32 MFMA; opt-in split-f16, labelled narrower than fp32) with their
                 own roofline blocks, the remaining single-GPU configurations (C3, C5 at K = 2, 3, 4), a
                 rotating-batch variant of C2 (64 distinct batches, > 256 MB: not cache-resident), batch sweeps,
                 the filter-only HBM fraction, the argmax-D2H-inclusive rate, the rollout step
@@ -390,6 +392,130 @@ def compact_summary(d):
     return out
 
 
+DRIVER_LINE_MAX_BYTES = 6144            # a 23 KB line was not recovered by the driver (BENCH_r05 parsed: null)
+
+
+def _sig(x, n=6):
+    """Floats of the printed line to n significant digits (the side file keeps full precision)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float('%.*g' % (n, x))
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if k in d}
+
+
+def driver_line(result, details_file=None):
+    """The ONE line rank 0 prints: the driver contract's keys + `roofline` + `cpu_baseline` + `parity` + `summary`,
+    at most DRIVER_LINE_MAX_BYTES characters.  Everything else of `result` (secondary records, sweeps, shard records,
+    prose notes, near-tie list) goes to the side file named by `details_file`, whose path the line carries.  A pure
+    function of `result`: tests/test_host_logic.py feeds it canned results."""
+    out = _pick(result, ('metric', 'value', 'unit', 'n_gpus', 'ranks_in_group', 'rank_devices', 'dist_backend', 'steps',
+                         'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+                         'precision', 'timing'))
+    if 'regions_ms' in result:
+        out['regions_ms'] = [_sig(x, 5) for x in result['regions_ms']]
+    out['config'] = _pick(result['config'], ('workload', 'name', 'agents', 'taps', 'batch_per_gpu', 'global_batch',
+                                             'mean_degree', 'parallelism'))
+    rl = result.get('roofline')
+    if rl is not None:
+        o = _pick(rl, ('kernel', 'bound', 'instruction', 'achieved', 'peak', 'unit', 'frac', 'mfma_products_per_fp32_mac',
+                       'frac_of_arithmetic_ceiling', 'avg_launch_us', 'flops_per_launch', 'executed_over_algorithmic_flops',
+                       'column_fill', 'pipe_busy_frac', 'traffic', 'algorithmic_bytes', 'effective_clock_GHz'))
+        o['kernel'] = o.get('kernel', '').split(' (')[0]
+        td = rl.get('traffic_detail') or {}
+        if 'note' in td:
+            o['traffic_note'] = str(td['note'])[:120]
+        out['roofline'] = o
+    if 'step_breakdown_us' in result:
+        out['step_breakdown_us'] = _pick(result['step_breakdown_us'], tuple(result['step_breakdown_us']))
+    par = result.get('parity')
+    if par is not None:
+        out['parity'] = _pick(par, ('max_abs_dlogit', 'tolerance', 'argmax_equal_on_clear_rows', 'near_tie_rows', 'rows',
+                                    'range_flag'))
+    cb = result.get('cpu_baseline')
+    if cb is not None:
+        o = _pick(cb, ('value', 'unit', 'cores', 'usable_cores', 'kind', 'ms_per_step', 'speedup_gpu_over_cpu'))
+        o['sample'] = str(cb.get('sample', ''))[:200]
+        if 'c1_b1' in cb:
+            o['c1_b1'] = _pick(cb['c1_b1'], ('cpu_ms_per_step', 'gpu_ms_per_step', 'speedup_gpu_over_cpu', 'cores'))
+        if 'one_thread' in cb:
+            o['one_thread_value'] = _sig(cb['one_thread'].get('agent_steps_per_s'))
+        out['cpu_baseline'] = o
+    if 'summary' in result:
+        out['summary'] = result['summary']
+    out['details_file'] = details_file
+    line = json.dumps(out)
+    if len(line) > DRIVER_LINE_MAX_BYTES:                 # never print an unparseable line: drop the optional blocks
+        for k in ('regions_ms', 'timing', 'step_breakdown_us', 'summary'):
+            out.pop(k, None)
+            line = json.dumps(out)
+            if len(line) <= DRIVER_LINE_MAX_BYTES:
+                break
+    assert len(line) <= DRIVER_LINE_MAX_BYTES, len(line)
+    return line
+
+
+def write_details(result, path):
+    """The full result (what earlier rounds printed as one 20 KB line) as a side file; returns the path written, relative
+    to the repo root where possible, or None when no location is writable."""
+    cands = [path] if path else []
+    cands += [os.path.join(ROOT, 'gpurun_out', 'bench', 'bench_%s_full.json' % result['config']['name']),
+              os.path.join(tempfile.gettempdir(), 'gnnpp_bench_%s_full.json' % result['config']['name'])]
+    for p in cands:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(p)), exist_ok=True)
+            with open(p, 'w') as f:
+                json.dump(result, f)
+                f.write('\n')
+            ap = os.path.abspath(p)
+            return os.path.relpath(ap, ROOT) if ap.startswith(ROOT + os.sep) else ap
+        except OSError:
+            continue
+    return None
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): run the N ranks ourselves,
+    exactly as the driver's torch.distributed.run line would (one process per GPU, rendezvous on 127.0.0.1), and hand
+    back its exit code.  Refuses loudly when the box has fewer GPUs than ranks -- unless GNNPP_BENCH_DEVICE pins all
+    ranks to one device (the gloo code-path check on a one-GPU box)."""
+    import socket
+    if not args.launch_check and 'GNNPP_BENCH_DEVICE' not in os.environ:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit('bench.py --gpus %d: this box has %d GPU(s); refusing to print a mislabelled line'
+                             % (args.gpus, n_dev))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args):
+    """Hidden mode (--launch-check): every rank joins a gloo group and rank 0 prints the group's shape -- what the CPU
+    test of the launcher-less `--gpus N` path runs (no GPU, no kernels)."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group('gloo')
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        assert t.item() == world * (world + 1) / 2
+    assert world == args.gpus, (world, args.gpus)
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': world,
+                          'ranks_in_group': dist.get_world_size() if world > 1 else 1}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 class rank_local_block:
     """Everything rank 0 does AFTER the timed regions (roofline probes, secondary records, parity gate, CPU baseline) is
     rank-local: the other ranks are already waiting in the final barrier.  A collective started in here would never be
@@ -607,15 +733,26 @@ def main():
     ap.add_argument('--pmc', default='auto', choices=('auto', 'off'),
                     help='auto: rank 0 at N=1 measures roofline.traffic with two rocprofv3 --pmc passes')
     ap.add_argument('--pmc-target', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--launch-check', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--details-file', default=None,
+                    help='where the full result (secondary records, sweeps, notes) is written; default '
+                         'gpurun_out/bench/bench_<config>_full.json.  The printed line stays <= %d bytes and names it'
+                         % DRIVER_LINE_MAX_BYTES)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:   # no launcher around us: run the N ranks ourselves
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.launch_check:
+        return launch_check(args)
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     if args.pmc_target:
         return pmc_target(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d inside a group of WORLD_SIZE=%d ranks: the line would be mislabelled'
+                         % (args.gpus, world))
     dev_index = int(os.environ.get('GNNPP_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -1143,8 +1280,17 @@ def main():
               cb['one_thread'] = {'agent_steps_per_s': B * N / medt, 'ms_per_step': medt * 1e3, 'repetitions': repst,
                                   'c1_b1_agent_steps_per_s': N / medt1}
               result['cpu_baseline'] = cb
-          result['summary'] = compact_summary(result)           # LAST key: what a 2 000-character tail of the line keeps
-          print(json.dumps(result))
+          result['summary'] = compact_summary(result)
+          # one process per GPU, really: as many ranks in the group as the line claims, each on its own device (unless
+          # GNNPP_BENCH_DEVICE pinned them to one on purpose: the gloo code-path check)
+          assert result['ranks_in_group'] == result['n_gpus'] == args.gpus, (result['ranks_in_group'], args.gpus)
+          if 'GNNPP_BENCH_DEVICE' not in os.environ:
+              assert len(set(map(str, rank_devices))) == args.gpus, rank_devices
+          else:
+              result['device_override'] = os.environ['GNNPP_BENCH_DEVICE']
+          # the line the driver parses: <= 6 KB (contract keys, roofline, cpu_baseline, parity, summary); the rest
+          # (secondary records, sweeps, notes) in the side file it names
+          print(driver_line(result, write_details(result, args.details_file)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -242,3 +242,30 @@ def test_rank_local_block_refuses_unmatched_collectives():
     assert res[0][1] is True and res[1][1] is None
     for _, _, thr, units, t in res:
         assert units == 30.0 and t == 2.0 and abs(thr - 15.0) < 1e-9
+
+
+def test_bench_gpus_n_without_a_launcher_runs_n_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it used to run ONE rank and
+    print `n_gpus: 1`.  bench.py now launches the N ranks itself (bench.self_launch); `--launch-check` is the GPU-less
+    body of that path: every rank joins a gloo group, rank 0 prints the group's shape."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-check'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d == {'launch_check': True, 'n_gpus': 2, 'ranks_in_group': 2}
+    # a launcher whose group does not match --gpus is refused instead of printing a mislabelled line
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-check'],
+                       env=dict(env, WORLD_SIZE='1', RANK='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, cwd=root)
+    assert r.returncode != 0
+    # without --launch-check and without GPUs the launcher refuses before starting any rank
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, cwd=root)
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and b'refusing' in r.stderr

@@ -339,6 +339,45 @@ def test_committed_bench_lines_follow_the_contract():
             assert any(x['batch'] >= 8192 for x in sec['batch_sweep_filter_only'])
 
 
+def test_driver_line_is_bounded_and_round_trips():
+    """the driver could not parse the 23 KB line of round 5 (BENCH_r05.json parsed: null).  The line
+    bench.py prints is now bench.driver_line(result): the contract keys + roofline + cpu_baseline + parity + summary in
+    at most 6 KB, everything else in the side file it names.  Canned results: every full line committed in r04 / r05."""
+    import glob
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    assert bench.DRIVER_LINE_MAX_BYTES == 6144
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r0[45]_bench_c*.json')))
+    assert len(files) >= 6
+    for f in files:
+        full = json.loads(open(f).read().strip().splitlines()[-1])
+        line = bench.driver_line(full, 'gpurun_out/bench/bench_%s_full.json' % full['config']['name'])
+        assert len(line) <= 6144 and '\n' not in line, (f, len(line))
+        d = json.loads(line)
+        assert json.loads(json.dumps(d)) == d
+        for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                    'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'details_file'):
+            assert key in d, (f, key)
+        assert ('summary' in d) == ('summary' in full)
+        assert 'workload' in d['config'] and 'secondary' not in d and 'near_tie_list' not in d['parity']
+        for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'instruction', 'avg_launch_us',
+                    'algorithmic_bytes', 'pipe_busy_frac', 'executed_over_algorithmic_flops'):
+            assert key in d['roofline'], (f, key)
+        assert 'peak_note' not in d['roofline']
+        for key in ('value', 'unit', 'cores', 'kind', 'sample', 'ms_per_step', 'speedup_gpu_over_cpu', 'c1_b1'):
+            assert key in d['cpu_baseline'], (f, key)
+        # six significant digits: the arithmetic of the contract still closes on the printed numbers
+        assert abs(d['value'] - full['value']) <= 1e-5 * full['value']
+        assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) <= 1e-5
+    # a pathological result (huge summary) is cut down rather than printed oversize
+    fat = dict(full, summary={'x': 'y' * 9000})
+    line = bench.driver_line(fat, None)
+    assert len(line) <= 6144 and 'summary' not in json.loads(line) and 'roofline' in json.loads(line)
+
+
 def test_torch_ops_registration_shapes_and_loud_cpu_failure():
     """torch.ops.gnnpp.* (gnn_pathplanning_amd/ops.py): registered with fake implementations (output shapes / dtypes
     under FakeTensorMode, which is what torch.compile / export use) and -- like every entry of the package -- no CPU
