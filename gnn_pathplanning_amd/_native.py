@@ -403,12 +403,13 @@ class device_guard:
 # of this package (encoder, Linear, graph filter) ask grad_out() for the tensor a parameter's gradient is written to,
 # so the gradients of a step are BORN inside the bucket and the data-parallel exchange is one all-reduce + one scale
 # (the exchange used to pack / unpack with 2 x 26 copy launches around the one collective).
-_grad_sinks = {}            # parameter data_ptr -> (weakref to the parameter, bucket, offset in elements)
+_grad_sinks = {}            # parameter data_ptr -> [weakref to the parameter, bucket, offset in elements, weakref to
+                            # the view handed out last]
 
 
 def register_grad_sink(param, bucket, offset):
     import weakref
-    _grad_sinks[param.data_ptr()] = (weakref.ref(param), bucket, int(offset))
+    _grad_sinks[param.data_ptr()] = [weakref.ref(param), bucket, int(offset), None]
 
 
 def unregister_grad_sinks(bucket):
@@ -416,20 +417,46 @@ def unregister_grad_sinks(bucket):
         del _grad_sinks[k]
 
 
+_sinks_bypassed = 0
+
+
+class no_grad_sinks:
+    """Inside this context grad_out() always returns fresh memory.  ops.lsigf_backward runs in it: a registered custom
+    op declared with mutates_args=() must return tensors nobody else can write to, never a view of a live gradient
+    bucket."""
+
+    def __enter__(self):
+        global _sinks_bypassed
+        _sinks_bypassed += 1
+
+    def __exit__(self, *exc):
+        global _sinks_bypassed
+        _sinks_bypassed -= 1
+        return False
+
+
 def grad_out(param_ptr, shape, device):
     """The tensor a backward kernel writes the gradient of the parameter stored at `param_ptr` into: a FRESH view of
     the registered bucket slice when the parameter has no gradient yet (autograd then adopts that view as `.grad` --
     a new tensor object nobody else references -- without a copy), else a new tensor (an existing `.grad` -- kept by
     zero_grad(set_to_none=False), or a second backward of an accumulation step -- is added to in place by autograd:
-    handing out its own memory would double it)."""
-    e = _grad_sinks.get(param_ptr)
+    handing out its own memory would double it).  The slice is handed out ONCE at a time: while the
+    view of an earlier request is still alive and not yet adopted -- a parameter consumed by two backward nodes of one
+    pass (shared weights, a module called twice before one backward), or two torch.autograd.grad() calls -- a second
+    request gets fresh memory, so the second kernel cannot overwrite the first one's result before autograd adds
+    them."""
+    import weakref
+    e = _grad_sinks.get(param_ptr) if not _sinks_bypassed else None
     if e is not None:
         p = e[0]()
         if p is None or p.data_ptr() != param_ptr:
             del _grad_sinks[param_ptr]                       # the parameter died / moved: a stale entry
-        elif p.grad is None and tuple(p.shape) == tuple(shape) and p.dtype is torch.float32 and e[1].device == device:
+        elif (p.grad is None and (e[3] is None or e[3]() is None) and tuple(p.shape) == tuple(shape)
+              and p.dtype is torch.float32 and e[1].device == device):
             n = p.numel()
-            return e[1][e[2]:e[2] + n].view(shape)
+            v = e[1][e[2]:e[2] + n].view(shape)
+            e[3] = weakref.ref(v)
+            return v
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 

@@ -62,7 +62,7 @@ def lsigf_backward(h: torch.Tensor, S: torch.Tensor, x: torch.Tensor, bias: Opti
         return h.new_empty(0), h.new_empty(0), h.new_empty(0)
     packed = gml._cached_pack(h, False)
     packed_T = gml._cached_pack(h, True) if want_x else None
-    with torch.enable_grad():
+    with torch.enable_grad(), _native.no_grad_sinks():        # (h.detach() keeps the parameter's address: no bucket views out)
         hh, xx = h.detach().requires_grad_(want_h), x.detach().requires_grad_(want_x)
         bb = bias.detach().requires_grad_(want_b) if bias is not None else None
         y = gml._LSIGFFunction.apply(hh, S.detach(), xx, bb, batched, packed, False, bool(relu), int(precision),

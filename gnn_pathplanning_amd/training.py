@@ -11,6 +11,7 @@
 The reference has no distributed code at all; this is the build's addition.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -241,6 +242,8 @@ class FlatBucketDP:
                 _native.register_grad_sink(p, self.bucket, off)
             off += p.numel()
         self.last_reduce_copies = 0
+        # the sinks hold the bucket strongly: forget them when this object dies without close()
+        self._finalizer = weakref.finalize(self, _native.unregister_grad_sinks, self.bucket)
         if self.world > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -248,7 +251,7 @@ class FlatBucketDP:
 
     def close(self):
         """Forget the gradient sinks (the bucket stays alive as long as a `.grad` views it)."""
-        _native.unregister_grad_sinks(self.bucket)
+        self._finalizer()
 
     def _in_bucket(self, g, v):
         return g is not None and g.data_ptr() == v.data_ptr() and g.stride() == v.stride() and g.dtype is v.dtype

@@ -124,8 +124,38 @@ def _sink_check(rank, world):
     m(x).sum().backward()
     dp.reduce_gradients()
     ok = ok and dp.last_reduce_copies == 0 and torch.allclose(m.b.grad, 6.0 * (torch.arange(3.0) + 1))
+    # a parameter consumed by TWO backward nodes of one pass.  `.grad` stays None until AccumulateGrad
+    # runs, so the slice used to be handed out twice: the second kernel overwrote the first one's result and autograd
+    # then added the two aliased views (2 x the last gradient instead of the sum).  The slice is handed out once at a time.
+    for p in m.parameters():
+        p.grad = None
+    x2 = torch.full((4, 3), 10.0 * (rank + 1))
+    (_SinkScale.apply(x, m.a).sum() + _SinkScale.apply(x2, m.a).sum()).backward()
+    ok = ok and torch.allclose(m.a.grad, torch.full((3,), 44.0 * (rank + 1)))
+    m.a.grad = None
+    g1, = torch.autograd.grad(_SinkScale.apply(x, m.a).sum(), [m.a])        # two grad() calls, results both alive
+    g2, = torch.autograd.grad(_SinkScale.apply(x2, m.a).sum(), [m.a])
+    ok = ok and torch.allclose(g1, torch.full((3,), 4.0 * (rank + 1))) and torch.allclose(g2, torch.full((3,), 40.0 * (rank + 1)))
+    del g1, g2
+    # inside no_grad_sinks() (what the registered custom op gnnpp::lsigf_backward runs in) nothing comes out of the bucket
+    from gnn_pathplanning_amd import _native
+    with _native.no_grad_sinks():
+        g3 = _native.grad_out(m.a.data_ptr(), m.a.shape, m.a.device)
+    lo, hi = dp.bucket.data_ptr(), dp.bucket.data_ptr() + dp.bucket.numel() * 4
+    ok = ok and not (lo <= g3.data_ptr() < hi)
+    g4 = _native.grad_out(m.a.data_ptr(), m.a.shape, m.a.device)
+    ok = ok and lo <= g4.data_ptr() < hi
+    del g3, g4
     dp.close()
     m(x).sum().backward()                                   # sinks forgotten: plain tensors again, still correct
+    # a FlatBucketDP that dies without close() takes its sinks with it (they held the bucket strongly)
+    m2 = M()
+    dp2 = FlatBucketDP(m2)
+    n_sinks = len(_native._grad_sinks)
+    del dp2
+    import gc
+    gc.collect()
+    ok = ok and len(_native._grad_sinks) == n_sinks - 2
     return bool(ok)
 
 

@@ -94,6 +94,69 @@ def test_policy_golden(dev, policy_golden, enc_variant):
         assert (acts == want.argmax(-1)).all()
 
 
+@pytest.mark.parametrize('B,N,W', [(1, 10, 20), (16, 100, 100), (6, 7, 12)])
+def test_forward_list_is_a_real_list_and_is_recycled_only_when_dropped(dev, B, N, W):
+    """the reference's return type (list of N tensors [B,5], decentralplanner.py:304-318) costs the
+    host ~30 us per step at N = 100.  forward() re-uses the previous step's buffer and view objects when the caller has
+    dropped them (decentralplanner._OutputSlot) and is otherwise exactly what it was: a real list (C-level consumers
+    such as torch.stack work), contiguous [B,5] elements, held results never overwritten."""
+    K = 3
+    sd = orc.init_state_dict(K, seed=11)
+    net = _net(N, K, dev, sd)
+    obs = [orc.synth_obs(B, N, seed=s).to(dev) for s in (1, 2, 3)]
+    S = [torch.from_numpy(orc.synth_gso_geometric(B, N, W, seed=s)).float().to(dev) for s in (1, 2, 3)]
+
+    def run(i):
+        net.addGSO(S[i])
+        return net(obs[i])
+
+    def ref(i):
+        net.addGSO(S[i])
+        return net.forward_logits(obs[i]).clone()
+    want = [ref(i) for i in range(3)]
+    slot = net._out_slot
+    out = run(0)
+    assert type(out) is list and len(out) == N and out[0].shape == (B, 5) and all(o.is_contiguous() for o in out)
+    assert torch.equal(torch.stack(out, 1), want[0].permute(1, 0, 2)) and torch.equal(torch.stack(list(iter(out))), want[0])
+    assert out[-1].data_ptr() == out[0].data_ptr() + (N - 1) * B * 5 * 4 and len(out[2:5]) == min(3, max(0, N - 2))
+    held, p_held = out, out[0].data_ptr()
+    out1 = run(1)                                           # `held` is alive: fresh memory
+    assert out1[0].data_ptr() != p_held
+    assert torch.equal(torch.stack(held), want[0]) and torch.equal(torch.stack(out1), want[1])
+    p1 = out1[0].data_ptr()
+    del out, out1
+    f0, r0 = slot.fresh, slot.recycled
+    out2 = run(2)                                           # out1 was dropped: its buffer and view objects again
+    assert (slot.fresh, slot.recycled) == (f0, r0 + 1) and out2[0].data_ptr() == p1
+    assert torch.equal(torch.stack(out2), want[2]) and torch.equal(torch.stack(held), want[0])
+    one = out2[N // 2]                                      # a single element kept: never overwritten
+    del out2
+    out3 = run(0)
+    assert slot.fresh == f0 + 1 and torch.equal(one, want[2][N // 2]) and torch.equal(torch.stack(out3), want[0])
+    del out3, one, held
+    for i in (1, 2, 0, 1):                                  # the steady state of a rollout loop: every step recycled
+        o = run(i)
+        assert torch.equal(torch.stack(o), want[i])
+        del o
+    assert slot.fresh <= f0 + 2
+    # a HIP-graph capture never takes a recycled (non-pool) buffer, and what it leaves behind is not recycled into
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run(0)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    n_entries = len(slot.entries)
+    with torch.cuda.graph(g):
+        og = run(1)
+    assert len(slot.entries) == n_entries
+    eager = run(2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.stack(og), want[1]) and torch.equal(torch.stack(eager), want[2])
+    assert all(a.data_ptr() != b.data_ptr() for a, b in zip(og, eager))
+
+
 def test_policy_large_teams_golden(dev, policy_golden, policy_large_golden, enc_variant):
     """Teams of 50 / 64 / 100 agents against logits computed by the REFERENCE (tests/golden/policy_large.npz): the
     two-kernel policy step with policy_filter_kernel (default) and with the general filter kernel."""

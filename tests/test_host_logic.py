@@ -339,6 +339,62 @@ def test_committed_bench_lines_follow_the_contract():
             assert any(x['batch'] >= 8192 for x in sec['batch_sweep_filter_only'])
 
 
+def test_output_slot_recycles_only_what_nobody_can_observe():
+    """eval-mode forward() hands the previous step's [N,B,5] buffer and its N views out again
+    (decentralplanner._OutputSlot) -- only when the caller has dropped the previous list and everything derived from
+    it: a kept list, one kept view, a slice of a view, a tensor autograd saved, a different stream or shape all force
+    fresh memory."""
+    import torch
+    from gnn_pathplanning_amd.decentralplanner import _OutputSlot
+    s, dev = _OutputSlot(), torch.device('cpu')
+
+    def step(stream=0, N=12, B=4):
+        t = s.acquire(N, B, dev, stream)
+        assert s.views is not None and len(s.views) == N and s.views[0]._base is t
+        return t, list(s.views)
+
+    t1, l1 = step()
+    p1 = t1.data_ptr()
+    assert isinstance(l1, list) and l1[3].shape == (4, 5) and l1[3].data_ptr() == p1 + 3 * 4 * 5 * 4
+    t2, l2 = step()                                       # l1 is alive: its memory must not be written again
+    assert t2.data_ptr() != p1 and (s.fresh, s.recycled) == (2, 0)
+    p2 = t2.data_ptr()
+    del t1, l1, t2, l2
+    t3, l3 = step()                                       # everything dropped: same buffer, same view objects
+    assert t3.data_ptr() == p2 and (s.fresh, s.recycled) == (2, 1)
+    ids = [id(v) for v in l3]
+    l3.append(None)                                       # the caller's list is its own: mutating it changes nothing
+    del t3, l3
+    t4, l4 = step()
+    assert [id(v) for v in l4] == ids and len(l4) == 12 and s.recycled == 2
+    keep = l4[5]                                          # ONE view kept
+    del t4, l4
+    t5, l5 = step()
+    assert t5.data_ptr() != keep._base.data_ptr() and s.fresh == 3
+    sub = l5[2][:, :2]                                    # a slice of a view kept (storage use count)
+    del t5, l5
+    t6, l6 = step()
+    assert t6.data_ptr() != sub._base.data_ptr() if sub._base is not None else True
+    assert s.fresh == 4
+    w = torch.ones(4, 5, requires_grad=True)
+    z = (w * l6[0]).sum()                                 # autograd saved l6[0] (TensorImpl use count)
+    del t6, l6
+    t7, l7 = step()
+    assert s.fresh == 5
+    z.backward()
+    del t7, l7, z
+    n_fresh = s.fresh
+    step(stream=7)                                        # another stream / another shape: their own entries
+    step(N=3)
+    assert s.fresh == n_fresh + 2
+    for _ in range(5):
+        step()
+    assert s.fresh == n_fresh + 2 and s.recycled >= 7
+    s.clear()
+    step()
+    assert s.fresh == n_fresh + 3
+
+
 def test_driver_line_is_bounded_and_round_trips():
     """the driver could not parse the 23 KB line of round 5 (BENCH_r05.json parsed: null).  The line
     bench.py prints is now bench.driver_line(result): the contract keys + roofline + cpu_baseline + parity + summary in
