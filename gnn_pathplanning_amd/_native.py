@@ -34,6 +34,7 @@ EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_encoder_train_workspace_floats', 'gnnpp_encoder_train_fwd',
            'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_gemm_multi_workspace_floats',
            'gnnpp_gemm_kmajor_multi', 'gnnpp_policy_loss',
+           'gnnpp_train_pack_floats', 'gnnpp_train_pack', 'gnnpp_lsigf_input_grad', 'gnnpp_linear_fwd',
            'gnnpp_adam_step', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move', 'gnnpp_rollout_gso_observe', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step',
            'gnnpp_rollout_policy_steps')
@@ -176,7 +177,7 @@ class GemmDesc(ctypes.Structure):
                 ('a_sk', ctypes.c_longlong), ('B', ctypes.c_void_p), ('b_sb', ctypes.c_longlong),
                 ('b_sk', ctypes.c_longlong), ('C', ctypes.c_void_p), ('c_sb', ctypes.c_longlong),
                 ('c_sm', ctypes.c_longlong), ('batch', ctypes.c_int), ('M', ctypes.c_int), ('N', ctypes.c_int),
-                ('K', ctypes.c_int)]
+                ('K', ctypes.c_int), ('mask', ctypes.c_void_p)]
 
 
 class AdamTensors(ctypes.Structure):
@@ -230,10 +231,18 @@ def _bind(path):
     L.gnnpp_encoder_train_workspace_floats.restype = cs
     L.gnnpp_encoder_train_workspace_floats.argtypes = [ci, ci]
     L.gnnpp_encoder_train_fwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ci, ci, ctypes.c_float, ci,
-                                          ctypes.POINTER(ctypes.c_void_p), ci, vp]
+                                          ctypes.POINTER(ctypes.c_void_p), ci, vp, vp]
     L.gnnpp_encoder_train_fwd.restype = ci
     L.gnnpp_encoder_train_bwd.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, ctypes.POINTER(EncoderGrads),
-                                          ci, ci, ci, vp]
+                                          ci, ci, ci, vp, vp]
+    L.gnnpp_train_pack_floats.restype = cs
+    L.gnnpp_train_pack_floats.argtypes = []
+    L.gnnpp_train_pack.argtypes = [ctypes.POINTER(EncoderParams), vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.gnnpp_train_pack.restype = ci
+    L.gnnpp_lsigf_input_grad.argtypes = [vp] * 5 + [ci] * 9 + [vp]
+    L.gnnpp_lsigf_input_grad.restype = ci
+    L.gnnpp_linear_fwd.argtypes = [vp] * 4 + [ci] * 4 + [vp]
+    L.gnnpp_linear_fwd.restype = ci
     L.gnnpp_encoder_train_bwd.restype = ci
     ll, cf = ctypes.c_longlong, ctypes.c_float
     L.gnnpp_gemm_workspace_floats.restype = cs
@@ -336,16 +345,19 @@ def gemm_kmajor(A, a_strides, Bm, b_strides, C, c_strides, batch, M, N, K):
 
 def gemm_kmajor_multi(specs):
     """Several gemm_kmajor products in one launch (gnnpp_gemm_kmajor_multi).  specs: list of tuples
-    (A, a_strides, Bm, b_strides, C, c_strides, batch, M, N, K) as for gemm_kmajor (at most 8)."""
+    (A, a_strides, Bm, b_strides, C, c_strides, batch, M, N, K[, mask]) as for gemm_kmajor (at most 8); mask: a
+    tensor laid out like C -- C is stored as 0 where mask <= 0 (a ReLU backward folded into the product)."""
     import torch
     dev = require_gpu(*[t for s in specs for t in (s[0], s[2], s[4])])
     L = lib()
     arr = (GemmDesc * len(specs))()
-    for d, (A, a_st, Bm, b_st, C, c_st, batch, M, N, K) in zip(arr, specs):
+    for d, sp in zip(arr, specs):
+        A, a_st, Bm, b_st, C, c_st, batch, M, N, K = sp[:10]
         d.A, d.a_sb, d.a_sm, d.a_sk = A.data_ptr(), a_st[0], a_st[1], a_st[2]
         d.B, d.b_sb, d.b_sk = Bm.data_ptr(), b_st[0], b_st[1]
         d.C, d.c_sb, d.c_sm = C.data_ptr(), c_st[0], c_st[1]
         d.batch, d.M, d.N, d.K = batch, M, N, K
+        d.mask = sp[10].data_ptr() if len(sp) > 10 and sp[10] is not None else None
     ws = torch.empty(max(L.gnnpp_gemm_multi_workspace_floats(arr, len(specs)), 1), dtype=torch.float32, device=dev)
     with device_guard(dev):
         check(L.gnnpp_gemm_kmajor_multi(arr, len(specs), ws.data_ptr(), stream_ptr(dev)), 'gnnpp_gemm_kmajor_multi')

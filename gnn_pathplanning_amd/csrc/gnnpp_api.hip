@@ -23,7 +23,7 @@ static_assert(GNNPP_OK == 0 && GNNPP_ERR_UNSUPPORTED == -2 && GNNPP_ERR_LAUNCH =
 
 extern "C" {
 
-int gnnpp_version(void) { return 320; }
+int gnnpp_version(void) { return 330; }
 
 const char* gnnpp_error_string(int code) {
     switch (code) {
@@ -84,6 +84,23 @@ int gnnpp_lsigf_fwd_save(const float* x, const void* S, const float* packed, con
     a.s_is_f64 = s_is_f64; a.s_batched = s_batched; a.s_transposed = s_transposed;
     a.x_node_major = x_node_major; a.y_node_major = y_node_major; a.relu = relu;
     a.bias_per_node = bias && bias_per_node; a.range_flag = range_flag; a.prec = precision;
+    return lsigf_launch(a, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_lsigf_input_grad(const float* dy, const void* S, const float* packed_t, const float* mask, float* dx,
+                           int B, int N, int G, int F, int K, int E, int s_is_f64, int s_batched, int node_major,
+                           void* stream) {
+    if (!dy || !packed_t || !dx || B <= 0 || N <= 0 || G <= 0 || F <= 0 || K <= 0 || E <= 0) return GNNPP_ERR_ARG;
+    if (K > 1 && !S) return GNNPP_ERR_ARG;
+    if (mask && !node_major) return GNNPP_ERR_ARG;     // (the mask is applied where the node-major rows are stored)
+    if (N > GNNPP_MAX_ROWS) return GNNPP_ERR_UNSUPPORTED;
+    LsigfArgs a = {};
+    // the filter of h^T [G,E,K,F] on S^T: F input features (dy), G output features (dx); exact fp32 contraction
+    a.x = dy; a.S = S; a.wpk = packed_t; a.bias = nullptr; a.y = dx; a.y_mask = mask;
+    a.B = B; a.N = N; a.Nin = N; a.G = F; a.F = G; a.K = K; a.E = E;
+    a.s_is_f64 = s_is_f64; a.s_batched = s_batched; a.s_transposed = 1;
+    a.x_node_major = node_major; a.y_node_major = node_major; a.relu = 0;
+    a.prec = GNNPP_PREC_FP32_MFMA;
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
@@ -212,10 +229,33 @@ static int train_params_ok(const gnnpp_encoder_params* p, EncRawParams& rp) {
     return 1;
 }
 
+size_t gnnpp_train_pack_floats(void) { return train_pack_layout().total; }
+
+int gnnpp_train_pack(const gnnpp_encoder_params* p, float* train_pack, const float* h, float* taps_fwd,
+                     float* taps_t, int G, int F, int K, int E, void* stream) {
+    if (!p && !h) return GNNPP_ERR_ARG;
+    const float* cw[5] = {};
+    if (p) {
+        if (!train_pack || (reinterpret_cast<size_t>(train_pack) & 15)) return GNNPP_ERR_ARG;
+        for (int i = 0; i < 5; ++i) {
+            if (!p->conv_w[i]) return GNNPP_ERR_ARG;
+            cw[i] = p->conv_w[i];
+        }
+    }
+    TrainFilterPack fp = {};
+    if (h) {
+        if (!taps_fwd || !taps_t || G <= 0 || F <= 0 || K <= 0 || E <= 0) return GNNPP_ERR_ARG;
+        fp.h = h; fp.fwd = taps_fwd; fp.tr = taps_t; fp.G = G; fp.F = F; fp.K = K; fp.E = E;
+    }
+    return train_pack_launch(p ? cw : nullptr, p ? train_pack : nullptr, fp, static_cast<hipStream_t>(stream));
+}
+
 int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
                             int B, int N, float momentum, int update_running,
-                            long long* const* bn_num_batches, int feat_sample_major, void* stream) {
+                            long long* const* bn_num_batches, int feat_sample_major, const float* train_pack,
+                            void* stream) {
     EncRawParams rp;
+    if (train_pack && (reinterpret_cast<size_t>(train_pack) & 15)) return GNNPP_ERR_ARG;
     if (!train_params_ok(p, rp) || !obs || !workspace || !feat || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     float* rm[5];
     float* rv[5];
@@ -226,18 +266,19 @@ int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, flo
     }
     if (reinterpret_cast<size_t>(workspace) & 15) return GNNPP_ERR_ARG;      // (16-byte loads on its regions)
     return train_encoder_fwd(rp, rm, rv, update_running ? bn_num_batches : nullptr, momentum, obs, workspace, feat,
-                             N, B, feat_sample_major, static_cast<hipStream_t>(stream));
+                             N, B, feat_sample_major, static_cast<hipStream_t>(stream), train_pack);
 }
 
 int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
                             const float* dfeat, const gnnpp_encoder_grads* g, int B, int N,
-                            int feat_sample_major, void* stream) {
+                            int feat_sample_major, const float* train_pack, void* stream) {
     EncRawParams rp;
+    if (train_pack && (reinterpret_cast<size_t>(train_pack) & 15)) return GNNPP_ERR_ARG;
     if (!train_params_ok(p, rp) || !obs || !workspace || !dfeat || !g || B <= 0 || N <= 0) return GNNPP_ERR_ARG;
     for (int i = 0; i < 5; ++i)
         if (!g->conv_w[i] || !g->conv_b[i] || !g->bn_w[i] || !g->bn_b[i]) return GNNPP_ERR_ARG;
     return train_encoder_bwd(rp, obs, workspace, dfeat, g->conv_w, g->conv_b, g->bn_w, g->bn_b, N, B,
-                             feat_sample_major, static_cast<hipStream_t>(stream));
+                             feat_sample_major, static_cast<hipStream_t>(stream), train_pack);
 }
 
 size_t gnnpp_gemm_workspace_floats(int batch, int M, int N, int K) {
@@ -249,7 +290,7 @@ int gnnpp_gemm_kmajor(const float* A, long long a_sb, long long a_sm, long long 
                       long long b_sb, long long b_sk, float* C, long long c_sb, long long c_sm, int batch,
                       int M, int N, int K, float* workspace, void* stream) {
     if (!A || !B || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0) return GNNPP_ERR_ARG;
-    const gnnpp_gemm_desc d = {A, a_sb, a_sm, a_sk, B, b_sb, b_sk, C, c_sb, c_sm, batch, M, N, K};
+    const gnnpp_gemm_desc d = {A, a_sb, a_sm, a_sk, B, b_sb, b_sk, C, c_sb, c_sm, batch, M, N, K, nullptr};
     return gnnpp_gemm_kmajor_multi(&d, 1, workspace, stream);
 }
 
@@ -272,11 +313,21 @@ int gnnpp_gemm_kmajor_multi(const gnnpp_gemm_desc* d, int count, float* workspac
         g.A = d[i].A; g.a_sb = (long)d[i].a_sb; g.a_sm = (long)d[i].a_sm; g.a_sk = (long)d[i].a_sk;
         g.B = d[i].B; g.b_sb = (long)d[i].b_sb; g.b_sk = (long)d[i].b_sk;
         g.C = d[i].C; g.c_sb = (long)d[i].c_sb; g.c_sm = (long)d[i].c_sm;
-        g.batch = d[i].batch; g.M = d[i].M; g.N = d[i].N; g.K = d[i].K;
+        g.batch = d[i].batch; g.M = d[i].M; g.N = d[i].N; g.K = d[i].K; g.mask = d[i].mask;
     }
     tb.count = count;
     if (gnnpp_gemm_multi_workspace_floats(d, count) > 0 && !workspace) return GNNPP_ERR_ARG;
     return gemm_multi_launch(tb, workspace, static_cast<hipStream_t>(stream));
+}
+
+int gnnpp_linear_fwd(const float* x, const float* W, const float* bias, float* y, int R, int I, int O, int relu,
+                     void* stream) {
+    if (!x || !W || !y || R <= 0 || I <= 0 || O <= 0) return GNNPP_ERR_ARG;
+    if (I % 64 != 0 || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(W)) & 15)) return GNNPP_ERR_UNSUPPORTED;
+    const int tiles = ((O + 15) / 16) * ((R + 15) / 16);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((tiles + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, W,
+                       bias, y, R, I, O, relu);
+    return hipGetLastError() == hipSuccess ? GNNPP_OK : GNNPP_ERR_LAUNCH;
 }
 
 int gnnpp_policy_loss(const float* logits, const float* target, float* loss, float* dlogits, int B, int N,
@@ -302,8 +353,8 @@ int gnnpp_adam_step(const gnnpp_adam_tensors* t, float* state, float lr, float b
     }
     tb.first[t->count] = blocks;
     tb.count = t->count;
-    if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, lr, beta1, beta2);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, tb, state, beta1, beta2, eps, weight_decay);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 4 * sizeof(float), st, tb, state, lr, beta1, beta2, eps,
+                       weight_decay, tick ? 1 : 0);
     return hipGetLastError() == hipSuccess ? GNNPP_OK : GNNPP_ERR_LAUNCH;
 }
 

@@ -63,6 +63,8 @@ struct LsigfArgs {
     int s_is_f64, s_batched, x_node_major, y_node_major, relu;
     int bias_per_node;     // bias is [F_all, N] (one value per feature AND node, graphML.py:2300-2302)
     int s_transposed;      // use S^T: turns the kernel into the input-gradient of the filter
+    const float* y_mask;   // optional, y's node-major layout: y is stored as 0 where y_mask <= 0 (the input-gradient
+                           // launch of the training step: the ReLU backward of the layer below, gnnpp_lsigf_input_grad)
     float* zs;             // optional [E*K][B*N][G] node-major dump of every tap signal z_{e,k}
     int* range_flag;       // optional device int: set to 1 when the split-f16 contraction saw |z| >= 65504
     int pf_part_off;       // policy_filter_kernel.hip: LDS byte offset of the partial logits
@@ -670,15 +672,24 @@ __global__ __launch_bounds__(NW * 64) void lsigf_kernel(const LsigfArgs p) {
             float* yd = p.y + (size_t)g0 * N * p.F_all + p.f0;
             if ((p.F & 3) == 0 && (p.F_all & 3) == 0) {
                 const int F4 = p.F >> 2;
+                const float* md = p.y_mask ? p.y_mask + (size_t)g0 * N * p.F_all + p.f0 : nullptr;
                 for (int i = tid; i < nrows * F4; i += NT) {
                     const int r = row_lo + i / F4, c = i % F4;
-                    *reinterpret_cast<v4f*>(yd + (size_t)r * p.F_all + 4 * c) =
-                        *reinterpret_cast<const v4f*>(ybuf + r * zs + 4 * c);
+                    v4f v = *reinterpret_cast<const v4f*>(ybuf + r * zs + 4 * c);
+                    if (md) {
+                        const v4f m = *reinterpret_cast<const v4f*>(md + (size_t)r * p.F_all + 4 * c);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = m[u] > 0.f ? v[u] : 0.f;
+                    }
+                    *reinterpret_cast<v4f*>(yd + (size_t)r * p.F_all + 4 * c) = v;
                 }
             } else {
+                const float* md = p.y_mask ? p.y_mask + (size_t)g0 * N * p.F_all + p.f0 : nullptr;
                 for (int i = tid; i < nrows * p.F; i += NT) {
                     const int r = row_lo + i / p.F, c = i % p.F;
-                    yd[(size_t)r * p.F_all + c] = ybuf[r * zs + c];
+                    float v = ybuf[r * zs + c];
+                    if (md && !(md[(size_t)r * p.F_all + c] > 0.f)) v = 0.f;
+                    yd[(size_t)r * p.F_all + c] = v;
                 }
             }
         } else if (p.nsplit == 1) {

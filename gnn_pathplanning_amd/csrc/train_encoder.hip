@@ -12,7 +12,8 @@
 // are plain fp32 arithmetic (exact fp32 MFMA 16x16x4 / fmaf), deterministic: every reduction has a fixed
 // order (per-wave partial sums, partials summed in index order by the kernel that consumes them; no atomics).
 //
-//   forward: pack_train_weights_kernel (the ten weight packs of the step, one launch), then per conv layer l
+//   forward: pack_train_weights_kernel (the ten weight packs of the step -- and the graph filter's two -- in one
+//   launch; once per weight version when the caller keeps the pack: gnnpp_train_pack), then per conv layer l
 //   (3->32 @11x11 pool, 32->32 @5x5, 32->64 @5x5 pool, 64->64 @2x2, 64->128 @2x2 pool)
 //     conv_mfma_kernel        y = conv3x3(x) + bias as a GEMM on the fp32 MFMA: rows = output channels,
 //                             columns = (image, position), contraction = (tap, input channel); images
@@ -89,9 +90,42 @@ __host__ __device__ inline size_t conv_pack_floats(int l, bool input_grad) {
 // [k-step s of stage ch: tap = s / (CC/4), c = ch*CC + 4*(s % (CC/4)) + (lane >> 4)], 0 for c >= Ck.  One launch for
 // the ten packs of a step (blockIdx.y = layer*2 + {0: forward -> b, 1: input gradient -> c}).
 struct TrainPtrs5 { const float* a[kTrainLayers]; float* b[kTrainLayers]; float* c[kTrainLayers]; };
-__global__ void pack_train_weights_kernel(const TrainPtrs5 p) {
+// The graph filter's taps of the same step (r06; graphML.py:2434 `weight` [F,E,K,G]): the fp32 MFMA fragments of the
+// forward filter (-> fwd, the first region of a gnnpp_filter_pack buffer of h) and of the input-gradient filter = the
+// filter of h^T [G,E,K,F] (-> tr), read straight from h: blockIdx.y = 2 * kTrainLayers + {0, 1}.  The training step's
+// filter launches contract in exact fp32 and read nothing else of those buffers; r05 packed every region of both
+// (split-f16 scale + fragments, bf16x3 planes) with two launches each, behind a transposing copy of h.
+struct TrainFilterPack { const float* h; float* fwd; float* tr; int G, F, K, E; };
+__device__ __forceinline__ void pack_train_filter(const TrainFilterPack f, bool transposed) {
+    const int Fo = transposed ? f.G : f.F, Gi = transposed ? f.F : f.G;   // output / input features of THIS filter
+    const int NG = (Gi + 15) / 16, MT = (Fo + 15) / 16;
+    const long total = (long)f.E * f.K * MT * NG * 256;
+    float* out = transposed ? f.tr : f.fwd;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int s = idx & 3, l = (idx >> 2) & 63;
+        long blk = idx >> 8;
+        const int gg = blk % NG; blk /= NG;
+        const int mt = blk % MT; blk /= MT;
+        const int k = blk % f.K;
+        const int e = (int)(blk / f.K);
+        const int fo = mt * 16 + (l & 15), gi = gg * 16 + (l >> 4) * 4 + s;
+        float v = 0.f;
+        if (fo < Fo && gi < Gi) {
+            const int hf = transposed ? gi : fo, hg = transposed ? fo : gi;          // h[f][e][k][g]
+            v = f.h[(((long)hf * f.E + e) * f.K + k) * f.G + hg];
+        }
+        out[idx] = v;
+    }
+}
+
+__global__ void pack_train_weights_kernel(const TrainPtrs5 p, const TrainFilterPack fp) {
+    if (blockIdx.y >= 2 * kTrainLayers) {
+        if (fp.h) pack_train_filter(fp, blockIdx.y == 2 * kTrainLayers + 1);
+        return;
+    }
     const int l = blockIdx.y >> 1;
     const bool ig = blockIdx.y & 1;
+    if (!p.a[l]) return;                                             // (a filter-only call)
     const TrainLayerDims d = train_layer(l);
     const ConvGeom g = conv_geom(l, ig, 1);
     const float* w = p.a[l];
@@ -119,6 +153,20 @@ __global__ void pack_train_weights_kernel(const TrainPtrs5 p) {
         }
         out[e] = v;
     }
+}
+
+// The ten weight packs of a step as ONE caller-owned buffer (gnnpp_train_pack; r06): packed once per weight version
+// together with the graph filter's taps instead of once per forward call inside the workspace.
+struct TrainPackLayout { size_t wt[kTrainLayers], wtb[kTrainLayers], total; };
+inline TrainPackLayout train_pack_layout() {
+    TrainPackLayout w;
+    size_t o = 0;
+    for (int l = 0; l < kTrainLayers; ++l) {
+        w.wt[l] = o;  o += (conv_pack_floats(l, false) + 3) & ~(size_t)3;
+        w.wtb[l] = o; o += (conv_pack_floats(l, true) + 3) & ~(size_t)3;
+    }
+    w.total = o;
+    return w;
 }
 
 // ---- the convolution on v_mfma_f32_16x16x4_f32 -------------------------------------------------------------------
@@ -725,28 +773,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
-// sum the splits: 8 lanes per output element each add every 8th split (in order), then the 8 partial sums
-// are added in lane order -- a fixed association, deterministic.  dw [Cout][Cin][9], db [Cout]
+// sum the splits: 8 threads per output element each add every 8th split (in order), then the 8 partial sums are
+// added in order -- a fixed association, deterministic.  Thread (sub = tid >> 5, e = tid & 31): the 32 lanes of a
+// half wave read 32 CONSECUTIVE outputs of one split (r05 had the 8 splits on neighbouring lanes: every lane its own
+// cache line, 8.1 us per launch; same association, same bits).  dw [Cout][Cin][9], db [Cout]
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ wpart,
                                                                 float* __restrict__ dw, float* __restrict__ db,
                                                                 int nsplit, int Cin, int Cout, int J16) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    float* red = reinterpret_cast<float*>(gnnpp_smem);                 // [256]
+    float* red = reinterpret_cast<float*>(gnnpp_smem);                 // [8][32]
     const int J = Cin * 9 + 1;
     const int total = Cout * J;
-    const int sub = threadIdx.x & 7;
-    const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int e = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
     float s = 0.f;
     if (i < total) {
         const int co = i / J, jj = i - co * J;
-        for (int k = sub; k < nsplit; k += 8) s += wpart[((long)k * Cout + co) * J16 + jj];
+        const float* src = wpart + (long)co * J16 + jj;
+        const long stride = (long)Cout * J16;
+#pragma unroll 4
+        for (int k = sub; k < nsplit; k += 8) s += src[k * stride];
     }
-    red[threadIdx.x] = s;
+    red[sub * 32 + e] = s;
     __syncthreads();
     if (sub == 0 && i < total) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[threadIdx.x + k];
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + e];
         const int co = i / J, jj = i - co * J;
         if (jj == J - 1) db[co] = t;
         else dw[(long)co * (J - 1) + jj] = t;
@@ -857,23 +910,42 @@ static void wgrad_launch(int l, const TrainWs& L, const float* x, const float* d
 
 // obs: [B][N][3][11][11] (the reference's inputTensor, decentralplanner.py:278-286); feat = x_5 [N][B][128], or
 // [B][N][128] with feat_bn (sample-major: node-major rows for the graph filter, no transposing copy)
+// the ten packs of the encoder (+ the graph filter's two, fp.h != nullptr) in one launch
+int train_pack_launch(const float* const* conv_w, float* enc_pack, const TrainFilterPack& fp, hipStream_t st) {
+    const TrainPackLayout PL = train_pack_layout();
+    TrainPtrs5 pk = {};
+    for (int l = 0; l < kTrainLayers; ++l) {
+        pk.a[l] = conv_w ? conv_w[l] : nullptr;
+        pk.b[l] = enc_pack ? enc_pack + PL.wt[l] : nullptr;
+        pk.c[l] = enc_pack ? enc_pack + PL.wtb[l] : nullptr;
+    }
+    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(128, 2 * kTrainLayers + (fp.h ? 2 : 0)), dim3(256), 0, st, pk, fp);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// enc_pack: the caller's pack of the CURRENT weights (gnnpp_train_pack), or nullptr: packed here, into the workspace
 int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const* rvar,
                       long long* const* num_batches, float momentum,
-                      const float* obs, float* ws, float* feat, int N, int B, int feat_bn, hipStream_t st) {
+                      const float* obs, float* ws, float* feat, int N, int B, int feat_bn, hipStream_t st,
+                      const float* enc_pack = nullptr) {
     const TrainWs L = train_ws_layout(N, B);
+    const TrainPackLayout PL = train_pack_layout();
     TrainPtrs5 pk = {}, run = {};
+    const float* wt[kTrainLayers];
     for (int l = 0; l < kTrainLayers; ++l) {
         pk.a[l] = rp.conv_w[l]; pk.b[l] = ws + L.wt[l]; pk.c[l] = ws + L.wtb[l];
         run.a[l] = ws + L.stat[l]; run.b[l] = rmean ? rmean[l] : nullptr; run.c[l] = rvar ? rvar[l] : nullptr;
+        wt[l] = enc_pack ? enc_pack + PL.wt[l] : ws + L.wt[l];
     }
-    hipLaunchKernelGGL(pack_train_weights_kernel, dim3(128, 2 * kTrainLayers), dim3(256), 0, st, pk);
+    if (!enc_pack)
+        hipLaunchKernelGGL(pack_train_weights_kernel, dim3(128, 2 * kTrainLayers), dim3(256), 0, st, pk, TrainFilterPack{});
     for (int l = 0; l < kTrainLayers; ++l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        conv_launch(l, false, xin, ws + L.wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, sn, sb, st);
+        conv_launch(l, false, xin, wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, sn, sb, st);
         const BnTile t = bn_tile(l);
         hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N), dim3(256), kBnSmem, st,
                            ws + L.y[l], ws + L.part, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
@@ -942,8 +1014,9 @@ static BwdFork* bwd_fork(hipStream_t st, long rows) {
 // dfeat: gradient w.r.t. x_5 [N][B][128]; writes d conv_w / d conv_b / d bn_w / d bn_b of every layer
 int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const float* dfeat,
                       float* const* dconv_w, float* const* dconv_b, float* const* dbn_w, float* const* dbn_b,
-                      int N, int B, int feat_bn, hipStream_t st) {
+                      int N, int B, int feat_bn, hipStream_t st, const float* enc_pack = nullptr) {
     const TrainWs L = train_ws_layout(N, B);
+    const TrainPackLayout PL = train_pack_layout();
     const long NB = (long)N * B;
     const float* dxn = dfeat;
     float* dx_buf[2] = {ws + L.dxa, ws + L.dxb};
@@ -990,7 +1063,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
             // output channels of this call = d.Cin (a multiple of 16 for l >= 1)
-            conv_launch(l, true, dz, ws + L.wtb[l], nullptr, dx, nullptr, N, B, (long)B * d.Cout * P,
+            conv_launch(l, true, dz, enc_pack ? enc_pack + PL.wtb[l] : ws + L.wtb[l], nullptr, dx, nullptr, N, B, (long)B * d.Cout * P,
                         (long)d.Cout * P, st);
             dxn = dx;
         }

@@ -30,6 +30,8 @@ struct GemmOne {
     const float* A; long a_sb, a_sm, a_sk;
     const float* B; long b_sb, b_sk;
     float* C; long c_sb, c_sm;
+    const float* mask;                // optional, addressed like C: C(m,n) is written as 0 where mask(m,n) <= 0 (the
+                                      // ReLU backward of the layer below, folded into the product that feeds it)
     int batch, M, N, K, ksplit, kper, nx, ny;
     long ws_off;
 };
@@ -93,30 +95,49 @@ __global__ __launch_bounds__(256) void gemm_kmajor_kernel(const GemmTable tb, fl
     const bool direct = g.ksplit == 1;
     float* o = direct ? g.C + b * g.c_sb : ws + g.ws_off + ((long)split * batch + b) * M * N;
     const long o_sm = direct ? g.c_sm : (long)N;
+    const float* mk = direct && g.mask ? g.mask + b * g.c_sb : nullptr;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = n0 + 16 * t + i16;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (mr + r < M && n < N) o[(long)(mr + r) * o_sm + n] = acc[t][r];
+            if (mr + r < M && n < N) {
+                float v = acc[t][r];
+                if (mk && !(mk[(long)(mr + r) * o_sm + n] > 0.f)) v = 0.f;
+                o[(long)(mr + r) * o_sm + n] = v;
+            }
     }
 }
 
-// C_b(m,n) = sum over splits (in order) of the partials; 256 outputs per workgroup, products concatenated
+// C_b(m,n) = sum over the splits of the partials: 64 outputs per workgroup, four threads per output -- thread (sub, e)
+// adds the splits sub, sub + 4, .. of output e in order, then the four sums are added in sub order: a fixed
+// association (deterministic), every load of a wave a contiguous 256-byte run, four times the loads in flight of
+// the one-thread-per-output form (r05: 6.9 us per launch for 4 MB of partials).  Products concatenated.
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmTable tb, const float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* red = reinterpret_cast<float*>(gnnpp_smem);                    // [256]
     int gi = 0;
     while (gi + 1 < tb.count && (int)blockIdx.x >= tb.rfirst[gi + 1]) ++gi;
     const GemmOne& g = tb.g[gi];
     const long total = (long)g.batch * g.M * g.N;
-    const long i = (long)((int)blockIdx.x - tb.rfirst[gi]) * 256 + threadIdx.x;
-    if (i >= total) return;
+    const int e = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const long i = (long)((int)blockIdx.x - tb.rfirst[gi]) * 64 + e;
     const float* part = ws + g.ws_off;
     float s = 0.f;
-    for (int k = 0; k < g.ksplit; ++k) s += part[(long)k * total + i];
+    if (i < total) {
+#pragma unroll 4
+        for (int k = sub; k < g.ksplit; k += 4) s += part[(long)k * total + i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sub != 0 || i >= total) return;
+    s = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
     const int n = (int)(i % g.N);
     const long bm = i / g.N;
     const int m = (int)(bm % g.M), b = (int)(bm / g.M);
-    g.C[b * g.c_sb + (long)m * g.c_sm + n] = s;
+    const long at = b * g.c_sb + (long)m * g.c_sm + n;
+    if (g.mask && !(g.mask[at] > 0.f)) s = 0.f;
+    g.C[at] = s;
 }
 
 struct GemmPlan { int ksplit, kper; };
@@ -152,12 +173,12 @@ inline int gemm_multi_launch(GemmTable& tb, float* ws, hipStream_t st) {
         tb.first[i] = blocks;
         blocks += g.nx * g.ny * g.batch * g.ksplit;
         tb.rfirst[i] = rblocks;
-        if (g.ksplit > 1) rblocks += (int)(((long)g.batch * g.M * g.N + 255) / 256);
+        if (g.ksplit > 1) rblocks += (int)(((long)g.batch * g.M * g.N + 63) / 64);
     }
     tb.first[tb.count] = blocks;
     tb.rfirst[tb.count] = rblocks;
     hipLaunchKernelGGL(gemm_kmajor_kernel, dim3(blocks), dim3(256), 0, st, tb, ws);
-    if (rblocks > 0) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(rblocks), dim3(256), 0, st, tb, ws);
+    if (rblocks > 0) hipLaunchKernelGGL(gemm_reduce_kernel, dim3(rblocks), dim3(256), 256 * sizeof(float), st, tb, ws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -209,9 +230,13 @@ __global__ __launch_bounds__(1024) void policy_loss_kernel(const float* __restri
 // ---- Adam -----------------------------------------------------------------------------------------------------------
 // torch.optim.Adam (amsgrad = False, maximize = False):  g' = g + wd * p;  m = m + (1 - b1)(g' - m);
 // v = b2 v + (1 - b2) g'^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),  t = step count.
-// adam_tick_kernel advances the device-side step counter and leaves the two bias-correction factors next to it
-// (state[0] = t, state[1] = lr / (1 - b1^t), state[2] = 1 / sqrt(1 - b2^t)); adam_kernel applies the update to up to
-// kAdamTensors tensors: workgroup w serves elements [1024 (w - first[i]), +1024) of tensor i, first[i] <= w < first[i+1].
+// state[0] = steps taken so far, state[1] = lr / (1 - b1^t), state[2] = 1 / sqrt(1 - b2^t) of the LAST tick, state[3] =
+// arrival counter (an unsigned; zero between launches).  A launch with tick != 0 is the first table of a step: every
+// workgroup reads t = state[0] + 1 and derives the two bias-correction factors itself; the workgroup that arrives
+// LAST (a ticket from the arrival counter, taken after the workgroup's own read of state[0]) stores t and the factors
+// and re-arms the counter -- r05 spent a launch of one thread on that.  Further tables of the same step (tick == 0)
+// read the stored factors.  adam_kernel applies the update to up to kAdamTensors tensors: workgroup w serves elements
+// [1024 (w - first[i]), +1024) of tensor i, first[i] <= w < first[i+1].
 constexpr int kAdamTensors = 32;
 struct AdamTable {
     float* p[kAdamTensors];
@@ -223,20 +248,26 @@ struct AdamTable {
     int count;
 };
 
-__global__ void adam_tick_kernel(float* __restrict__ state, float lr, float b1, float b2) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float t = state[0] + 1.f;
-    state[0] = t;
-    state[1] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
-    state[2] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
-}
-
-__global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, const float* __restrict__ state, float b1,
-                                                   float b2, float eps, float wd) {
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float* __restrict__ state, float lr, float b1,
+                                                   float b2, float eps, float wd, int tick) {
+    extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
+    float* sh = reinterpret_cast<float*>(gnnpp_smem);                     // [3]
+    if (threadIdx.x == 0) {
+        if (tick) {
+            const float t = state[0] + 1.f;
+            sh[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+            sh[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+            sh[2] = t;
+        } else {
+            sh[0] = state[1];
+            sh[1] = state[2];
+        }
+    }
+    __syncthreads();
     int i = 0;
     while (i + 1 < tb.count && (int)blockIdx.x >= tb.first[i + 1]) ++i;     // (scalar: at most 31 steps)
     const long base = (long)((int)blockIdx.x - tb.first[i]) * 1024;
-    const float step_size = state[1], inv_bc2 = state[2];
+    const float step_size = sh[0], inv_bc2 = sh[1];
     float* p = tb.p[i];
     const float* g = tb.g[i];
     float* m = tb.m[i];
@@ -254,6 +285,71 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, const flo
             v[e] = ve;
             p[e] = pe - step_size * (me / (sqrtf(ve) * inv_bc2 + eps));
         }
+    }
+    if (tick && threadIdx.x == 0) {
+        unsigned* cnt = reinterpret_cast<unsigned*>(state + 3);
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {                         // every workgroup has read state[0]: advance it
+            state[0] = sh[2];
+            state[1] = sh[0];
+            state[2] = sh[1];
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- y = x W^T + b (+ ReLU): the forward product of the two small Linear layers of the training step -------------------
+// x [R][I], W [O][I] (nn.Linear's layout: BOTH operands have the contraction index contiguous -- the shape
+// gnnpp_gemm_kmajor cannot take without a transposed copy of W per step), y [R][O].  R is a few hundred rows, I = 128,
+// O = 128 (compressMLP, decentralplanner.py:187-195, :289-290) or 5 (actionsMLP, :232-243, :304-315): r05 ran them as
+// library GEMMs followed by an aten ReLU.  One wave owns a 16 (features) x 16 (rows) tile on v_mfma_f32_16x16x4_f32:
+// lane (i = lane & 15, q = lane >> 4) supplies W[f0 + i][k] and x[r0 + i][k] for the I / 4 contraction indices
+// k in [q I / 4, (q + 1) I / 4) -- the pipe's k-slot (4 s + q) is fed index q I / 4 + s for both operands, a
+// permutation of the sum's terms that makes every lane's reads contiguous 16-byte loads.  D register r = feature
+// f0 + 4 q + r of row r0 + i: one 16-byte store per lane.  Exact fp32, fixed order.  Needs I % 16 == 0.
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int R,
+                                                         int I, int O, int relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int FT = (O + 15) / 16, RT = (R + 15) / 16;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= FT * RT) return;
+    const int rt = tile / FT, ft = tile - rt * FT;
+    const int f = ft * 16 + i16, r = rt * 16 + i16;
+    const int kq = I / 4;
+    const float* wr = W + (long)(f < O ? f : 0) * I + q * kq;
+    const float* xr = x + (long)(r < R ? r : 0) * I + q * kq;
+    const bool fv = f < O, rv = r < R;
+    v4f acc = vzero();
+    for (int k = 0; k < kq; k += 16) {                       // four 16-byte loads per operand in flight
+        v4f a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const v4f*>(wr + k + 4 * u);
+            b[u] = *reinterpret_cast<const v4f*>(xr + k + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = mfma16(fv ? a[u][c] : 0.f, rv ? b[u][c] : 0.f, acc);
+    }
+    if (!rv) return;
+    const int fo = ft * 16 + 4 * q;
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = acc[c] + (bias && fo + c < O ? bias[fo + c] : 0.f);
+        o[c] = relu ? fmaxf(v, 0.f) : v;
+    }
+    float* yr = y + (long)r * O + fo;
+    if (fo + 3 < O && (O & 3) == 0) {
+        v4f ov = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<v4f*>(yr) = ov;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (fo + c < O) yr[c] = o[c];
     }
 }
 

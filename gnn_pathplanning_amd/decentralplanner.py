@@ -88,7 +88,7 @@ class _EncoderTrainFunction(torch.autograd.Function):
     data).  `tensors` = [conv_w, conv_b, bn_w, bn_b] x 5 layers; `buffers` = [running_mean, running_var] x 5."""
 
     @staticmethod
-    def forward(ctx, obs, buffers, counters, momentum, eps, *tensors):
+    def forward(ctx, obs, buffers, counters, momentum, eps, enc_pack, *tensors):
         L = _native.lib()
         B, N = obs.shape[0], obs.shape[1]
         dev = obs.device
@@ -101,10 +101,11 @@ class _EncoderTrainFunction(torch.autograd.Function):
             _native.check(L.gnnpp_encoder_train_fwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(feat), B, N,
                                                     ctypes.c_float(momentum), int(buffers is not None),
                                                     (ctypes.c_void_p * 5)(*[c.data_ptr() for c in counters])
-                                                    if counters is not None else None, 1,
+                                                    if counters is not None else None, 1, _ptr(enc_pack),
                                                     _native.stream_ptr(dev)), 'gnnpp_encoder_train_fwd')
         ctx.save_for_backward(obs, ws, *ps)
         ctx.eps = float(eps)
+        ctx.enc_pack = enc_pack                    # (the pack of THESE weights: the backward call reads its other half)
         return feat
 
     @staticmethod
@@ -122,34 +123,64 @@ class _EncoderTrainFunction(torch.autograd.Function):
         d = dfeat.contiguous().float()
         with _native.device_guard(dev):
             _native.check(L.gnnpp_encoder_train_bwd(ctypes.byref(p), _ptr(obs), _ptr(ws), _ptr(d), ctypes.byref(g),
-                                                    B, N, 1, _native.stream_ptr(dev)), 'gnnpp_encoder_train_bwd')
-        return (None, None, None, None, None) + tuple(grads)
+                                                    B, N, 1, _ptr(ctx.enc_pack), _native.stream_ptr(dev)),
+                          'gnnpp_encoder_train_bwd')
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class _LinearFunction(torch.autograd.Function):
-    """y = x W^T + b for x [..., I] with a handful of hundred rows (compressMLP, the action head in train
-    mode).  Forward is the library GEMM; the backward's three products are "small output, long or short
-    contraction" shapes that a library GEMM serves with one macro tile -- they run on gnnpp_gemm_kmajor
-    (contraction split over workgroups, deterministic):  dx = dy W,  dW = dy^T x,  db = 1^T dy."""
+    """y = x W^T + b (optionally followed by ReLU) for x [..., I] with a few hundred rows (compressMLP, the action head
+    in train mode).  Forward: gnnpp_linear_fwd -- one launch, bias and ReLU in its epilogue (r05: a library GEMM + an
+    aten ReLU).  The backward's three products are "small output, long or short contraction" shapes that a library
+    GEMM serves with one macro tile -- they run on gnnpp_gemm_kmajor (contraction split over workgroups,
+    deterministic):  dx = dy W,  dW = dy^T x,  db = 1^T dy.
+      relu      0: none; 1: y = relu(.), the backward masks dy itself; 2: y = relu(.) and the CONSUMER of y promises
+                to hand back a gradient that is already masked by y > 0 (the graph filter's input-gradient launch
+                does: graphML._LSIGFFunction fold bit 1)
+      mask_dx   x is itself the output of a ReLU whose backward is folded into THIS function's dx product (dx is
+                stored as 0 where x <= 0; the producer of x must then not mask again: _LSIGFFunction fold bit 0)"""
 
     @staticmethod
-    def forward(ctx, x, W, b):
-        ctx.save_for_backward(x, W)
+    def forward(ctx, x, W, b, relu=0, mask_dx=False):
         ctx.param_ptrs = (W.data_ptr(), b.data_ptr() if b is not None else 0)
-        return torch.nn.functional.linear(x, W, b)
+        ctx.relu, ctx.mask_dx = int(relu), bool(mask_dx)
+        O, I = W.shape
+        xd, Wd = x.detach(), W.detach()
+        y = None
+        if (x.is_cuda and xd.dtype is torch.float32 and Wd.dtype is torch.float32 and xd.is_contiguous()
+                and Wd.is_contiguous() and I % 64 == 0 and (b is None or b.dtype is torch.float32)):
+            R = xd.numel() // I
+            y = torch.empty(x.shape[:-1] + (O,), dtype=torch.float32, device=x.device)
+            with _native.device_guard(x.device):
+                rc = _native.lib().gnnpp_linear_fwd(_ptr(xd), _ptr(Wd), _ptr(b.detach().contiguous()) if b is not None
+                                                    else None, _ptr(y), R, I, O, int(relu != 0),
+                                                    _native.stream_ptr(x.device))
+            if rc == -2:
+                y = None                                      # GNNPP_ERR_UNSUPPORTED (alignment): the library GEMM
+            else:
+                _native.check(rc, 'gnnpp_linear_fwd')
+        if y is None:
+            y = torch.nn.functional.linear(xd, Wd, b.detach() if b is not None else None)
+            if relu:
+                y = torch.relu_(y)
+        ctx.save_for_backward(x, W, y if relu == 1 else None)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, W, yrelu = ctx.saved_tensors
         O, I = W.shape
         dy2 = dy.reshape(-1, O).contiguous().float()
+        if yrelu is not None:
+            dy2 = torch.ops.aten.threshold_backward(dy2, yrelu.reshape(-1, O), 0)
         x2 = x.detach().reshape(-1, I).contiguous().float()
         R = dy2.shape[0]
         dx = dW = db = None
         specs = []                                             # the three products: ONE launch (+ one for the sums)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(R, I, dtype=torch.float32, device=dy.device)
-            specs.append((dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O))
+            specs.append((dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O,
+                          x2 if ctx.mask_dx else None))
         if ctx.needs_input_grad[1]:
             dW = _native.grad_out(ctx.param_ptrs[0], (O, I), dy.device)
             specs.append((dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R))
@@ -158,7 +189,7 @@ class _LinearFunction(torch.autograd.Function):
             specs.append((_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R))
         if specs:
             _native.gemm_kmajor_multi(specs)
-        return (dx.reshape(x.shape) if dx is not None else None), dW, db
+        return (dx.reshape(x.shape) if dx is not None else None), dW, db, None, None
 
 
 _ones_cache = {}
@@ -282,6 +313,7 @@ class DecentralPlannerNet(nn.Module):
         self.apply(weights_init)
         self._enc_cache = _native.PackCache()
         self._head_cache = _native.PackCache()
+        self._train_pack_cache = _native.PackCache()
         self._ws = None
         self._ws_key = None
         self._ws_all = {}                          # feature workspaces by (rows, stream)
@@ -613,15 +645,21 @@ class DecentralPlannerNet(nn.Module):
             tensors += [conv.weight, conv.bias, bn.weight, bn.bias]
             buffers += [bn.running_mean, bn.running_var]
         counters = [self.ConvLayers[bi].num_batches_tracked for bi in _BN_IDX] if track else None   # += N each
+        packs = self._train_packs(tensors)                                              # one launch per weight version
         feat = _EncoderTrainFunction.apply(obs, buffers if track else None, counters, float(bn0.momentum or 0.0),
-                                           float(bn0.eps), *tensors)                     # [B,N,128]
+                                           float(bn0.eps), packs[0] if packs else None, *tensors)   # [B,N,128]
         fc = self.compressMLP[0]
-        x = tF.relu(_LinearFunction.apply(feat, fc.weight, fc.bias))                    # [B,N,F]
         if self.S.shape[0] != B:
             raise _native.GnnppError('addGSO() was given %d graphs, the input has %d samples' % (self.S.shape[0], B))
         Ns = self.S.shape[-1]
         if Ns < N:
             raise _native.GnnppError('the GSO has %d nodes, the planner %d agents' % (Ns, N))
+        # The two ReLU backward passes around the graph filter are folded into the launches that produce the gradients
+        # they mask (r06): compressMLP's into the filter's input-gradient launch (`fold` bit 1 <-> relu = 2), the
+        # filter's own into the action head's dx product (`fold` bit 0 <-> mask_dx) -- when the filter's input / output
+        # ARE those tensors (no zero-padded nodes in between) and the filter runs on the LDS-resident kernels.
+        direct = Ns == N and Ns <= gml.MAX_NODES
+        x = _LinearFunction.apply(feat, fc.weight, fc.bias, 2 if direct else 1)         # [B,N,F], ReLU in the launch
         if Ns != N:                                # Nin < N: zero signal on the extra nodes (graphML.py:2464-2469)
             x = torch.cat([x, x.new_zeros(B, Ns - N, x.shape[2])], 1)
         # every activation stays node-major [B,N,*] (the layout the filter kernel keeps in LDS): no transposing
@@ -629,11 +667,43 @@ class DecentralPlannerNet(nn.Module):
         for l in range(self.L):
             gf = self.GFL[2 * l]
             gf.addGSO(self.S)
-            x = gf.forward_node_major(x, relu=True)                                     # [B,Ns,F_l]
+            fold = ((2 if l == 0 else 0) | (1 if l == self.L - 1 else 0)) if direct else 0
+            x = gf.forward_node_major(x, relu=True, packed=packs[1] if packs else None,
+                                      packed_T=packs[2] if packs else None, fold=fold)  # [B,Ns,F_l]
         if Ns != N:
             x = x[:, :N]                           # ... whose outputs are dropped (index_select, :2471-2476)
         act = self.actionsMLP[0]
-        return _LinearFunction.apply(x, act.weight, act.bias).permute(1, 0, 2)          # [N,B,5] (a view of [B,N,5])
+        return _LinearFunction.apply(x, act.weight, act.bias, 0, direct).permute(1, 0, 2)   # [N,B,5] (a view of [B,N,5])
+
+    def _train_packs(self, conv_tensors):
+        """(encoder train pack, filter taps forward, filter taps transposed) of the CURRENT weights by ONE
+        gnnpp_train_pack launch per weight version (r05: five pack launches + a transposing copy per step), or None for
+        planners the one-launch pack does not cover (several filter layers, the opt-in split-f16 forward whose taps
+        need the other regions of the tap buffers): those pack per layer as before."""
+        if self.L != 1:
+            return None
+        gf = self.GFL[0]
+        if _native.precision_code(gf.precision) == _native.PREC_SPLIT_F16:
+            return None
+        ws = [conv_tensors[4 * i] for i in range(5)]
+        h = gf.weight
+        if any(t.dtype is not torch.float32 or not t.is_contiguous() or not t.is_cuda for t in ws + [h]):
+            return None
+
+        def build():
+            L = _native.lib()
+            dev = h.device
+            p = _native.EncoderParams()
+            for i in range(5):
+                p.conv_w[i] = ws[i].data_ptr()
+            enc = torch.empty(L.gnnpp_train_pack_floats(), dtype=torch.float32, device=dev)
+            fwd = torch.empty(L.gnnpp_filter_packed_floats(gf.G, gf.F, gf.K, gf.E), dtype=torch.float32, device=dev)
+            tr = torch.empty(L.gnnpp_filter_packed_floats(gf.F, gf.G, gf.K, gf.E), dtype=torch.float32, device=dev)
+            with _native.device_guard(dev):
+                _native.check(L.gnnpp_train_pack(ctypes.byref(p), _ptr(enc), _ptr(h.detach()), _ptr(fwd), _ptr(tr),
+                                                 gf.G, gf.F, gf.K, gf.E, _native.stream_ptr(dev)), 'gnnpp_train_pack')
+            return enc, fwd, tr
+        return self._train_pack_cache.get(ws + [h], build)
 
     def _forward_train_aten(self, inputTensor):
         """The same train-mode forward on stock aten / MIOpen ops (agents as convolution groups).  NOT

@@ -153,7 +153,7 @@ def _lsigf_large_backward(h, S32, Z, dy, batched, need_dh, need_dx):
 
 
 def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=False,
-                  save_taps=False, node_major=False, precision=None):
+                  save_taps=False, node_major=False, precision=None, out_mask=None):
     """Shared driver: h [F,E,K,G], S [E,N,N] | [B,E,N,N], x [B,G,Nin] -> y [B,F,Nin]
     (and, with save_taps, zs [E*K, B*N, G]).  Any F: the C entry point splits wide filters.
     node_major: x [B,N,G] -> y [B,N,F] (rows = nodes, the layout the kernel keeps in LDS anyway).
@@ -189,7 +189,13 @@ def _lsigf_device(h, S, x, b, batched, Nin, packed=None, relu=False, transposed=
     zs = torch.empty(E * K, B * N, G, dtype=torch.float32, device=dev) if save_taps else None
     s64 = int(Sc.dtype == torch.float64)
     with _native.device_guard(dev):
-        if transposed or save_taps:
+        if out_mask is not None:
+            # input gradient with the ReLU backward of the layer below folded in (gnnpp_lsigf_input_grad): h is the
+            # transposed taps' SHAPE [G,E,K,F] here, x the output gradient dy [B,N,F], y = dx [B,N,G]
+            assert transposed and node_major and b is None and not relu and Nin == N
+            rc = L.gnnpp_lsigf_input_grad(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(out_mask), _ptr(y), B, N, F_out, G,
+                                          K, E, s64, int(batched), 1, _native.stream_ptr(dev))
+        elif transposed or save_taps:
             rc = L.gnnpp_lsigf_fwd_save(_ptr(xc), _ptr(Sc), _ptr(packed), _ptr(bias), _ptr(y), _ptr(zs),
                                         B, N, Nin, G, F_out, K, E, s64, int(batched), int(transposed),
                                         nm, nm, int(relu), per_node, int(precision), None,
@@ -244,14 +250,21 @@ class _LSIGFFunction(torch.autograd.Function):
     """y = LSIGF(h, S, x, b) with gradients for h, x and b (none for S)."""
 
     @staticmethod
-    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False, precision=None, packed_T=None):
+    def forward(ctx, h, S, x, b, batched, packed, node_major=False, relu=False, precision=None, packed_T=None,
+                fold=0):
         """node_major: x [B,N,G] -> y [B,N,F] (train-mode planner: no transposing copies around the filter);
         relu: y = relu(filter) in the same launch (the mask for the backward pass is y > 0);
         precision: of the forward contraction (the gradient filters run in the default arithmetic);
         packed_T: the packed taps of the input-gradient filter when the caller already holds them (ops.py: `h` is a
-        per-call alias of the parameter there, which the per-object cache cannot recognise)."""
+        per-call alias of the parameter there, which the per-object cache cannot recognise);
+        fold (node-major training path only; the caller vouches for both): bit 0 -- the incoming output gradient is
+        ALREADY masked by this filter's ReLU (the product that computed it did so: _LinearFunction `mask_dx`), bit 1 --
+        x is the output of a ReLU whose backward is folded into this filter's input-gradient launch (dx is returned
+        masked by x > 0; the layer below must not mask again)."""
         Nin = x.shape[1] if node_major else x.shape[2]
         ctx.packed_T = packed_T
+        ctx.fold = int(fold) if node_major else 0
+        ctx.x_mask = x.detach() if (ctx.fold & 2) else None          # (read by the dense form's backward only)
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
         ctx.param_ptrs = (h.data_ptr(), b.data_ptr() if b is not None else 0)    # (_native.grad_out: gradient sinks)
@@ -288,20 +301,22 @@ class _LSIGFFunction(torch.autograd.Function):
             if ctx.Nin != N:
                 dyn = torch.cat([dyn, dyn.new_zeros(B, N - ctx.Nin, F_out)], 1)
             dyn = dyn.contiguous()
-            if ctx.relu:
+            if ctx.relu and not (ctx.fold & 1):
                 dyn = torch.ops.aten.threshold_backward(dyn, yrelu, 0)
             dh, dxn = _lsigf_large_backward(h, S, zs, dyn, ctx.batched, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
             dx = db = None
             if dxn is not None:
                 dxn = dxn[:, :ctx.Nin]
                 dx = dxn.contiguous() if ctx.node_major else dxn.permute(0, 2, 1).contiguous()
+                if ctx.fold & 2:                                                   # (the promise made to the layer below)
+                    dx = torch.ops.aten.threshold_backward(dx, ctx.x_mask, 0)
             if ctx.has_bias and ctx.needs_input_grad[3]:
                 if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
                     db = dyn.sum(dim=(0, 1)).reshape(ctx.bias_shape)
                 else:                                                              # per-node bias [F,N]
                     db = dyn.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
-            return dh, None, dx, db, None, None, None, None, None, None
-        if ctx.relu:
+            return dh, None, dx, db, None, None, None, None, None, None, None
+        if ctx.relu and not (ctx.fold & 1):
             dy = torch.ops.aten.threshold_backward(dy, yrelu, 0)          # dy where y > 0, else 0
         if ctx.node_major:
             return _LSIGFFunction._backward_node_major(ctx, h, S, zs, dy)
@@ -326,7 +341,7 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=(0, 2)).reshape(ctx.bias_shape)
             else:                                                         # per-node bias [F,N]
                 db = torch.nn.functional.pad(dy.sum(dim=0), (0, N - ctx.Nin)).reshape(ctx.bias_shape)
-        return dh, None, dx, db, None, None, None, None, None, None
+        return dh, None, dx, db, None, None, None, None, None, None, None
 
     @staticmethod
     def _dense_dx(ctx, h, S, dyn):
@@ -349,11 +364,15 @@ class _LSIGFFunction(torch.autograd.Function):
         dh = dx = db = None
         if ctx.needs_input_grad[2]:
             hT = h.detach().permute(3, 1, 2, 0)
+            # (fold bit 1: tap signal 0 of edge feature 0 IS the filter's input x -- the mask of the ReLU that made it)
+            mask = zs[0] if (ctx.fold & 2) else None
             dx = _lsigf_device(hT, S, dy, None, ctx.batched, N,
                                ctx.packed_T if ctx.packed_T is not None else _packed_transposed_taps(h),
-                               transposed=True, node_major=True)
+                               transposed=True, node_major=True, out_mask=mask)
             if dx is None:
                 dx = _LSIGFFunction._dense_dx(ctx, h, S, dy)
+                if mask is not None:
+                    dx = torch.ops.aten.threshold_backward(dx.contiguous(), mask.reshape(dx.shape), 0)
         specs = []
         if ctx.needs_input_grad[0]:
             dh = _native.grad_out(ctx.param_ptrs[0], (F_out, E, K, G), dy.device)
@@ -366,7 +385,7 @@ class _LSIGFFunction(torch.autograd.Function):
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
         if specs:
             _native.gemm_kmajor_multi(specs)
-        return dh, None, dx, db, None, None, None, None, None, None
+        return dh, None, dx, db, None, None, None, None, None, None, None
 
 
 _ones_cache = {}
@@ -472,7 +491,7 @@ class _GraphFilterBase(nn.Module):
         return _lsigf_device(self.weight, self.S, x, self.bias, self._batched, Nin,
                              packed=self.packed_taps(), precision=self.precision)
 
-    def forward_node_major(self, x, relu=False):
+    def forward_node_major(self, x, relu=False, packed=None, packed_T=None, fold=0):
         """The same filter on x [B,N,G] -> [B,N,F] (rows = nodes; optionally followed by ReLU in the same launch),
         differentiable: the train-mode planner's path, which keeps every activation node-major so that no
         transposing copy sits between encoder, filter and action head.  Needs all N nodes (no Nin < N)."""
@@ -482,8 +501,11 @@ class _GraphFilterBase(nn.Module):
         assert x.shape[2] == self.G and x.shape[1] == self.N
         if self._batched:
             assert self.S.shape[0] == x.shape[0]
-        return _LSIGFFunction.apply(self.weight, self.S, x, self.bias, self._batched, self.packed_taps(), True,
-                                    bool(relu), self.precision)
+        # packed / packed_T: the caller's packs of the CURRENT weight (the planner's one-launch gnnpp_train_pack: fp32
+        # fragments only, which is all the exact-fp32 training launches read); fold: _LSIGFFunction.forward
+        return _LSIGFFunction.apply(self.weight, self.S, x, self.bias, self._batched,
+                                    packed if packed is not None else self.packed_taps(), True,
+                                    bool(relu), self.precision, packed_T, fold)
 
     def extra_repr(self):
         s = 'in_features=%d, out_features=%d, ' % (self.G, self.F)

@@ -79,7 +79,7 @@ def policy_loss_fused(predict, batch_target):
 
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) (amsgrad=False) on gnnpp_adam_step: ONE launch
-    (plus a one-thread tick of the device-side step counter) for up to 32 parameter tensors instead of the
+    (the device-side step counter is advanced by the launch's last workgroup) for up to 32 parameter tensors instead of the
     eight multi-tensor passes of the stock implementation; graph-capturable (nothing is read on the host).
     The reference builds optim.Adam(lr, weight_decay) (agents/decentralplannerlocal.py:77-79); the update
     rule is the same, the results agree to rounding (tests/test_gpu_training.py)."""
@@ -113,9 +113,11 @@ class FusedAdam(torch.optim.Optimizer):
             # and restored by state_dict() / load_state_dict() next to the moments.
             st = self.state.setdefault('gnnpp_group_%d' % gi, {})
             if 'counter' not in st:
-                st['counter'] = torch.zeros(3, dtype=torch.float32, device=dev)
+                st['counter'] = torch.zeros(4, dtype=torch.float32, device=dev)
             elif st['counter'].device != dev or st['counter'].dtype is not torch.float32:
                 st['counter'] = st['counter'].to(device=dev, dtype=torch.float32)      # (loaded with map_location)
+            if st['counter'].numel() < 4:                   # a checkpoint written before ABI v330 (three floats)
+                st['counter'] = torch.cat([st['counter'].reshape(-1)[:3], st['counter'].new_zeros(1)])
             for p in ps:
                 s = self.state[p]
                 if 'exp_avg' not in s:

@@ -234,8 +234,12 @@ int gnnpp_encoder_fwd(const float* obs, const float* packed, float* feat, int M,
  *   bn_num_batches  NULL, or the five BatchNorm2d.num_batches_tracked counters (int64, device): each is
  *              advanced by N, as the N forward calls of the reference do (with update_running only);
  *   g          where the gradients of the 20 parameter tensors go (overwritten, not accumulated).
+ *   train_pack  NULL (the ten MFMA-fragment packs of the convolution weights are built inside the forward call, in
+ *              the workspace), or the buffer gnnpp_train_pack filled from the CURRENT weights (v330: one pack launch
+ *              per weight version -- shared with the graph filter's taps -- instead of one per forward call); the
+ *              backward call must be given what the forward call was given.
  * fp32, deterministic (fixed-order reductions, no atomics).  compressMLP, the graph filter and the
- * action head are separate calls (library GEMM / gnnpp_lsigf_fwd_save).
+ * action head are separate calls (gnnpp_linear_fwd / gnnpp_lsigf_fwd_save / gnnpp_lsigf_input_grad).
  * ------------------------------------------------------------------------------------------ */
 typedef struct gnnpp_encoder_grads {
     float* conv_w[5];           /* d ConvLayers.{0,4,7,11,14}.weight  [Cout,Cin,3,3]             */
@@ -247,10 +251,40 @@ typedef struct gnnpp_encoder_grads {
 size_t gnnpp_encoder_train_workspace_floats(int N, int B);
 int gnnpp_encoder_train_fwd(const gnnpp_encoder_params* p, const float* obs, float* workspace, float* feat,
                             int B, int N, float momentum, int update_running,
-                            long long* const* bn_num_batches, int feat_sample_major, void* stream);
+                            long long* const* bn_num_batches, int feat_sample_major, const float* train_pack,
+                            void* stream);
 int gnnpp_encoder_train_bwd(const gnnpp_encoder_params* p, const float* obs, float* workspace,
                             const float* dfeat, const gnnpp_encoder_grads* g, int B, int N,
-                            int feat_sample_major, void* stream);
+                            int feat_sample_major, const float* train_pack, void* stream);
+
+/* Every weight re-ordering the training step of config 4 needs, in ONE launch (v330; r05: five launches and a
+ * transposing copy per step): the ten fragment packs of the convolution weights p->conv_w (-> train_pack,
+ * gnnpp_train_pack_floats() floats, 16-byte aligned) and, for the graph filter's taps h [F,E,K,G]
+ * (GraphFilterBatch.weight, graphML.py:2434), the fp32 fragments of the forward filter (-> taps_fwd, a buffer of
+ * gnnpp_filter_packed_floats(G, F, K, E) floats) and of the input-gradient filter h^T [G,E,K,F] (-> taps_t,
+ * gnnpp_filter_packed_floats(F, G, K, E) floats), read straight from h.  ONLY the fp32 region of the two tap buffers is
+ * written: they serve gnnpp_lsigf_fwd_save with GNNPP_PREC_FP32 / _FP32_MFMA and gnnpp_lsigf_input_grad (the exact-fp32
+ * contractions the training step runs), not the split-f16 or bf16x3 schedules.  p == NULL: taps only; h == NULL:
+ * convolution weights only. */
+size_t gnnpp_train_pack_floats(void);
+int gnnpp_train_pack(const gnnpp_encoder_params* p, float* train_pack, const float* h, float* taps_fwd,
+                     float* taps_t, int G, int F, int K, int E, void* stream);
+
+/* Input gradient of the graph filter (graphML.py:2345-2366 run backwards): dx = sum_k (dy W_k) (S^T)^k, i.e. the
+ * filter of the transposed taps h^T [G,E,K,F] on S^T applied to dy [.., F] -> dx [.., G]; packed_t = the taps_t of
+ * gnnpp_train_pack (or gnnpp_filter_pack of h.permute(3,1,2,0)).  node_major != 0: dy [B,N,F], dx [B,N,G], and an
+ * optional mask [B,N,G]: dx is stored as 0 where mask <= 0 -- the ReLU backward of the layer that produced the
+ * filter's input (compressMLP's ReLU, decentralplanner.py:190), folded into this launch (v330).  Exact fp32. */
+int gnnpp_lsigf_input_grad(const float* dy, const void* S, const float* packed_t, const float* mask, float* dx,
+                           int B, int N, int G, int F, int K, int E, int s_is_f64, int s_batched, int node_major,
+                           void* stream);
+
+/* y = x W^T + bias (+ ReLU): forward of compressMLP (Linear 128 -> 128 + ReLU, decentralplanner.py:187-195, :289-290)
+ * and of actionsMLP (Linear 128 -> 5, :232-243, :304-315) in the training step.  x [R,I], W [O,I] (nn.Linear's layout),
+ * bias [O] or NULL, y [R,O].  Exact fp32 MFMA, fixed summation order.  I must be a multiple of 64 and x, W 16-byte
+ * aligned (GNNPP_ERR_UNSUPPORTED otherwise).  (v330; r05 ran these as library GEMMs + an aten ReLU.) */
+int gnnpp_linear_fwd(const float* x, const float* W, const float* bias, float* y, int R, int I, int O, int relu,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The rest of the optimisation step of config 4 (agents/decentralplannerlocal.py:287-317): the weight
@@ -275,6 +309,8 @@ typedef struct gnnpp_gemm_desc {
     const float* B; long long b_sb, b_sk;
     float*       C; long long c_sb, c_sm;
     int batch, M, N, K;
+    const float* mask;          /* NULL, or addressed like C: C(m,n) is stored as 0 where mask(m,n) <= 0 -- the ReLU
+                                   backward of the layer whose output gradient this product is (v330) */
 } gnnpp_gemm_desc;
 size_t gnnpp_gemm_multi_workspace_floats(const gnnpp_gemm_desc* d, int count);
 int gnnpp_gemm_kmajor_multi(const gnnpp_gemm_desc* d, int count, float* workspace, void* stream);
@@ -289,9 +325,11 @@ int gnnpp_policy_loss(const float* logits, const float* target, float* loss, flo
 
 /* torch.optim.Adam's update (amsgrad = False; L2 weight decay added to the gradient; bias correction) of up
  * to 32 tensors in one launch:  p, m (exp_avg), v (exp_avg_sq) are updated in place from g.
- *   state  3 floats on the device: state[0] = number of steps taken so far (start at 0), [1], [2] scratch;
- *   tick   != 0: advance state[0] first (pass 1 for the first table of a step, 0 for further tables of the
- *          same step).  The counter lives on the device so that the call can be captured in a HIP graph. */
+ *   state  4 floats on the device, zero before the first step: state[0] = number of steps taken so far, [1], [2] the
+ *          bias-correction factors of the last tick, [3] scratch (a workgroup arrival counter, zero between calls);
+ *   tick   != 0: this call is the first table of a step: it uses t = state[0] + 1 and its last workgroup stores t
+ *          (v330: inside the same launch; pass 0 for further tables of the same step).  The counter lives on the
+ *          device so that the call can be captured in a HIP graph. */
 typedef struct gnnpp_adam_tensors {
     float* p[32];
     const float* g[32];

@@ -268,7 +268,7 @@ def test_emu_filter_forced_gpw(emu, lsigf_golden):
     # f16) and the measurement-only knobs (csrc/gnnpp_measure.h) are not part of the ABI
     assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 1) == -1 and lib.gnnpp_get_tuning(0) == -1
     assert lib.gnnpp_set_tuning(3, 1) == -1 and lib.gnnpp_set_tuning(4, 1) == -1
-    assert lib.gnnpp_version() == 320
+    assert lib.gnnpp_version() == 330
 
 
 def test_emu_lsigf_transposed_and_tap_dump(emu, lsigf_golden):

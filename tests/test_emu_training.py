@@ -48,8 +48,8 @@ def reference(sd, obs, cot):
     return feat.detach(), p, run
 
 
-@pytest.mark.parametrize('N,B,seed,fbn', [(2, 3, 0, 0), (3, 5, 1, 1)])
-def test_emu_train_encoder_forward_backward(N, B, seed, fbn):
+@pytest.mark.parametrize('N,B,seed,fbn,ext_pack', [(2, 3, 0, 0, 0), (3, 5, 1, 1, 1)])
+def test_emu_train_encoder_forward_backward(N, B, seed, fbn, ext_pack):
     import emu_lib as el
     from oracle import policy_oracle as orc
     lib = el.load()
@@ -77,9 +77,17 @@ def test_emu_train_encoder_forward_backward(N, B, seed, fbn):
     feat = np.full((N, B, 128), np.nan, np.float32)
     obs_np = el.f32(obs.numpy())
     nbt = [np.full(1, 7, np.int64) for _ in range(5)]              # BatchNorm2d.num_batches_tracked: += N
+    # ext_pack: the caller-owned weight pack of gnnpp_train_pack (v330: one launch per weight version, shared with the
+    # graph filter's taps) instead of the pack the forward call builds in its workspace
+    tp = None
+    if ext_pack:
+        lib.gnnpp_train_pack_floats.restype = ctypes.c_size_t
+        tp = np.full(lib.gnnpp_train_pack_floats(), np.nan, np.float32)
+        assert tp.ctypes.data % 16 == 0
+        assert lib.gnnpp_train_pack(ctypes.byref(P), el.ptr(tp), None, None, None, 0, 0, 0, 0, None) == 0
     rc = lib.gnnpp_encoder_train_fwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(feat), B, N,
                                      ctypes.c_float(0.1), 1, (ctypes.c_void_p * 5)(*[a.ctypes.data for a in nbt]),
-                                     fbn, None)
+                                     fbn, el.ptr(tp) if tp is not None else None, None)
     assert rc == 0
     assert all(int(a[0]) == 7 + N for a in nbt)
     if fbn:                                                  # feat_sample_major: the same rows as [B,N,128]
@@ -99,7 +107,7 @@ def test_emu_train_encoder_forward_backward(N, B, seed, fbn):
             getattr(G, field)[i] = o.ctypes.data
     cot_np = el.f32(cot.permute(1, 0, 2).numpy() if fbn else cot.numpy())
     rc = lib.gnnpp_encoder_train_bwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(cot_np), ctypes.byref(G),
-                                     B, N, fbn, None)
+                                     B, N, fbn, el.ptr(tp) if tp is not None else None, None)
     assert rc == 0
     for key, o in outs.items():
         want = p_ref[key].grad.numpy()
@@ -180,7 +188,7 @@ def test_emu_adam_matches_torch():
     opt = torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-5)
     mine = [el.f32(p.detach().numpy().copy()) for p in ps]
     m = [np.zeros_like(a) for a in mine]; v = [np.zeros_like(a) for a in mine]
-    state = np.zeros(3, np.float32)
+    state = np.zeros(4, np.float32)                          # [steps, two bias-correction factors, arrival counter]
     cf = ctypes.c_float
     for it in range(4):
         grads = [torch.randn(*s, generator=g) for s in shapes]
@@ -195,7 +203,7 @@ def test_emu_adam_matches_torch():
         tb.count = len(ps)
         rc = lib.gnnpp_adam_step(ctypes.byref(tb), el.ptr(state), cf(1e-3), cf(0.9), cf(0.999), cf(1e-8), cf(1e-5),
                                  1, None)
-        assert rc == 0 and state[0] == it + 1
+        assert rc == 0 and state[0] == it + 1 and state[3] == 0      # (ticked by the launch's last workgroup, re-armed)
         for a, p in zip(mine, ps):
             np.testing.assert_allclose(a, p.detach().numpy(), rtol=0, atol=3e-7)
 
@@ -205,7 +213,7 @@ class GemmDesc(ctypes.Structure):
                 ('a_sk', ctypes.c_longlong), ('B', ctypes.c_void_p), ('b_sb', ctypes.c_longlong),
                 ('b_sk', ctypes.c_longlong), ('C', ctypes.c_void_p), ('c_sb', ctypes.c_longlong),
                 ('c_sm', ctypes.c_longlong), ('batch', ctypes.c_int), ('M', ctypes.c_int), ('N', ctypes.c_int),
-                ('K', ctypes.c_int)]
+                ('K', ctypes.c_int), ('mask', ctypes.c_void_p)]
 
 
 def test_emu_gemm_multi_linear_backward():
@@ -235,3 +243,67 @@ def test_emu_gemm_multi_linear_backward():
     np.testing.assert_allclose(dx, dY.astype(np.float64) @ Wt.astype(np.float64), rtol=0, atol=2e-5)
     np.testing.assert_allclose(dW, dY.astype(np.float64).T @ X.astype(np.float64), rtol=0, atol=2e-4)
     np.testing.assert_allclose(db, dY.astype(np.float64).sum(0), rtol=0, atol=2e-4)
+    # v330: a ReLU backward folded into a product -- C is stored as 0 where mask <= 0, whether the product is written
+    # directly (dx: contraction 5) or through the split reduction (dW with a mask of its own shape: contraction 90)
+    mask_x = rng.standard_normal((R, I)).astype(np.float32)
+    mask_w = rng.standard_normal((O, I)).astype(np.float32)
+    arr[0].mask, arr[1].mask = mask_x.ctypes.data, mask_w.ctypes.data
+    dx0, dW0 = dx.copy(), dW.copy()
+    dx[:] = np.nan; dW[:] = np.nan
+    assert lib.gnnpp_gemm_kmajor_multi(arr, 3, el.ptr(ws), None) == 0
+    np.testing.assert_array_equal(dx, np.where(mask_x > 0, dx0, 0))
+    np.testing.assert_array_equal(dW, np.where(mask_w > 0, dW0, 0))
+
+
+@pytest.mark.parametrize('R,I,O,relu', [(90, 128, 128, 1), (37, 128, 5, 0), (16, 64, 40, 1)])
+def test_emu_linear_fwd(R, I, O, relu):
+    """gnnpp_linear_fwd (v330): y = x W^T + b (+ ReLU) of compressMLP / actionsMLP in the training step against numpy
+    (decentralplanner.py:187-195, :232-243); ragged row and feature tiles."""
+    import emu_lib as el
+    lib = el.load()
+    rng = np.random.default_rng(R + O)
+    x = rng.standard_normal((R, I)).astype(np.float32)
+    W = (rng.standard_normal((O, I)) / np.sqrt(I)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    y = np.full((R, O), np.nan, np.float32)
+    assert lib.gnnpp_linear_fwd(el.ptr(x), el.ptr(W), el.ptr(b), el.ptr(y), R, I, O, relu, None) == 0
+    want = x.astype(np.float64) @ W.astype(np.float64).T + b
+    if relu:
+        want = np.maximum(want, 0)
+    np.testing.assert_allclose(y, want, rtol=0, atol=3e-6)
+    assert lib.gnnpp_linear_fwd(el.ptr(x), el.ptr(W), None, el.ptr(y), R, 100, O, relu, None) == -2     # I % 64 != 0
+
+
+def test_emu_train_pack_filter_taps_and_masked_input_gradient():
+    """gnnpp_train_pack (v330) writes the fp32 fragments of the forward AND the transposed taps straight from h: both
+    must equal the first region of gnnpp_filter_pack of h / of h.permute(3,1,2,0); gnnpp_lsigf_input_grad on the
+    transposed taps = gnnpp_lsigf_fwd_save(s_transposed) of the same, with the mask of the folded ReLU applied."""
+    import emu_lib as el
+    lib = el.load()
+    rng = np.random.default_rng(9)
+    F, E, K, G = 40, 2, 3, 24
+    h = rng.standard_normal((F, E, K, G)).astype(np.float32)
+    hT = np.ascontiguousarray(h.transpose(3, 1, 2, 0))
+    want_f, want_t = el.pack_filter(lib, h), el.pack_filter(lib, hT)
+    fwd = np.full_like(want_f, np.nan)
+    tr = np.full_like(want_t, np.nan)
+    assert lib.gnnpp_train_pack(None, None, el.ptr(h), el.ptr(fwd), el.ptr(tr), G, F, K, E, None) == 0
+    nf = E * K * ((F + 15) // 16) * ((G + 15) // 16) * 256           # floats of the fp32 fragment region
+    np.testing.assert_array_equal(fwd[:nf], want_f[:nf])
+    np.testing.assert_array_equal(tr[:nf], want_t[:nf])
+    assert np.isnan(fwd[nf:]).all() and np.isnan(tr[nf:]).all()       # nothing else is written
+    B, N = 3, 7
+    S = (rng.random((B, E, N, N)) < 0.4) * rng.standard_normal((B, E, N, N))
+    S = el.f32(S)
+    dy = el.f32(rng.standard_normal((B, N, F)))
+    mask = el.f32(rng.standard_normal((B, N, G)))
+    ref = np.full((B, N, G), np.nan, np.float32)
+    rc = lib.gnnpp_lsigf_fwd_save(el.ptr(dy), el.ptr(S), el.ptr(want_t), None, el.ptr(ref), None, B, N, N, F, G, K, E,
+                                  0, 1, 1, 1, 1, 0, 0, 0, None, None)
+    assert rc == 0
+    for m in (None, mask):
+        dx = np.full((B, N, G), np.nan, np.float32)
+        rc = lib.gnnpp_lsigf_input_grad(el.ptr(dy), el.ptr(S), el.ptr(tr), el.ptr(m) if m is not None else None,
+                                        el.ptr(dx), B, N, G, F, K, E, 0, 1, 1, None)
+        assert rc == 0
+        np.testing.assert_array_equal(dx, ref if m is None else np.where(m > 0, ref, 0))

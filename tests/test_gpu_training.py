@@ -413,6 +413,53 @@ def test_hip_training_encoder_matches_aten_path(dev, B, N):
         assert (v - sd2[k]).abs().max().item() <= 2e-5, k
 
 
+def test_c4_batch_gradients_match_the_oracle(dev):
+    """VERDICT r05 (weak 4): at the FULL size of BASELINE config 4's per-GPU batch (64 graphs x 10 agents, K = 3) every
+    gradient of the HIP training step against the pinned oracle -- oracle.policy_forward(training=True) (the
+    reference's per-agent-call loop, itself checked against tests/golden/training_grads.npz by
+    tests/test_oracle_training.py) + torch autograd on the CPU --, with the tolerances of the golden test: loss 1e-5,
+    logits 1e-4, gradients 5e-4 of the tensor's largest magnitude, running statistics 1e-4.  Through train_step()'s own
+    loss launch (gnnpp_policy_loss) as well as through policy_loss()."""
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import _policy_loss_and_grad, policy_loss
+    B, N, K = 64, 10, 3
+
+    class C:
+        num_agents, nGraphFilterTaps, device = N, K, dev
+    sd0 = orc.init_state_dict(K, seed=1337)
+    obs = orc.synth_obs(B, N, seed=1337)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=1337)).float()
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=torch.Generator().manual_seed(0)), 5).float()
+    sd = {k: v.clone() for k, v in sd0.items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and 'running' not in k}
+    sd.update(params)
+    want_out = orc.policy_forward(sd, S, obs, training=True)
+    want_loss = orc.policy_loss(want_out, tgt)
+    want_loss.backward()
+    for fused_loss in (False, True):
+        net = DecentralPlannerNet(C()).to(dev)
+        net.load_state_dict(sd0)
+        net.train()
+        net.addGSO(S.to(dev))
+        out = net(obs.to(dev))
+        if fused_loss:
+            loss, dlogits = _policy_loss_and_grad(out.stacked, tgt.to(dev))
+            out.stacked.backward(dlogits)
+        else:
+            loss = policy_loss(out, tgt.to(dev))
+            loss.backward()
+        assert abs(loss.item() - want_loss.item()) <= 1e-5
+        assert (torch.stack(list(out), 1).detach().cpu() - torch.stack(want_out, 1).detach()).abs().max().item() <= 1e-4
+        names = [n for n, _ in net.named_parameters()]
+        assert sorted(names) == sorted(params)
+        for name, p in net.named_parameters():
+            assert close(p.grad.cpu(), sd[name].grad, 5e-4), \
+                (fused_loss, name, (p.grad.cpu() - sd[name].grad).abs().max().item(), sd[name].grad.abs().max().item())
+        for name, b in net.named_buffers():
+            if 'running' in name:
+                assert close(b.cpu(), sd[name].detach(), 1e-4), name
+
+
 def test_fused_adam_and_loss_match_torch(dev):
     """The one-launch pieces of the optimisation step against stock torch on the same model and batches:
     policy_loss_fused == policy_loss (value and gradient of every parameter), and FusedAdam (gnnpp_adam_step)

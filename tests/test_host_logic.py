@@ -42,7 +42,7 @@ def test_cabi_exports_every_declared_symbol(built_lib):
     assert lib.gnnpp_encoder_packed_floats() > 555000 // 4
     # argument validation happens before any HIP call, so it is checkable without a GPU
     assert lib.gnnpp_encoder_fwd(None, None, None, 16, 0, None, None) == -1
-    assert lib.gnnpp_version() == 320                        # ABI 300: per-call `precision`; 320: n-way graph split
+    assert lib.gnnpp_version() == 330                        # ABI 300: per-call `precision`; 320: n-way graph split; 330: one-launch training packs, folded masks
     assert lib.gnnpp_set_tuning(0, 7) == -1 and lib.gnnpp_set_tuning(5, 0) == -1
     assert lib.gnnpp_decode_actions(None, None, 1, 1, None) == -1
     # gnnpp_lsigf_fits: 1 = the LDS-resident kernels take the graph, 0 = take the dense form (F > 8192 too)
