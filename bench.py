@@ -125,26 +125,32 @@ def fused_rule(L, B, N, K, prec):
     return bool(knob != 0 and prec != 1 and N <= 16 and 2 <= K <= 4 and (B <= 512 or N >= 13 or knob == 2))
 
 
-def filter_head_roofline(N, K, B, mean_deg, prec, t):
+FILTER_HEAD_MODES = {0: 'split-f16 planes', 1: 'exact fp32 MFMA', 2: 'bf16x3 planes (own LDS buffer)',
+                     3: 'bf16x3 planes aliased onto the dead z buffer', -1: 'general filter kernels'}
+
+
+def filter_head_roofline(L, N, K, B, mean_deg, prec, t):
     """Roofline figures of the policy step's SECOND launch (features -> logits: K-tap filter + bias + ReLU + action
-    head; csrc/policy_filter_kernel.hip for teams of 17 .. 100 agents).  Which matrix instruction contracts the taps
-    depends on the team size (policy_filter_dispatch): bf16x3 planes (six v_mfma_f32_16x16x32_bf16 per 32 channels)
-    while the planes of a workgroup's own rows fit the LDS beside the graph -- up to about 64 agents, more when the
-    graph is split over several workgroups --, the exact v_mfma_f32_16x16x4_f32 otherwise and for 'fp32_mfma'.  `frac`
-    = algorithmic FLOP/s over the dense peak of THAT instruction; `pipe_busy_frac` = executed MFMA FLOP/s (six plane
+    head; csrc/policy_filter_kernel.hip for teams of 17 .. 100 agents).  Which matrix instruction contracts the taps is
+    ASKED of the library (gnnpp_filter_head_mode: it depends on the team size AND, through the workgroups-per-graph
+    heuristic, on the batch -- ADVICE r05): bf16x3 planes (six v_mfma_f32_16x16x32_bf16 per 32 channels) in a buffer of
+    their own (mode 2) or aliased onto the dead z buffer (mode 3, r06: split teams of 65 .. 100 agents), the exact
+    v_mfma_f32_16x16x4_f32 (mode 1: 'fp32_mfma', and one-workgroup teams of 65 .. 100 agents), split-f16 (mode 0).
+    `frac` = algorithmic FLOP/s over the dense peak of THAT instruction; `pipe_busy_frac` = executed MFMA FLOP/s (plane
     products, rows padded to 16-row tiles) over the same peak."""
     alg = 2.0 * (K * 128 * 128 + (K - 1) * mean_deg * 128 + 640) * B * N
     tiles = (N + 15) // 16
-    bf16 = prec == 0 and N <= 64          # (the split heuristic can extend this; the instruction is stated, not guessed)
-    if prec == 2:
+    mode = L.gnnpp_filter_head_mode(B, N, K, prec)
+    if mode == 0 or (mode < 0 and prec == 2):
         instr, peak, products = 'v_mfma_f32_16x16x32_f16', 2500.0, 3
-    elif bf16:
+    elif mode in (2, 3) or (mode < 0 and prec == 0 and N <= 16):
         instr, peak, products = 'v_mfma_f32_16x16x32_bf16', 2500.0, 6
     else:
         instr, peak, products = 'v_mfma_f32_16x16x4_f32', 157.3, 1
     exe = 2.0 * products * K * 128 * 128 * 16 * tiles * B + 2.0 * 640 * 16 * tiles * B * (16 / 5.0)
     return {'us': t * 1e6, 'instruction': instr, 'peak_TFLOPs': peak, 'algorithmic_TFLOPs': alg / t / 1e12,
             'frac': alg / t / 1e12 / peak, 'pipe_busy_frac': exe / t / 1e12 / peak,
+            'mode': mode, 'schedule': FILTER_HEAD_MODES.get(mode, '?'),
             'note': 'latency-scheduled kernel: one or a few workgroups per graph, every global load issued up front'}
 
 
@@ -232,7 +238,7 @@ def quick_config(orc, L, _native, name, k_over, dev, timed_regions, time_kernel,
     info = PRECISION_INFO[prec]
     rl = roofline_block('gnnpp::encoder_kernel_b3<false, 3>', info, 2.0 * ENC_MACS_PER_AGENT * M, t_enc,
                         8028 * 16384.0 * tiles)       # ({0, 1} observations: L0 issues 3 of 6 plane products)
-    fh = filter_head_roofline(N, K, B, mean_deg, prec, t_fh)
+    fh = filter_head_roofline(L, N, K, B, mean_deg, prec, t_fh)
     with torch.no_grad():
         want = orc.policy_forward(sd, S_cpu, obs_cpu)
     got = [o.cpu() for o in out]

@@ -34,7 +34,7 @@ EXPORTS = ('gnnpp_version', 'gnnpp_error_string', 'gnnpp_set_tuning', 'gnnpp_get
            'gnnpp_encoder_pack', 'gnnpp_encoder_fwd', 'gnnpp_encoder_train_workspace_floats', 'gnnpp_encoder_train_fwd',
            'gnnpp_encoder_train_bwd', 'gnnpp_gemm_workspace_floats', 'gnnpp_gemm_kmajor', 'gnnpp_gemm_multi_workspace_floats',
            'gnnpp_gemm_kmajor_multi', 'gnnpp_policy_loss',
-           'gnnpp_train_pack_floats', 'gnnpp_train_pack', 'gnnpp_lsigf_input_grad', 'gnnpp_linear_fwd',
+           'gnnpp_filter_head_mode', 'gnnpp_train_pack_floats', 'gnnpp_train_pack', 'gnnpp_lsigf_input_grad', 'gnnpp_linear_fwd',
            'gnnpp_adam_step', 'gnnpp_policy_fwd', 'gnnpp_filter_head_fwd', 'gnnpp_decode_actions', 'gnnpp_rollout_observe', 'gnnpp_rollout_gso',
            'gnnpp_rollout_move', 'gnnpp_rollout_gso_observe', 'gnnpp_rollout_step', 'gnnpp_rollout_policy_step',
            'gnnpp_rollout_policy_steps')
@@ -261,6 +261,8 @@ def _bind(path):
     L.gnnpp_filter_head_fwd.argtypes = [vp] * 7 + [ci] * 8 + [vp, vp]
     L.gnnpp_filter_head_fwd.restype = ci
     L.gnnpp_decode_actions.argtypes = [vp, vp, ci, ci, vp]
+    L.gnnpp_filter_head_mode.argtypes = [ci, ci, ci, ci]
+    L.gnnpp_filter_head_mode.restype = ci
     for f in ('gnnpp_rollout_observe', 'gnnpp_rollout_gso', 'gnnpp_rollout_move', 'gnnpp_rollout_gso_observe',
               'gnnpp_rollout_step'):
         getattr(L, f).argtypes = [ctypes.POINTER(RolloutStruct), vp]

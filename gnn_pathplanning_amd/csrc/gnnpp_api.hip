@@ -212,6 +212,22 @@ int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, co
     return lsigf_launch(a, static_cast<hipStream_t>(stream));
 }
 
+int gnnpp_filter_head_mode(int B, int N, int K, int precision) {
+    if (B <= 0 || N <= 0 || K <= 0 || precision < 0 || precision > 2) return -1;
+    if (N > GNNPP_MAX_ROWS) return -1;
+    alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};   // (never dereferenced: the plan only tests pointers)
+    LsigfArgs a = {};
+    a.x = dummy; a.S = dummy; a.wpk = dummy; a.act_w = dummy; a.act_b = dummy;
+    a.logits = const_cast<float*>(dummy);
+    a.B = B; a.N = N; a.Nin = N; a.G = 128; a.F = 128; a.K = K; a.E = 1;
+    a.s_batched = 1; a.x_node_major = 1; a.y_node_major = 1; a.relu = 1; a.prec = precision;
+    a.F_all = 128;
+    LsigfPlan plan;
+    if (lsigf_plan(a, plan) != 0) return -1;
+    PfLaunch L;
+    return policy_filter_plan(a, L) ? L.mode : -1;
+}
+
 size_t gnnpp_encoder_train_workspace_floats(int N, int B) {
     if (N <= 0 || B <= 0) return 0;
     return train_ws_layout(N, B).total;
@@ -381,6 +397,8 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_POLICY_CP: return g_policy_column_packing.load();
         case GNNPP_TUNE_ENCODER_CP_TILE: return g_encoder_cp_tile.load();
         case GNNPP_TUNE_TRAIN_FORK: return g_train_fork.load();
+        case GNNPP_TUNE_FILTER_PLANE_ALIAS: return g_filter_plane_alias.load();
+        case GNNPP_TUNE_TRAIN_WGRAD_WGS: return g_train_wgrad_wgs.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -430,6 +448,14 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_TRAIN_FORK:
             if (value < 0 || value > 2) return GNNPP_ERR_ARG;
             g_train_fork.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_FILTER_PLANE_ALIAS:
+            if (value < 0 || value > 1) return GNNPP_ERR_ARG;
+            g_filter_plane_alias.store(value);
+            return GNNPP_OK;
+        case GNNPP_TUNE_TRAIN_WGRAD_WGS:
+            if (value < 16 || value > 2048) return GNNPP_ERR_ARG;
+            g_train_wgrad_wgs.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:
             if (value < 0 || value > 3) return GNNPP_ERR_ARG;

@@ -118,7 +118,7 @@ __device__ __forceinline__ void pf_gather(const float* __restrict__ Sl, const un
             *reinterpret_cast<v4f*>(row + 4 * ql) = acc0;
             *reinterpret_cast<v4f*>(row + 64 + 4 * ql) = acc1;
         }
-        if (MODE == 2) {
+        if (MODE == 2 && planes) {
             v2f p0[3], p1[3];
             b3_split4(acc0, p0);
             b3_split4(acc1, p1);
@@ -191,7 +191,23 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
     unsigned char* const cnt = idx + (K > 1 ? N * Ns : 0);
     float* cb = reinterpret_cast<float*>(gnnpp_smem + p.pf_const_off);
     float* const part_sums = reinterpret_cast<float*>(gnnpp_smem + p.pf_part_off);      // [8][N][8]
-    char* const PB = gnnpp_smem + p.pf_plane_off;      // MODE 2: bf16x3 planes of this workgroup's own rows
+    // MODE 2: bf16x3 planes of this workgroup's own rows, one tap at a time.  Two layouts (policy_filter_dispatch):
+    //   separate (pf_plane_off >= 0): a buffer of its own behind the partial logits -- teams up to ~64 agents;
+    //   aliased  (pf_plane_off < 0, r06): the planes of tap k live in whichever z buffer is DEAD while tap k is
+    //   contracted -- teams of 65 .. 100 agents, whose two fp32 z buffers + S slab + lists fill the LDS (r05 ran
+    //   those on the exact fp32 MFMA: 2.7x the matrix-pipe time, 9 of the 24 us of a 128 x 100 launch):
+    //     tap 0        -> z buffer 1 (written by the staging loop; shift 1 overwrites it after the barrier)
+    //     tap k < K-1  -> z buffer (k-1) & 1 = the SOURCE of shift k, dead behind the shift's barrier: a conversion
+    //                     pass over the workgroup's own rows of z_k (0.3 us) fills it
+    //     tap K-1      -> z buffer (K-1) & 1 = where the last shift would have put fp32 rows: it writes planes instead
+    //   needs own rows x 800 B <= N x 544 B: any split of the graph over >= 2 workgroups.
+    const bool pb_alias = p.pf_plane_off < 0;
+    auto plane_buf = [&](int k) -> char* {
+        if (!pb_alias) return gnnpp_smem + p.pf_plane_off;
+        const int b = (k == 0) ? 1 : (k + 1 == K) ? (k & 1) : ((k - 1) & 1);
+        return reinterpret_cast<char*>(b ? zbuf1 : zbuf0);
+    };
+    char* PB = plane_buf(0);
 
     GNNPP_STAMP(blockIdx.x, 0, tid == 0);
     // ---- every global load of the kernel, issued now -------------------------------------------------------
@@ -417,10 +433,23 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
                                                        // whose tap finished before the previous shift's barrier)
             GNNPP_STAMP(blockIdx.x, 4, tid == 0 && k == 1);
             GNNPP_STAMP(blockIdx.x, 7, tid == 0 && k == 2);
+            if (B3) PB = plane_buf(k);
             pf_gather<MODE>(Sl, idx, cnt, zsrc, (B3 && last) ? nullptr : zdst, nullptr, Ns, last ? row_lo : 0,
-                            last ? row_hi : N, wave, lane, bad, PB, row_lo, row_hi);
+                            last ? row_hi : N, wave, lane, bad, (B3 && pb_alias && !last) ? nullptr : PB, row_lo, row_hi);
             GNNPP_STAMP(blockIdx.x, 8, tid == 0 && k == 2);
             __syncthreads();                           // z_k visible
+            if (B3 && pb_alias && !last) {
+                // aliased planes: z_{k-1} (zsrc, = PB) is dead now -- the own rows of z_k (fp32, zdst) as planes into it
+                for (int i = tid; i < (row_hi - row_lo) * 32; i += NT) {
+                    const int r = i >> 5, c4 = i & 31;
+                    v2f pl[3];
+                    b3_split4(*reinterpret_cast<const v4f*>(zdst + (row_lo + r) * kPfZs + 4 * c4), pl);
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+                        *reinterpret_cast<v2f*>(PB + r * kPfPRow + pp * 256 + 8 * c4) = pl[pp];
+                }
+                __syncthreads();
+            }
             GNNPP_STAMP(blockIdx.x, 5, tid == 0 && k == 1);
             GNNPP_STAMP(blockIdx.x, 9, tid == 0 && k == 2);
             contract(zdst, Acur);
@@ -504,6 +533,7 @@ __global__ __launch_bounds__(1024) void policy_filter_kernel(const LsigfArgs p) 
 }
 
 std::atomic<int> g_filter_policy_kernel{1};            // GNNPP_TUNE_FILTER_POLICY_KERNEL: 0 = lsigf_kernel everywhere
+std::atomic<int> g_filter_plane_alias{1};              // GNNPP_TUNE_FILTER_PLANE_ALIAS: 0 = never alias planes onto z buffers
 
 // Does the planned filter launch have the policy step's shape?  (a is complete: lsigf_plan ran.)
 static bool policy_filter_applies(const LsigfArgs& a) {
@@ -537,37 +567,52 @@ static hipError_t policy_filter_launch_rtw(int rtw, const LsigfArgs& a, int grid
     }
 }
 
-// Launches the policy filter for a planned call; returns 1 when the shape is not the policy's (the caller runs
-// lsigf_kernel), 0 on success, -3 on a launch error.
-static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st) {
-    if (!policy_filter_applies(a)) return 1;
+// What the policy filter would run for a planned call: mode 0 split-f16 | 1 exact fp32 MFMA | 2 bf16x3 planes in a buffer
+// of their own | 3 bf16x3 planes aliased onto the dead z buffer (kernel MODE 2, pf_plane_off < 0); fills the LDS offsets
+// of `a`.  Returns false when the shape is not the policy's (the caller runs lsigf_kernel).
+struct PfLaunch { int mode, rtw; size_t smem; };
+static bool policy_filter_plan(LsigfArgs& a, PfLaunch& L) {
+    if (!policy_filter_applies(a)) return false;
     const int tiles = (a.rt_total + a.nsplit - 1) / a.nsplit;           // row tiles of the largest part
-    if ((tiles + 1) / 2 > 4) return 1;
+    if ((tiles + 1) / 2 > 4) return false;
     const size_t base = pf_lds_base(a.N, a.Ns, a.K) + kPfConsts * 4;
     const size_t parts = (size_t)8 * a.N * 8 * 4;
-    // GNNPP_PREC_FP32: bf16x3 planes of the workgroup's own rows when the LDS has room for them, else the exact
-    // fp32 MFMA (same accuracy class, 2.7x the matrix-pipe time)
+    // GNNPP_PREC_FP32: bf16x3 planes of the workgroup's own rows -- in a buffer of their own while the LDS has room
+    // (teams up to ~64 agents), else ALIASED onto whichever z buffer is dead while a tap is contracted (r06: possible
+    // as soon as the graph is split over >= 2 workgroups: own rows x 800 B <= N x 544 B), else the exact fp32 MFMA
+    // (same accuracy class, 2.7x the matrix-pipe time; a whole team of 65 .. 100 agents in ONE workgroup).
+    // (r04 built planes beside COMPACT neighbour lists for those teams -- "MODE 3" -- and measured it no faster than
+    // the exact fp32 MFMA: what its contraction saved its plane production spent; removed in r05.)
     int mode = a.prec == kPrecSplitF16 ? 0 : a.prec == kPrecFp32Mfma ? 1 : 2;
     const size_t planes = (size_t)tiles * 16 * kPfPRow;
     a.pf_const_off = (int)pf_lds_base(a.N, a.Ns, a.K);
-    // (teams of 65 .. 100 agents: 2 x 54 KB of fp32 rows + 40 KB slab + 10 KB lists + 41 KB planes > 160 KB.  r04 built
-    // bf16x3 planes beside COMPACT neighbour lists for them -- "MODE 3" -- and measured it no faster than the exact
-    // fp32 MFMA: 26.4 against 25.8 us at 128 graphs of 100 agents, what its contraction saved its plane production
-    // spent, profiles/r04_filter_stamps.jsonl; removed in r05.)
-    if (mode == 2 && base + parts + planes > (size_t)kLdsBytes) mode = 1;
-    size_t smem = base + parts + (mode == 2 ? planes : 0);
     a.pf_part_off = (int)base;
     a.pf_plane_off = (int)(base + parts);
+    if (mode == 2 && base + parts + planes > (size_t)kLdsBytes) {
+        const bool alias_ok = g_filter_plane_alias.load(std::memory_order_relaxed) &&
+                              planes <= (size_t)a.N * kPfZs * 4;
+        mode = alias_ok ? 3 : 1;
+        if (alias_ok) a.pf_plane_off = -1;
+    }
+    size_t smem = base + parts + (mode == 2 ? planes : 0);
     if (smem > (size_t)kLdsBytes) {
         // large graphs: the partial logits reuse the S slab (dead after the last shift)
-        if (a.K < 2 || (size_t)a.N * a.Ns * 4 < parts || base > (size_t)kLdsBytes) return 1;
+        if (a.K < 2 || (size_t)a.N * a.Ns * 4 < parts || base > (size_t)kLdsBytes) return false;
         smem = base;
         a.pf_part_off = 2 * a.N * kPfZs * 4;
     }
-    const int rtw = (tiles + 1) / 2;
-    const hipError_t err = mode == 0 ? policy_filter_launch_rtw<0>(rtw, a, plan.grid, smem, st)
-                         : mode == 1 ? policy_filter_launch_rtw<1>(rtw, a, plan.grid, smem, st)
-                                     : policy_filter_launch_rtw<2>(rtw, a, plan.grid, smem, st);
+    L.mode = mode; L.rtw = (tiles + 1) / 2; L.smem = smem;
+    return true;
+}
+
+// Launches the policy filter for a planned call; returns 1 when the shape is not the policy's (the caller runs
+// lsigf_kernel), 0 on success, -3 on a launch error.
+static int policy_filter_dispatch(LsigfArgs a, const LsigfPlan& plan, hipStream_t st) {
+    PfLaunch L;
+    if (!policy_filter_plan(a, L)) return 1;
+    const hipError_t err = L.mode == 0 ? policy_filter_launch_rtw<0>(L.rtw, a, plan.grid, L.smem, st)
+                         : L.mode == 1 ? policy_filter_launch_rtw<1>(L.rtw, a, plan.grid, L.smem, st)
+                                       : policy_filter_launch_rtw<2>(L.rtw, a, plan.grid, L.smem, st);
     return err == hipSuccess ? 0 : -3;
 }
 

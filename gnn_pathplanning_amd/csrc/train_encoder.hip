@@ -820,6 +820,11 @@ struct TrainWs {
     int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
 };
 
+// GNNPP_TUNE_TRAIN_WGRAD_WGS: workgroups per layer of conv_wgrad_kernel (image splits x output-channel tiles).  More
+// splits = shorter workgroups but more partial slabs for conv_wgrad_reduce_kernel to sum.  Set it BEFORE a forward call:
+// the workspace size depends on it.
+std::atomic<int> g_train_wgrad_wgs{320};
+
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
     size_t o = 0, max_y = 0, max_part = 0, max_x = 0, max_wp = 0;
@@ -848,7 +853,8 @@ inline TrainWs train_ws_layout(int N, int B) {
         // weight-gradient splits: ~320 workgroups per layer (one per 16 output channels and image range)
         w.jt[l] = (d.Cin * 9 + 1 + 15) / 16;
         w.kw[l] = w.jt[l] <= 2 ? 2 : 1;
-        int ns = (320 + d.Cout / 16 - 1) / (d.Cout / 16);
+        const int wgs = g_train_wgrad_wgs.load(std::memory_order_relaxed);
+        int ns = (wgs + d.Cout / 16 - 1) / (d.Cout / 16);
         if ((size_t)ns > NB) ns = (int)NB;
         w.ips[l] = (int)((NB + ns - 1) / ns);
         w.nsplit[l] = (int)((NB + w.ips[l] - 1) / w.ips[l]);

@@ -230,8 +230,9 @@ __global__ __launch_bounds__(1024) void policy_loss_kernel(const float* __restri
 // ---- Adam -----------------------------------------------------------------------------------------------------------
 // torch.optim.Adam (amsgrad = False, maximize = False):  g' = g + wd * p;  m = m + (1 - b1)(g' - m);
 // v = b2 v + (1 - b2) g'^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),  t = step count.
-// state[0] = steps taken so far, state[1] = lr / (1 - b1^t), state[2] = 1 / sqrt(1 - b2^t) of the LAST tick, state[3] =
-// arrival counter (an unsigned; zero between launches).  A launch with tick != 0 is the first table of a step: every
+// state (8 floats): [0] = steps taken so far, [1] = lr / (1 - b1^t), [2] = 1 / sqrt(1 - b2^t) of the LAST tick, [3] =
+// arrival counter (an unsigned; zero between launches), [4], [5] = the betas and [6], [7] = the two bias-correction
+// factors of the NEXT step, precomputed by the last workgroup of the tick.  A launch with tick != 0 is the first table of a step: every
 // workgroup reads t = state[0] + 1 and derives the two bias-correction factors itself; the workgroup that arrives
 // LAST (a ticket from the arrival counter, taken after the workgroup's own read of state[0]) stores t and the factors
 // and re-arms the counter -- r05 spent a launch of one thread on that.  Further tables of the same step (tick == 0)
@@ -251,12 +252,23 @@ struct AdamTable {
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float* __restrict__ state, float lr, float b1,
                                                    float b2, float eps, float wd, int tick) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
-    float* sh = reinterpret_cast<float*>(gnnpp_smem);                     // [3]
+    float* sh = reinterpret_cast<float*>(gnnpp_smem);                     // [4]
     if (threadIdx.x == 0) {
         if (tick) {
             const float t = state[0] + 1.f;
-            sh[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
-            sh[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+            // 1 / (1 - b1^t) and 1 / sqrt(1 - b2^t): left behind for THIS step by the previous step's last workgroup
+            // (state[6], [7], valid for the betas in state[4], [5]); two double-precision pow() per workgroup on the
+            // critical path of every workgroup cost 3 us of an 8.7 us launch
+            float c1, c2;
+            if (state[4] == b1 && state[5] == b2 && state[6] != 0.f) {
+                c1 = state[6];
+                c2 = state[7];
+            } else {
+                c1 = (float)(1.0 / (1.0 - pow((double)b1, (double)t)));
+                c2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+            }
+            sh[0] = lr * c1;
+            sh[1] = c2;
             sh[2] = t;
         } else {
             sh[0] = state[1];
@@ -289,10 +301,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tb, float* __
     if (tick && threadIdx.x == 0) {
         unsigned* cnt = reinterpret_cast<unsigned*>(state + 3);
         const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {                         // every workgroup has read state[0]: advance it
-            state[0] = sh[2];
+        if (old == gridDim.x - 1) {                         // every workgroup has read the state: advance it
+            const float t = sh[2];
+            state[0] = t;
             state[1] = sh[0];
             state[2] = sh[1];
+            state[4] = b1;
+            state[5] = b2;
+            state[6] = (float)(1.0 / (1.0 - pow((double)b1, (double)t + 1.0)));
+            state[7] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t + 1.0)));
             __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

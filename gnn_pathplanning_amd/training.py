@@ -113,11 +113,11 @@ class FusedAdam(torch.optim.Optimizer):
             # and restored by state_dict() / load_state_dict() next to the moments.
             st = self.state.setdefault('gnnpp_group_%d' % gi, {})
             if 'counter' not in st:
-                st['counter'] = torch.zeros(4, dtype=torch.float32, device=dev)
+                st['counter'] = torch.zeros(8, dtype=torch.float32, device=dev)
             elif st['counter'].device != dev or st['counter'].dtype is not torch.float32:
                 st['counter'] = st['counter'].to(device=dev, dtype=torch.float32)      # (loaded with map_location)
-            if st['counter'].numel() < 4:                   # a checkpoint written before ABI v330 (three floats)
-                st['counter'] = torch.cat([st['counter'].reshape(-1)[:3], st['counter'].new_zeros(1)])
+            if st['counter'].numel() < 8:                   # a checkpoint written before ABI v330 (three floats)
+                st['counter'] = torch.cat([st['counter'].reshape(-1)[:3], st['counter'].new_zeros(5)])
             for p in ps:
                 s = self.state[p]
                 if 'exp_avg' not in s:

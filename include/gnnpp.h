@@ -114,6 +114,15 @@ const char* gnnpp_error_string(int code);
                                          1 (default) = from 4096 agent-samples (N x B) on -- measured + 7 % eager at
                                          512 x 10, - 16 % at 64 x 10 --, 0 = never, 2 = always.  Same gradients to the
                                          bit (v320)                                                                  */
+#define GNNPP_TUNE_FILTER_PLANE_ALIAS 16 /* 1 (default): the filter + head launch of teams whose bf16x3 operand planes do
+                                         not fit the LDS beside the graph (65 .. 100 agents) keeps the planes in the z buffer
+                                         that is dead while a tap is contracted -- possible whenever the graph is split
+                                         over >= 2 workgroups -- instead of contracting on the exact fp32 MFMA (2.7x the
+                                         matrix-pipe time); 0 = r05's behaviour.  Same accuracy class (v330)              */
+#define GNNPP_TUNE_TRAIN_WGRAD_WGS   17  /* workgroups per layer of the training step's weight-gradient kernel (image splits x
+                                         output-channel tiles), 16 .. 2048, default 320: more splits = shorter workgroups,
+                                         more partial sums to add.  Set before gnnpp_encoder_train_workspace_floats /
+                                         _train_fwd: the workspace size depends on it.  Same gradients to rounding (v330) */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 
@@ -325,8 +334,9 @@ int gnnpp_policy_loss(const float* logits, const float* target, float* loss, flo
 
 /* torch.optim.Adam's update (amsgrad = False; L2 weight decay added to the gradient; bias correction) of up
  * to 32 tensors in one launch:  p, m (exp_avg), v (exp_avg_sq) are updated in place from g.
- *   state  4 floats on the device, zero before the first step: state[0] = number of steps taken so far, [1], [2] the
- *          bias-correction factors of the last tick, [3] scratch (a workgroup arrival counter, zero between calls);
+ *   state  8 floats on the device, zero before the first step: state[0] = number of steps taken so far, [1], [2] the
+ *          bias-correction factors of the last tick, [3] scratch (a workgroup arrival counter, zero between calls),
+ *          [4] .. [7] the betas and the factors of the NEXT step (precomputed by the tick's last workgroup);
  *   tick   != 0: this call is the first table of a step: it uses t = state[0] + 1 and its last workgroup stores t
  *          (v330: inside the same launch; pass 0 for further tables of the same step).  The counter lives on the
  *          device so that the call can be captured in a HIP graph. */
@@ -368,6 +378,14 @@ int gnnpp_policy_fwd(const float* obs, const void* S, const float* enc_packed,
 int gnnpp_filter_head_fwd(const float* x, const void* S, const float* packed, const float* bias,
                           const float* act_w, const float* act_b, float* logits, int B, int N, int G,
                           int F, int K, int E, int s_is_f64, int precision, int* range_flag, void* stream);
+
+/* Which schedule gnnpp_filter_head_fwd / the second launch of gnnpp_policy_fwd would run for this shape under the
+ * current tuning: 0 split-f16 planes (v_mfma_f32_16x16x32_f16), 1 exact fp32 MFMA (v_mfma_f32_16x16x4_f32), 2 bf16x3 planes
+ * (v_mfma_f32_16x16x32_bf16) in an LDS buffer of their own, 3 bf16x3 planes aliased onto the dead z buffer;
+ * -1: the shape runs on the general filter kernels (lsigf_kernel / the small-graph kernels), GNNPP_ERR_ARG < -1 never.
+ * The answer depends on B through the workgroups-per-graph heuristic (GNNPP_TUNE_FILTER_SPLIT): a measurement states
+ * the instruction it priced from this call instead of guessing it.  (v330) */
+int gnnpp_filter_head_mode(int B, int N, int K, int precision);
 
 /* Action decode used by the rollout loop (utils/multirobotsim_dcenlocal.py:589-591: LogSoftmax
  * then argmax == argmax of the logits, first maximum wins like torch.max).

@@ -625,7 +625,7 @@ def test_emu_column_packed_encoder_tiles_are_bit_identical(emu, M, tile):
     assert lib.gnnpp_set_tuning(14, 13) == -1
 
 
-@pytest.mark.parametrize('N,K,f64,B', [(100, 3, 0, 2), (100, 2, 1, 1), (72, 3, 0, 2), (50, 4, 1, 1), (33, 3, 0, 9)])
+@pytest.mark.parametrize('N,K,f64,B', [(100, 3, 0, 2), (100, 2, 1, 1), (100, 4, 0, 1), (72, 3, 0, 2), (50, 4, 1, 1), (33, 3, 0, 9)])
 def test_emu_policy_filter_kernel_n_way_split(emu, N, K, f64, B):
     """VERDICT r04 item 2: up to ceil(N / 16) workgroups per graph in policy_filter_kernel (GNNPP_TUNE_FILTER_SPLIT = n;
     lsigf_plan picks n itself when few graphs would leave CUs idle).  Every part stages the graph and runs the early
@@ -650,7 +650,7 @@ def test_emu_policy_filter_kernel_n_way_split(emu, N, K, f64, B):
     packed = el.pack_filter(lib, h)
     rt = (N + 15) // 16
     splits = sorted({1, 2, 3, rt, 7})                        # (values above the row tiles are clamped to them)
-    outs = {}
+    outs, modes = {}, {}
     lib.gnnpp_set_tuning(2, 0)
     try:
         assert lib.gnnpp_set_tuning(1, 1) == 0
@@ -662,9 +662,24 @@ def test_emu_policy_filter_kernel_n_way_split(emu, N, K, f64, B):
                                                  el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, prec, None,
                                                  None) == 0
                 outs[prec, split] = logits
+                modes[prec, split] = lib.gnnpp_filter_head_mode(B, N, K, prec)
         assert lib.gnnpp_set_tuning(7, 8) == -1
+        # r06: the default arithmetic of a SPLIT team of 65 .. 100 agents keeps its bf16x3 planes in the dead z buffer
+        # (mode 3) instead of falling back to the exact fp32 MFMA (mode 1: what one workgroup per graph still runs);
+        # GNNPP_TUNE_FILTER_PLANE_ALIAS = 0 restores the fallback, whose logits are those of precision 1 bit for bit
+        if N == 100:
+            assert modes[0, 1] == 1 and modes[0, 2] == 3 and modes[0, 3] == 3 and modes[0, 7] == 3, modes
+            assert lib.gnnpp_set_tuning(16, 0) == 0 and lib.gnnpp_set_tuning(7, 2) == 0
+            assert lib.gnnpp_filter_head_mode(B, N, K, 0) == 1
+            logits = np.full((N, B, 5), np.nan, dtype=np.float32)
+            assert lib.gnnpp_filter_head_fwd(el.ptr(x), el.ptr(S), el.ptr(packed), el.ptr(bias), el.ptr(aw),
+                                             el.ptr(ab), el.ptr(logits), B, N, 128, 128, K, 1, f64, 0, None, None) == 0
+            assert np.array_equal(logits, outs[1, 2])
+        if N == 72:
+            assert modes[0, 1] == 1 and modes[0, 2] == 3 and modes[0, 3] == 2, modes
+        assert all(modes[1, sp] == 1 for sp in splits)
     finally:
-        lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0)
+        lib.gnnpp_set_tuning(7, 0); lib.gnnpp_set_tuning(1, 0); lib.gnnpp_set_tuning(16, 1)
     z = x.astype(np.float64)
     y = np.zeros((B, N, 128))
     for k in range(K):

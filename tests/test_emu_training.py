@@ -188,7 +188,7 @@ def test_emu_adam_matches_torch():
     opt = torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-5)
     mine = [el.f32(p.detach().numpy().copy()) for p in ps]
     m = [np.zeros_like(a) for a in mine]; v = [np.zeros_like(a) for a in mine]
-    state = np.zeros(4, np.float32)                          # [steps, two bias-correction factors, arrival counter]
+    state = np.zeros(8, np.float32)                          # [steps, 2 factors, arrival counter, betas, 2 factors of the next step]
     cf = ctypes.c_float
     for it in range(4):
         grads = [torch.randn(*s, generator=g) for s in shapes]

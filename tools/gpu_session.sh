@@ -31,6 +31,10 @@ if has trainab; then stamp "train bench: weight-gradient fork on / off (graphed 
   for b in 64 512; do for g in "--graph" ""; do for f in "--fork" "--no-fork"; do
     timeout 300 python tools/train_bench.py --steps 100 $g --batch $b $f 2>&1 | tail -1 | tee -a $OUT/train_fork_ab.jsonl
   done; done; done; fi
+if has wgradsweep; then stamp "train bench: workgroups per layer of the weight-gradient kernel (graphed, B = 64)"
+  for w in 96 128 192 256 320 448; do
+    timeout 300 python tools/train_bench.py --steps 100 --graph --wgrad-wgs $w 2>&1 | tail -1 | tee -a $OUT/train_wgrad_sweep.jsonl
+  done; fi
 if has hostov; then stamp "host-side cost of one policy step"
   timeout 300 python tools/host_overhead.py 2>&1 | grep -v amdgpu.ids | head -70 | tee $OUT/host_overhead.txt; fi
 if has shardgap; then stamp "eager 16 x 100 policy step: host cost of the pieces, device-side gaps"
@@ -40,6 +44,8 @@ if has shardgap; then stamp "eager 16 x 100 policy step: host cost of the pieces
   find $OUT/shardgap -name "*.csv" -size +1M -delete; fi
 if has traincpu; then stamp "train bench with the CPU oracle's training step beside it"
   timeout 300 python tools/train_bench.py --steps 50 --graph --cpu-seconds 8 2>&1 | tail -1 | tee $OUT/train_bench_cpu.json; fi
+if has trainops; then stamp "which op launches the stray fill / copy kernels of the training step"
+  timeout 300 python tools/train_host_profile.py ops 2>&1 | grep -v amdgpu.ids | head -90 | tee $OUT/train_ops.txt; fi
 if has trainprof; then stamp "host profile of the eager training step"
   timeout 300 python tools/train_host_profile.py 2>&1 | grep -v amdgpu.ids | head -60 | tee $OUT/train_host_profile.txt; fi
 if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path check only)"

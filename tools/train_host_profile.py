@@ -30,6 +30,26 @@ def main():
     for _ in range(30):
         train_step(net, opt, obs, tgt, S)
     torch.cuda.synchronize()
+    if len(sys.argv) > 1 and sys.argv[1] == 'ops':
+        # which aten / autograd op launches which device kernel (the stray fill / copy launches of the step)
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            for _ in range(5):
+                train_step(net, opt, obs, tgt, S)
+            torch.cuda.synchronize()
+        rows = [e for e in prof.events() if e.device_type is not None]
+        seen = {}
+        for e in prof.events():
+            nm = e.name
+            if any(k in nm for k in ('fill', 'copy', 'Memcpy', 'zero', 'clamp', 'threshold', 'contiguous', 'clone', 'empty_like')):
+                key = (nm, tuple((e.stack or [])[:6]))
+                seen[key] = seen.get(key, 0) + 1
+        for (nm, stack), c in sorted(seen.items(), key=lambda kv: -kv[1])[:24]:
+            print('%4d  %s' % (c, nm))
+            for fr in stack:
+                if 'site-packages/torch' not in fr:
+                    print('        ', fr)
+        return
     steps = 300
     pr = cProfile.Profile()
     pr.enable()
