@@ -30,7 +30,7 @@
 //                             with per-wave partial sums of dz and dz * yhat
 //     bn_bwd_apply_kernel     partials -> per (agent, channel) coefficients in the workgroup's prologue, then
 //                             dy = gamma * invstd * (dz - mean(dz) - yhat * mean(dz * yhat)), in place
-//     (after the last layer)  bn_bwd_dparam_kernel: d gamma, d beta of every layer, summed over agents in order
+//     (d gamma, d beta of the layer, summed over agents in order: one workgroup of conv_wgrad_reduce_kernel below)
 //     conv_wgrad_kernel       dW[co][ci][tap] (and d bias) = sum over all columns of dy x patch(x): a GEMM with
 //                             the columns as the contraction index, on the fp32 MFMA 16x16x4, operands staged
 //                             through LDS, split over image ranges; conv_wgrad_reduce_kernel sums the splits in order
@@ -779,9 +779,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 // cache line, 8.1 us per launch; same association, same bits).  dw [Cout][Cin][9], db [Cout]
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ wpart,
                                                                 float* __restrict__ dw, float* __restrict__ db,
-                                                                int nsplit, int Cin, int Cout, int J16) {
+                                                                int nsplit, int Cin, int Cout, int J16,
+                                                                const float* __restrict__ pn,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int N) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* red = reinterpret_cast<float*>(gnnpp_smem);                 // [8][32]
+    // The layer's BatchNorm parameter gradients ride along (r06; r05: a launch of their own behind the last layer):
+    // d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz) from bn_bwd_apply_kernel's per-agent sums pn (complete:
+    // that kernel precedes this layer's weight-gradient kernels in stream order), agents in order, one thread per channel
+    // of the LAST workgroup (the one with the fewest outputs to sum).
+    if (pn && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < Cout) {
+        const int c = threadIdx.x;
+        double tb = 0.0, tg = 0.0;
+        for (int n = 0; n < N; ++n) {
+            tb += (double)pn[((long)n * Cout + c) * 2];
+            tg += (double)pn[((long)n * Cout + c) * 2 + 1];
+        }
+        dgamma[c] = (float)tg;
+        dbeta[c] = (float)tb;
+    }
     const int J = Cin * 9 + 1;
     const int total = Cout * J;
     const int e = threadIdx.x & 31, sub = threadIdx.x >> 5;
@@ -823,7 +840,8 @@ struct TrainWs {
 // GNNPP_TUNE_TRAIN_WGRAD_WGS: workgroups per layer of conv_wgrad_kernel (image splits x output-channel tiles).  More
 // splits = shorter workgroups but more partial slabs for conv_wgrad_reduce_kernel to sum.  Set it BEFORE a forward call:
 // the workspace size depends on it.
-std::atomic<int> g_train_wgrad_wgs{320};
+std::atomic<int> g_train_wgrad_wgs{256};       // (r06 sweep at 64 x 10, graphed step: 96: 0.458, 128: 0.437, 192: 0.423,
+                                                // 256: 0.416, 320: 0.428, 448: 0.428 ms -- profiles/r06_train_wgrad_sweep.jsonl)
 
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
@@ -1001,6 +1019,12 @@ static BwdFork* bwd_fork(hipStream_t st, long rows) {
     if (knob == 0 || (knob == 1 && rows < kTrainForkMinRows)) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    {   // the side stream / events are per DEVICE: they must be the ones of the device `st` belongs to; a
+        // stream of another device than the current one stays on one stream
+        hipDevice_t sdev;
+        if (st != nullptr && hipStreamGetDevice(st, &sdev) == hipSuccess && (int)sdev != dev) return nullptr;
+        (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lock(mu);
     BwdFork& f = forks[dev];
     if (!f.ok) {
@@ -1029,6 +1053,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     float* dz_buf[2] = {ws + L.dz, ws + L.dz2};
     TrainPtrs5 dp = {};
     BwdFork* const fk = bwd_fork(st, NB);
+    bool fork_ok = true;
     hipStream_t const sw = fk ? fk->side : st;              // where the weight-gradient branch runs
     std::unique_lock<std::mutex> enqueue_lock;
     if (fk) enqueue_lock = std::unique_lock<std::mutex>(fk->enqueue);
@@ -1036,7 +1061,7 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
         float* dz = dz_buf[l & 1];
-        if (fk && l + 2 < kTrainLayers) hipStreamWaitEvent(st, fk->w_done[l + 2], 0);      // W(l + 2) has read this buffer
+        if (fk && l + 2 < kTrainLayers) fork_ok &= hipStreamWaitEvent(st, fk->w_done[l + 2], 0) == hipSuccess;   // W(l + 2) has read this buffer
 #define GNNPP_BNR(HH, WW, PL)                                                                                    \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<HH, WW, PL>), dim3(N * L.chunks[l], d.Cout / 4), dim3(256), 0, st,  \
                        ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout,    \
@@ -1057,14 +1082,14 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
         if (fk) {                                            // fork: the side stream waits for dz of this layer
-            hipEventRecord(fk->dz_ready[l], st);
-            hipStreamWaitEvent(sw, fk->dz_ready[l], 0);
+            fork_ok &= hipEventRecord(fk->dz_ready[l], st) == hipSuccess;
+            fork_ok &= hipStreamWaitEvent(sw, fk->dz_ready[l], 0) == hipSuccess;
         }
         wgrad_launch(l, L, xin, dz, ws + L.wpart, (int)NB, sn, sb, B, sw);
-        if (fk) hipEventRecord(fk->w_done[l], sw);           // (the reduction reads wpart only)
+        if (fk) fork_ok &= hipEventRecord(fk->w_done[l], sw) == hipSuccess;           // (the reduction reads wpart only)
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((d.Cout * (d.Cin * 9 + 1) + 31) / 32), dim3(256),
                            256 * sizeof(float), sw, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l] * L.kw[l],
-                           d.Cin, d.Cout, L.jt[l] * 16);
+                           d.Cin, d.Cout, L.jt[l] * 16, pn, dbn_w[l], dbn_b[l], N);
         if (l > 0) {
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
@@ -1075,10 +1100,13 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
         }
     }
     if (fk) {                                                // join: everything behind this call sees every gradient
-        hipEventRecord(fk->join, sw);
-        hipStreamWaitEvent(st, fk->join, 0);
+        fork_ok &= hipEventRecord(fk->join, sw) == hipSuccess;
+        fork_ok &= hipStreamWaitEvent(st, fk->join, 0) == hipSuccess;
+        // a failed record / wait (a capture-mode restriction, a stream of another device) would silently drop
+        // the dz_ready / w_done ordering the ping-pong dz buffers rely on: the call fails instead of racing
+        if (!fork_ok) { (void)hipGetLastError(); return -3; }
     }
-    hipLaunchKernelGGL(bn_bwd_dparam_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, dp, N);
+    (void)dp;                                                // (d gamma / d beta: inside conv_wgrad_reduce_kernel since r06)
     return launched_ok() ? 0 : -3;
 }
 

@@ -22,7 +22,7 @@ namespace gnnpp {
 // concatenation of every product's (column tiles x row tiles x batch*ksplit) workgroups; a workgroup finds its
 // product by its index.  block = 256: wave w owns rows [m0 + 16w, +16) x 64 columns (four 16x16 accumulators) over
 // the K range of its split.  Lane (i = lane & 15, q = lane >> 4): A value (row i, k = 4s + q), B values (k = 4s + q,
-// column 16t + i).  Four k-steps of operands (4 + 16 loads) are in flight before their 16 MFMAs.
+// column 16t + i).  Eight k-steps of operands (8 + 32 loads) are in flight before their 32 MFMAs.
 // out: ksplit == 1 -> C directly; else the partial of (split, b) -> ws + ws_off + ((split*batch + b)*M + m)*N + n,
 // summed in split order by gemm_reduce_kernel (one launch for all products that were split).
 constexpr int kGemmMax = 8;
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void gemm_kmajor_kernel(const GemmTable tb, fl
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = vzero();
     const int k0 = split * g.kper, k1 = min(K, k0 + g.kper);
-    constexpr int U = 4;
+    constexpr int U = 8;          // 32 contraction indices = a whole default K slice in ONE round of loads (r05: U = 4,
+                                  // two dependent rounds of ~2 us each in a kernel of 11 us)
     for (int ks = k0; ks < k1; ks += 4 * U) {
         float av[U], bv[U][4];
 #pragma unroll

@@ -386,10 +386,21 @@ class GraphedPolicyStep:
         self.S = S.clone()
         self.warmup = warmup
         self.recaptures = -1
+        self._retired = []                                 # graphs (and their output pools) replaced by a re-capture
         self._capture()
 
     def _capture(self):
         model = self.model
+        if self.recaptures >= 0:
+            # a re-capture used to release the old graph's private pool while logits returned by earlier
+            # calls still viewed it, and ran warm-up + capture inside a latency-critical step without a word.  The
+            # replaced graph (and with it the memory its outputs live in) is kept -- the last few of them -- and the
+            # caller is told.
+            import warnings
+            self._retired = (self._retired + [(self.graph, self.out)])[-4:]
+            warnings.warn('GraphedPolicyStep: the model\'s weights changed since the capture -- re-capturing (warm-up + '
+                          'capture inside this call; outputs of earlier calls keep their old values)', RuntimeWarning,
+                          stacklevel=3)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():

@@ -120,7 +120,7 @@ const char* gnnpp_error_string(int code);
                                          over >= 2 workgroups -- instead of contracting on the exact fp32 MFMA (2.7x the
                                          matrix-pipe time); 0 = r05's behaviour.  Same accuracy class (v330)              */
 #define GNNPP_TUNE_TRAIN_WGRAD_WGS   17  /* workgroups per layer of the training step's weight-gradient kernel (image splits x
-                                         output-channel tiles), 16 .. 2048, default 320: more splits = shorter workgroups,
+                                         output-channel tiles), 16 .. 2048, default 256: more splits = shorter workgroups,
                                          more partial sums to add.  Set before gnnpp_encoder_train_workspace_floats /
                                          _train_fwd: the workspace size depends on it.  Same gradients to rounding (v330) */
 int         gnnpp_set_tuning(int key, int value);
