@@ -544,8 +544,10 @@ class GraphFilterBatch(_GraphFilterBase):
 def matrixPowersBatch(S, K):
     """S^k for k = 0..K-1 per batch element (graphML.py:2063-2113).  S [B,N,N] -> [B,K,N,N];
     S [B,E,N,N] -> [B,E,K,N,N].  The result tensor is allocated once and power k is written in place
-    by one batched library GEMM from power k-1 (K-2 GEMMs, no concatenation copies); the return value
-    is a [B,E,K,N,N] view of that power-major buffer."""
+    from power k-1 (K-2 batched products, no concatenation copies); the return value is a [B,E,K,N,N] view of
+    that power-major buffer.  fp32 GSOs on the GPU: each product is ONE gnnpp_gemm_kmajor launch (exact fp32 MFMA,
+    batch = B*E, r06; r05: torch.bmm); anything else (fp64 GSOs keep the reference's fp64 powers; CPU tensors of the
+    host-side tests) goes through torch.bmm."""
     assert S.dim() in (3, 4)
     scalar = S.dim() == 3
     S4 = S.unsqueeze(1) if scalar else S
@@ -556,8 +558,14 @@ def matrixPowersBatch(S, K):
     P[0].diagonal(dim1=-2, dim2=-1).fill_(1)
     if K > 1:
         P[1] = flat
+    own = flat.is_cuda and flat.dtype is torch.float32
+    if own and K > 2 and not flat.is_contiguous():
+        flat = flat.contiguous()
     for k in range(2, K):
-        torch.bmm(P[k - 1], flat, out=P[k])
+        if own:     # P[k][b] (m, n) = sum_j P[k-1][b] (m, j) * S[b] (j, n): A rows contiguous in j, B rows contiguous in n
+            _native.gemm_kmajor(P[k - 1], (N * N, N, 1), flat, (N * N, N), P[k], (N * N, N), B * E, N, N, N)
+        else:
+            torch.bmm(P[k - 1], flat, out=P[k])
     SK = P.reshape(max(K, 1), B, E, N, N).permute(1, 2, 0, 3, 4)
     return SK.squeeze(1) if scalar else SK
 

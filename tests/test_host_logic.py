@@ -288,14 +288,40 @@ def test_committed_bench_lines_follow_the_contract():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench_c*.json')) +
                    glob.glob(os.path.join(root, 'profiles', 'r04_bench_c*.json')) +
-                   glob.glob(os.path.join(root, 'profiles', 'r05_bench_c*.json')))
+                   glob.glob(os.path.join(root, 'profiles', 'r05_bench_c*.json')) +
+                   [x for x in glob.glob(os.path.join(root, 'profiles', 'r06_bench_c*.json')) if not x.endswith('_full.json')])
     assert len(files) >= 3
+    assert any(os.path.basename(x).startswith('r06_bench_c2') for x in files), 'the r06 bench lines are missing'
     for f in files:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
+        raw = open(f).read().strip().splitlines()[-1]
+        d = json.loads(raw)
         if os.path.basename(f).startswith('r04'):
             _check_r04_extras(f, d)
         if os.path.basename(f).startswith('r05'):
             _check_r05_extras(f, d)
+        if os.path.basename(f).startswith('r06'):
+            # r06: the file holds the line AS PRINTED -- at most 6 KB, every contract block in it --
+            # and names the side file with everything else; the printed line is bench.driver_line() of that side file
+            import sys
+            sys.path.insert(0, root)
+            import bench
+            assert len(raw) <= bench.DRIVER_LINE_MAX_BYTES == 6144, (f, len(raw))
+            for key in ('roofline', 'cpu_baseline', 'parity', 'summary', 'details_file'):
+                assert key in d, (f, key)
+            assert 'secondary' not in d and d['details_file'].endswith('_full.json')
+            full = json.loads(open(f[:-len('.json')] + '_full.json').read())
+            assert bench.driver_line(full, d['details_file']) == raw, f
+            if full['config']['name'] == 'c2':
+                for key in ('c3_K3', 'c5_K2', 'c5_K3', 'c5_K4', 'c5_shard_K3', 'c4_shard_train', 'c2_best_batch',
+                            'dispatch_rule', 'filter_hbm_frac', 'cpu_M_per_s'):
+                    assert key in d['summary'], (f, key)
+                # the filter-and-head records state the schedule the LIBRARY reported (gnnpp_filter_head_mode), and the
+                # split 100-agent teams run bf16x3 planes aliased onto the dead z buffer (mode 3), not the fp32 MFMA
+                oc = full['secondary']['other_configs']
+                assert oc['c3_K3']['filter_and_head']['mode'] == 2 and oc['c5_K3']['filter_and_head']['mode'] == 3
+                assert oc['c5_K3']['filter_and_head']['instruction'] == 'v_mfma_f32_16x16x32_bf16'
+            d = full                                          # (the checks below: on the full record)
+            _check_r04_extras(f, d)
         for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
                     'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
             assert key in d, (f, key)

@@ -19,9 +19,9 @@ if has test; then stamp "pytest -m gpu"
 if has smoke; then stamp smoke
   timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log; fi
 if has bench; then stamp "bench c2"
-  timeout 400 python bench.py --steps 200 --warmup 20 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
+  timeout 400 python bench.py --steps 200 --warmup 20 --details-file $OUT/bench_c2_full.json 2>&1 | tail -1 | tee $OUT/bench_c2.json; fi
 if has benchdrv; then stamp "bench c2 with the driver's flags"
-  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 | tee $OUT/bench_c2_driverflags.json; fi
+  timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --details-file $OUT/bench_c2_driverflags_full.json 2>&1 | tail -1 | tee $OUT/bench_c2_driverflags.json; fi
 if has train; then stamp "train bench"
   timeout 300 python tools/train_bench.py --steps 50 2>&1 | tail -1 | tee $OUT/train_bench.json
   timeout 300 python tools/train_bench.py --steps 50 --graph 2>&1 | tail -3 | tee $OUT/train_bench_graph.json
@@ -35,6 +35,8 @@ if has wgradsweep; then stamp "train bench: workgroups per layer of the weight-g
   for w in 96 128 192 256 320 448; do
     timeout 300 python tools/train_bench.py --steps 100 --graph --wgrad-wgs $w 2>&1 | tail -1 | tee -a $OUT/train_wgrad_sweep.jsonl
   done; fi
+if has fusedrule; then stamp "one-launch policy kernel at 1, 2, 4 rounds of the chip vs the two-kernel path"
+  timeout 300 python tools/fused_rule_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/fused_rule_probe.jsonl; fi
 if has hostov; then stamp "host-side cost of one policy step"
   timeout 300 python tools/host_overhead.py 2>&1 | grep -v amdgpu.ids | head -70 | tee $OUT/host_overhead.txt; fi
 if has shardgap; then stamp "eager 16 x 100 policy step: host cost of the pieces, device-side gaps"
@@ -48,8 +50,12 @@ if has trainops; then stamp "which op launches the stray fill / copy kernels of 
   timeout 300 python tools/train_host_profile.py ops 2>&1 | grep -v amdgpu.ids | head -90 | tee $OUT/train_ops.txt; fi
 if has trainprof; then stamp "host profile of the eager training step"
   timeout 300 python tools/train_host_profile.py 2>&1 | grep -v amdgpu.ids | head -60 | tee $OUT/train_host_profile.txt; fi
-if has distcheck; then stamp "2-rank gloo run of bench.py on one GPU (code-path check only)"
-  GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee $OUT/distcheck.log
+if has distcheck; then stamp "launcher-less bench.py --gpus 2 (bench.py starts its two ranks itself; gloo, both ranks on GPU 0)"
+  GNNPP_BENCH_DEVICE=0 timeout 300 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --pmc off --dist-backend gloo --details-file $OUT/bench_selflaunch_full.json 2>&1 | tail -1 | cut -c1-700 | tee $OUT/distcheck.log
+  stamp "... and without the device override: refused (one GPU here)"
+  timeout 120 python bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --pmc off 2>&1 | tail -1 | cut -c1-300 | tee -a $OUT/distcheck.log
+  stamp "2-rank gloo run of bench.py on one GPU under torch.distributed.run (code-path check only)"
+  GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --dist-backend gloo 2>&1 | tail -2 | cut -c1-600 | tee -a $OUT/distcheck.log
   stamp "2 ranks over RCCL on ONE GPU: GraphedTrainStep(dp=FlatBucketDP) -- the captured all-reduce must execute"
   GNNPP_BENCH_DEVICE=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 tools/train_bench.py --steps 20 --graph > $OUT/rccl_one_gpu.log 2>&1; echo "exit $?" >> $OUT/rccl_one_gpu.log
   grep -i "error\|duplicate\|invalid\|agent-steps\|^exit" $OUT/rccl_one_gpu.log | grep -v amdgpu.ids | head -12 | cut -c1-400 | tee -a $OUT/distcheck.log
@@ -72,7 +78,7 @@ if has filtersweep; then stamp "filter-only throughput sweep"
 if has stamps; then stamp "phase stamps of the rollout kernels"
   timeout 300 python tools/phase_stamps.py 2>&1 | grep -v "amdgpu.ids\|warning\|note:" | tail -14 | tee $OUT/phase_stamps.jsonl; fi
 if has bench35; then for c in c3 c5; do stamp "bench $c"
-  timeout 400 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 4 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
+  timeout 400 python bench.py --config $c --steps 100 --warmup 10 --cpu-seconds 4 --details-file $OUT/bench_${c}_full.json 2>&1 | tail -1 | tee $OUT/bench_$c.json; done; fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then stamp "rocprofv3 kernel trace"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --pipeline-streams 0 --pmc off > $OUT/prof_run.log 2>&1
