@@ -329,8 +329,8 @@ def _c4_shard_record(orc, dev, cpu_seconds, train_bench, DecentralPlannerNet, po
            'value': B * N / t_graph, 'unit': 'agent-steps/s (training step)', 'ms_per_step': 1e3 * t_graph,
            'how': 'HIP-graph replay of the whole step (GraphedTrainStep), wall clock over 40 steps',
            'eager_value': B * N / t_eager, 'eager_ms_per_step': 1e3 * t_eager,
-           'dominant_kernel': 'none: ~60 launches of 3-35 us each (profiles/r02a_train_kernel_stats.csv); the step is '
-                              'launch- and latency-bound at 640 agents',
+           'dominant_kernel': 'none: ~50 launches of 4-24 us each (profiles/r06_train_kernel_stats.csv); the step is the '
+                              'sum of latency-bound kernels at 640 agent-samples',
            'predicted_8gpu_value_without_allreduce': 8 * B * N / t_graph,
            'parity_train_mode_max_abs_dlogit': err, 'parity_loss_gpu': loss_g, 'parity_loss_oracle': loss_w}
     if cpu_seconds > 0:
