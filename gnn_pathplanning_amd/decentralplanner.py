@@ -23,8 +23,8 @@ updates its running statistics N times per forward (decentralplanner.py:284-290)
 batch-wide reductions per agent between the layers, so train mode is a layer-by-layer schedule of
 hand-written HIP kernels, forward and backward (csrc/train_encoder.hip behind
 gnnpp_encoder_train_fwd / _bwd), plus the graph filter (forward, input gradient, tap gradient) on
-lsigf_kernel through graphML._LSIGFFunction; the FORWARD products of compressMLP and the action head are
-library GEMMs (plain GEMMs), their backward products run on gnnpp_gemm_kmajor_multi.
+lsigf_kernel through graphML._LSIGFFunction; compressMLP and the action head forward on gnnpp_linear_fwd, their
+backward products on gnnpp_gemm_kmajor_multi.
 There is no CPU path.
 """
 import ctypes
@@ -245,6 +245,13 @@ class _OutputSlot:
     def clear(self):
         self.entries.clear()
         self.views = None
+
+    # a copied / pickled model starts with an empty slot (the entries are this process's device buffers)
+    def __deepcopy__(self, memo):
+        return _OutputSlot()
+
+    def __reduce__(self):
+        return (_OutputSlot, ())
 
     def acquire(self, N, B, dev, stream):
         if _tensor_use_count is None or _storage_use_count is None or _stream_capturing():
@@ -623,11 +630,11 @@ class DecentralPlannerNet(nn.Module):
         running-statistics updates per forward) as _EncoderTrainFunction over all agents at once
         (csrc/train_encoder.hip, forward and backward); the graph-filter layers on lsigf_kernel
         (graphML._LSIGFFunction: forward with tap dump, input gradient = the transposed filter, tap gradient on
-        gnnpp_gemm_kmajor); the backward products of compressMLP and the action head on gnnpp_gemm_kmajor_multi.
-        Library / aten: the FORWARD of compressMLP and of the action head (torch.nn.functional.linear -> hipBLASLt:
-        plain 640 x 128 x 128 GEMMs) and the ReLU mask of compressMLP.  A GSO with more nodes than numAgents
-        (graphML.py:2464-2469 zero-pads the signal) is honoured as in eval mode."""
-        import torch.nn.functional as tF
+        gnnpp_gemm_kmajor); compressMLP and the action head forward on gnnpp_linear_fwd (bias + ReLU in the launch),
+        their backward products on gnnpp_gemm_kmajor_multi; every weight re-ordering of the step in one
+        gnnpp_train_pack launch per weight version; both ReLU backward passes around the filter folded into the
+        launches that produce the masked gradients.  No library GEMM and no aten kernel is left in the step (r06).  A
+        GSO with more nodes than numAgents (graphML.py:2464-2469 zero-pads the signal) is honoured as in eval mode."""
         if self.S is None:
             raise TypeError('addGSO() must be called before forward()')
         _native.require_gpu(inputTensor, self.S, self.compressMLP[0].weight)
