@@ -60,6 +60,9 @@ __host__ __device__ inline TrainLayerDims train_layer(int l) {
 //   5/9 of its multiplications on the zero border.
 //   input gradient: the same with the transposed, flipped kernel (rows = the layer's input channels).
 // IB images per workgroup, CC contraction channels per LDS stage.
+constexpr int kDenseIB = 32;                // images per workgroup of the dense (2x2) layers (r06: 64 -> 32: the 32 row-tile
+                                            // workgroups of an image chunk each re-stage the chunk -- per-workgroup staging latency is
+                                            // the launch; conv_mfma_kernel<1, 1> 11.4 -> 9.2 us per launch, 16 images: 10.5)
 struct ConvGeom { int H, W, P, TAPS, RPC, IB, CC, M, Ck, nchunk, SPC, chunks_per_agent; };
 __host__ __device__ inline ConvGeom conv_geom(int l, bool input_grad, int B) {
     const TrainLayerDims d = train_layer(l);
@@ -68,7 +71,7 @@ __host__ __device__ inline ConvGeom conv_geom(int l, bool input_grad, int B) {
     g.H = dense ? 1 : d.H; g.W = dense ? 1 : d.W; g.P = g.H * g.W;
     g.TAPS = dense ? 1 : 9;
     g.RPC = dense ? 4 : 1;
-    g.IB = dense ? 64 : d.H == 5 ? 4 : 2;
+    g.IB = dense ? kDenseIB : d.H == 5 ? 4 : 2;
     g.CC = dense ? 256 : d.H == 5 ? 32 : 4;
     const int rows = input_grad ? d.Cin : d.Cout, ck = input_grad ? d.Cout : d.Cin;
     g.M = rows * g.RPC;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     constexpr bool kDense = H == 1 && W == 1;
     constexpr int P = H * W, TAPS = kDense ? 1 : 9, RPC = kDense ? 4 : 1;
     constexpr int PP = kDense ? 1 : (H + 2) * (W + 2);
-    constexpr int IB = kDense ? 64 : H == 5 ? 4 : 2, CC = kDense ? 256 : H == 5 ? 32 : 4;
+    constexpr int IB = kDense ? kDenseIB : H == 5 ? 4 : 2, CC = kDense ? 256 : H == 5 ? 32 : 4;
     constexpr int SPC = TAPS * CC / 4, NT = (IB * P + 15) / 16, TN = (NT + 3) / 4;
     // floats between two channels' rows in LDS, padded against bank conflicts (64 banks): the B read's four
     // channel groups q sit 16 banks apart (stride = 16 mod 64); the dense layers' 64 one-float "images" get a
