@@ -399,7 +399,7 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
 constexpr size_t kBnSmem = 512 * sizeof(double) + 32 * 5 * sizeof(float);
 struct BnTile { int CG, BR; };
 __host__ __device__ inline BnTile bn_tile(int l) {
-    const BnTile t[kTrainLayers] = {{2, 16}, {8, 8}, {8, 8}, {32, 16}, {32, 16}};
+    const BnTile t[kTrainLayers] = {{2, 8}, {8, 8}, {8, 8}, {32, 16}, {32, 16}};
     return t[l];
 }
 
@@ -860,9 +860,9 @@ inline TrainWs train_ws_layout(int N, int B) {
         w.stat[l] = take((size_t)N * d.Cout * 4);
         w.wt[l] = take(conv_pack_floats(l, false));
         w.wtb[l] = take(conv_pack_floats(l, true));
-        {   // column splits of bn_bwd_reduce_kernel: >= ~2 500 waves per layer and at most four 64-column trips
+        {   // column splits of bn_bwd_reduce_kernel: >= ~2 500 waves per layer and at most two (r05: four) 64-column trips
             // per wave (each trip is one dependent round of loads), at least 64 columns each
-            const int by_waves = (2560 + N * d.Cout - 1) / (N * d.Cout), by_trips = (B * P + 255) / 256;
+            const int by_waves = (2560 + N * d.Cout - 1) / (N * d.Cout), by_trips = (B * P + 127) / 128;
             const int sp = by_waves > by_trips ? by_waves : by_trips, spmax = (B * P + 63) / 64;
             w.chunks[l] = sp < 1 ? 1 : sp > spmax ? spmax : sp > 64 ? 64 : sp;
         }
