@@ -203,13 +203,13 @@ def test_prepowered_gso_api_surface():
     assert m.N == 5 and m.B == 2 and 'number_nodes=5' in m.extra_repr()
 
 
-def _check_r04_extras(f, d):
+def _check_r04_extras(f, d, summary_last=True):
     """r04: the line ends with a compact `summary` (so that a 2 000-character tail keeps the per-config figures), the
     roofline says how many MFMA FLOPs were issued per algorithmic FLOP and how full the tiles' columns were, and the
     C2 line holds the per-GPU SHARDS of the 8-GPU configs (C5: 16 graphs x 100 agents, K = 2, 3, 4; C4: a 64 x 10
     optimisation step with the CPU oracle's training step beside it)."""
     import json
-    assert list(d)[-1] == 'summary', f
+    assert list(d)[-1] == 'summary' or not summary_last, f     # (r04 / r05: a 2 000-character tail had to keep it)
     sm, rl = d['summary'], d['roofline']
     assert len(json.dumps(sm)) <= 1900, (f, len(json.dumps(sm)))
     name = d['config']['name']
@@ -321,7 +321,7 @@ def test_committed_bench_lines_follow_the_contract():
                 assert oc['c3_K3']['filter_and_head']['mode'] == 2 and oc['c5_K3']['filter_and_head']['mode'] == 3
                 assert oc['c5_K3']['filter_and_head']['instruction'] == 'v_mfma_f32_16x16x32_bf16'
             d = full                                          # (the checks below: on the full record)
-            _check_r04_extras(f, d)
+            _check_r04_extras(f, d, summary_last=False)
         for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
                     'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
             assert key in d, (f, key)
