@@ -30,7 +30,7 @@
 //                             with per-wave partial sums of dz and dz * yhat
 //     bn_bwd_apply_kernel     partials -> per (agent, channel) coefficients in the workgroup's prologue, then
 //                             dy = gamma * invstd * (dz - mean(dz) - yhat * mean(dz * yhat)), in place
-//     (d gamma, d beta of the layer, summed over agents in order: one workgroup of conv_wgrad_reduce_kernel below)
+//     (after the first layer: ONE conv_wgrad_reduce_kernel launch sums the splits of all five layers, and d gamma / d beta)
 //     conv_wgrad_kernel       dW[co][ci][tap] (and d bias) = sum over all columns of dy x patch(x): a GEMM with
 //                             the columns as the contraction index, on the fp32 MFMA 16x16x4, operands staged
 //                             through LDS, split over image ranges; conv_wgrad_reduce_kernel sums the splits in order
@@ -629,11 +629,12 @@ __global__ void bn_bwd_dparam_kernel(const TrainPtrs5 p, int N) {
 //   writing its own partial.  Partials -> wpart[split*KW + kgroup][Cout][J16], summed by conv_wgrad_reduce_kernel.
 __host__ __device__ constexpr int wgrad_ib(int H) { return H == 11 ? 4 : H == 5 ? 6 : 8; }   // images per LDS batch
 
+// (a __device__ body: one layer per launch -- conv_wgrad_kernel -- or all five layers in ONE launch --
+// conv_wgrad_all_kernel; bx = output-channel tile, by = image split of the workgroup)
 template <int H, int W, int Cin, int TJ, int KW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x,
-                                                         const float* __restrict__ dy,
-                                                         float* __restrict__ wpart, int NB, int Cout,
-                                                         long x_sn, long x_sb, int B, int imgs_per_split, int JT) {
+__device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                float* __restrict__ wpart, int NB, int Cout, long x_sn, long x_sb,
+                                                int B, int imgs_per_split, int JT, int bx, int by) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     constexpr int P = H * W, PP = (H + 2) * (W + 2), SPI = (P + 3) / 4, P4 = SPI * 4, JW = 4 / KW;
     constexpr int IB = wgrad_ib(H);
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, q = lane >> 4;
     const int jw = wave % JW, kw = wave / JW;
-    const int co0 = blockIdx.x * 16, split = blockIdx.y;
+    const int co0 = bx * 16, split = by;
     const int J = Cin * 9 + 1, J16 = JT * 16;
     float* xs = reinterpret_cast<float*>(gnnpp_smem);            // [Cin][RS >= IB*PP]
     float* dys = xs + Cin * RS;                                  // [16][dstride]
@@ -776,40 +777,94 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
+template <int H, int W, int Cin, int TJ, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ dy,
+                                                         float* __restrict__ wpart, int NB, int Cout,
+                                                         long x_sn, long x_sb, int B, int imgs_per_split, int JT) {
+    conv_wgrad_body<H, W, Cin, TJ, KW>(x, dy, wpart, NB, Cout, x_sn, x_sb, B, imgs_per_split, JT, blockIdx.x, blockIdx.y);
+}
+
+// The weight gradients of ALL five layers in one launch (r06b).  Nothing downstream of a layer's weight gradient is
+// needed before the optimizer, and at the reference's batch (64 x 10) each per-layer launch is ~256 workgroups of 9 .. 19 us
+// of latency that fill a fraction of the chip: run one after the other inside the backward chain they cost 65 us, the fp32
+// MFMAs of all five together are 14 us of the pipe.  So the backward chain only runs R -> A -> D per layer (every layer
+// keeps its dy in a buffer of its own) and the five weight gradients run as ONE grid behind it: workgroup w belongs to
+// layer l with first[l] <= w < first[l + 1], its (output-channel tile, image split) = ((w - first[l]) % nx[l], / nx[l]).
+struct WgradAllTable {
+    const float* x[kTrainLayers];
+    const float* dy[kTrainLayers];
+    float* wpart[kTrainLayers];
+    long x_sn[kTrainLayers], x_sb[kTrainLayers];
+    int ips[kTrainLayers], jt[kTrainLayers], nx[kTrainLayers], first[kTrainLayers + 1];
+    int NB, B;
+};
+__global__ __launch_bounds__(256) void conv_wgrad_all_kernel(const WgradAllTable tb) {
+    int l = 0;
+    while (l + 1 < kTrainLayers && (int)blockIdx.x >= tb.first[l + 1]) ++l;       // (scalar: at most 4 steps)
+    const int local = (int)blockIdx.x - tb.first[l];
+    const int bx = local % tb.nx[l], by = local / tb.nx[l];
+    const int Cout = tb.nx[l] * 16;
+    if (l == 0)
+        conv_wgrad_body<11, 11, 3, 1, 2>(tb.x[0], tb.dy[0], tb.wpart[0], tb.NB, Cout, tb.x_sn[0], tb.x_sb[0], tb.B,
+                                         tb.ips[0], tb.jt[0], bx, by);
+    else if (l <= 2)
+        conv_wgrad_body<5, 5, 32, 5, 1>(tb.x[l], tb.dy[l], tb.wpart[l], tb.NB, Cout, tb.x_sn[l], tb.x_sb[l], tb.B,
+                                        tb.ips[l], tb.jt[l], bx, by);
+    else
+        conv_wgrad_body<2, 2, 64, 10, 1>(tb.x[l], tb.dy[l], tb.wpart[l], tb.NB, Cout, tb.x_sn[l], tb.x_sb[l], tb.B,
+                                         tb.ips[l], tb.jt[l], bx, by);
+}
+
 // sum the splits: 8 threads per output element each add every 8th split (in order), then the 8 partial sums are
 // added in order -- a fixed association, deterministic.  Thread (sub = tid >> 5, e = tid & 31): the 32 lanes of a
 // half wave read 32 CONSECUTIVE outputs of one split (r05 had the 8 splits on neighbouring lanes: every lane its own
-// cache line, 8.1 us per launch; same association, same bits).  dw [Cout][Cin][9], db [Cout]
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ wpart,
-                                                                float* __restrict__ dw, float* __restrict__ db,
-                                                                int nsplit, int Cin, int Cout, int J16,
-                                                                const float* __restrict__ pn,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int N) {
+// cache line, 8.1 us per launch; same association, same bits).  dw [Cout][Cin][9], db [Cout].
+// ONE launch for all five layers (r06b; r05 / r06a: one per layer, 5 us each inside the backward chain): every layer's
+// partial slabs have a region of their own in the workspace, nothing downstream of a layer's weight gradient is needed
+// before the optimizer, so the five reductions run once, behind the last weight-gradient kernel.  A workgroup finds its
+// layer by its index (first[l] <= blockIdx.x < first[l + 1]).
+struct WgradReduceTable {
+    const float* wpart[kTrainLayers];
+    float* dw[kTrainLayers];
+    float* db[kTrainLayers];
+    const float* pn[kTrainLayers];                 // bn_bwd_apply_kernel's per-agent sums of the layer
+    float* dgamma[kTrainLayers];
+    float* dbeta[kTrainLayers];
+    int nsplit[kTrainLayers], J16[kTrainLayers], first[kTrainLayers + 1];
+    int N;
+};
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradReduceTable tb) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     float* red = reinterpret_cast<float*>(gnnpp_smem);                 // [8][32]
+    int l = 0;
+    while (l + 1 < kTrainLayers && (int)blockIdx.x >= tb.first[l + 1]) ++l;       // (scalar: at most 4 steps)
+    const TrainLayerDims d = train_layer(l);
+    const int Cin = d.Cin, Cout = d.Cout, J16 = tb.J16[l], nsplit = tb.nsplit[l];
+    const int blk = (int)blockIdx.x - tb.first[l];
     // The layer's BatchNorm parameter gradients ride along (r06; r05: a launch of their own behind the last layer):
     // d gamma[c] = sum_n sum(dz * yhat), d beta[c] = sum_n sum(dz) from bn_bwd_apply_kernel's per-agent sums pn (complete:
-    // that kernel precedes this layer's weight-gradient kernels in stream order), agents in order, one thread per channel
-    // of the LAST workgroup (the one with the fewest outputs to sum).
-    if (pn && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < Cout) {
+    // that kernel precedes this launch in stream order), agents in order, one thread per channel of the layer's LAST
+    // workgroup (the one with the fewest outputs to sum).
+    if (tb.pn[l] && (int)blockIdx.x == tb.first[l + 1] - 1 && (int)threadIdx.x < Cout) {
         const int c = threadIdx.x;
-        double tb = 0.0, tg = 0.0;
-        for (int n = 0; n < N; ++n) {
-            tb += (double)pn[((long)n * Cout + c) * 2];
-            tg += (double)pn[((long)n * Cout + c) * 2 + 1];
+        const float* pn = tb.pn[l];
+        double sb = 0.0, sg = 0.0;
+        for (int n = 0; n < tb.N; ++n) {
+            sb += (double)pn[((long)n * Cout + c) * 2];
+            sg += (double)pn[((long)n * Cout + c) * 2 + 1];
         }
-        dgamma[c] = (float)tg;
-        dbeta[c] = (float)tb;
+        tb.dgamma[l][c] = (float)sg;
+        tb.dbeta[l][c] = (float)sb;
     }
     const int J = Cin * 9 + 1;
     const int total = Cout * J;
     const int e = threadIdx.x & 31, sub = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + e;
+    const int i = blk * 32 + e;
     float s = 0.f;
     if (i < total) {
         const int co = i / J, jj = i - co * J;
-        const float* src = wpart + (long)co * J16 + jj;
+        const float* src = tb.wpart[l] + (long)co * J16 + jj;
         const long stride = (long)Cout * J16;
 #pragma unroll 4
         for (int k = sub; k < nsplit; k += 8) s += src[k * stride];
@@ -821,20 +876,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k * 32 + e];
         const int co = i / J, jj = i - co * J;
-        if (jj == J - 1) db[co] = t;
-        else dw[(long)co * (J - 1) + jj] = t;
+        if (jj == J - 1) tb.db[l][co] = t;
+        else tb.dw[l][(long)co * (J - 1) + jj] = t;
     }
 }
 
 // ---- host side: workspace layout and the two entry points -----------------------------------------------------
 // Workspace (floats), for N agents and B samples per agent:
 //   per layer l: y_l [N*B*Cout*P] | x_{l+1} [N*B*Cout*Po] | stat_l [N*Cout*4]
-//   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz, dz2 (largest y, ping-pong: the weight-
-//            gradient branch of layer l still reads dz while layer l - 1 writes the other one) | dxa, dxb
-//            (gradients w.r.t. layer inputs, ping-pong) | coef (per-agent BN-backward sums) | wpart
+//   scratch: wt (packed forward weights, all layers) | part (partial sums) | dz x 5 (the gradient w.r.t. y_l of every
+//            layer: all of them are read again by the ONE weight-gradient launch at the end) | dxa, dxb
+//            (gradients w.r.t. layer inputs, ping-pong) | coef (per-agent BN-backward sums) | wpart x 5 (per layer)
 struct TrainWs {
     size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers], wtb[kTrainLayers];
-    size_t part, dz, dz2, dxa, dxb, coef, wpart, total;
+    size_t part, dz[kTrainLayers], dxa, dxb, coef, wpart[kTrainLayers], total;
     int chunks[kTrainLayers];
     // conv_wgrad_kernel: image splits, images per split, images per LDS batch, j tiles, K groups per workgroup
     int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
@@ -848,7 +903,7 @@ std::atomic<int> g_train_wgrad_wgs{256};       // (r06 sweep at 64 x 10, graphed
 
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
-    size_t o = 0, max_y = 0, max_part = 0, max_x = 0, max_wp = 0;
+    size_t o = 0, max_y = 0, max_part = 0, max_x = 0, wp[kTrainLayers];
     // every region starts on a 16-byte boundary (the kernels use 16-byte loads on image runs and packs)
     auto take = [&o](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
     const size_t NB = (size_t)N * B;
@@ -880,16 +935,17 @@ inline TrainWs train_ws_layout(int N, int B) {
         w.ips[l] = (int)((NB + ns - 1) / ns);
         w.nsplit[l] = (int)((NB + w.ips[l] - 1) / w.ips[l]);
         w.ib[l] = wgrad_ib(d.H);                           // LDS: [Cin][IB][(H+2)(W+2)] + [16][IB*P4] floats <= 64 KB
-        const size_t wp = (size_t)w.nsplit[l] * w.kw[l] * d.Cout * w.jt[l] * 16;
-        max_wp = max_wp > wp ? max_wp : wp;
+        wp[l] = (size_t)w.nsplit[l] * w.kw[l] * d.Cout * w.jt[l] * 16;
     }
     w.part = take(max_part);
-    w.dz = take(max_y);
-    w.dz2 = take(max_y);
+    for (int l = 0; l < kTrainLayers; ++l) {               // dz / dy of every layer in a buffer of its own: the weight
+        const TrainLayerDims d = train_layer(l);           // gradients of all layers read them in ONE launch at the end
+        w.dz[l] = take(NB * d.Cout * d.H * d.W);
+    }
     w.dxa = take(max_x);
     w.dxb = take(max_x);
     w.coef = take((size_t)kTrainLayers * N * 128 * 2);   // per-agent sums of the BN backward, [layer][N][128][2]
-    w.wpart = take(max_wp);
+    for (int l = 0; l < kTrainLayers; ++l) w.wpart[l] = take(wp[l]);   // (one per layer: summed by ONE launch at the end)
     w.total = o;
     return w;
 }
@@ -1000,6 +1056,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
 // 0.486 -> 0.566 ms, eager 1.158 -> 1.270 ms -- eleven cross-stream edges cost more than the overlap of 5 .. 20 us kernels
 // buys.  GNNPP_TUNE_TRAIN_FORK: 1 (default) = fork from kTrainForkMinRows agent-samples on, 0 = never, 2 = always.
 std::atomic<int> g_train_fork{1};
+std::atomic<int> g_train_wgrad_merged{1};       // GNNPP_TUNE_TRAIN_WGRAD_MERGED
 constexpr long kTrainForkMinRows = 4096;
 
 struct BwdFork {
@@ -1053,18 +1110,22 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     const long NB = (long)N * B;
     const float* dxn = dfeat;
     float* dx_buf[2] = {ws + L.dxa, ws + L.dxb};
-    float* dz_buf[2] = {ws + L.dz, ws + L.dz2};
     TrainPtrs5 dp = {};
-    BwdFork* const fk = bwd_fork(st, NB);
+    // GNNPP_TUNE_TRAIN_WGRAD_MERGED (default 1): the weight gradients of all five layers as ONE launch behind the chain
+    // (conv_wgrad_all_kernel); 0: one launch per layer inside the chain, where the fork rule below can put them on a
+    // side stream (r05).  Same kernels' bodies, same partial layout, same reduction: bit-identical gradients.
+    const bool merged = g_train_wgrad_merged.load(std::memory_order_relaxed) != 0;
+    BwdFork* const fk = merged ? nullptr : bwd_fork(st, NB);
     bool fork_ok = true;
+    WgradReduceTable rt = {};
+    WgradAllTable wa = {};
     hipStream_t const sw = fk ? fk->side : st;              // where the weight-gradient branch runs
     std::unique_lock<std::mutex> enqueue_lock;
     if (fk) enqueue_lock = std::unique_lock<std::mutex>(fk->enqueue);
     for (int l = kTrainLayers - 1; l >= 0; --l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
-        float* dz = dz_buf[l & 1];
-        if (fk && l + 2 < kTrainLayers) fork_ok &= hipStreamWaitEvent(st, fk->w_done[l + 2], 0) == hipSuccess;   // W(l + 2) has read this buffer
+        float* dz = ws + L.dz[l];                            // (every layer its own: no buffer is re-used inside the call)
 #define GNNPP_BNR(HH, WW, PL)                                                                                    \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<HH, WW, PL>), dim3(N * L.chunks[l], d.Cout / 4), dim3(256), 0, st,  \
                        ws + L.y[l], ws + L.stat[l], rp.bn_w[l], rp.bn_b[l], dxn, dz, ws + L.part, B, d.Cout,    \
@@ -1088,11 +1149,15 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
             fork_ok &= hipEventRecord(fk->dz_ready[l], st) == hipSuccess;
             fork_ok &= hipStreamWaitEvent(sw, fk->dz_ready[l], 0) == hipSuccess;
         }
-        wgrad_launch(l, L, xin, dz, ws + L.wpart, (int)NB, sn, sb, B, sw);
-        if (fk) fork_ok &= hipEventRecord(fk->w_done[l], sw) == hipSuccess;           // (the reduction reads wpart only)
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((d.Cout * (d.Cin * 9 + 1) + 31) / 32), dim3(256),
-                           256 * sizeof(float), sw, ws + L.wpart, dconv_w[l], dconv_b[l], L.nsplit[l] * L.kw[l],
-                           d.Cin, d.Cout, L.jt[l] * 16, pn, dbn_w[l], dbn_b[l], N);
+        if (merged) {
+            wa.x[l] = xin; wa.dy[l] = dz; wa.wpart[l] = ws + L.wpart[l]; wa.x_sn[l] = sn; wa.x_sb[l] = sb;
+            wa.ips[l] = L.ips[l]; wa.jt[l] = L.jt[l]; wa.nx[l] = d.Cout / 16;
+        } else {
+            wgrad_launch(l, L, xin, dz, ws + L.wpart[l], (int)NB, sn, sb, B, sw);
+        }
+        rt.wpart[l] = ws + L.wpart[l]; rt.dw[l] = dconv_w[l]; rt.db[l] = dconv_b[l];
+        rt.pn[l] = pn; rt.dgamma[l] = dbn_w[l]; rt.dbeta[l] = dbn_b[l];
+        rt.nsplit[l] = L.nsplit[l] * L.kw[l]; rt.J16[l] = L.jt[l] * 16;
         if (l > 0) {
             // dx [N][B][Cin][P] = conv(dy) with the flipped kernel; here "Cin" of the call = Cout of the layer
             float* dx = dx_buf[l & 1];
@@ -1101,6 +1166,33 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
                         (long)d.Cout * P, st);
             dxn = dx;
         }
+    }
+    if (merged) {                                            // the five weight gradients: ONE grid
+        int blocks = 0;
+        size_t smem = 0;
+        for (int l = 0; l < kTrainLayers; ++l) {
+            const TrainLayerDims d = train_layer(l);
+            const int P = d.H * d.W, PP = (d.H + 2) * (d.W + 2), P4 = (P + 3) / 4 * 4;
+            const int IB = L.ib[l], dstride = ((IB * P4 + 63) / 64) * 64 + 4;
+            const size_t sm = ((size_t)d.Cin * ((IB * PP) | 1) + 16 * (size_t)dstride) * sizeof(float);
+            smem = smem > sm ? smem : sm;
+            wa.first[l] = blocks;
+            blocks += wa.nx[l] * L.nsplit[l];
+        }
+        wa.first[kTrainLayers] = blocks;
+        wa.NB = (int)NB; wa.B = B;
+        hipLaunchKernelGGL(conv_wgrad_all_kernel, dim3(blocks), dim3(256), smem, st, wa);
+    }
+    {   // the five layers' split sums (+ d gamma / d beta) in ONE launch, behind the last weight-gradient kernel
+        int blocks = 0;
+        for (int l = 0; l < kTrainLayers; ++l) {
+            const TrainLayerDims d = train_layer(l);
+            rt.first[l] = blocks;
+            blocks += (d.Cout * (d.Cin * 9 + 1) + 31) / 32;
+        }
+        rt.first[kTrainLayers] = blocks;
+        rt.N = N;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 256 * sizeof(float), sw, rt);
     }
     if (fk) {                                                // join: everything behind this call sees every gradient
         fork_ok &= hipEventRecord(fk->join, sw) == hipSuccess;

@@ -123,6 +123,11 @@ const char* gnnpp_error_string(int code);
                                          output-channel tiles), 16 .. 2048, default 256: more splits = shorter workgroups,
                                          more partial sums to add.  Set before gnnpp_encoder_train_workspace_floats /
                                          _train_fwd: the workspace size depends on it.  Same gradients to rounding (v330) */
+#define GNNPP_TUNE_TRAIN_WGRAD_MERGED 18 /* 1 (default): gnnpp_encoder_train_bwd computes the weight gradients of all five
+                                         layers in ONE launch behind the backward chain (nothing downstream needs them before
+                                         the optimizer; at 64 x 10 the five per-layer launches are 65 us of latency, their
+                                         MFMAs 14 us); 0: one launch per layer inside the chain, where GNNPP_TUNE_TRAIN_FORK
+                                         can move them to a second stream.  Same gradients to the bit (v330)               */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

@@ -109,6 +109,23 @@ def test_emu_train_encoder_forward_backward(N, B, seed, fbn, ext_pack):
     rc = lib.gnnpp_encoder_train_bwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(cot_np), ctypes.byref(G),
                                      B, N, fbn, el.ptr(tp) if tp is not None else None, None)
     assert rc == 0
+    # r06b: the weight gradients of all five layers come from ONE launch behind the chain (GNNPP_TUNE_TRAIN_WGRAD_MERGED,
+    # default); the per-layer launches of r05 (knob 18 = 0) give the same bits
+    assert lib.gnnpp_get_tuning(18) == 1 and lib.gnnpp_set_tuning(18, 0) == 0
+    try:
+        G2, outs2 = Grads(), {}
+        for i in range(5):
+            for field, key in (('conv_w', 'ConvLayers.%d.weight' % CONV[i]), ('conv_b', 'ConvLayers.%d.bias' % CONV[i]),
+                               ('bn_w', 'ConvLayers.%d.weight' % BN[i]), ('bn_b', 'ConvLayers.%d.bias' % BN[i])):
+                o = np.full(tuple(sd[key].shape), np.nan, np.float32); outs2[key] = o
+                getattr(G2, field)[i] = o.ctypes.data
+        rc = lib.gnnpp_encoder_train_bwd(ctypes.byref(P), el.ptr(obs_np), el.ptr(ws), el.ptr(cot_np), ctypes.byref(G2),
+                                         B, N, fbn, el.ptr(tp) if tp is not None else None, None)
+        assert rc == 0
+        for key in outs:
+            assert np.array_equal(outs[key], outs2[key]), key
+    finally:
+        assert lib.gnnpp_set_tuning(18, 1) == 0
     for key, o in outs.items():
         want = p_ref[key].grad.numpy()
         scale = np.abs(want).max()

@@ -273,7 +273,10 @@ def test_backward_weight_gradient_fork_is_bit_identical(dev, B):
         batches.append((obs, tgt, S))
     sd0 = orc.init_state_dict(3, seed=13)
 
-    def run(fork, graphed):
+    def run(fork, graphed, merged=0):
+        # merged (r06b, GNNPP_TUNE_TRAIN_WGRAD_MERGED, the default): all five weight gradients as ONE launch behind the
+        # chain -- the fork rule only applies to the per-layer launches (merged = 0)
+        assert L.gnnpp_set_tuning(18, merged) == 0 and L.gnnpp_get_tuning(18) == merged
         assert L.gnnpp_set_tuning(15, fork) == 0 and L.gnnpp_get_tuning(15) == fork
         net = DecentralPlannerNet(Cfg()).to(dev).train()
         net.load_state_dict(sd0)
@@ -292,15 +295,17 @@ def test_backward_weight_gradient_fork_is_bit_identical(dev, B):
         return losses, grads, [p.detach().clone() for p in net.parameters()]
     try:
         ref = run(0, False)
-        for fork, graphed in ((2, False), (2, False), (2, True), (0, True), (1, False)):
-            got = run(fork, graphed)
+        for fork, graphed, merged in ((2, False, 0), (2, False, 0), (2, True, 0), (0, True, 0), (1, False, 0),
+                                      (1, False, 1), (1, True, 1), (2, True, 1)):
+            got = run(fork, graphed, merged)
             assert got[0] == ref[0], (fork, graphed, got[0], ref[0])
             assert all(torch.equal(a, b) for a, b in zip(got[2], ref[2])), (fork, graphed)
             if got[1] is not None:
                 assert all(torch.equal(a, b) for a, b in zip(got[1], ref[1])), (fork, graphed)
-        assert L.gnnpp_set_tuning(15, 3) == -1
+        assert L.gnnpp_set_tuning(15, 3) == -1 and L.gnnpp_set_tuning(18, 2) == -1
     finally:
         L.gnnpp_set_tuning(15, 1)
+        L.gnnpp_set_tuning(18, 1)
 
 
 def test_small_cotangents_keep_relative_accuracy(dev):

@@ -31,6 +31,10 @@ if has trainab; then stamp "train bench: weight-gradient fork on / off (graphed 
   for b in 64 512; do for g in "--graph" ""; do for f in "--fork" "--no-fork"; do
     timeout 300 python tools/train_bench.py --steps 100 $g --batch $b $f 2>&1 | tail -1 | tee -a $OUT/train_fork_ab.jsonl
   done; done; done; fi
+if has wgradab; then stamp "train bench: weight gradients merged into one launch (default) vs per layer (+ fork rule), B = 64 and 512"
+  for b in 64 512; do for g in "--graph" ""; do for m in "" "--wgrad-per-layer"; do
+    timeout 300 python tools/train_bench.py --steps 100 $g --batch $b $m 2>&1 | tail -1 | tee -a $OUT/train_wgrad_merged_ab.jsonl
+  done; done; done; fi
 if has wgradsweep; then stamp "train bench: workgroups per layer of the weight-gradient kernel (graphed, B = 64)"
   for w in 96 128 192 256 320 448; do
     timeout 300 python tools/train_bench.py --steps 100 --graph --wgrad-wgs $w 2>&1 | tail -1 | tee -a $OUT/train_wgrad_sweep.jsonl

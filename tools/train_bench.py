@@ -145,6 +145,8 @@ def main():
     ap.add_argument('--fork', action='store_true', help='GNNPP_TUNE_TRAIN_FORK = 2: fork whatever the batch size')
     ap.add_argument('--wgrad-wgs', type=int, default=0,
                     help='GNNPP_TUNE_TRAIN_WGRAD_WGS: workgroups per layer of the weight-gradient kernel (default 320)')
+    ap.add_argument('--wgrad-per-layer', action='store_true',
+                    help='GNNPP_TUNE_TRAIN_WGRAD_MERGED = 0: one weight-gradient launch per layer inside the chain (r05)')
     ap.add_argument('--dist-backend', default='nccl',
                     help='nccl (= RCCL, default); gloo only to exercise the data-parallel code path on a box with '
                          'fewer GPUs than ranks (with GNNPP_BENCH_DEVICE=0; eager mode only)')
@@ -163,6 +165,8 @@ def main():
             dist.init_process_group(args.dist_backend)
     from gnn_pathplanning_amd.sharding import gather_rank_devices
     from gnn_pathplanning_amd import _native
+    if args.wgrad_per_layer:
+        assert _native.lib().gnnpp_set_tuning(18, 0) == 0
     if args.wgrad_wgs:
         assert _native.lib().gnnpp_set_tuning(17, args.wgrad_wgs) == 0
     if args.no_fork or args.fork:
@@ -177,7 +181,7 @@ def main():
                 'backend': dist.get_backend() if world > 1 else None,
                 'batch_per_gpu': B, 'ms_per_step': 1e3 * per_step,
                 'final_loss': loss, 'hip_graph': bool(args.graph), 'adam': args.adam,
-                'wgrad_wgs': _native.lib().gnnpp_get_tuning(17),
+                'wgrad_wgs': _native.lib().gnnpp_get_tuning(17), 'wgrad_merged': _native.lib().gnnpp_get_tuning(18),
                 'backward_fork_knob': _native.lib().gnnpp_get_tuning(15)}
         if args.cpu_seconds > 0 and world == 1:
             cb = cpu_baseline(B, args.cpu_seconds)
