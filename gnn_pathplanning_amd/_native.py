@@ -365,6 +365,37 @@ def gemm_kmajor_multi(specs):
         check(L.gnnpp_gemm_kmajor_multi(arr, len(specs), ws.data_ptr(), stream_ptr(dev)), 'gnnpp_gemm_kmajor_multi')
 
 
+# ---- parameter-gradient products that can wait for the end of the backward pass ---------------------------------------
+# The backward pass of the planner's training step is a CHAIN of launches (each needs the gradient the one before
+# produced), and at the reference's batch every launch is mostly latency.  The products that only yield PARAMETER
+# gradients (dW, db of the two Linear layers, the filter's tap / bias gradient) are not on that chain: nothing needs them
+# before the optimizer.  They are queued here and launched together with the next product that IS needed -- the compress
+# layer's backward launch flushes the queue into its own gemm_kmajor_multi call -- so three multiply + three reduce launches
+# become one of each.  A queued product's OUTPUT tensor has already been handed to autograd (which only stores it: the
+# callers queue a product only while the parameter has no `.grad` yet, so nothing reads it early), and the autograd engine
+# runs flush_deferred_gemms as a final callback of the pass, which covers passes that never reach the flushing node.
+_deferred_gemms = []
+
+
+def defer_gemms(specs):
+    """Queue gemm_kmajor specs (tuples as for gemm_kmajor_multi; they keep their tensors alive) until flush_deferred_gemms /
+    the end of the running backward pass."""
+    if not specs:
+        return
+    if not _deferred_gemms:
+        from torch.autograd import Variable
+        Variable._execution_engine.queue_callback(flush_deferred_gemms)     # safety net: end of THIS backward pass
+    _deferred_gemms.extend(specs)
+
+
+def flush_deferred_gemms(extra=()):
+    """Launch every queued product (+ `extra`, the caller's own) in as few gemm_kmajor_multi calls as 8 products each allow."""
+    specs = list(_deferred_gemms) + list(extra)
+    del _deferred_gemms[:]
+    for i in range(0, len(specs), 8):
+        gemm_kmajor_multi(specs[i:i + 8])
+
+
 def require_gpu(*tensors):
     """Every tensor must live on one HIP device; returns that device."""
     dev = None

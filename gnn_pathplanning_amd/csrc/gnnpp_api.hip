@@ -459,7 +459,7 @@ int gnnpp_set_tuning(int key, int value) {
             g_train_wgrad_merged.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_TRAIN_WGRAD_WGS:
-            if (value < 16 || value > 2048) return GNNPP_ERR_ARG;
+            if (value != 0 && (value < 16 || value > 2048)) return GNNPP_ERR_ARG;
             g_train_wgrad_wgs.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_FILTER_SMALL:

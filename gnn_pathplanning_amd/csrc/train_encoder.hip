@@ -797,12 +797,14 @@ struct WgradAllTable {
     float* wpart[kTrainLayers];
     long x_sn[kTrainLayers], x_sb[kTrainLayers];
     int ips[kTrainLayers], jt[kTrainLayers], nx[kTrainLayers], first[kTrainLayers + 1];
+    int order[kTrainLayers];       // slot -> layer: the grid's slots hold the layers LONGEST workgroups first (below)
     int NB, B;
 };
 __global__ __launch_bounds__(256) void conv_wgrad_all_kernel(const WgradAllTable tb) {
-    int l = 0;
-    while (l + 1 < kTrainLayers && (int)blockIdx.x >= tb.first[l + 1]) ++l;       // (scalar: at most 4 steps)
-    const int local = (int)blockIdx.x - tb.first[l];
+    int sl = 0;
+    while (sl + 1 < kTrainLayers && (int)blockIdx.x >= tb.first[sl + 1]) ++sl;    // (scalar: at most 4 steps)
+    const int l = tb.order[sl];
+    const int local = (int)blockIdx.x - tb.first[sl];
     const int bx = local % tb.nx[l], by = local / tb.nx[l];
     const int Cout = tb.nx[l] * 16;
     if (l == 0)
@@ -895,11 +897,13 @@ struct TrainWs {
     int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
 };
 
-// GNNPP_TUNE_TRAIN_WGRAD_WGS: workgroups per layer of conv_wgrad_kernel (image splits x output-channel tiles).  More
-// splits = shorter workgroups but more partial slabs for conv_wgrad_reduce_kernel to sum.  Set it BEFORE a forward call:
-// the workspace size depends on it.
-std::atomic<int> g_train_wgrad_wgs{256};       // (r06 sweep at 64 x 10, graphed step: 96: 0.458, 128: 0.437, 192: 0.423,
-                                                // 256: 0.416, 320: 0.428, 448: 0.428 ms -- profiles/r06_train_wgrad_sweep.jsonl)
+// GNNPP_TUNE_TRAIN_WGRAD_WGS: workgroups per layer of the weight-gradient kernel (image splits x output-channel tiles).
+// More splits = shorter workgroups but more partial slabs for conv_wgrad_reduce_kernel to sum.  0 (default) = by the
+// batch: 128 up to 1 280 agent-samples, 256 beyond -- with the five layers in ONE launch the parallelism comes from
+// the layers (r06b, graphed step, `profiles/r06_train_wgrad_sweep.jsonl`: 64 x 10: 64: 0.370, 96: 0.358, 128: 0.350,
+// 192: 0.354, 256: 0.359, 320: 0.363, 448: 0.373 ms; 512 x 10: 128: 1.335, 256: 1.317, 512: 1.332, 1024: 1.377 ms;
+// per-layer launches, r06a: 256 was best at 64 x 10).  Set it BEFORE a forward call: the workspace size depends on it.
+std::atomic<int> g_train_wgrad_wgs{0};
 
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
@@ -929,7 +933,8 @@ inline TrainWs train_ws_layout(int N, int B) {
         // weight-gradient splits: ~320 workgroups per layer (one per 16 output channels and image range)
         w.jt[l] = (d.Cin * 9 + 1 + 15) / 16;
         w.kw[l] = w.jt[l] <= 2 ? 2 : 1;
-        const int wgs = g_train_wgrad_wgs.load(std::memory_order_relaxed);
+        const int knob = g_train_wgrad_wgs.load(std::memory_order_relaxed);
+        const int wgs = knob > 0 ? knob : NB <= 1280 ? 128 : 256;
         int ns = (wgs + d.Cout / 16 - 1) / (d.Cout / 16);
         if ((size_t)ns > NB) ns = (int)NB;
         w.ips[l] = (int)((NB + ns - 1) / ns);
@@ -1170,13 +1175,19 @@ int train_encoder_bwd(const EncRawParams& rp, const float* obs, float* ws, const
     if (merged) {                                            // the five weight gradients: ONE grid
         int blocks = 0;
         size_t smem = 0;
-        for (int l = 0; l < kTrainLayers; ++l) {
+        // slots in the order of the workgroups' durations, longest first (measured per-layer launches at 64 x 10: layer 2
+        // 19 us, 4: 13, 1: 12, 0: 11, 3: 9): the grid is ~2 rounds of the chip and the dispatcher hands out workgroups in
+        // index order -- short workgroups at the end fill the tail instead of long ones starting last
+        const int order[kTrainLayers] = {2, 4, 1, 0, 3};
+        for (int sl = 0; sl < kTrainLayers; ++sl) {
+            const int l = order[sl];
             const TrainLayerDims d = train_layer(l);
             const int P = d.H * d.W, PP = (d.H + 2) * (d.W + 2), P4 = (P + 3) / 4 * 4;
             const int IB = L.ib[l], dstride = ((IB * P4 + 63) / 64) * 64 + 4;
             const size_t sm = ((size_t)d.Cin * ((IB * PP) | 1) + 16 * (size_t)dstride) * sizeof(float);
             smem = smem > sm ? smem : sm;
-            wa.first[l] = blocks;
+            wa.order[sl] = l;
+            wa.first[sl] = blocks;
             blocks += wa.nx[l] * L.nsplit[l];
         }
         wa.first[kTrainLayers] = blocks;

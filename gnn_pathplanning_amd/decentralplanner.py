@@ -138,12 +138,16 @@ class _LinearFunction(torch.autograd.Function):
                 to hand back a gradient that is already masked by y > 0 (the graph filter's input-gradient launch
                 does: graphML._LSIGFFunction fold bit 1)
       mask_dx   x is itself the output of a ReLU whose backward is folded into THIS function's dx product (dx is
-                stored as 0 where x <= 0; the producer of x must then not mask again: _LSIGFFunction fold bit 0)"""
+                stored as 0 where x <= 0; the producer of x must then not mask again: _LSIGFFunction fold bit 0)
+      defer     1: the products that only yield parameter gradients (dW, db) wait in _native's queue for a later launch
+                of the same backward pass (r06b: they are not on the backward chain) -- only while W / b have no `.grad`
+                yet, so that autograd stores the result tensors without reading them; 2: this backward launch carries
+                the queue with it (one multiply + one reduce launch for everything queued so far and its own products)"""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu=0, mask_dx=False):
+    def forward(ctx, x, W, b, relu=0, mask_dx=False, defer=0):
         ctx.param_ptrs = (W.data_ptr(), b.data_ptr() if b is not None else 0)
-        ctx.relu, ctx.mask_dx = int(relu), bool(mask_dx)
+        ctx.relu, ctx.mask_dx, ctx.defer = int(relu), bool(mask_dx), int(defer)
         O, I = W.shape
         xd, Wd = x.detach(), W.detach()
         y = None
@@ -163,12 +167,12 @@ class _LinearFunction(torch.autograd.Function):
             y = torch.nn.functional.linear(xd, Wd, b.detach() if b is not None else None)
             if relu:
                 y = torch.relu_(y)
-        ctx.save_for_backward(x, W, y if relu == 1 else None)
+        ctx.save_for_backward(x, W, y if relu == 1 else None, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W, yrelu = ctx.saved_tensors
+        x, W, yrelu, b = ctx.saved_tensors
         O, I = W.shape
         dy2 = dy.reshape(-1, O).contiguous().float()
         if yrelu is not None:
@@ -176,20 +180,26 @@ class _LinearFunction(torch.autograd.Function):
         x2 = x.detach().reshape(-1, I).contiguous().float()
         R = dy2.shape[0]
         dx = dW = db = None
-        specs = []                                             # the three products: ONE launch (+ one for the sums)
+        specs, pspecs = [], []                                 # the three products: ONE launch (+ one for the sums)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(R, I, dtype=torch.float32, device=dy.device)
             specs.append((dy2, (0, O, 1), W.detach().contiguous().float(), (0, I), dx, (0, I), 1, R, I, O,
                           x2 if ctx.mask_dx else None))
         if ctx.needs_input_grad[1]:
             dW = _native.grad_out(ctx.param_ptrs[0], (O, I), dy.device)
-            specs.append((dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R))
+            pspecs.append((dy2, (0, 1, O), x2, (0, I), dW, (0, I), 1, O, I, R))
         if ctx.needs_input_grad[2]:
             db = _native.grad_out(ctx.param_ptrs[1], (O,), dy.device)
-            specs.append((_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R))
-        if specs:
-            _native.gemm_kmajor_multi(specs)
-        return (dx.reshape(x.shape) if dx is not None else None), dW, db, None, None
+            pspecs.append((_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R))
+        if ctx.defer == 2:
+            _native.flush_deferred_gemms(specs + pspecs)
+        elif ctx.defer == 1 and W.grad is None and (b is None or b.grad is None):
+            _native.defer_gemms(pspecs)
+            if specs:
+                _native.gemm_kmajor_multi(specs)
+        elif specs or pspecs:
+            _native.gemm_kmajor_multi(specs + pspecs)
+        return (dx.reshape(x.shape) if dx is not None else None), dW, db, None, None, None
 
 
 _ones_cache = {}
@@ -666,7 +676,8 @@ class DecentralPlannerNet(nn.Module):
         # filter's own into the action head's dx product (`fold` bit 0 <-> mask_dx) -- when the filter's input / output
         # ARE those tensors (no zero-padded nodes in between) and the filter runs on the LDS-resident kernels.
         direct = Ns == N and Ns <= gml.MAX_NODES
-        x = _LinearFunction.apply(feat, fc.weight, fc.bias, 2 if direct else 1)         # [B,N,F], ReLU in the launch
+        # (`direct`: the head's and the filter's parameter-gradient products wait for the compress layer's backward launch)
+        x = _LinearFunction.apply(feat, fc.weight, fc.bias, 2 if direct else 1, False, 2 if direct else 0)   # [B,N,F]
         if Ns != N:                                # Nin < N: zero signal on the extra nodes (graphML.py:2464-2469)
             x = torch.cat([x, x.new_zeros(B, Ns - N, x.shape[2])], 1)
         # every activation stays node-major [B,N,*] (the layout the filter kernel keeps in LDS): no transposing
@@ -676,11 +687,11 @@ class DecentralPlannerNet(nn.Module):
             gf.addGSO(self.S)
             fold = ((2 if l == 0 else 0) | (1 if l == self.L - 1 else 0)) if direct else 0
             x = gf.forward_node_major(x, relu=True, packed=packs[1] if packs else None,
-                                      packed_T=packs[2] if packs else None, fold=fold)  # [B,Ns,F_l]
+                                      packed_T=packs[2] if packs else None, fold=fold | (4 if direct else 0))  # [B,Ns,F_l]
         if Ns != N:
             x = x[:, :N]                           # ... whose outputs are dropped (index_select, :2471-2476)
         act = self.actionsMLP[0]
-        return _LinearFunction.apply(x, act.weight, act.bias, 0, direct).permute(1, 0, 2)   # [N,B,5] (a view of [B,N,5])
+        return _LinearFunction.apply(x, act.weight, act.bias, 0, direct, 1 if direct else 0).permute(1, 0, 2)   # [N,B,5]
 
     def _train_packs(self, conv_tensors):
         """(encoder train pack, filter taps forward, filter taps transposed) of the CURRENT weights by ONE

@@ -260,11 +260,14 @@ class _LSIGFFunction(torch.autograd.Function):
         fold (node-major training path only; the caller vouches for both): bit 0 -- the incoming output gradient is
         ALREADY masked by this filter's ReLU (the product that computed it did so: _LinearFunction `mask_dx`), bit 1 --
         x is the output of a ReLU whose backward is folded into this filter's input-gradient launch (dx is returned
-        masked by x > 0; the layer below must not mask again)."""
+        masked by x > 0; the layer below must not mask again), bit 2 -- the tap / bias gradient products wait in
+        _native's queue for a later launch of the same backward pass (_native.defer_gemms; only while h / b have no
+        `.grad` yet)."""
         Nin = x.shape[1] if node_major else x.shape[2]
         ctx.packed_T = packed_T
         ctx.fold = int(fold) if node_major else 0
         ctx.x_mask = x.detach() if (ctx.fold & 2) else None          # (read by the dense form's backward only)
+        ctx.bias_ref = b
         ctx.batched, ctx.Nin, ctx.has_bias = batched, Nin, b is not None
         ctx.bias_shape = None if b is None else tuple(b.shape)
         ctx.param_ptrs = (h.data_ptr(), b.data_ptr() if b is not None else 0)    # (_native.grad_out: gradient sinks)
@@ -384,7 +387,10 @@ class _LSIGFFunction(torch.autograd.Function):
             else:                                                         # per-node bias [F,N]: sum over b
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
         if specs:
-            _native.gemm_kmajor_multi(specs)
+            if (ctx.fold & 4) and h.grad is None and (ctx.bias_ref is None or ctx.bias_ref.grad is None):
+                _native.defer_gemms(specs)
+            else:
+                _native.gemm_kmajor_multi(specs)
         return dh, None, dx, db, None, None, None, None, None, None, None
 
 

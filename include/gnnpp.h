@@ -120,9 +120,10 @@ const char* gnnpp_error_string(int code);
                                          over >= 2 workgroups -- instead of contracting on the exact fp32 MFMA (2.7x the
                                          matrix-pipe time); 0 = r05's behaviour.  Same accuracy class (v330)              */
 #define GNNPP_TUNE_TRAIN_WGRAD_WGS   17  /* workgroups per layer of the training step's weight-gradient kernel (image splits x
-                                         output-channel tiles), 16 .. 2048, default 256: more splits = shorter workgroups,
-                                         more partial sums to add.  Set before gnnpp_encoder_train_workspace_floats /
-                                         _train_fwd: the workspace size depends on it.  Same gradients to rounding (v330) */
+                                         output-channel tiles): 0 (default) = by the batch (128 up to 1 280 agent-samples, 256
+                                         beyond), or 16 .. 2048: more splits = shorter workgroups, more partial sums to add.
+                                         Set before gnnpp_encoder_train_workspace_floats / _train_fwd: the workspace size
+                                         depends on it.  Same gradients to rounding (v330)                              */
 #define GNNPP_TUNE_TRAIN_WGRAD_MERGED 18 /* 1 (default): gnnpp_encoder_train_bwd computes the weight gradients of all five
                                          layers in ONE launch behind the backward chain (nothing downstream needs them before
                                          the optimizer; at 64 x 10 the five per-layer launches are 65 us of latency, their

@@ -465,6 +465,50 @@ def test_c4_batch_gradients_match_the_oracle(dev):
                 assert close(b.cpu(), sd[name].detach(), 1e-4), name
 
 
+def test_deferred_parameter_gradient_products(dev):
+    """r06b: the products that only yield parameter gradients (the action head's and the graph filter's dW / dh / db) are
+    not on the backward chain; they wait in _native's queue and ride with the compress layer's backward launch.  Queued
+    only while the parameter has no `.grad` yet (autograd then stores the result tensor without reading it): a SECOND
+    backward without zero_grad() must accumulate correctly, and a pass that never reaches the flushing node (gradients
+    of the head alone) is completed by the engine's final callback."""
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    from gnn_pathplanning_amd.training import policy_loss
+    B, N, K = 16, 10, 3
+
+    class C:
+        num_agents, nGraphFilterTaps, device = N, K, dev
+    sd0 = orc.init_state_dict(K, seed=21)
+    obs = orc.synth_obs(B, N, seed=21).to(dev)
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20, seed=21)).float().to(dev)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, N), generator=torch.Generator().manual_seed(1)), 5).float().to(dev)
+
+    def fresh():
+        net = DecentralPlannerNet(C()).to(dev)
+        net.load_state_dict(sd0)
+        net.train()
+        net.addGSO(S)
+        return net
+    net = fresh()
+    policy_loss(net(obs), tgt).backward()
+    assert not _native._deferred_gemms                       # everything queued was launched inside the pass
+    once = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.load_state_dict(sd0)                                 # (the first forward moved the running statistics)
+    policy_loss(net(obs), tgt).backward()                    # accumulate: `.grad` exists -> nothing may be deferred
+    for k, p in net.named_parameters():
+        assert close(p.grad.cpu(), 2 * once[k].cpu(), 1e-5), k
+    # a partial pass: only the head's parameters -> the compress layer's node (the flushing one) never runs
+    net2 = fresh()
+    out = net2(obs)
+    gw, gb = torch.autograd.grad(policy_loss(out, tgt), [net2.actionsMLP[0].weight, net2.actionsMLP[0].bias])
+    assert not _native._deferred_gemms
+    assert torch.equal(gw, once['actionsMLP.0.weight']) and torch.equal(gb, once['actionsMLP.0.bias'])
+    # ... and the filter's alone
+    net3 = fresh()
+    gh, = torch.autograd.grad(policy_loss(net3(obs), tgt), [net3.GFL[0].weight])
+    assert not _native._deferred_gemms and torch.equal(gh, once['GFL.0.weight'])
+
+
 def test_fused_adam_and_loss_match_torch(dev):
     """The one-launch pieces of the optimisation step against stock torch on the same model and batches:
     policy_loss_fused == policy_loss (value and gradient of every parameter), and FusedAdam (gnnpp_adam_step)
