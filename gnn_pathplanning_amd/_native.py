@@ -377,21 +377,36 @@ def gemm_kmajor_multi(specs):
 _deferred_gemms = []
 
 
-def defer_gemms(specs):
-    """Queue gemm_kmajor specs (tuples as for gemm_kmajor_multi; they keep their tensors alive) until flush_deferred_gemms /
-    the end of the running backward pass."""
+def defer_gemms(specs, params):
+    """Queue gemm_kmajor specs (tuples as for gemm_kmajor_multi; they keep their INPUT tensors alive) until
+    flush_deferred_gemms / the end of the running backward pass.  params[i] = the parameter whose gradient spec i
+    computes.  The OUTPUT tensor of a spec is held WEAKLY: autograd adopts a gradient as `.grad` without a copy only
+    when nobody else references it (AccumulateGrad's use-count test), so a strong reference from this queue would make
+    it clone the still-uncomputed buffer.  At flush time the product is written to the tensor that then IS the gradient:
+    the one handed to autograd if it is still alive (adopted as `.grad`, or captured by torch.autograd.grad), else the
+    parameter's `.grad` (autograd cloned after all)."""
+    import weakref
     if not specs:
         return
     if not _deferred_gemms:
         from torch.autograd import Variable
         Variable._execution_engine.queue_callback(flush_deferred_gemms)     # safety net: end of THIS backward pass
-    _deferred_gemms.extend(specs)
+    for sp, prm in zip(specs, params):
+        _deferred_gemms.append((sp[:4], weakref.ref(sp[4]), tuple(sp[4].shape), sp[5:], prm))
 
 
 def flush_deferred_gemms(extra=()):
     """Launch every queued product (+ `extra`, the caller's own) in as few gemm_kmajor_multi calls as 8 products each allow."""
-    specs = list(_deferred_gemms) + list(extra)
+    specs = []
+    for head, ref, shape, tail, prm in _deferred_gemms:
+        out = ref()
+        if out is None:
+            out = prm.grad                                # (autograd cloned the gradient: the clone is the gradient now)
+        if out is None or tuple(out.shape) != shape or not out.is_contiguous():
+            continue                                      # nobody holds the result any more
+        specs.append(head + (out,) + tail)
     del _deferred_gemms[:]
+    specs += list(extra)
     for i in range(0, len(specs), 8):
         gemm_kmajor_multi(specs[i:i + 8])
 

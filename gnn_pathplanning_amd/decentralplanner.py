@@ -194,7 +194,7 @@ class _LinearFunction(torch.autograd.Function):
         if ctx.defer == 2:
             _native.flush_deferred_gemms(specs + pspecs)
         elif ctx.defer == 1 and W.grad is None and (b is None or b.grad is None):
-            _native.defer_gemms(pspecs)
+            _native.defer_gemms(pspecs, ([W] if dW is not None else []) + ([b] if db is not None else []))
             if specs:
                 _native.gemm_kmajor_multi(specs)
         elif specs or pspecs:

@@ -376,19 +376,21 @@ class _LSIGFFunction(torch.autograd.Function):
                 dx = _LSIGFFunction._dense_dx(ctx, h, S, dy)
                 if mask is not None:
                     dx = torch.ops.aten.threshold_backward(dx.contiguous(), mask.reshape(dx.shape), 0)
-        specs = []
+        specs, prms = [], []
         if ctx.needs_input_grad[0]:
             dh = _native.grad_out(ctx.param_ptrs[0], (F_out, E, K, G), dy.device)
             specs.append((dy, (0, 1, F_out), zs, (B * N * G, G), dh, (G, E * K * G), E * K, F_out, G, B * N))
+            prms.append(h)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             if ctx.bias_shape[-1] == 1 or len(ctx.bias_shape) == 1:
                 db = _native.grad_out(ctx.param_ptrs[1], ctx.bias_shape, dy.device)          # sum over (b, n)
                 specs.append((_ones(B * N, dy.device), (0, 0, 1), dy, (0, F_out), db, (0, F_out), 1, 1, F_out, B * N))
+                prms.append(ctx.bias_ref)
             else:                                                         # per-node bias [F,N]: sum over b
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
         if specs:
             if (ctx.fold & 4) and h.grad is None and (ctx.bias_ref is None or ctx.bias_ref.grad is None):
-                _native.defer_gemms(specs)
+                _native.defer_gemms(specs, prms)
             else:
                 _native.gemm_kmajor_multi(specs)
         return dh, None, dx, db, None, None, None, None, None, None, None
