@@ -421,6 +421,72 @@ def test_output_slot_recycles_only_what_nobody_can_observe():
     assert s.fresh == n_fresh + 3
 
 
+def test_deferred_gemm_queue_writes_to_whatever_is_the_gradient(monkeypatch):
+    """r06b: products that only yield parameter gradients wait in _native's queue until a later launch of the same
+    backward pass (_native.defer_gemms / flush_deferred_gemms).  The queue holds a product's OUTPUT weakly -- a strong
+    reference would make autograd's AccumulateGrad clone the still-uncomputed buffer -- and at flush time writes to the
+    tensor that then IS the gradient: the adopted `.grad` (same storage, new tensor object), the tensor captured by
+    torch.autograd.grad, or nothing when nobody holds the result.  The autograd engine runs the flush as a final callback
+    of the pass.  (GPU twin with the real GEMM: tests/test_gpu_training.py::test_deferred_parameter_gradient_products.)"""
+    import torch
+    from gnn_pathplanning_amd import _native
+    launches = []
+
+    def fake_multi(specs):                                   # C = A^T-ish products of this test: out <- A @ B
+        launches.append(len(specs))
+        for sp in specs:
+            sp[4].copy_(sp[0] @ sp[2])
+    monkeypatch.setattr(_native, 'gemm_kmajor_multi', fake_multi)
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, W, flush):
+            ctx.save_for_backward(x, W)
+            ctx.flush = flush
+            return x @ W.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, W = ctx.saved_tensors
+            dW = torch.full_like(W, float('nan'))            # "uncomputed"
+            spec = (g.t().contiguous(), None, x, None, dW, None, 1, 0, 0, 0)
+            if ctx.flush:
+                _native.flush_deferred_gemms([spec])
+            elif W.grad is None:
+                _native.defer_gemms([spec], [W])
+            else:
+                _native.gemm_kmajor_multi([spec])
+            return g @ W, dW, None
+    x = torch.arange(12.0).reshape(4, 3)
+    W1, W2 = torch.nn.Parameter(torch.ones(2, 3)), torch.nn.Parameter(torch.ones(3, 3))
+    want1 = (torch.ones(4, 2).t() @ (x @ W2.detach().t()))
+    # (1) the queued product of the LAST layer rides with the flushing (first) layer's launch: one launch, two products
+    Lin.apply(Lin.apply(x, W2, True), W1, False).sum().backward()
+    assert launches == [2] and not _native._deferred_gemms
+    assert torch.equal(W1.grad, want1) and torch.isfinite(W2.grad).all()
+    # (2) accumulation: `.grad` exists -> the caller computes at once (nothing queued), autograd adds
+    launches.clear()
+    Lin.apply(Lin.apply(x, W2, True), W1, False).sum().backward()
+    assert launches == [1, 1] and torch.equal(W1.grad, 2 * want1)
+    # (3) a pass that never reaches a flushing node: the engine's final callback launches the queue
+    W1.grad = None
+    launches.clear()
+    g1, = torch.autograd.grad(Lin.apply(x @ W2.detach().t(), W1, False).sum(), [W1])
+    assert launches == [1] and not _native._deferred_gemms and torch.equal(g1, want1)
+    W1.grad = None
+    launches.clear()
+    Lin.apply(x @ W2.detach().t(), W1, False).sum().backward()
+    assert launches == [1] and torch.equal(W1.grad, want1)
+    # (4) nobody holds the result any more at flush time: skipped, not written into freed memory
+    launches.clear()
+    t = torch.empty(2, 3)
+    _native._deferred_gemms.append(((torch.ones(2, 4), None, torch.ones(4, 3), None), __import__('weakref').ref(t), (2, 3),
+                                    (None, 1, 0, 0, 0), torch.nn.Parameter(torch.ones(2, 3))))
+    del t
+    _native.flush_deferred_gemms()
+    assert launches == [] and not _native._deferred_gemms
+
+
 def test_driver_line_is_bounded_and_round_trips():
     """the driver could not parse the 23 KB line of round 5 (BENCH_r05.json parsed: null).  The line
     bench.py prints is now bench.driver_line(result): the contract keys + roofline + cpu_baseline + parity + summary in
