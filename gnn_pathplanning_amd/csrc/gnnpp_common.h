@@ -353,5 +353,27 @@ struct EncLayout {
     static constexpr int kTotal = kBss + kBssFloats;
 };
 
+// ---- in-launch hand-off between workgroups (cdna_hip_programming.md, guideline 16) ---------------------------------
+// Per-XCD L2s are not coherent with each other and a CU's L1 is not refreshed by other CUs' stores: data one workgroup
+// wrote for another workgroup of the SAME launch is published by  every writing wave drains its stores -> barrier ->
+// one lane: agent-scope RELEASE fence (+ the drain restated where the compiler cannot drop it) -> relaxed agent-scope
+// ticket;  the workgroup that draws the last ticket: one lane agent-scope ACQUIRE fence -> barrier -> plain loads.
+__device__ __forceinline__ void handoff_drain_stores() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void handoff_release() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void handoff_acquire() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+
 }  // namespace gnnpp
 #endif

@@ -408,10 +408,38 @@ __device__ __forceinline__ float bn_act(float yv, float mean, float invstd, floa
     return fmaxf(fmaf((yv - mean) * invstd, g, be), 0.f);
 }
 
+// The running-statistics update (nn.BatchNorm2d in train mode: r <- (1 - momentum) r + momentum * batch statistic,
+// unbiased variance; the N per-agent-call updates in agent order) INSIDE the forward's last bn_relu_pool launch (r06b;
+// r05 / r06a: bn_running_kernel, a launch of its own).  mode 1 (the first layer's launch): zero the arrival counters.
+// mode 2 (the last layer's launch, grid z = N + 1): the extra z plane updates layers 0 .. L-2, whose statistics earlier
+// launches wrote (workgroup x = layer); the last layer's statistics are written by THIS launch's workgroups (x, 0, n),
+// n = 0 .. N-1, so the N workgroups of a channel tile x publish them with the release / ticket / acquire hand-off of
+// gnnpp_common.h and the one that arrives last updates the tile's channels.
+struct BnRunningFuse {
+    const float* stat[kTrainLayers];
+    float* rmean[kTrainLayers];
+    float* rvar[kTrainLayers];
+    long long* nb[kTrainLayers];                   // num_batches_tracked (+= N) or nullptr
+    unsigned* tick;                                // [C_last / CG_last <= 8] arrival counters
+    float momentum;
+    int mode, N;
+};
+__device__ __forceinline__ void bn_running_update(const float* __restrict__ stat, float* __restrict__ rmean,
+                                                  float* __restrict__ rvar, int C, int c, int N, float momentum) {
+    float m = rmean[c], v = rvar[c];
+    for (int n = 0; n < N; ++n) {
+        const float* st = stat + ((long)n * C + c) * 4;
+        m = (1.f - momentum) * m + momentum * st[0];
+        v = (1.f - momentum) * v + momentum * st[2];
+    }
+    rmean[c] = m;
+    rvar[c] = v;
+}
+
 // grid = (C / CG, ceil(B / BR), N), block = 256: BatchNorm statistics of the workgroup's channels from the
 // convolution's partial sums (m = B * P values each), then the element-wise part over images [b0, b0 + BR).
 // stat[(n*C + c)*4 + {0: mean, 1: invstd, 2: unbiased variance (running stats), 3: unused}] is written by
-// the workgroups of the first image range (the backward pass and bn_running_kernel read it).
+// the workgroups of the first image range (the backward pass and the running-statistics update read it).
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ y,
                                                            const float* __restrict__ part,
                                                            float* __restrict__ stat,
@@ -419,10 +447,23 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ xn, int B, int C, int H, int W,
                                                            int pool, int chunks, int CG, int BR, float eps,
-                                                           int out_bn) {
+                                                           int out_bn, const BnRunningFuse rf) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     double* red = reinterpret_cast<double*>(gnnpp_smem);                               // [512]
     float (*sm)[5] = reinterpret_cast<float (*)[5]>(gnnpp_smem + 512 * sizeof(double));  // mean, invstd, gamma, beta
+    const int N = rf.mode == 2 ? rf.N : (int)gridDim.z;
+    if (rf.mode == 1 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8)
+        rf.tick[threadIdx.x] = 0u;                               // (a later launch of this stream takes the tickets)
+    if (rf.mode == 2 && (int)blockIdx.z == N) {                  // the extra plane: layers 0 .. L-2
+        const int l = blockIdx.x;
+        if (blockIdx.y == 0 && l < kTrainLayers - 1) {
+            const int Cl = train_layer(l).Cout;
+            if ((int)threadIdx.x < Cl)
+                bn_running_update(rf.stat[l], rf.rmean[l], rf.rvar[l], Cl, threadIdx.x, N, rf.momentum);
+            if (threadIdx.x == 0 && rf.nb[l]) *rf.nb[l] += N;
+        }
+        return;
+    }
     const int n = blockIdx.z, c0 = blockIdx.x * CG, b0 = blockIdx.y * BR;
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W, Po = Ho * Wo, P = H * W;
     reduce_partials(part, n, chunks, C, c0, CG, red);
@@ -466,8 +507,29 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
         }
         // out_bn: image (n, b) of the OUTPUT sits at b*N + n (sample-major, what the graph filter reads
         // node-major) instead of n*B + b
-        const long io = out_bn ? ((long)(b0 + bi) * gridDim.z + n) * C + c0 + cc : ic;
+        const long io = out_bn ? ((long)(b0 + bi) * N + n) * C + c0 + cc : ic;
         xn[io * Po + po] = v;
+    }
+    if (rf.mode == 2 && blockIdx.y == 0) {
+        // this workgroup wrote the statistics of (agent n, channels c0 .. c0 + CG): publish them; the last of the tile's N
+        // workgroups to arrive runs the N sequential updates of those channels
+        const int L = kTrainLayers - 1;
+        handoff_drain_stores();
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(&sm[0][0]);        // (the statistics table is dead now)
+        if (threadIdx.x == 0) {
+            handoff_release();
+            const unsigned t = __hip_atomic_fetch_add(rf.tick + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = t == (unsigned)N - 1u;
+            if (last) handoff_acquire();
+            *flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flag) {
+            if ((int)threadIdx.x < CG)
+                bn_running_update(rf.stat[L], rf.rmean[L], rf.rvar[L], C, c0 + threadIdx.x, N, rf.momentum);
+            if (threadIdx.x == 0 && blockIdx.x == 0 && rf.nb[L]) *rf.nb[L] += N;
+        }
     }
 }
 
@@ -891,7 +953,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradReduc
 //            (gradients w.r.t. layer inputs, ping-pong) | coef (per-agent BN-backward sums) | wpart x 5 (per layer)
 struct TrainWs {
     size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers], wtb[kTrainLayers];
-    size_t part, dz[kTrainLayers], dxa, dxb, coef, wpart[kTrainLayers], total;
+    size_t part, dz[kTrainLayers], dxa, dxb, coef, wpart[kTrainLayers], tick, total;
     int chunks[kTrainLayers];
     // conv_wgrad_kernel: image splits, images per split, images per LDS batch, j tiles, K groups per workgroup
     int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
@@ -904,6 +966,7 @@ struct TrainWs {
 // 192: 0.354, 256: 0.359, 320: 0.363, 448: 0.373 ms; 512 x 10: 128: 1.335, 256: 1.317, 512: 1.332, 1024: 1.377 ms;
 // per-layer launches, r06a: 256 was best at 64 x 10).  Set it BEFORE a forward call: the workspace size depends on it.
 std::atomic<int> g_train_wgrad_wgs{0};
+std::atomic<int> g_train_running_fused{1};      // GNNPP_TUNE_TRAIN_RUNNING_FUSED
 
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
@@ -950,6 +1013,7 @@ inline TrainWs train_ws_layout(int N, int B) {
     w.dxa = take(max_x);
     w.dxb = take(max_x);
     w.coef = take((size_t)kTrainLayers * N * 128 * 2);   // per-agent sums of the BN backward, [layer][N][128][2]
+    w.tick = take(8);                                      // arrival counters of the fused running-statistics update
     for (int l = 0; l < kTrainLayers; ++l) w.wpart[l] = take(wp[l]);   // (one per layer: summed by ONE launch at the end)
     w.total = o;
     return w;
@@ -1027,6 +1091,19 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
     }
     if (!enc_pack)
         hipLaunchKernelGGL(pack_train_weights_kernel, dim3(128, 2 * kTrainLayers), dim3(256), 0, st, pk, TrainFilterPack{});
+    // GNNPP_TUNE_TRAIN_RUNNING_FUSED (default 1): the running-statistics update inside the last bn_relu_pool launch
+    const BnTile tl = bn_tile(kTrainLayers - 1);
+    const int last_tiles = train_layer(kTrainLayers - 1).Cout / tl.CG;
+    const bool fuse_running = rmean && rvar && g_train_running_fused.load(std::memory_order_relaxed) != 0 &&
+                              last_tiles >= kTrainLayers - 1 && last_tiles <= 8;
+    BnRunningFuse rf = {};
+    for (int l = 0; l < kTrainLayers; ++l) {
+        rf.stat[l] = ws + L.stat[l];
+        rf.rmean[l] = rmean ? rmean[l] : nullptr; rf.rvar[l] = rvar ? rvar[l] : nullptr;
+        rf.nb[l] = num_batches ? num_batches[l] : nullptr;
+    }
+    rf.tick = reinterpret_cast<unsigned*>(ws + L.tick);
+    rf.momentum = momentum; rf.N = N;
     for (int l = 0; l < kTrainLayers; ++l) {
         const TrainLayerDims d = train_layer(l);
         const int P = d.H * d.W;
@@ -1035,12 +1112,18 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
         conv_launch(l, false, xin, wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, sn, sb, st);
         const BnTile t = bn_tile(l);
-        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N), dim3(256), kBnSmem, st,
-                           ws + L.y[l], ws + L.part, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
-                           l == kTrainLayers - 1 ? feat : ws + L.xn[l], B, d.Cout, d.H, d.W, d.pool,
-                           conv_chunks(l, B), t.CG, t.BR, rp.bn_eps, (l == kTrainLayers - 1 && feat_bn) ? 1 : 0);
+        BnRunningFuse f = {};
+        const bool last = l == kTrainLayers - 1;
+        if (fuse_running && (l == 0 || last)) {
+            f = rf;
+            f.mode = last ? 2 : 1;
+        }
+        hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N + (f.mode == 2 ? 1 : 0)),
+                           dim3(256), kBnSmem, st, ws + L.y[l], ws + L.part, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
+                           last ? feat : ws + L.xn[l], B, d.Cout, d.H, d.W, d.pool,
+                           conv_chunks(l, B), t.CG, t.BR, rp.bn_eps, (last && feat_bn) ? 1 : 0, f);
     }
-    if (rmean && rvar) {
+    if (rmean && rvar && !fuse_running) {
         TrainCounters nb = {};
         for (int l = 0; l < kTrainLayers; ++l) nb.c[l] = num_batches ? num_batches[l] : nullptr;
         hipLaunchKernelGGL(bn_running_kernel, dim3(1, kTrainLayers), dim3(128), 0, st, run, nb, N, momentum);

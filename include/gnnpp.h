@@ -129,6 +129,10 @@ const char* gnnpp_error_string(int code);
                                          the optimizer; at 64 x 10 the five per-layer launches are 65 us of latency, their
                                          MFMAs 14 us); 0: one launch per layer inside the chain, where GNNPP_TUNE_TRAIN_FORK
                                          can move them to a second stream.  Same gradients to the bit (v330)               */
+#define GNNPP_TUNE_TRAIN_RUNNING_FUSED 19 /* 1 (default): gnnpp_encoder_train_fwd updates the BatchNorm running statistics inside
+                                         its last BatchNorm launch (the workgroups of a channel tile publish their statistics
+                                         with an agent-scope release / ticket / acquire hand-off and the last one to arrive
+                                         runs the N updates); 0: a launch of its own (r05).  Same statistics to the bit (v330) */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

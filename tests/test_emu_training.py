@@ -90,6 +90,26 @@ def test_emu_train_encoder_forward_backward(N, B, seed, fbn, ext_pack):
                                      fbn, el.ptr(tp) if tp is not None else None, None)
     assert rc == 0
     assert all(int(a[0]) == 7 + N for a in nbt)
+    # r06b: the running-statistics update rides in the forward's last BatchNorm launch (GNNPP_TUNE_TRAIN_RUNNING_FUSED,
+    # default); the launch of its own (knob 19 = 0) gives the same bits
+    assert lib.gnnpp_get_tuning(19) == 1 and lib.gnnpp_set_tuning(19, 0) == 0
+    try:
+        arrs2 = {k: el.f32(sd[k].numpy().copy()) for k in arrs if 'running' in k}
+        P2 = el.EncParams()
+        ctypes.memmove(ctypes.byref(P2), ctypes.byref(P), ctypes.sizeof(P))
+        for i in range(5):
+            P2.bn_mean[i] = arrs2['ConvLayers.%d.running_mean' % BN[i]].ctypes.data
+            P2.bn_var[i] = arrs2['ConvLayers.%d.running_var' % BN[i]].ctypes.data
+        ws2, feat2 = np.zeros_like(ws), np.full((N, B, 128), np.nan, np.float32)
+        nbt2 = [np.full(1, 7, np.int64) for _ in range(5)]
+        rc = lib.gnnpp_encoder_train_fwd(ctypes.byref(P2), el.ptr(obs_np), el.ptr(ws2), el.ptr(feat2), B, N,
+                                         ctypes.c_float(0.1), 1, (ctypes.c_void_p * 5)(*[a.ctypes.data for a in nbt2]),
+                                         fbn, el.ptr(tp) if tp is not None else None, None)
+        assert rc == 0 and all(int(a[0]) == 7 + N for a in nbt2)
+        for k, a2 in arrs2.items():
+            assert np.array_equal(a2, arrs[k]), k
+    finally:
+        assert lib.gnnpp_set_tuning(19, 1) == 0
     if fbn:                                                  # feat_sample_major: the same rows as [B,N,128]
         feat = np.ascontiguousarray(feat.reshape(B, N, 128).transpose(1, 0, 2))
     assert np.abs(feat - want_feat.numpy()).max() <= 2e-5 * max(1.0, want_feat.abs().max().item())

@@ -465,6 +465,55 @@ def test_c4_batch_gradients_match_the_oracle(dev):
                 assert close(b.cpu(), sd[name].detach(), 1e-4), name
 
 
+@pytest.mark.parametrize('B,N', [(64, 10), (7, 3), (33, 50)])
+def test_running_statistics_inside_the_last_batchnorm_launch(dev, B, N):
+    """r06b: the BatchNorm running-statistics update rides in the forward's LAST BatchNorm launch
+    (GNNPP_TUNE_TRAIN_RUNNING_FUSED): the N workgroups of a channel tile publish the statistics they computed with an
+    agent-scope release / ticket / acquire hand-off (per-XCD L2s are not coherent) and the last one to arrive runs the N
+    sequential updates.  Against the launch of its own (knob 19 = 0): the same running_mean / running_var /
+    num_batches_tracked BIT FOR BIT over many repetitions (a stale cross-XCD read would show up as a difference), and
+    against the oracle's per-agent-call loop."""
+    from gnn_pathplanning_amd import _native
+    from gnn_pathplanning_amd.decentralplanner import DecentralPlannerNet
+    L = _native.lib()
+
+    class C:
+        num_agents, nGraphFilterTaps, device = N, 3, dev
+    sd0 = orc.init_state_dict(3, seed=B + N)
+    obs = [orc.synth_obs(B, N, seed=s).to(dev) for s in range(4)]
+    S = torch.from_numpy(orc.synth_gso_geometric(B, N, 20 if N <= 10 else 50, seed=1)).float().to(dev)
+
+    def run(fused, reps):
+        assert L.gnnpp_set_tuning(19, fused) == 0 and L.gnnpp_get_tuning(19) == fused
+        net = DecentralPlannerNet(C()).to(dev)
+        net.load_state_dict(sd0)
+        net.train()
+        net.addGSO(S)
+        with torch.no_grad():
+            for r in range(reps):
+                net(obs[r % 4])
+        torch.cuda.synchronize()
+        return {k: b.detach().clone() for k, b in net.named_buffers()}
+    try:
+        reps = 60
+        ref = run(0, reps)
+        for _ in range(3):
+            got = run(1, reps)
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), k
+        one = run(1, 1)
+    finally:
+        L.gnnpp_set_tuning(19, 1)
+    sd2 = {k: v.clone() for k, v in sd0.items()}
+    with torch.no_grad():
+        orc.policy_forward(sd2, S.cpu(), obs[0].cpu(), training=True)
+    for k, v in one.items():
+        if 'running' in k:
+            assert (v.cpu() - sd2[k]).abs().max().item() <= 2e-5, k
+        elif 'num_batches' in k:
+            assert int(v) == int(sd0[k]) + N, k
+
+
 def test_deferred_parameter_gradient_products(dev):
     """r06b: the products that only yield parameter gradients (the action head's and the graph filter's dW / dh / db) are
     not on the backward chain; they wait in _native's queue and ride with the compress layer's backward launch.  Queued
