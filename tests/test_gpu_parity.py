@@ -1251,3 +1251,35 @@ def test_general_filter_n_way_split_is_bit_identical(dev, B, N, G, F_out, K, E):
     assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max())
     assert np.abs(outs[7][2].numpy() - orc.lsigf_f64(h.numpy(), S.numpy(), x.permute(0, 2, 1).numpy(),
                                                       bias.numpy().reshape(F_out, 1))).max() <= TOL * max(1.0, np.abs(want).max())
+
+
+def test_bench_prints_one_parseable_line_of_at_most_6_kb(dev, tmp_path):
+    """VERDICT r05 item 1, end to end on the GPU: `python bench.py` (short regions, the secondary block and the CPU baseline
+    off to keep the test short) prints ONE JSON line of <= 6 144 bytes carrying the contract keys, `roofline` and `parity`,
+    names the side file it wrote, and that side file holds the full record the line was derived from."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    details = str(tmp_path / 'bench_full.json')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3',
+                        '--repeats', '3', '--no-secondary', '--no-cpu-baseline', '--pmc', 'off', '--details-file', details],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 6144, (len(lines), [len(x) for x in lines])
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'parity', 'summary', 'details_file'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 10 and d['warmup'] == 3 and d['vs_baseline'] is None
+    assert d['value'] > 1e7 and abs(d['value'] - 5120 / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+    assert d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1 / 6
+    assert d['parity']['max_abs_dlogit'] <= 1e-4 and d['parity']['argmax_equal_on_clear_rows'] is True
+    full = json.load(open(details))
+    assert full['value'] == pytest.approx(d['value'], rel=1e-5) and 'step_breakdown_us' in full
+    sys.path.insert(0, root)
+    import bench
+    assert bench.driver_line(full, d['details_file']) == lines[0]
