@@ -375,6 +375,33 @@ def gemm_kmajor_multi(specs):
 # callers queue a product only while the parameter has no `.grad` yet, so nothing reads it early), and the autograd engine
 # runs flush_deferred_gemms as a final callback of the pass, which covers passes that never reach the flushing node.
 _deferred_gemms = []
+_defer_depth = 0
+
+
+class allow_deferred_gemms:
+    """Deferral is OPT-IN per backward pass: training.train_step (and with it GraphedTrainStep) runs its backward inside
+    this context.  A plain `loss.backward()` of a caller of the reference API computes every gradient inside the node
+    that returns it, as autograd's contract says -- a tensor hook on a parameter, or the post-accumulate hooks
+    torch.nn.parallel.DistributedDataParallel hangs on every parameter's AccumulateGrad node, READ the gradient the
+    moment the node has returned it and would see a queued product's still-uncomputed buffer."""
+
+    def __enter__(self):
+        global _defer_depth
+        _defer_depth += 1
+
+    def __exit__(self, *exc):
+        global _defer_depth
+        _defer_depth -= 1
+        if _deferred_gemms:                               # (a pass that raised half-way: nothing may stay queued)
+            if exc[0] is None:
+                flush_deferred_gemms()
+            else:
+                del _deferred_gemms[:]
+        return False
+
+
+def deferral_allowed():
+    return _defer_depth > 0
 
 
 def defer_gemms(specs, params):

@@ -193,7 +193,7 @@ class _LinearFunction(torch.autograd.Function):
             pspecs.append((_ones(R, dy.device), (0, 0, 1), dy2, (0, O), db, (0, O), 1, 1, O, R))
         if ctx.defer == 2:
             _native.flush_deferred_gemms(specs + pspecs)
-        elif ctx.defer == 1 and W.grad is None and (b is None or b.grad is None):
+        elif (ctx.defer == 1 and _native.deferral_allowed() and W.grad is None and (b is None or b.grad is None)):
             _native.defer_gemms(pspecs, ([W] if dW is not None else []) + ([b] if db is not None else []))
             if specs:
                 _native.gemm_kmajor_multi(specs)

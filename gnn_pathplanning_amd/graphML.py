@@ -389,7 +389,8 @@ class _LSIGFFunction(torch.autograd.Function):
             else:                                                         # per-node bias [F,N]: sum over b
                 db = dy.sum(dim=0).t().contiguous().reshape(ctx.bias_shape)
         if specs:
-            if (ctx.fold & 4) and h.grad is None and (ctx.bias_ref is None or ctx.bias_ref.grad is None):
+            if ((ctx.fold & 4) and _native.deferral_allowed() and h.grad is None
+                    and (ctx.bias_ref is None or ctx.bias_ref.grad is None)):
                 _native.defer_gemms(specs, prms)
             else:
                 _native.gemm_kmajor_multi(specs)

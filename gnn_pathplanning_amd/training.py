@@ -167,10 +167,14 @@ def train_step(model, optimizer, batch_input, batch_target, batch_GSO, dp=None):
         # loss and d loss / d logits from one launch; backward starts at the logits (what loss.backward() does,
         # minus the ones_like fill and the multiplication by it)
         loss, dlogits = _policy_loss_and_grad(stacked, batch_target)
-        stacked.backward(dlogits)
+        # (this step owns its backward pass -- no hooks read a gradient before the pass has ended --, so the products that
+        # only yield parameter gradients may wait for one later launch of the pass: _native.allow_deferred_gemms)
+        with _native.allow_deferred_gemms():
+            stacked.backward(dlogits)
     else:
         loss = policy_loss(predict, batch_target)
-        loss.backward()
+        with _native.allow_deferred_gemms():
+            loss.backward()
     if dp is not None:
         dp.reduce_gradients()
     optimizer.step()

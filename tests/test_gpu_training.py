@@ -538,23 +538,45 @@ def test_deferred_parameter_gradient_products(dev):
         net.train()
         net.addGSO(S)
         return net
-    net = fresh()
-    policy_loss(net(obs), tgt).backward()
+    # deferral is opt-in per backward pass (training.train_step): a plain loss.backward() computes every gradient inside
+    # the node that returns it -- a tensor hook (or DistributedDataParallel's accumulate hooks) reads it right there
+    net0 = fresh()
+    seen = {}
+    net0.actionsMLP[0].weight.register_hook(lambda g: seen.__setitem__('head', g.clone()))
+    net0.GFL[0].weight.register_hook(lambda g: seen.__setitem__('taps', g.clone()))
+    queued = []
+    orig_defer = _native.defer_gemms
+    _native.defer_gemms = lambda specs, prms: (queued.append(len(specs)), orig_defer(specs, prms))[1]
+    try:
+        policy_loss(net0(obs), tgt).backward()
+        assert queued == [] and torch.equal(seen['head'], net0.actionsMLP[0].weight.grad)
+        assert torch.equal(seen['taps'], net0.GFL[0].weight.grad)
+        net = fresh()
+        with _native.allow_deferred_gemms():
+            policy_loss(net(obs), tgt).backward()
+        assert queued == [2, 2]                              # the head's and the filter's dW / dh + db waited
+    finally:
+        _native.defer_gemms = orig_defer
     assert not _native._deferred_gemms                       # everything queued was launched inside the pass
     once = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for k, p in net0.named_parameters():
+        assert torch.equal(p.grad, once[k]), k               # the same kernels on the same data: the same bits
     net.load_state_dict(sd0)                                 # (the first forward moved the running statistics)
-    policy_loss(net(obs), tgt).backward()                    # accumulate: `.grad` exists -> nothing may be deferred
+    with _native.allow_deferred_gemms():
+        policy_loss(net(obs), tgt).backward()                # accumulate: `.grad` exists -> nothing may be deferred
     for k, p in net.named_parameters():
         assert close(p.grad.cpu(), 2 * once[k].cpu(), 1e-5), k
     # a partial pass: only the head's parameters -> the compress layer's node (the flushing one) never runs
     net2 = fresh()
     out = net2(obs)
-    gw, gb = torch.autograd.grad(policy_loss(out, tgt), [net2.actionsMLP[0].weight, net2.actionsMLP[0].bias])
+    with _native.allow_deferred_gemms():
+        gw, gb = torch.autograd.grad(policy_loss(out, tgt), [net2.actionsMLP[0].weight, net2.actionsMLP[0].bias])
     assert not _native._deferred_gemms
     assert torch.equal(gw, once['actionsMLP.0.weight']) and torch.equal(gb, once['actionsMLP.0.bias'])
     # ... and the filter's alone
     net3 = fresh()
-    gh, = torch.autograd.grad(policy_loss(net3(obs), tgt), [net3.GFL[0].weight])
+    with _native.allow_deferred_gemms():
+        gh, = torch.autograd.grad(policy_loss(net3(obs), tgt), [net3.GFL[0].weight])
     assert not _native._deferred_gemms and torch.equal(gh, once['GFL.0.weight'])
 
 
