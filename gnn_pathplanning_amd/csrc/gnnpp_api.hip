@@ -401,7 +401,6 @@ int gnnpp_get_tuning(int key) {
         case GNNPP_TUNE_TRAIN_WGRAD_WGS: return g_train_wgrad_wgs.load();
         case GNNPP_TUNE_TRAIN_WGRAD_MERGED: return g_train_wgrad_merged.load();
         case GNNPP_TUNE_TRAIN_RUNNING_FUSED: return g_train_running_fused.load();
-        case GNNPP_TUNE_TRAIN_BN_FUSED: return g_train_bn_fused.load();
 #ifdef GNNPP_MEASURE
         case GNNPP_TUNE_FILTER_ABLATE: return g_filter_ablate.load();
         case GNNPP_TUNE_ENCODER_STOP: return g_encoder_stop.load();
@@ -463,10 +462,6 @@ int gnnpp_set_tuning(int key, int value) {
         case GNNPP_TUNE_TRAIN_RUNNING_FUSED:
             if (value < 0 || value > 1) return GNNPP_ERR_ARG;
             g_train_running_fused.store(value);
-            return GNNPP_OK;
-        case GNNPP_TUNE_TRAIN_BN_FUSED:
-            if (value < 0 || value > 1) return GNNPP_ERR_ARG;
-            g_train_bn_fused.store(value);
             return GNNPP_OK;
         case GNNPP_TUNE_TRAIN_WGRAD_WGS:
             if (value != 0 && (value < 16 || value > 2048)) return GNNPP_ERR_ARG;

@@ -183,31 +183,11 @@ inline TrainPackLayout train_pack_layout() {
 // Epilogue: + bias, store, and (part != nullptr) the BatchNorm partial sums of the workgroup's channels over
 // its valid columns -> part[((n*chunks + chunk)*C + c)*2 + {sum, sum of squares}] (16-lane butterflies, then
 // the four waves in order: deterministic).
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int n, int chunks, int C, int c0,
-                                                int CG, double* red);
-
-// relu(bn(.)) of the PREVIOUS layer applied while this convolution stages its input (r06c; layers whose input is not
-// pooled: 1 -> 2 and 3 -> 4): the previous layer's bn_relu_pool launch disappears.  x then is the previous layer's raw
-// convolution output y_{l-1} (same [n][b][c][p] layout as its activation), the workgroup sums that layer's BatchNorm
-// partials itself -- bn_relu_pool_kernel's reduction, 32 channels at a time (double sums: the statistics agree with the
-// unfused launch to the last bit or two of the float they are rounded to) -- and the workgroups of
-// the first row tile also store what the backward pass reads: the activation x_l (-> xn) and, first image chunk only,
-// the statistics (-> stat).  Needs the whole contraction in ONE stage (nchunk == 1) and 16-byte image loads.
-struct ConvBnIn {
-    const float* part;             // partial (sum, sum of squares) pairs of the previous layer; nullptr = off
-    const float* gamma;
-    const float* beta;
-    float* stat;
-    float* xn;
-    int chunks_p, Cp, Pp;          // previous layer: conv workgroups per agent, channels, positions per channel
-    float eps;
-};
-
 template <int H, int W>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         float* __restrict__ part, int B, int Ck, int M, long x_sn,
-                                                        long x_sb, int chunks, int nchunk, const ConvBnIn bi) {
+                                                        long x_sb, int chunks, int nchunk) {
     extern __shared__ __attribute__((aligned(16))) char gnnpp_smem[];
     constexpr bool kDense = H == 1 && W == 1;
     constexpr int P = H * W, TAPS = kDense ? 1 : 9, RPC = kDense ? 4 : 1;
@@ -226,7 +206,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     const int m0 = blockIdx.y * 16;
     float* wsm = reinterpret_cast<float*>(gnnpp_smem);          // [SPC][64]
     float* xs = wsm + SPC * 64;                                  // [CC][RS >= IB*PP]
-    float* coef = xs + CC * RS;                                  // [Cp <= 64][mean, invstd, gamma, beta] (bi.part only)
     int cb[TN], cimg[TN], cp[TN];
     bool cv[TN];
 #pragma unroll
@@ -296,18 +275,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
                 const int e = (tid + u * 256) * 4;
                 const int im = e / (CC * P), r = e - im * (CC * P);
                 if (e < XE && im < nimg) {
-                    v4f v = xv[u];
-                    if (bi.part) {                                // relu(bn(.)) of the previous layer, element by element
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float* cf = coef + ((r + k) / bi.Pp) * 4;
-                            v[k] = fmaxf(fmaf((v[k] - cf[0]) * cf[1], cf[2], cf[3]), 0.f);
-                        }
-                        if (blockIdx.y == 0)                      // x_l for the backward pass (one row tile writes it)
-                            *reinterpret_cast<v4f*>(bi.xn + n * x_sn + (long)(b0 + im) * x_sb + r) = v;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) xs[xs_at(im, r + k)] = v[k];
+                    for (int k = 0; k < 4; ++k) xs[xs_at(im, r + k)] = xv[u][k];
                 }
             }
         } else {
@@ -322,35 +291,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     };
     issue(0);
     for (int i = tid; i < CC * RS; i += 256) xs[i] = 0.f;        // borders / missing images stay zero
-    if (bi.part) {
-        // BatchNorm statistics of the previous layer for agent n, 32 channels at a time (bn_relu_pool_kernel's own
-        // reduction, the A-fragment region as scratch: it is written by commit(0) below)
-        double* red = reinterpret_cast<double*>(wsm);
-        const int mcount = B * bi.Pp;
-        for (int c0 = 0; c0 < bi.Cp; c0 += 32) {
-            reduce_partials(bi.part, n, bi.chunks_p, bi.Cp, c0, 32, red);
-            if (tid < 32) {
-                const int c = c0 + tid;
-                const double s1 = red[tid * 8 * 2], s2 = red[tid * 8 * 2 + 1];
-                const double mean = s1 / mcount;
-                double var = s2 / mcount - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const float invstd = (float)(1.0 / sqrt(var + (double)bi.eps));
-                coef[c * 4] = (float)mean;
-                coef[c * 4 + 1] = invstd;
-                coef[c * 4 + 2] = bi.gamma[c];
-                coef[c * 4 + 3] = bi.beta[c];
-                if (blockIdx.y == 0 && chunk == 0) {
-                    float* o = bi.stat + ((long)n * bi.Cp + c) * 4;
-                    o[0] = (float)mean;
-                    o[1] = invstd;
-                    o[2] = (float)(mcount > 1 ? var * mcount / (mcount - 1) : var);
-                    o[3] = 0.f;
-                }
-            }
-            __syncthreads();                                     // (red is re-used by the next 32 channels)
-        }
-    }
     __syncthreads();
     commit(0);
     __syncthreads();
@@ -1013,7 +953,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const WgradReduc
 //            (gradients w.r.t. layer inputs, ping-pong) | coef (per-agent BN-backward sums) | wpart x 5 (per layer)
 struct TrainWs {
     size_t y[kTrainLayers], xn[kTrainLayers], stat[kTrainLayers], wt[kTrainLayers], wtb[kTrainLayers];
-    size_t part, part2[2], dz[kTrainLayers], dxa, dxb, coef, wpart[kTrainLayers], tick, total;
+    size_t part, dz[kTrainLayers], dxa, dxb, coef, wpart[kTrainLayers], tick, total;
     int chunks[kTrainLayers];
     // conv_wgrad_kernel: image splits, images per split, images per LDS batch, j tiles, K groups per workgroup
     int nsplit[kTrainLayers], ips[kTrainLayers], ib[kTrainLayers], jt[kTrainLayers], kw[kTrainLayers];
@@ -1027,7 +967,6 @@ struct TrainWs {
 // per-layer launches, r06a: 256 was best at 64 x 10).  Set it BEFORE a forward call: the workspace size depends on it.
 std::atomic<int> g_train_wgrad_wgs{0};
 std::atomic<int> g_train_running_fused{1};      // GNNPP_TUNE_TRAIN_RUNNING_FUSED
-std::atomic<int> g_train_bn_fused{1};           // GNNPP_TUNE_TRAIN_BN_FUSED
 
 inline TrainWs train_ws_layout(int N, int B) {
     TrainWs w;
@@ -1067,8 +1006,6 @@ inline TrainWs train_ws_layout(int N, int B) {
         wp[l] = (size_t)w.nsplit[l] * w.kw[l] * d.Cout * w.jt[l] * 16;
     }
     w.part = take(max_part);
-    w.part2[0] = take(max_part);                           // forward conv partials, ping-pong (layer l + 1's convolution
-    w.part2[1] = take(max_part);                           // reads layer l's while it writes its own: r06c)
     for (int l = 0; l < kTrainLayers; ++l) {               // dz / dy of every layer in a buffer of its own: the weight
         const TrainLayerDims d = train_layer(l);           // gradients of all layers read them in ONE launch at the end
         w.dz[l] = take(NB * d.Cout * d.H * d.W);
@@ -1088,18 +1025,18 @@ static inline bool launched_ok() { return hipGetLastError() == hipSuccess; }
 static int conv_chunks(int l, int B) { return conv_geom(l, false, B).chunks_per_agent; }
 
 static void conv_launch(int l, bool input_grad, const float* x, const float* wpack, const float* bias, float* y,
-                        float* part, int N, int B, long sn, long sb, hipStream_t st, const ConvBnIn bi = ConvBnIn{}) {
+                        float* part, int N, int B, long sn, long sb, hipStream_t st) {
     const ConvGeom g = conv_geom(l, input_grad, B);
     const dim3 grid(N * g.chunks_per_agent, g.M / 16);
     const size_t smem = ((size_t)g.SPC * 64 +
                          (size_t)g.CC * conv_row_stride(g.TAPS == 1 ? g.IB : g.IB * (g.H + 2) * (g.W + 2),
-                                                        g.TAPS == 1) + 64 * 4) * sizeof(float);   // (+ the ConvBnIn table)
+                                                        g.TAPS == 1)) * sizeof(float);
 #define GNNPP_CONV(HH, WW)                                                                                     \
     do {                                                                                                       \
         static LdsAttrOnce once;                               /* (the dense stages use 80 KB of LDS) */     \
         set_lds_attr_once(once, reinterpret_cast<const void*>(&conv_mfma_kernel<HH, WW>), (int)smem);          \
         hipLaunchKernelGGL((conv_mfma_kernel<HH, WW>), grid, dim3(256), smem, st, x, wpack, bias, y, part, B,  \
-                           g.Ck, g.M, sn, sb, g.chunks_per_agent, g.nchunk, bi);                               \
+                           g.Ck, g.M, sn, sb, g.chunks_per_agent, g.nchunk);                                   \
     } while (0)
     if (g.H == 11) GNNPP_CONV(11, 11);
     else if (g.H == 5) GNNPP_CONV(5, 5);
@@ -1161,7 +1098,6 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
     for (int l = 0; l < kTrainLayers && have_running; ++l) have_running = rmean[l] && rvar[l];
     const bool fuse_running = have_running && g_train_running_fused.load(std::memory_order_relaxed) != 0 &&
                               last_tiles >= kTrainLayers - 1 && last_tiles <= 8;
-    const bool fuse_bn = g_train_bn_fused.load(std::memory_order_relaxed) != 0;
     BnRunningFuse rf = {};
     for (int l = 0; l < kTrainLayers; ++l) {
         rf.stat[l] = ws + L.stat[l];
@@ -1176,21 +1112,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
         const float* xin = l == 0 ? obs : ws + L.xn[l - 1];
         const long sn = l == 0 ? (long)d.Cin * P : (long)B * d.Cin * P;        // obs is [B][N]: n is the inner index
         const long sb = l == 0 ? (long)N * d.Cin * P : (long)d.Cin * P;
-        // r06c: BatchNorm + ReLU of an UNPOOLED layer l - 1 (1, 3) happen while this convolution stages its input
-        ConvBnIn bi = {};
-        const bool fused_in = fuse_bn && l >= 1 && !train_layer(l - 1).pool && conv_geom(l, false, B).nchunk == 1 &&
-                              train_layer(l - 1).Cout <= 64 && train_layer(l - 1).Cout % 32 == 0;
-        if (fused_in) {
-            const TrainLayerDims dp = train_layer(l - 1);
-            bi.part = ws + L.part2[(l - 1) & 1]; bi.gamma = rp.bn_w[l - 1]; bi.beta = rp.bn_b[l - 1];
-            bi.stat = ws + L.stat[l - 1]; bi.xn = ws + L.xn[l - 1];
-            bi.chunks_p = conv_chunks(l - 1, B); bi.Cp = dp.Cout; bi.Pp = dp.H * dp.W; bi.eps = rp.bn_eps;
-        }
-        float* part_l = ws + L.part2[l & 1];                 // (ping-pong: the next convolution may still read layer l - 1's)
-        conv_launch(l, false, fused_in ? ws + L.y[l - 1] : xin, wt[l], rp.conv_b[l], ws + L.y[l], part_l, N, B, sn, sb, st, bi);
-        const bool fused_out = fuse_bn && l + 1 < kTrainLayers && !d.pool && conv_geom(l + 1, false, B).nchunk == 1 &&
-                               d.Cout <= 64 && d.Cout % 32 == 0;
-        if (fused_out) continue;                             // (layer l + 1's convolution does this layer's BatchNorm + ReLU)
+        conv_launch(l, false, xin, wt[l], rp.conv_b[l], ws + L.y[l], ws + L.part, N, B, sn, sb, st);
         const BnTile t = bn_tile(l);
         BnRunningFuse f = {};
         const bool last = l == kTrainLayers - 1;
@@ -1199,7 +1121,7 @@ int train_encoder_fwd(const EncRawParams& rp, float* const* rmean, float* const*
             f.mode = last ? 2 : 1;
         }
         hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(d.Cout / t.CG, (B + t.BR - 1) / t.BR, N + (f.mode == 2 ? 1 : 0)),
-                           dim3(256), kBnSmem, st, ws + L.y[l], part_l, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
+                           dim3(256), kBnSmem, st, ws + L.y[l], ws + L.part, ws + L.stat[l], rp.bn_w[l], rp.bn_b[l],
                            last ? feat : ws + L.xn[l], B, d.Cout, d.H, d.W, d.pool,
                            conv_chunks(l, B), t.CG, t.BR, rp.bn_eps, (last && feat_bn) ? 1 : 0, f);
     }

@@ -133,10 +133,6 @@ const char* gnnpp_error_string(int code);
                                          its last BatchNorm launch (the workgroups of a channel tile publish their statistics
                                          with an agent-scope release / ticket / acquire hand-off and the last one to arrive
                                          runs the N updates); 0: a launch of its own (r05).  Same statistics to the bit (v330) */
-#define GNNPP_TUNE_TRAIN_BN_FUSED     20 /* 1 (default): gnnpp_encoder_train_fwd applies BatchNorm + ReLU of the two UNPOOLED layers
-                                         (1 and 3) while the next layer's convolution stages its input, instead of a launch
-                                         of their own; 0: r05's launches.  Same results to rounding (the statistics are the
-                                         same double sums in another association) (v330)                              */
 int         gnnpp_set_tuning(int key, int value);
 int         gnnpp_get_tuning(int key);   /* current value of a knob; GNNPP_ERR_ARG for an unknown key */
 

@@ -108,16 +108,17 @@ def test_emu_train_encoder_forward_backward(N, B, seed, fbn, ext_pack):
         assert rc == 0 and all(int(a[0]) == 7 + N for a in nbt2)
         for k, a2 in arrs2.items():
             assert np.array_equal(a2, arrs[k]), k
-        # r06c: BatchNorm + ReLU of the unpooled layers inside the next convolution's staging (GNNPP_TUNE_TRAIN_BN_FUSED,
-        # default) vs the launches of their own (knob 20 = 0): the same features to rounding
-        assert lib.gnnpp_get_tuning(20) == 1 and lib.gnnpp_set_tuning(20, 0) == 0
+        # update_running = 0 (BatchNorm2d(track_running_stats=False)): the running-statistic pointers arrive as NULL -- the
+        # fused update must stay off (r06c fix: it dereferenced them) and the features are the same
+        assert lib.gnnpp_set_tuning(19, 1) == 0
         ws3, feat3 = np.zeros_like(ws), np.full((N, B, 128), np.nan, np.float32)
         rc = lib.gnnpp_encoder_train_fwd(ctypes.byref(P2), el.ptr(obs_np), el.ptr(ws3), el.ptr(feat3), B, N,
                                          ctypes.c_float(0.1), 0, None, fbn, el.ptr(tp) if tp is not None else None, None)
-        assert rc == 0
-        assert np.abs(feat3 - feat).max() <= 2e-6 * max(1.0, np.abs(feat).max())        # (both in the call's own layout)
+        assert rc == 0 and np.array_equal(feat3, feat)
+        for k, a2 in arrs2.items():
+            assert np.array_equal(a2, arrs[k]), k            # (untouched by that call)
     finally:
-        assert lib.gnnpp_set_tuning(19, 1) == 0 and lib.gnnpp_set_tuning(20, 1) == 0
+        assert lib.gnnpp_set_tuning(19, 1) == 0
     if fbn:                                                  # feat_sample_major: the same rows as [B,N,128]
         feat = np.ascontiguousarray(feat.reshape(B, N, 128).transpose(1, 0, 2))
     assert np.abs(feat - want_feat.numpy()).max() <= 2e-5 * max(1.0, want_feat.abs().max().item())
